@@ -1,0 +1,644 @@
+"""Host-side mirror of the reference's `cds` plugin surface, over the C ABI of libcds_hip.so.
+
+Same names, argument meaning and error behaviour as the Java interfaces it replaces
+(API/ = colormipsearch-api/src/main/java/org/janelia/colormipsearch/):
+
+  ColorDepthSearchAlgorithm            API/cds/ColorDepthSearchAlgorithm.java:17-62
+  ColorDepthSearchAlgorithmProvider    API/cds/ColorDepthSearchAlgorithmProvider.java:12-38
+  ColorDepthSearchAlgorithmProviderFactory  API/cds/ColorDepthSearchAlgorithmProviderFactory.java:30-127
+  ColorDepthSearchParams               API/cds/ColorDepthSearchParams.java:9-86
+  ColorMIPSearch                       API/cds/ColorMIPSearch.java:12-47
+  PixelMatchScore / ShapeMatchScore    API/cds/PixelMatchScore.java, API/cds/ShapeMatchScore.java
+  ComputeFileType                      API/model/ComputeFileType.java:5-28 (the two members the path uses)
+
+Images are numpy arrays: RGB uint8[H,W,3] (byte order of ColorImageArray), gradients uint16[H,W].
+Java's IllegalArgumentException maps to capi.CdsInvalidArgument (a ValueError).
+
+On top of the per-pair `calculateMatchingScore` the GPU-native granularity is exposed too:
+`Library` (a resident shard of targets) and `searchLibrary` / `scoreLibraryPairs`, which is what a
+`ColorMIPSearchProcessor` replacement would call (one launch per library, not one JNI call per pair).
+Everything computes on the GPU through the C ABI; there is no CPU fallback in this package.
+"""
+import ctypes
+import enum
+import os
+import threading
+
+import numpy as np
+
+from . import capi
+from .capi import CdsError, CdsInvalidArgument  # noqa: F401  (re-exported)
+
+
+class ComputeFileType(enum.Enum):
+    InputColorDepthImage = "InputColorDepthImage"
+    GradientImage = "GradientImage"
+    ZGapImage = "ZGapImage"
+
+
+# --------------------------------------------------------------------------------------------------
+# excluded regions (ImageRegionDefinition) -- rectangles [x0,y0,x1,y1)
+# --------------------------------------------------------------------------------------------------
+def label_regions(width, has_name_label=True, has_color_scale_label=True):
+    """tools cmd/AbstractColorDepthMatchArgs.java:101-119 (== test ImageTestUtils.java:12-24)."""
+    rects = []
+    if has_color_scale_label and width > 270:
+        rects.append((width - 270, 0, width, 90))
+    if has_name_label:
+        rects.append((0, 0, 330, 100))
+    return rects
+
+
+def _resolve_regions(regions, width):
+    if regions is None:
+        return []
+    if callable(regions):
+        return list(regions(width))
+    return list(regions)
+
+
+# --------------------------------------------------------------------------------------------------
+# context / library
+# --------------------------------------------------------------------------------------------------
+class Context:
+    """One GPU (cds_context)."""
+
+    def __init__(self, device=0):
+        self._lib = capi.load()
+        h = ctypes.c_void_p()
+        capi.check(self._lib.cds_context_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cds_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        """Launch on an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+        capi.check(self._lib.cds_context_set_stream(self._h, ctypes.c_void_p(int(hip_stream) if hip_stream else None)))
+
+    def synchronize(self):
+        capi.check(self._lib.cds_context_synchronize(self._h))
+
+    def device_rcp_table(self):
+        out = np.zeros(256, dtype=np.float32)
+        capi.check(self._lib.cds_debug_device_rcp(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        return out
+
+    def make_zgap(self, target, threshold, radius=10, excluded_regions=None):
+        """clearRegion -> mask(threshold) -> unsafeMaxFilter(radius), on the GPU."""
+        img = capi.rgb_images(target)[0]
+        H, W, _ = img.shape
+        r, n = capi.rect_array(_resolve_regions(excluded_regions, W))
+        out = np.empty_like(img)
+        capi.check(self._lib.cds_make_zgap(self._h, capi.as_u8p(img), W, H, int(threshold), float(radius), r, n,
+                                           capi.as_u8p(out)))
+        return out
+
+
+_default_ctx = {}
+_ctx_lock = threading.Lock()
+
+
+def default_context(device=None):
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    with _ctx_lock:
+        if device not in _default_ctx:
+            _default_ctx[device] = Context(device)
+        return _default_ctx[device]
+
+
+class Library:
+    """A resident shard of target MIPs in HBM (cds_library); replaces the host-side MIP cache."""
+
+    def __init__(self, width, height, capacity, context=None, device_buffer=None):
+        self.ctx = context or default_context()
+        self._lib = capi.load()
+        self.width, self.height, self.capacity = int(width), int(height), int(capacity)
+        h = ctypes.c_void_p()
+        self._keepalive = device_buffer
+        if device_buffer is None:
+            capi.check(self._lib.cds_library_create(self.ctx._h, self.width, self.height, self.capacity, ctypes.byref(h)))
+        else:  # e.g. a torch uint8 CUDA tensor
+            ptr, nbytes = int(device_buffer.data_ptr()), int(device_buffer.numel() * device_buffer.element_size())
+            capi.check(self._lib.cds_library_wrap(self.ctx._h, self.width, self.height, self.capacity,
+                                                  ctypes.c_void_p(ptr), nbytes, ctypes.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def bytes_required(width, height, capacity):
+        return int(capi.load().cds_library_bytes(int(width), int(height), int(capacity)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cds_library_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, first, images):
+        imgs = capi.rgb_images(images)
+        if imgs.shape[1:3] != (self.height, self.width):
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "image size does not match the library")
+        capi.check(self._lib.cds_library_upload(self._h, int(first), imgs.shape[0], capi.as_u8p(imgs)))
+
+    def download(self, first, count):
+        out = np.empty((int(count), self.height, self.width, 3), dtype=np.uint8)
+        capi.check(self._lib.cds_library_download(self._h, int(first), int(count), capi.as_u8p(out)))
+        return out
+
+    def upload_variants(self, first, gradients=None, zgaps=None):
+        n = None
+        gp = zp = None
+        if gradients is not None:
+            gradients = np.ascontiguousarray(gradients, dtype=np.uint16)
+            if gradients.ndim == 2:
+                gradients = gradients[None]
+            n = gradients.shape[0]
+            gp = capi.as_u16p(gradients)
+        if zgaps is not None:
+            zgaps = capi.rgb_images(zgaps, n)
+            n = zgaps.shape[0]
+            zp = capi.as_u8p(zgaps)
+        if n is None:
+            return
+        capi.check(self._lib.cds_library_upload_variants(self._h, int(first), n, gp, zp))
+
+    def download_variants(self, first, count):
+        g = np.empty((int(count), self.height, self.width), dtype=np.uint16)
+        z = np.empty((int(count), self.height, self.width, 3), dtype=np.uint8)
+        capi.check(self._lib.cds_library_download_variants(self._h, int(first), int(count), capi.as_u16p(g), capi.as_u8p(z)))
+        return g, z
+
+    def generate_synthetic(self, seed, first_index, first_slot, count, kind=0, with_variants=False):
+        capi.check(self._lib.cds_library_generate_synthetic(self._h, ctypes.c_uint64(int(seed)), int(first_index),
+                                                            int(first_slot), int(count), int(kind), int(bool(with_variants))))
+
+
+# --------------------------------------------------------------------------------------------------
+# scores
+# --------------------------------------------------------------------------------------------------
+class PixelMatchScore:
+    """API/cds/PixelMatchScore.java:3-31"""
+
+    def __init__(self, matchingPixNum, matchingPixNumToMaskRatio, mirrored):
+        self._n, self._ratio, self._mirrored = int(matchingPixNum), float(matchingPixNumToMaskRatio), bool(mirrored)
+
+    def getScore(self):
+        return self._n
+
+    def getNormalizedScore(self):
+        return float(np.float32(self._ratio))
+
+    def isMirrored(self):
+        return self._mirrored
+
+    def __repr__(self):
+        return f"PixelMatchScore(score={self._n}, ratio={self._ratio:.6f}, mirrored={self._mirrored})"
+
+
+class ShapeMatchScore:
+    """API/cds/ShapeMatchScore.java:5-65 (gradient-area-gap constructor)."""
+
+    def __init__(self, gradientAreaGap, highExpressionArea, maxGradientAreaGap=-1, mirrored=False):
+        self._gap, self._high, self._max, self._mirrored = int(gradientAreaGap), int(highExpressionArea), int(maxGradientAreaGap), bool(mirrored)
+
+    def getGradientAreaGap(self):
+        return self._gap
+
+    def getHighExpressionArea(self):
+        return self._high
+
+    def getScore(self):
+        v = int(capi.load().cds_shape_score_value(self._gap, self._high))
+        return int(np.int64(v).astype(np.int32))  # (int) cast of ShapeMatchScore.java:29-33
+
+    def getNormalizedScore(self):
+        s = self.getScore()
+        return float(np.float32(s) / np.float32(self._max)) if self._max > 0 else float(s)
+
+    def isMirrored(self):
+        return self._mirrored
+
+    def __repr__(self):
+        return f"ShapeMatchScore(gradientAreaGap={self._gap}, highExpressionArea={self._high}, mirrored={self._mirrored})"
+
+
+def calculate2DShapeScore(gradientAreaGap, highExpressionArea):
+    """GradientAreaGapUtils.calculate2DShapeScore (API/cds/GradientAreaGapUtils.java:199-207)."""
+    if gradientAreaGap is None or highExpressionArea is None:
+        return -1
+    return int(capi.load().cds_shape_score_value(int(gradientAreaGap), int(highExpressionArea)))
+
+
+def calculateNormalizedScore(pixelMatchScore, shapeScore, maxPixelMatch, maxShapeScore):
+    """GradientAreaGapUtils.calculateNormalizedScore (API/cds/GradientAreaGapUtils.java:219-235)."""
+    return float(capi.load().cds_normalized_score(int(pixelMatchScore), int(shapeScore), int(maxPixelMatch), int(maxShapeScore)))
+
+
+# --------------------------------------------------------------------------------------------------
+# parameters
+# --------------------------------------------------------------------------------------------------
+class ColorDepthSearchParams:
+    """API/cds/ColorDepthSearchParams.java:9-86"""
+
+    def __init__(self, params=None):
+        self._p = dict(params or {})
+
+    def setParam(self, name, value):
+        if value is not None:
+            self._p[name] = value
+        return self
+
+    def asMap(self):
+        return dict(self._p)
+
+    def getParam(self, name, default=None):
+        v = self._p.get(name)
+        return default if v is None else v
+
+    def getIntParam(self, name, default=None):
+        v = self._p.get(name)
+        return default if v is None else int(v)
+
+    def getDoubleParam(self, name, default=None):
+        v = self._p.get(name)
+        return default if v is None else float(v)
+
+    def getBoolParam(self, name, default=None):
+        v = self._p.get(name)
+        if v is None:
+            return default
+        if isinstance(v, str):
+            return v.lower() == "true"
+        return bool(v)
+
+
+# --------------------------------------------------------------------------------------------------
+# algorithms
+# --------------------------------------------------------------------------------------------------
+class ColorDepthSearchAlgorithm:
+    """API/cds/ColorDepthSearchAlgorithm.java:17-62"""
+
+    def getQueryImage(self):
+        raise NotImplementedError
+
+    def getQuerySize(self):
+        raise NotImplementedError
+
+    def getQueryFirstPixelIndex(self):
+        raise NotImplementedError
+
+    def getQueryLastPixelIndex(self):
+        raise NotImplementedError
+
+    def getRequiredTargetVariantTypes(self):
+        raise NotImplementedError
+
+    def calculateMatchingScore(self, targetImageArray, variantImageSuppliers=None):
+        raise NotImplementedError
+
+
+class PixelMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
+    """API/cds/PixelMatchColorDepthSearchAlgorithm.java:20-265 for one mask (or a batch of masks that share
+    the parameters: pass uint8[n,H,W,3]; the per-pair methods then address mask 0 unless told otherwise).
+    The negative-query arguments of the reference constructor are not supported (the factory never passes
+    them: ColorDepthSearchAlgorithmProviderFactory.java:65-67)."""
+
+    def __init__(self, queryImage, queryThreshold, mirrorQuery, negQueryImage, negQueryThreshold, mirrorNegQuery,
+                 targetThreshold, zTolerance, xyshift, excludedRegions=None, context=None):
+        if negQueryImage is not None:
+            raise CdsError(capi.CDS_ERR_UNSUPPORTED, "negative query images are not supported")
+        self.ctx = context or default_context()
+        self._lib = capi.load()
+        self._masks = capi.rgb_images(queryImage)
+        n, H, W, _ = self._masks.shape
+        self.width, self.height, self.n_masks = W, H, n
+        self.queryThreshold, self.targetThreshold = int(queryThreshold), int(targetThreshold)
+        self.zTolerance, self.xyShift, self.mirrorQuery = float(zTolerance), int(xyshift), bool(mirrorQuery)
+        self._rects = _resolve_regions(excludedRegions, W)
+        params = capi.PixMatchParams(self.queryThreshold, self.targetThreshold, self.zTolerance, self.xyShift,
+                                     int(self.mirrorQuery))
+        r, nr = capi.rect_array(self._rects)
+        h = ctypes.c_void_p()
+        capi.check(self._lib.cds_maskset_create(self.ctx._h, n, capi.as_u8p(self._masks), W, H, ctypes.byref(params),
+                                                r, nr, ctypes.byref(h)))
+        self._h = h
+        sizes = np.zeros(n, dtype=np.int32)
+        capi.check(self._lib.cds_maskset_query_sizes(self._h, capi.as_i32p(sizes)))
+        self._sizes = sizes
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cds_maskset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- ColorDepthSearchAlgorithm ----
+    def getQueryImage(self):
+        return self._masks[0]
+
+    def getQuerySize(self, mask_index=0):
+        return int(self._sizes[mask_index])
+
+    def getQuerySizes(self):
+        return self._sizes.copy()
+
+    def _positions(self, mask_index=0):
+        m = self._masks[mask_index]
+        sel = m.max(axis=2) > self.queryThreshold
+        for (x0, y0, x1, y1) in self._rects:
+            sel[max(0, y0):max(0, y1), max(0, x0):max(0, x1)] = False
+        return np.flatnonzero(sel.reshape(-1))
+
+    def _strip(self, mask_index=0):
+        # PixelMatchColorDepthSearchAlgorithm.java:59-100 on top of the (multiplying) super methods
+        # AbstractColorDepthSearchAlgorithm.java:76-84 -- informational only, quirks kept.
+        W, H = self.width, self.height
+        pos = self._positions(mask_index)
+        if len(pos) == 0:
+            first, last = H * W * W, 0
+            return first, last
+        xs, ys = pos % W, pos // W
+        first = int(ys.min()) * W * int(xs.min())
+        last = int(ys.max() + 1) * W * int(xs.max() + 1)
+        shifts = [(0, 0)] if self.xyShift == 0 else [(dx, dy) for dx in (-2, 0, 2) for dy in (-2, 0, 2)]
+        lists = []
+        for dx, dy in shifts:
+            x, y = xs + dx, ys + dy
+            ok = (x >= 0) & (x < W) & (y >= 0) & (y < H)
+            lists.append(np.where(ok, y * W + x, -1))
+        if self.mirrorQuery:
+            lists += [np.where(l == -1, -1, l + (W - 1) - 2 * (l % W)) for l in list(lists)]
+        for l in lists:
+            first = min(first, int(l[0]))
+            last = max(last, int(l[-1]))
+        return first, last
+
+    def getQueryFirstPixelIndex(self):
+        return self._strip()[0]
+
+    def getQueryLastPixelIndex(self):
+        return self._strip()[1]
+
+    def getRequiredTargetVariantTypes(self):
+        return set()
+
+    def calculateMatchingScore(self, targetImageArray, variantImageSuppliers=None, mask_index=0):
+        P = self.getQuerySize(mask_index)
+        if P == 0:
+            return PixelMatchScore(0, 0, False)
+        t = np.ascontiguousarray(targetImageArray, dtype=np.uint8)
+        if t.ndim != 3 or t.shape[2] != 3:
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, f"expected an RGB image, got {t.shape}")
+        s, m = ctypes.c_int32(), ctypes.c_uint8()
+        capi.check(self._lib.cds_score_pair(self._h, int(mask_index), capi.as_u8p(t), t.shape[1], t.shape[0],
+                                            ctypes.byref(s), ctypes.byref(m)))
+        return PixelMatchScore(s.value, s.value / float(P), bool(m.value))
+
+    # ---- GPU-native granularity ----
+    def searchLibrary(self, library, first=0, count=None):
+        """All masks x library slots [first, first+count): (scores int32[n_masks,count], mirrored bool[...])."""
+        count = library.capacity - first if count is None else int(count)
+        scores = np.zeros((self.n_masks, count), dtype=np.int32)
+        mir = np.zeros((self.n_masks, count), dtype=np.uint8)
+        capi.check(self._lib.cds_search(self._h, library._h, int(first), count, capi.as_i32p(scores), capi.as_u8p(mir)))
+        return scores, mir.astype(bool)
+
+    def searchLibraryCounts(self, library, first=0, count=None):
+        count = library.capacity - first if count is None else int(count)
+        counts = np.zeros((self.n_masks, count, capi.CDS_N_TRANSFORMS), dtype=np.int32)
+        capi.check(self._lib.cds_search_counts(self._h, library._h, int(first), count, capi.as_i32p(counts)))
+        return counts
+
+    def searchLibraryDevice(self, library, first, count, d_scores_ptr):
+        """Asynchronous; d_scores_ptr = device pointer to int32[n_masks*count] (score | mirrored<<31)."""
+        capi.check(self._lib.cds_search_device(self._h, library._h, int(first), int(count), ctypes.c_void_p(int(d_scores_ptr))))
+
+    def lastKernelMs(self):
+        ms, n = ctypes.c_double(), ctypes.c_int32()
+        capi.check(self._lib.cds_maskset_last_kernel_ms(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+
+class Shape2DMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
+    """API/cds/Shape2DMatchColorDepthSearchAlgorithm.java:23-247 for one mask (or a batch), prepared as
+    ColorDepthSearchAlgorithmProviderFactory.java:91-125 does (queryBorderSize 0 only)."""
+
+    def __init__(self, queryImage, queryThreshold, mirrorQuery, roiMask=None, excludedRegions=None, context=None):
+        self.ctx = context or default_context()
+        self._lib = capi.load()
+        self._masks = capi.rgb_images(queryImage)
+        n, H, W, _ = self._masks.shape
+        self.width, self.height, self.n_masks = W, H, n
+        self.queryThreshold, self.mirrorQuery = int(queryThreshold), bool(mirrorQuery)
+        self._rects = _resolve_regions(excludedRegions, W)
+        r, nr = capi.rect_array(self._rects)
+        roi_p = None
+        if roiMask is not None:
+            roi = np.ascontiguousarray(roiMask)
+            if roi.ndim == 3:
+                roi = roi.max(axis=2)
+            roi = np.ascontiguousarray(roi != 0, dtype=np.uint8)
+            if roi.shape != (H, W):
+                raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "ROI mask size must match the query size")
+            self._roi = roi
+            roi_p = capi.as_u8p(roi)
+        h = ctypes.c_void_p()
+        capi.check(self._lib.cds_shapeset_create(self.ctx._h, n, capi.as_u8p(self._masks), W, H, self.queryThreshold,
+                                                 int(self.mirrorQuery), roi_p, r, nr, ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cds_shapeset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _cleared(self, mask_index=0):
+        m = self._masks[mask_index].copy()
+        for (x0, y0, x1, y1) in self._rects:
+            m[max(0, y0):max(0, y1), max(0, x0):max(0, x1)] = 0
+        return m
+
+    def getQueryImage(self):
+        return self._cleared()
+
+    def getQuerySize(self, mask_index=0):
+        return int((self._cleared(mask_index).max(axis=2) > self.queryThreshold).sum())
+
+    def getQueryFirstPixelIndex(self):
+        nz = np.flatnonzero((self._cleared().max(axis=2) > self.queryThreshold).reshape(-1))
+        return int(nz[0]) if len(nz) else -1
+
+    def getQueryLastPixelIndex(self):
+        nz = np.flatnonzero((self._cleared().max(axis=2) > self.queryThreshold).reshape(-1))
+        return int(nz[-1]) if len(nz) else -1
+
+    def getRequiredTargetVariantTypes(self):
+        return {ComputeFileType.GradientImage, ComputeFileType.ZGapImage}
+
+    def maskStats(self):
+        """(sum of the query mask, sum of the high-expression mask) per mask."""
+        a = np.zeros(self.n_masks, dtype=np.int64)
+        b = np.zeros(self.n_masks, dtype=np.int64)
+        capi.check(self._lib.cds_shapeset_mask_stats(self._h, capi.as_i64p(a), capi.as_i64p(b)))
+        return a, b
+
+    def calculateMatchingScore(self, targetImageArray, variantImageSuppliers=None, mask_index=0):
+        sup = variantImageSuppliers or {}
+        gs, zs = sup.get(ComputeFileType.GradientImage), sup.get(ComputeFileType.ZGapImage)
+        grad = gs() if gs is not None else None
+        zgap = zs() if zs is not None else None
+        if grad is None or zgap is None:
+            return ShapeMatchScore(-1, -1, -1, False)
+        t = np.ascontiguousarray(targetImageArray, dtype=np.uint8)
+        grad = np.ascontiguousarray(grad)
+        if grad.dtype == np.uint8:  # GRAY8 gradient: ImageArray.get() widens it
+            grad = grad.astype(np.uint16)
+        grad = np.ascontiguousarray(grad, dtype=np.uint16)
+        zgap = np.ascontiguousarray(zgap, dtype=np.uint8)
+        if t.ndim != 3 or grad.shape != t.shape[:2] or zgap.shape != t.shape:
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "target, gradient and zgap sizes differ")
+        g, h, m = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_uint8()
+        capi.check(self._lib.cds_shape_score_pair(self._h, int(mask_index), capi.as_u8p(t), capi.as_u16p(grad),
+                                                  capi.as_u8p(zgap), t.shape[1], t.shape[0], ctypes.byref(g),
+                                                  ctypes.byref(h), ctypes.byref(m)))
+        return ShapeMatchScore(g.value, h.value, -1, bool(m.value))
+
+    def scoreLibraryPairs(self, library, pair_mask, pair_slot):
+        """(gradientAreaGap int64[n], highExpressionArea int64[n], mirrored bool[n]) for (mask, slot) pairs."""
+        pm = np.ascontiguousarray(pair_mask, dtype=np.int32)
+        ps = np.ascontiguousarray(pair_slot, dtype=np.int64)
+        n = len(pm)
+        gap = np.zeros(n, dtype=np.int64)
+        high = np.zeros(n, dtype=np.int64)
+        mir = np.zeros(n, dtype=np.uint8)
+        capi.check(self._lib.cds_gradscore(self._h, library._h, n, capi.as_i32p(pm), capi.as_i64p(ps), capi.as_i64p(gap),
+                                           capi.as_i64p(high), capi.as_u8p(mir)))
+        return gap, high, mir.astype(bool)
+
+    def lastKernelMs(self):
+        ms, n = ctypes.c_double(), ctypes.c_int32()
+        capi.check(self._lib.cds_shapeset_last_kernel_ms(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+
+# --------------------------------------------------------------------------------------------------
+# providers / factory / ColorMIPSearch
+# --------------------------------------------------------------------------------------------------
+class ColorDepthSearchAlgorithmProvider:
+    """API/cds/ColorDepthSearchAlgorithmProvider.java:12-38"""
+
+    def getDefaultCDSParams(self):
+        raise NotImplementedError
+
+    def createColorDepthSearchAlgorithm(self, queryImage, queryThreshold, queryBorderSize, cdsParams):
+        raise NotImplementedError
+
+    def createColorDepthQuerySearchAlgorithmWithDefaultParams(self, queryImage, queryThreshold, queryBorderSize):
+        return self.createColorDepthSearchAlgorithm(queryImage, queryThreshold, queryBorderSize, ColorDepthSearchParams())
+
+
+class _PixMatchProvider(ColorDepthSearchAlgorithmProvider):
+    def __init__(self, mirrorMask, targetThreshold, pixColorFluctuation, xyShift, regions, context):
+        self._defaults = (ColorDepthSearchParams().setParam("mirrorMask", mirrorMask).setParam("dataThreshold", targetThreshold)
+                          .setParam("pixColorFluctuation", pixColorFluctuation).setParam("xyShift", xyShift))
+        self._m, self._t, self._f, self._s, self._regions, self._ctx = mirrorMask, targetThreshold, pixColorFluctuation, xyShift, regions, context
+
+    def getDefaultCDSParams(self):
+        return self._defaults
+
+    def createColorDepthSearchAlgorithm(self, queryImage, queryThreshold, queryBorderSize, cdsParams):
+        fl = cdsParams.getDoubleParam("pixColorFluctuation", self._f)
+        zTolerance = 0.0 if fl is None else fl / 100      # Factory:55-56
+        xyShift = cdsParams.getIntParam("xyShift", self._s)
+        if (xyShift & 1) == 1:                              # Factory:58-60
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "XY shift parameter must be an even number.")
+        return PixelMatchColorDepthSearchAlgorithm(queryImage, queryThreshold, cdsParams.getBoolParam("mirrorMask", self._m),
+                                                   None, 0, False, cdsParams.getIntParam("dataThreshold", self._t),
+                                                   zTolerance, xyShift, self._regions, context=self._ctx)
+
+
+class _ShapeMatchProvider(ColorDepthSearchAlgorithmProvider):
+    def __init__(self, mirrorMask, roiMask, regions, context):
+        self._defaults = ColorDepthSearchParams().setParam("mirrorMask", mirrorMask)
+        self._m, self._roi, self._regions, self._ctx = mirrorMask, roiMask, regions, context
+
+    def getDefaultCDSParams(self):
+        return self._defaults
+
+    def createColorDepthSearchAlgorithm(self, queryImage, queryThreshold, queryBorderSize, cdsParams):
+        if queryBorderSize:
+            raise CdsError(capi.CDS_ERR_UNSUPPORTED, "queryBorderSize != 0 is not supported")
+        return Shape2DMatchColorDepthSearchAlgorithm(queryImage, queryThreshold, cdsParams.getBoolParam("mirrorMask", self._m),
+                                                     self._roi, self._regions, context=self._ctx)
+
+
+class ColorDepthSearchAlgorithmProviderFactory:
+    """API/cds/ColorDepthSearchAlgorithmProviderFactory.java:30-127"""
+
+    @staticmethod
+    def createPixMatchCDSAlgorithmProvider(mirrorMask, targetThreshold, pixColorFluctuation, xyShiftParam,
+                                           ignoredRegionsProvider=None, context=None):
+        return _PixMatchProvider(mirrorMask, targetThreshold, pixColorFluctuation, xyShiftParam, ignoredRegionsProvider, context)
+
+    @staticmethod
+    def createShapeMatchCDSAlgorithmProvider(mirrorMask, roiMaskImageArray=None, excludedRegions=None, context=None):
+        return _ShapeMatchProvider(mirrorMask, roiMaskImageArray, excludedRegions, context)
+
+
+class ColorMIPSearch:
+    """API/cds/ColorMIPSearch.java:12-47"""
+
+    def __init__(self, pctPositivePixels, defaultQueryThreshold, cdsAlgorithmProvider):
+        self.pctPositivePixels, self.defaultQueryThreshold, self.cdsAlgorithmProvider = pctPositivePixels, defaultQueryThreshold, cdsAlgorithmProvider
+
+    def getCDSParameters(self):
+        p = dict(self.cdsAlgorithmProvider.getDefaultCDSParams().asMap())
+        p["pctPositivePixels"] = None if self.pctPositivePixels is None else str(self.pctPositivePixels)
+        p["defaultMaskThreshold"] = None if self.defaultQueryThreshold is None else str(self.defaultQueryThreshold)
+        return p
+
+    def createQueryColorDepthSearchWithDefaultThreshold(self, queryImage):
+        thr = 0 if self.defaultQueryThreshold is None else self.defaultQueryThreshold
+        return self.cdsAlgorithmProvider.createColorDepthQuerySearchAlgorithmWithDefaultParams(queryImage, thr, 0)
+
+    def createQueryColorDepthSearch(self, queryImage, queryThreshold, borderSize):
+        return self.cdsAlgorithmProvider.createColorDepthQuerySearchAlgorithmWithDefaultParams(queryImage, queryThreshold, borderSize)
+
+    def isMatch(self, pixelMatchScore):
+        thr = self.pctPositivePixels / 100 if self.pctPositivePixels is not None else 0.0
+        return pixelMatchScore.getScore() > 0 and pixelMatchScore.getNormalizedScore() > thr
+
+    def isMatchArray(self, scores, query_size):
+        """Vectorised isMatch for score arrays of one mask."""
+        thr = self.pctPositivePixels / 100 if self.pctPositivePixels is not None else 0.0
+        scores = np.asarray(scores)
+        if query_size == 0:
+            return np.zeros(scores.shape, dtype=bool)
+        ratio = (scores.astype(np.float64) / float(query_size)).astype(np.float32).astype(np.float64)
+        return (scores > 0) & (ratio > thr)

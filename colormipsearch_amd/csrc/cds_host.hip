@@ -1,0 +1,758 @@
+// cds_host.hip -- host side of libcds_hip.so: context, resident library, pixel-match mask preparation
+// (the exact integer restatement of the reference's double predicate) and the search entry points.
+//
+// Reference citations: API/ = colormipsearch-api/src/main/java/org/janelia/colormipsearch/.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+
+#include "cds_internal.hpp"
+
+namespace cds {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char *what) {
+    g_err = std::string("HIP error ") + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ") in " + what;
+    return e == hipErrorOutOfMemory ? CDS_ERR_OUT_OF_MEMORY : CDS_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ratio table.  A target pixel's hue ratio is second/max = n/d with 0 <= n < d <= 255; the reference
+// evaluates it as (double)n/(double)d (0.0 when n == 0: AbstractColorDepthSearchAlgorithm.java:195-256).
+// The device encodes it as bits(fl32(n) * rcp[d]) >> 1 with rcp[] = this GPU's v_rcp_f32.  The table
+// lists every distinct double value, sorted, with the code range of its representatives, and proves
+// that the code order equals the value order (so value intervals are code intervals).
+// ------------------------------------------------------------------------------------------------
+static inline uint32_t fbits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+uint32_t ratio_code(const float *rcp, int n, int d) {
+    volatile float x = (float)n * rcp[d];  // one IEEE single multiply, as v_mul_f32 / v_pk_mul_f32
+    return fbits(x) >> 1;
+}
+
+int build_ratio_table(const float *rcp, std::vector<RatioEntry> &out) {
+    struct Item {
+        double v;
+        uint32_t c;
+    };
+    std::vector<Item> items;
+    items.reserve(32640);
+    for (int d = 1; d <= 255; d++)
+        for (int n = 0; n < d; n++) {
+            double v = n == 0 ? 0.0 : (double)n / (double)d;
+            items.push_back({v, ratio_code(rcp, n, d)});
+        }
+    std::sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.v < b.v || (a.v == b.v && a.c < b.c); });
+    out.clear();
+    for (const Item &it : items) {
+        if (!out.empty() && out.back().value == it.v) {
+            out.back().code_hi = std::max(out.back().code_hi, it.c);
+            out.back().code_lo = std::min(out.back().code_lo, it.c);
+        } else {
+            out.push_back({it.v, it.c, it.c});
+        }
+    }
+    for (size_t i = 1; i < out.size(); i++)
+        if (!(out[i - 1].code_hi < out[i].code_lo))
+            return fail(CDS_ERR_UNSUPPORTED, "device reciprocal table does not preserve the order of hue ratios");
+    if (out.back().code_hi >= (1u << 29)) return fail(CDS_ERR_UNSUPPORTED, "hue ratio code overflow");
+    return CDS_OK;
+}
+
+// Hue class + ratio of a colour exactly as the reference (AbstractColorDepthSearchAlgorithm.java:195-225).
+enum { C_NONE = 0, C_BR, C_BG, C_GB, C_GR, C_RG, C_RB };
+static int hue_class(int r, int g, int b, double *ratio) {
+    *ratio = 0.0;
+    if (b > r && b > g) {
+        if (r > g) { *ratio = (double)r / (double)b; return C_BR; }
+        if (g != 0) *ratio = (double)g / (double)b;
+        return C_BG;
+    }
+    if (g > b && g > r) {
+        if (b > r) { *ratio = (double)b / (double)g; return C_GB; }
+        if (r != 0) *ratio = (double)r / (double)g;
+        return C_GR;
+    }
+    if (r > b && r > g) {
+        if (g > b) { *ratio = (double)g / (double)r; return C_RG; }
+        if (b != 0) *ratio = (double)b / (double)r;
+        return C_RB;
+    }
+    return C_NONE;
+}
+
+struct Intervals {
+    uint32_t lo1, len1, lo2, len2;
+};
+static const Intervals kEmptyIv = {1u, 0u, 1u, 0u};  // code 1 never occurs
+
+// The reference's adjacent-class rules (AbstractColorDepthSearchAlgorithm.java:269-381), from the point
+// of view of a mask pixel of class c1 with ratio a: which neighbour class can match, and how.
+struct Neighbour {
+    int cls;      // target class
+    bool low;     // true: (a-c)+(b-c) with a<la && b<lb;  false: (c-a)+(c-b) with a>la && b>lb
+    double la, lb, c;
+};
+static int neighbours_of(int c1, Neighbour nb[2]) {
+    const double BrBg = 0.354862745, BgGb = 0.996078431, GbGr = 0.505882353, GrRg = 0.996078431, RgRb = 0.505882353;
+    switch (c1) {
+        case C_BR: nb[0] = {C_BG, true, 0.44, 0.54, BrBg}; return 1;
+        case C_BG: nb[0] = {C_BR, true, 0.54, 0.44, BrBg}; nb[1] = {C_GB, false, 0.8, 0.8, BgGb}; return 2;
+        case C_GB: nb[0] = {C_BG, false, 0.8, 0.8, BgGb}; nb[1] = {C_GR, true, 0.7, 0.7, GbGr}; return 2;
+        case C_GR: nb[0] = {C_GB, true, 0.7, 0.7, GbGr}; nb[1] = {C_RG, false, 0.8, 0.8, GrRg}; return 2;
+        case C_RG: nb[0] = {C_GR, false, 0.8, 0.8, GrRg}; nb[1] = {C_RB, true, 0.7, 0.7, RgRb}; return 2;
+        case C_RB: nb[0] = {C_RG, true, 0.7, 0.7, RgRb}; return 1;
+    }
+    return 0;
+}
+
+static inline bool same_class_ok(double a, double b, double ztol) {
+    if (!(a > 0 && b > 0)) return false;
+    double gap = (a != b) ? std::fabs(b - a) : 0.0;
+    return gap <= ztol;
+}
+static inline bool neighbour_ok(const Neighbour &n, double a, double b, double ztol) {
+    if (n.low) {
+        if (!(a < n.la && b < n.lb)) return false;
+        volatile double ga = a - n.c, gb = b - n.c;  // no contraction / re-association
+        volatile double gap = ga + gb;
+        return gap <= ztol;
+    }
+    if (!(a > n.la && b > n.lb)) return false;
+    volatile double ga = n.c - a, gb = n.c - b;
+    volatile double gap = ga + gb;
+    return gap <= ztol;
+}
+
+// Acceptance intervals (in device-code space) of a mask colour of class c1 / ratio a.
+// Every predicate below is monotone along the sorted ratio table (IEEE subtraction, addition and
+// rounding are monotone), so the accepted set is one index range; binary search finds its ends with
+// the reference's own double expressions as the oracle of each probe.
+Intervals intervals_for(const std::vector<RatioEntry> &tab, int c1, double a, double ztol) {
+    Intervals iv = kEmptyIv;
+    if (c1 == C_NONE) return iv;
+    const int n = (int)tab.size();
+    // --- same class: a > 0, b > 0, |b - a| <= ztol
+    if (a > 0) {
+        int ia = (int)(std::lower_bound(tab.begin(), tab.end(), a, [](const RatioEntry &e, double v) { return e.value < v; }) - tab.begin());
+        if (ia < n && tab[ia].value == a && same_class_ok(a, a, ztol)) {
+            int lo = 1, hi = ia;  // index 0 is the value 0.0
+            while (lo < hi) {     // smallest j in [1, ia] accepted
+                int mid = (lo + hi) / 2;
+                if (same_class_ok(a, tab[mid].value, ztol)) hi = mid; else lo = mid + 1;
+            }
+            int jlo = lo;
+            lo = ia; hi = n - 1;
+            while (lo < hi) {     // largest j in [ia, n-1] accepted
+                int mid = (lo + hi + 1) / 2;
+                if (same_class_ok(a, tab[mid].value, ztol)) lo = mid; else hi = mid - 1;
+            }
+            int jhi = lo;
+            iv.lo1 = ((uint32_t)c1 << 29) | tab[jlo].code_lo;
+            iv.len1 = (((uint32_t)c1 << 29) | tab[jhi].code_hi) - iv.lo1;
+        }
+    }
+    // --- at most one adjacent class (the two conditions on a exclude each other)
+    Neighbour nb[2];
+    int k = neighbours_of(c1, nb);
+    for (int i = 0; i < k; i++) {
+        const Neighbour &q = nb[i];
+        if (q.low) {
+            if (!neighbour_ok(q, a, tab[0].value, ztol)) continue;
+            int lo = 0, hi = n - 1;
+            while (lo < hi) {  // largest accepted index (accepted set is down-closed)
+                int mid = (lo + hi + 1) / 2;
+                if (neighbour_ok(q, a, tab[mid].value, ztol)) lo = mid; else hi = mid - 1;
+            }
+            iv.lo2 = ((uint32_t)q.cls << 29) | tab[0].code_lo;
+            iv.len2 = (((uint32_t)q.cls << 29) | tab[lo].code_hi) - iv.lo2;
+            break;
+        } else {
+            if (!neighbour_ok(q, a, tab[n - 1].value, ztol)) continue;
+            int lo = 0, hi = n - 1;
+            while (lo < hi) {  // smallest accepted index (accepted set is up-closed)
+                int mid = (lo + hi) / 2;
+                if (neighbour_ok(q, a, tab[mid].value, ztol)) hi = mid; else lo = mid + 1;
+            }
+            iv.lo2 = ((uint32_t)q.cls << 29) | tab[lo].code_lo;
+            iv.len2 = (((uint32_t)q.cls << 29) | tab[n - 1].code_hi) - iv.lo2;
+            break;
+        }
+    }
+    return iv;
+}
+
+// Host model of the device's hue_code() (cds_scan.hip) -- used only by the diagnostics entry points.
+uint32_t host_hue_code(const float *rcp, int r, int g, int b, int thr) {
+    int mx = std::max(r, std::max(g, b));
+    int mn = std::min(r, std::min(g, b));
+    int md = r + g + b - mx - mn;
+    uint32_t idx = (r > g ? 4u : 0u) | (g > b ? 8u : 0u) | (b > r ? 16u : 0u);
+    uint32_t cls = (0x03125460u >> idx) & 7u;
+    if (!(mx > thr && mx > md)) return 0;
+    return (cls << 29) | ratio_code(rcp, md, mx);
+}
+
+static bool in_rects(const cds_rect *r, int n, int x, int y) {
+    for (int i = 0; i < n; i++)
+        if (x >= r[i].x0 && x < r[i].x1 && y >= r[i].y0 && y < r[i].y1) return true;
+    return false;
+}
+
+}  // namespace cds
+
+using namespace cds;
+
+// =================================================================================================
+//                                            C ABI
+// =================================================================================================
+extern "C" {
+
+const char *cds_last_error(void) { return g_err.c_str(); }
+const char *cds_version(void) { return "cds-hip 0.1 (gfx950)"; }
+
+int cds_context_create(int device_id, cds_context **out) {
+    if (!out) return fail(CDS_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(CDS_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return fail(CDS_ERR_INVALID_ARGUMENT, "device_id out of range");
+    hipDeviceProp_t prop;
+    CDS_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(CDS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
+    CDS_HIP(hipSetDevice(device_id));
+    cds_context *ctx = new cds_context();
+    ctx->device = device_id;
+    ctx->n_cus = prop.multiProcessorCount;
+    ctx->lds_per_block = prop.sharedMemPerBlock;
+    if (ctx->lds_per_block < 160 * 1024) ctx->lds_per_block = 160 * 1024;  // gfx950: 160 KiB per workgroup
+    hipError_t se = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        delete ctx;
+        return hip_fail(se, "hipStreamCreate");
+    }
+    ctx->stream = ctx->own_stream;
+    int rc = init_rcp_table(ctx);
+    if (rc == CDS_OK) rc = build_ratio_table(ctx->rcp, ctx->ratios);
+    if (rc != CDS_OK) {
+        hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return CDS_OK;
+}
+
+void cds_context_destroy(cds_context *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->d_slice_lut) hipFree(ctx->d_slice_lut);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int cds_context_set_stream(cds_context *ctx, void *hip_stream) {
+    if (!ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return CDS_OK;
+}
+
+int cds_context_synchronize(cds_context *ctx) {
+    if (!ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    CDS_HIP(hipSetDevice(ctx->device));
+    CDS_HIP(hipStreamSynchronize(ctx->stream));
+    return CDS_OK;
+}
+
+// ---- library ------------------------------------------------------------------------------------
+size_t cds_library_bytes(int32_t W, int32_t H, int64_t capacity) {
+    if (W <= 0 || H <= 0 || capacity <= 0) return 0;
+    return (size_t)capacity * (size_t)H * (size_t)rgb_pitch(W);
+}
+
+static int library_init(cds_context *ctx, int W, int H, int64_t capacity, cds_library **out) {
+    if (!ctx || !out) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (W < 8 || H < 1 || W > kMaxW || H > kMaxH) return fail(CDS_ERR_UNSUPPORTED, "image size outside 8..2000 x 1..1000");
+    if (capacity <= 0) return fail(CDS_ERR_INVALID_ARGUMENT, "capacity must be positive");
+    cds_library *lib = new cds_library();
+    lib->ctx = ctx; lib->W = W; lib->H = H; lib->capacity = capacity;
+    lib->pitch = rgb_pitch(W);
+    lib->img_stride = (size_t)H * lib->pitch;
+    lib->gpitch = grad_pitch(W);
+    lib->grad_stride = (size_t)H * lib->gpitch;
+    lib->has_grad.assign((size_t)capacity, 0);
+    lib->has_zgap.assign((size_t)capacity, 0);
+    *out = lib;
+    return CDS_OK;
+}
+
+int cds_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t capacity, cds_library **out) {
+    cds_library *lib = nullptr;
+    int rc = library_init(ctx, W, H, capacity, &lib);
+    if (rc) return rc;
+    hipSetDevice(ctx->device);
+    size_t bytes = cds_library_bytes(W, H, capacity);
+    hipError_t e = hipMalloc(&lib->d_rgb, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(lib->d_rgb, 0, bytes, ctx->stream);
+    if (e != hipSuccess) {
+        if (lib->d_rgb) hipFree(lib->d_rgb);
+        delete lib;
+        return hip_fail(e, "hipMalloc(library)");
+    }
+    lib->owns_rgb = true;
+    *out = lib;
+    return CDS_OK;
+}
+
+int cds_library_wrap(cds_context *ctx, int32_t W, int32_t H, int64_t capacity, void *device_ptr, size_t device_bytes,
+                     cds_library **out) {
+    if (!device_ptr) return fail(CDS_ERR_INVALID_ARGUMENT, "device_ptr is NULL");
+    if (((uintptr_t)device_ptr & 15) != 0) return fail(CDS_ERR_INVALID_ARGUMENT, "device_ptr must be 16-byte aligned");
+    if (device_bytes < cds_library_bytes(W, H, capacity)) return fail(CDS_ERR_INVALID_ARGUMENT, "device buffer too small");
+    cds_library *lib = nullptr;
+    int rc = library_init(ctx, W, H, capacity, &lib);
+    if (rc) return rc;
+    lib->d_rgb = (uint8_t *)device_ptr;
+    lib->owns_rgb = false;
+    *out = lib;
+    return CDS_OK;
+}
+
+void cds_library_destroy(cds_library *lib) {
+    if (!lib) return;
+    hipSetDevice(lib->ctx->device);
+    hipStreamSynchronize(lib->ctx->stream);
+    if (lib->owns_rgb && lib->d_rgb) hipFree(lib->d_rgb);
+    if (lib->d_grad) hipFree(lib->d_grad);
+    if (lib->d_zgap) hipFree(lib->d_zgap);
+    delete lib;
+}
+
+static int check_range(const cds_library *lib, int64_t first, int64_t count) {
+    if (!lib) return fail(CDS_ERR_INVALID_ARGUMENT, "library is NULL");
+    if (first < 0 || count < 0 || first + count > lib->capacity) return fail(CDS_ERR_INVALID_ARGUMENT, "slot range outside the library");
+    return CDS_OK;
+}
+
+int cds_library_upload(cds_library *lib, int64_t first, int64_t count, const uint8_t *rgb) {
+    int rc = check_range(lib, first, count);
+    if (rc) return rc;
+    if (count == 0) return CDS_OK;
+    if (!rgb) return fail(CDS_ERR_INVALID_ARGUMENT, "rgb is NULL");
+    CDS_HIP(hipSetDevice(lib->ctx->device));
+    // rows of consecutive images are consecutive rows of one tall pitched image
+    CDS_HIP(hipMemcpy2DAsync(lib->d_rgb + (size_t)first * lib->img_stride, lib->pitch, rgb, (size_t)3 * lib->W,
+                             (size_t)3 * lib->W, (size_t)lib->H * count, hipMemcpyHostToDevice, lib->ctx->stream));
+    CDS_HIP(hipStreamSynchronize(lib->ctx->stream));
+    return CDS_OK;
+}
+
+int cds_library_download(cds_library *lib, int64_t first, int64_t count, uint8_t *rgb) {
+    int rc = check_range(lib, first, count);
+    if (rc) return rc;
+    if (count == 0) return CDS_OK;
+    if (!rgb) return fail(CDS_ERR_INVALID_ARGUMENT, "rgb is NULL");
+    CDS_HIP(hipSetDevice(lib->ctx->device));
+    CDS_HIP(hipMemcpy2DAsync(rgb, (size_t)3 * lib->W, lib->d_rgb + (size_t)first * lib->img_stride, lib->pitch,
+                             (size_t)3 * lib->W, (size_t)lib->H * count, hipMemcpyDeviceToHost, lib->ctx->stream));
+    CDS_HIP(hipStreamSynchronize(lib->ctx->stream));
+    return CDS_OK;
+}
+
+int cds_library_ensure_variants(cds_library *lib) {
+    std::lock_guard<std::mutex> lk(lib->mu);
+    CDS_HIP(hipSetDevice(lib->ctx->device));
+    if (!lib->d_grad) {
+        size_t bytes = (size_t)lib->capacity * lib->grad_stride;
+        CDS_HIP(hipMalloc(&lib->d_grad, bytes));
+        CDS_HIP(hipMemsetAsync(lib->d_grad, 0, bytes, lib->ctx->stream));
+    }
+    if (!lib->d_zgap) {
+        size_t bytes = (size_t)lib->capacity * lib->img_stride;
+        CDS_HIP(hipMalloc(&lib->d_zgap, bytes));
+        CDS_HIP(hipMemsetAsync(lib->d_zgap, 0, bytes, lib->ctx->stream));
+    }
+    return CDS_OK;
+}
+
+int cds_library_upload_variants(cds_library *lib, int64_t first, int64_t count, const uint16_t *grad,
+                                const uint8_t *zgap_rgb) {
+    int rc = check_range(lib, first, count);
+    if (rc) return rc;
+    if (count == 0) return CDS_OK;
+    rc = cds_library_ensure_variants(lib);
+    if (rc) return rc;
+    if (grad) {
+        CDS_HIP(hipMemcpy2DAsync((uint8_t *)lib->d_grad + (size_t)first * lib->grad_stride, lib->gpitch, grad,
+                                 (size_t)2 * lib->W, (size_t)2 * lib->W, (size_t)lib->H * count, hipMemcpyHostToDevice,
+                                 lib->ctx->stream));
+        for (int64_t i = 0; i < count; i++) lib->has_grad[(size_t)(first + i)] = 1;
+    }
+    if (zgap_rgb) {
+        CDS_HIP(hipMemcpy2DAsync(lib->d_zgap + (size_t)first * lib->img_stride, lib->pitch, zgap_rgb, (size_t)3 * lib->W,
+                                 (size_t)3 * lib->W, (size_t)lib->H * count, hipMemcpyHostToDevice, lib->ctx->stream));
+        for (int64_t i = 0; i < count; i++) lib->has_zgap[(size_t)(first + i)] = 1;
+    }
+    CDS_HIP(hipStreamSynchronize(lib->ctx->stream));
+    return CDS_OK;
+}
+
+int cds_library_download_variants(cds_library *lib, int64_t first, int64_t count, uint16_t *grad, uint8_t *zgap_rgb) {
+    int rc = check_range(lib, first, count);
+    if (rc) return rc;
+    if (count == 0) return CDS_OK;
+    if (!lib->d_grad || !lib->d_zgap) return fail(CDS_ERR_INVALID_ARGUMENT, "library holds no variants");
+    CDS_HIP(hipSetDevice(lib->ctx->device));
+    if (grad)
+        CDS_HIP(hipMemcpy2DAsync(grad, (size_t)2 * lib->W, (uint8_t *)lib->d_grad + (size_t)first * lib->grad_stride,
+                                 lib->gpitch, (size_t)2 * lib->W, (size_t)lib->H * count, hipMemcpyDeviceToHost,
+                                 lib->ctx->stream));
+    if (zgap_rgb)
+        CDS_HIP(hipMemcpy2DAsync(zgap_rgb, (size_t)3 * lib->W, lib->d_zgap + (size_t)first * lib->img_stride, lib->pitch,
+                                 (size_t)3 * lib->W, (size_t)lib->H * count, hipMemcpyDeviceToHost, lib->ctx->stream));
+    CDS_HIP(hipStreamSynchronize(lib->ctx->stream));
+    return CDS_OK;
+}
+
+// ---- pixel-match mask set -----------------------------------------------------------------------
+int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_rgb, int32_t W, int32_t H,
+                       const cds_pixmatch_params *params, const cds_rect *excluded, int32_t n_excluded,
+                       cds_maskset **out) {
+    if (!ctx || !out || !params) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    if (n_masks <= 0 || !masks_rgb) return fail(CDS_ERR_INVALID_ARGUMENT, "no masks");
+    if (W < 8 || H < 1 || W > kMaxW || H > kMaxH) return fail(CDS_ERR_UNSUPPORTED, "image size outside 8..2000 x 1..1000");
+    if (params->xy_shift & 1) return fail(CDS_ERR_INVALID_ARGUMENT, "XY shift parameter must be an even number.");
+    if (params->xy_shift < 0 || params->xy_shift > 2)
+        return fail(CDS_ERR_UNSUPPORTED, "xy_shift must be 0 or 2 (the reference overruns its shift table for >= 4)");
+    if (n_excluded < 0 || n_excluded > CDS_MAX_RECTS || (n_excluded > 0 && !excluded))
+        return fail(CDS_ERR_INVALID_ARGUMENT, "bad excluded-region list");
+    const int shift = params->xy_shift;
+    const bool mirror = params->mirror != 0;
+    const size_t img_bytes = (size_t)3 * W * H;
+
+    struct Px {
+        int x, y;
+        Intervals iv;
+    };
+    std::vector<std::vector<Px>> per_mask((size_t)n_masks);
+    std::vector<int32_t> sizes((size_t)n_masks, 0);
+    int m0 = H, m1 = 0, xlo = W, xhi = 0;  // over all device pixels of all masks
+    std::unordered_map<uint64_t, Intervals> cache;
+    for (int m = 0; m < n_masks; m++) {
+        const uint8_t *img = masks_rgb + (size_t)m * img_bytes;
+        std::vector<Px> &list = per_mask[(size_t)m];
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                if (in_rects(excluded, n_excluded, x, y)) continue;
+                const uint8_t *p = img + 3 * ((size_t)y * W + x);
+                int r = p[0], g = p[1], b = p[2];
+                if (!(r > params->mask_threshold || g > params->mask_threshold || b > params->mask_threshold)) continue;
+                sizes[(size_t)m]++;  // getQuerySize counts every position, class or not
+                double a;
+                int c1 = hue_class(r, g, b, &a);
+                if (c1 == C_NONE) continue;  // pxGap is 10000 against everything
+                uint64_t key;
+                memcpy(&key, &a, 8);
+                key ^= (uint64_t)c1 << 61;   // a < 1 so the top bits of its encoding are free
+                auto it = cache.find(key);
+                Intervals iv;
+                if (it == cache.end()) {
+                    iv = intervals_for(ctx->ratios, c1, a, params->z_tolerance);
+                    cache.emplace(key, iv);
+                } else {
+                    iv = it->second;
+                }
+                if (iv.len1 == 0 && iv.lo1 == 1 && iv.len2 == 0 && iv.lo2 == 1) continue;  // can never match
+                list.push_back({x, y, iv});
+                m0 = std::min(m0, y); m1 = std::max(m1, y + 1);
+                xlo = std::min(xlo, x); xhi = std::max(xhi, x + 1);
+            }
+    }
+    cds_maskset *ms = new cds_maskset();
+    ms->ctx = ctx; ms->params = *params; ms->W = W; ms->H = H; ms->n_masks = n_masks; ms->sizes = sizes;
+    size_t total = 0;
+    for (auto &l : per_mask) total += l.size();
+    ms->n_px = total;
+    if (total == 0) {  // nothing can ever match: the search returns zeros without a launch
+        ms->m0 = ms->m1 = 0;
+        *out = ms;
+        return CDS_OK;
+    }
+    // column window: plain probes touch [xlo-shift, xhi+shift), mirrored ones [W-xhi-shift, W-xlo+shift)
+    int clo = xlo - shift, chi = xhi + shift;
+    if (mirror) {
+        clo = std::min(clo, W - xhi - shift);
+        chi = std::max(chi, W - xlo + shift);
+    }
+    ms->cx0 = floor4(clo);
+    ms->wc = std::max(8, ceil4(chi) - ms->cx0);
+    ms->m0 = m0; ms->m1 = m1;
+    if (ms->wc > 2047) {
+        delete ms;
+        return fail(CDS_ERR_UNSUPPORTED, "column window too wide");
+    }
+    const int nrows = m1 - m0;
+    std::vector<uint32_t> rowptr((size_t)n_masks * (nrows + 1));
+    std::vector<uint32_t> pos(total);
+    std::vector<uint4> ivs(total);
+    size_t k = 0;
+    for (int m = 0; m < n_masks; m++) {
+        uint32_t *rp = rowptr.data() + (size_t)m * (nrows + 1);
+        int row = 0;
+        rp[0] = (uint32_t)k;
+        for (const Px &p : per_mask[(size_t)m]) {  // already in row-major order
+            while (row < p.y - m0) rp[++row] = (uint32_t)k;
+            uint32_t cpl = (uint32_t)(p.x - ms->cx0), cmi = (uint32_t)(W - 1 - p.x - ms->cx0);
+            pos[k] = cpl | (cmi << 11) | ((uint32_t)(p.y - m0) << 22);
+            ivs[k] = make_uint4(p.iv.lo1, p.iv.len1, p.iv.lo2, p.iv.len2);
+            k++;
+        }
+        while (row < nrows) rp[++row] = (uint32_t)k;
+    }
+    hipSetDevice(ctx->device);
+    hipError_t e = hipMalloc(&ms->d_rowptr, rowptr.size() * 4);
+    if (e == hipSuccess) e = hipMalloc(&ms->d_px_pos, total * 4);
+    if (e == hipSuccess) e = hipMalloc(&ms->d_px_iv, total * sizeof(uint4));
+    if (e == hipSuccess) e = hipMemcpy(ms->d_rowptr, rowptr.data(), rowptr.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ms->d_px_pos, pos.data(), total * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ms->d_px_iv, ivs.data(), total * sizeof(uint4), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        cds_maskset_destroy(ms);
+        return hip_fail(e, "maskset upload");
+    }
+    *out = ms;
+    return CDS_OK;
+}
+
+void cds_maskset_destroy(cds_maskset *ms) {
+    if (!ms) return;
+    hipSetDevice(ms->ctx->device);
+    if (ms->d_rowptr) hipFree(ms->d_rowptr);
+    if (ms->d_px_pos) hipFree(ms->d_px_pos);
+    if (ms->d_px_iv) hipFree(ms->d_px_iv);
+    delete ms;
+}
+
+int cds_maskset_query_sizes(const cds_maskset *ms, int32_t *sizes) {
+    if (!ms || !sizes) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    memcpy(sizes, ms->sizes.data(), ms->sizes.size() * sizeof(int32_t));
+    return CDS_OK;
+}
+
+static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t first, int64_t count, int32_t *d_scores,
+                       int32_t *d_counts, bool timed_sync) {
+    if (!ms || !lib) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    int rc = check_range(lib, first, count);
+    if (rc) return rc;
+    if (lib->W != ms->W || lib->H != ms->H) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "Invalid image size - target's image size (%d, %d) must match query's image size: (%d, %d)",
+                 ms->W, ms->H, lib->W, lib->H);  // PixelMatchColorDepthSearchAlgorithm.java:171-175
+        return fail(CDS_ERR_INVALID_ARGUMENT, buf);
+    }
+    if (lib->ctx != ms->ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "mask set and library belong to different contexts");
+    if (count == 0) return CDS_OK;
+    cds_context *ctx = ms->ctx;
+    CDS_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    CDS_HIP(hipMemsetAsync(d_scores, 0, (size_t)ms->n_masks * count * sizeof(int32_t), st));
+    if (d_counts) CDS_HIP(hipMemsetAsync(d_counts, 0, (size_t)ms->n_masks * count * CDS_N_TRANSFORMS * sizeof(int32_t), st));
+    double ms_sum = 0;
+    int launches = 0;
+    if (ms->n_px > 0) {
+        int chunk = 32;  // masks per launch when batching
+        if (const char *e = getenv("CDS_SCAN_MASKS_PER_LAUNCH")) chunk = std::max(2, atoi(e));
+        if (ms->n_masks == 1) chunk = 1;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (timed_sync) {
+            CDS_HIP(hipEventCreate(&ev0));
+            CDS_HIP(hipEventCreate(&ev1));
+        }
+        for (int g0 = 0; g0 < ms->n_masks; g0 += chunk) {
+            ScanParams p{};
+            p.lib = lib->d_rgb + (size_t)first * lib->img_stride;
+            p.img_stride = lib->img_stride;
+            p.pitch = lib->pitch; p.W = lib->W; p.H = lib->H; p.wpad = lib->pitch / 3;
+            p.count = count;
+            p.n_masks = std::min(chunk, ms->n_masks - g0);
+            p.nrows = ms->m1 - ms->m0;
+            p.m0 = ms->m0;
+            p.halo = ms->params.xy_shift;
+            p.cx0 = ms->cx0; p.wc = ms->wc; p.gpr = ms->wc / 4;
+            p.gpr_magic = (uint32_t)(((1ull << 32) + p.gpr - 1) / p.gpr);
+            p.data_thr = (float)ms->params.data_threshold;
+            p.rowptr = ms->d_rowptr + (size_t)g0 * (p.nrows + 1);
+            p.px_pos = ms->d_px_pos;
+            p.px_iv = ms->d_px_iv;
+            p.out = d_scores + (size_t)g0 * count;
+            p.counts = d_counts ? d_counts + (size_t)g0 * count * CDS_N_TRANSFORMS : nullptr;
+            p.out_stride = count;
+            p.out_offset = 0;
+            if (timed_sync) CDS_HIP(hipEventRecord(ev0, st));
+            rc = launch_scan(ctx, p, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
+            if (rc) return rc;
+            if (timed_sync) {
+                CDS_HIP(hipEventRecord(ev1, st));
+                CDS_HIP(hipEventSynchronize(ev1));
+                float t = 0;
+                CDS_HIP(hipEventElapsedTime(&t, ev0, ev1));
+                ms_sum += t;
+            }
+            launches++;
+        }
+        if (timed_sync) {
+            hipEventDestroy(ev0);
+            hipEventDestroy(ev1);
+        }
+    }
+    if (timed_sync) {
+        std::lock_guard<std::mutex> lk(ms->mu);
+        ms->last_ms = launches ? ms_sum / launches : 0;
+        ms->last_launches = launches;
+    }
+    return CDS_OK;
+}
+
+int cds_search_device(const cds_maskset *ms, const cds_library *lib, int64_t first, int64_t count, int32_t *d_scores) {
+    if (!d_scores && count > 0) return fail(CDS_ERR_INVALID_ARGUMENT, "d_scores is NULL");
+    const bool timed = getenv("CDS_TIME_KERNELS") != nullptr;
+    return search_impl(ms, lib, first, count, d_scores, nullptr, timed);
+}
+
+static int search_host(const cds_maskset *ms, const cds_library *lib, int64_t first, int64_t count, int32_t *scores,
+                       uint8_t *mirrored, int32_t *counts) {
+    if (!ms || !lib) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    int rc = check_range(lib, first, count);
+    if (rc) return rc;
+    if (count == 0) return CDS_OK;
+    CDS_HIP(hipSetDevice(ms->ctx->device));
+    const size_t n = (size_t)ms->n_masks * count;
+    int32_t *d_scores = nullptr, *d_counts = nullptr;
+    CDS_HIP(hipMalloc(&d_scores, n * sizeof(int32_t)));
+    if (counts) {
+        hipError_t e = hipMalloc(&d_counts, n * CDS_N_TRANSFORMS * sizeof(int32_t));
+        if (e != hipSuccess) {
+            hipFree(d_scores);
+            return hip_fail(e, "hipMalloc(counts)");
+        }
+    }
+    rc = search_impl(ms, lib, first, count, d_scores, d_counts, true);
+    if (rc == CDS_OK) {
+        std::vector<int32_t> packed(n);
+        hipError_t e = hipMemcpyAsync(packed.data(), d_scores, n * sizeof(int32_t), hipMemcpyDeviceToHost, ms->ctx->stream);
+        if (e == hipSuccess && counts)
+            e = hipMemcpyAsync(counts, d_counts, n * CDS_N_TRANSFORMS * sizeof(int32_t), hipMemcpyDeviceToHost, ms->ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ms->ctx->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "copy scores");
+        else
+            for (size_t i = 0; i < n; i++) {
+                if (scores) scores[i] = packed[i] & 0x7fffffff;
+                if (mirrored) mirrored[i] = (uint8_t)((uint32_t)packed[i] >> 31);
+            }
+    }
+    hipFree(d_scores);
+    if (d_counts) hipFree(d_counts);
+    return rc;
+}
+
+int cds_search(const cds_maskset *ms, const cds_library *lib, int64_t first, int64_t count, int32_t *scores,
+               uint8_t *mirrored) {
+    return search_host(ms, lib, first, count, scores, mirrored, nullptr);
+}
+
+int cds_search_counts(const cds_maskset *ms, const cds_library *lib, int64_t first, int64_t count, int32_t *counts) {
+    if (!counts && count > 0) return fail(CDS_ERR_INVALID_ARGUMENT, "counts is NULL");
+    return search_host(ms, lib, first, count, nullptr, nullptr, counts);
+}
+
+int cds_score_pair(const cds_maskset *ms, int32_t mask_index, const uint8_t *target_rgb, int32_t W, int32_t H,
+                   int32_t *score, uint8_t *mirrored) {
+    if (!ms || !target_rgb || !score || !mirrored) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (mask_index < 0 || mask_index >= ms->n_masks) return fail(CDS_ERR_INVALID_ARGUMENT, "mask_index out of range");
+    if (ms->sizes[(size_t)mask_index] == 0) {  // PixelMatchColorDepthSearchAlgorithm.java:169-170
+        *score = 0; *mirrored = 0;
+        return CDS_OK;
+    }
+    if (W != ms->W || H != ms->H) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "Invalid image size - target's image size (%d, %d) must match query's image size: (%d, %d)",
+                 ms->W, ms->H, W, H);
+        return fail(CDS_ERR_INVALID_ARGUMENT, buf);
+    }
+    cds_library *lib = nullptr;
+    int rc = cds_library_create(ms->ctx, W, H, 1, &lib);
+    if (rc) return rc;
+    rc = cds_library_upload(lib, 0, 1, target_rgb);
+    std::vector<int32_t> s((size_t)ms->n_masks);
+    std::vector<uint8_t> m((size_t)ms->n_masks);
+    if (rc == CDS_OK) rc = cds_search(ms, lib, 0, 1, s.data(), m.data());
+    cds_library_destroy(lib);
+    if (rc == CDS_OK) {
+        *score = s[(size_t)mask_index];
+        *mirrored = m[(size_t)mask_index];
+    }
+    return rc;
+}
+
+float cds_pixel_match_normalized(int32_t score, int32_t query_size) {
+    if (query_size == 0) return 0.0f;
+    return (float)((double)score / (double)query_size);
+}
+
+int cds_is_match(int32_t score, int32_t query_size, double pct_positive_pixels) {
+    double thr = pct_positive_pixels / 100;
+    return score > 0 && (double)cds_pixel_match_normalized(score, query_size) > thr;
+}
+
+int cds_maskset_last_kernel_ms(const cds_maskset *ms, double *avg_ms, int32_t *launches) {
+    if (!ms) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(ms->mu);
+    if (avg_ms) *avg_ms = ms->last_ms;
+    if (launches) *launches = ms->last_launches;
+    return CDS_OK;
+}
+
+// ---- diagnostics used by the CPU-side tests of the host logic (include/cds_hip_debug.h) ----------
+int cds_debug_intervals(const float *rcp_table, int32_t r, int32_t g, int32_t b, double z_tolerance, uint32_t *out4) {
+    if (!rcp_table || !out4) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::vector<RatioEntry> tab;
+    static thread_local std::vector<RatioEntry> cached;
+    static thread_local float cached_rcp[256];
+    static thread_local bool have = false;
+    if (!have || memcmp(cached_rcp, rcp_table, sizeof cached_rcp) != 0) {
+        int rc = build_ratio_table(rcp_table, cached);
+        if (rc) return rc;
+        memcpy(cached_rcp, rcp_table, sizeof cached_rcp);
+        have = true;
+    }
+    double a;
+    int c1 = hue_class(r, g, b, &a);
+    Intervals iv = intervals_for(cached, c1, a, z_tolerance);
+    out4[0] = iv.lo1; out4[1] = iv.len1; out4[2] = iv.lo2; out4[3] = iv.len2;
+    return CDS_OK;
+}
+
+uint32_t cds_debug_hue_code(const float *rcp_table, int32_t r, int32_t g, int32_t b, int32_t threshold) {
+    return host_hue_code(rcp_table, r, g, b, threshold);
+}
+
+int cds_debug_device_rcp(const cds_context *ctx, float *out256) {
+    if (!ctx || !out256) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    memcpy(out256, ctx->rcp, sizeof ctx->rcp);
+    return CDS_OK;
+}
+
+}  // extern "C"

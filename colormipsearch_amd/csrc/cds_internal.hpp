@@ -1,0 +1,119 @@
+// cds_internal.hpp -- private structures of libcds_hip.so (MI355X / gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cds_hip.h"
+
+namespace cds {
+
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+
+#define CDS_HIP(call)                                      \
+    do {                                                   \
+        hipError_t _e = (call);                            \
+        if (_e != hipSuccess) return cds::hip_fail(_e, #call); \
+    } while (0)
+
+// ---- geometry limits (bit-packing of the mask pixel records, see cds_scan.hip) ----
+constexpr int kMaxW = 2000;
+constexpr int kMaxH = 1000;
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// floor to a multiple of 4, also for negatives
+inline int floor4(int v) { return v >= 0 ? v / 4 * 4 : -((-v + 3) / 4 * 4); }
+inline int ceil4(int v) { return -floor4(-v); }
+
+// Row pitch of a resident RGB image: multiple of 48 B so that rows are 16-B aligned AND a row is a
+// whole number of 12-byte (4 pixel) load groups.
+inline int rgb_pitch(int W) { return round_up(3 * W, 48); }
+inline int grad_pitch(int W) { return round_up(2 * W, 16); }
+
+// One distinct value of second/max (a fraction n/d, 0 <= n < d <= 255) as the reference computes it in
+// double, with the range of device codes its (n,d) representatives map to.
+struct RatioEntry {
+    double value;
+    uint32_t code_lo, code_hi;  // (float_bits(fl32(n) * rcp[d]) >> 1), min/max over equal fractions
+};
+
+}  // namespace cds
+
+struct cds_context {
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int n_cus = 0;
+    size_t lds_per_block = 0;
+    float rcp[256];                        // v_rcp_f32 of 0..255 as THIS device computes it
+    std::vector<cds::RatioEntry> ratios;   // sorted by value, distinct
+    uint8_t *d_slice_lut = nullptr;        // [6][256][256] slice number - 1 (shape scorer)
+    std::mutex mu;
+};
+
+struct cds_library {
+    cds_context *ctx = nullptr;
+    int W = 0, H = 0;
+    int pitch = 0;          // bytes per RGB row
+    size_t img_stride = 0;  // bytes per RGB image = H * pitch
+    int gpitch = 0;         // bytes per gradient row
+    size_t grad_stride = 0;
+    int64_t capacity = 0;
+    uint8_t *d_rgb = nullptr;
+    bool owns_rgb = false;
+    uint16_t *d_grad = nullptr;  // lazily allocated
+    uint8_t *d_zgap = nullptr;   // lazily allocated, same layout as d_rgb
+    std::vector<uint8_t> has_grad, has_zgap;  // per slot
+    std::mutex mu;
+};
+
+namespace cds {
+
+// Device-side view of a prepared pixel-match mask set.
+struct ScanParams {
+    const uint8_t *lib;  // first image of the scanned range
+    size_t img_stride;
+    int pitch, W, H, wpad;
+    int64_t count;
+    int n_masks;          // masks in this launch
+    int nrows;            // m1 - m0
+    int m0;               // first mask row of the union span
+    int halo;             // 0 or 2
+    int cx0, wc;          // column window [cx0, cx0+wc), both multiples of 4 (cx0 may be negative)
+    int gpr;              // wc / 4
+    uint32_t gpr_magic;   // ceil(2^32 / gpr)
+    float data_thr;
+    const uint32_t *rowptr;  // [n_masks][nrows+1]
+    const uint32_t *px_pos;  // cplain | cmir << 11 | yrel << 22
+    const uint4 *px_iv;      // lo1, len1, lo2, len2
+    int32_t *out;            // [n_masks][count]  score | mirrored << 31
+    int32_t *counts;         // optional [n_masks][count][18]
+    int64_t out_stride;      // elements between masks in out (== total count of the call)
+    int64_t out_offset;      // offset of this launch's first target in out
+};
+
+int launch_scan(cds_context *ctx, const ScanParams &p, bool xy2, bool mirror, hipStream_t stream);
+int init_rcp_table(cds_context *ctx);
+
+}  // namespace cds
+
+struct cds_maskset {
+    cds_context *ctx = nullptr;
+    cds_pixmatch_params params{};
+    int W = 0, H = 0, n_masks = 0;
+    std::vector<int32_t> sizes;  // query size P per mask (includes class-less pixels)
+    int m0 = 0, m1 = 0, cx0 = 0, wc = 0;
+    uint32_t *d_rowptr = nullptr;
+    uint32_t *d_px_pos = nullptr;
+    uint4 *d_px_iv = nullptr;
+    size_t n_px = 0;
+    // timing of the last search
+    mutable std::mutex mu;
+    mutable double last_ms = 0;
+    mutable int last_launches = 0;
+};

@@ -1,0 +1,584 @@
+// cds_shape.hip -- kernel 2: the GradientAreaGap ("shape") scorer for gfx950, its per-mask
+// preparation, and the circular max filter both need.
+//
+// Reference: API/cds/Shape2DMatchColorDepthSearchAlgorithm.java:28-42 (PIXEL_GAP_OP), :150-245;
+// API/cds/GradientAreaGapUtils.java:18-197 (slice numbers); API/cds/ColorDepthSearchAlgorithmProviderFactory.java:91-125
+// (mask preparation); API/imageprocessing/ImageTransformation.java:353-572 (max filter, makeLineRadii).
+//
+// Design: the reference evaluates ~2*W*H pixels per pair through nested boxed lambdas and searches the
+// colour LUT twice per pixel.  Here the slice number S(colour) is a table lookup (S factorises:
+// sliceGap(q,z) = |S(q) - S(z)|), the mask side is precomputed once per mask into one 16-bit plane per
+// orientation (S(q) | queryMask<<9 | highExpression<<10, mirror and ROI already applied), and one
+// workgroup streams the rows of ONE (mask,target) pair: zgap rows are converted to S(z) in LDS so the
+// mirrored orientation can read them reversed; both orientations are reduced in the same pass.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "cds_internal.hpp"
+#include "cds_lut.hpp"
+
+namespace cds {
+
+static bool in_rects_host(const cds_rect *r, int n, int x, int y) {
+    for (int i = 0; i < n; i++)
+        if (x >= r[i].x0 && x < r[i].x1 && y >= r[i].y0 && y < r[i].y1) return true;
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Slice-number table: S(first, second, sextant) - 1 for every colour with first > 0.
+// sextant = 2*firstChannel + (second is the later of the two remaining channels), channels R,G,B = 0,1,2
+// with the reference's ">=" precedence (GradientAreaGapUtils.java:31-91).
+// ---------------------------------------------------------------------------------------------
+static int slice_in_lut(int lo, int hi, double ratio) {  // GradientAreaGapUtils.java:131-197
+    int slice = 0;
+    double mingap = 1000;
+    for (int i = lo; i <= hi; i++) {
+        double R = kDepthLutHost[3 * i], G = kDepthLutHost[3 * i + 1], B = kDepthLutHost[3 * i + 2], lr = 0;
+        if (B > R && B > G) {
+            if (R > G) lr = R / B; else if (G > R) lr = G / B;
+        } else if (G > R && G > B) {
+            if (R > B) lr = R / G; else if (B > R) lr = B / G;
+        } else if (R > G && R > B) {
+            if (G > B) lr = G / R; else if (B > G) lr = B / R;
+        }
+        if (lr == ratio) return i + 1;
+        double gp = std::fabs(ratio - lr);
+        if (gp < mingap) { mingap = gp; slice = i + 1; }
+    }
+    return slice;
+}
+// sextant -> LUT index range (GradientAreaGapUtils.java:107-129)
+static const int kSextLo[6] = {171, 213, 128, 86, 0, 30};   // R/G, R/B, G/R, G/B, B/R, B/G
+static const int kSextHi[6] = {212, 255, 170, 127, 29, 85};
+
+static inline int sextant_of(int r, int g, int b, int *first, int *second) {
+    if (r >= g && r >= b) { *first = r; if (g >= b) { *second = g; return 0; } *second = b; return 1; }
+    if (g >= r && g >= b) { *first = g; if (r >= b) { *second = r; return 2; } *second = b; return 3; }
+    *first = b; if (r >= g) { *second = r; return 4; } *second = g; return 5;
+}
+
+static void build_slice_table(std::vector<uint8_t> &tab) {
+    tab.assign((size_t)6 * 256 * 256, 0);
+    for (int s = 0; s < 6; s++)
+        for (int first = 1; first < 256; first++)
+            for (int second = 0; second <= first; second++) {
+                double ratio = (double)second / (double)first;
+                tab[((size_t)s * 256 + first) * 256 + second] = (uint8_t)(slice_in_lut(kSextLo[s], kSextHi[s], ratio) - 1);
+            }
+}
+
+static const std::vector<uint8_t> &host_slice_table() {
+    static std::vector<uint8_t> t;
+    static std::once_flag once;
+    std::call_once(once, [] { build_slice_table(t); });
+    return t;
+}
+static inline int host_slice_number(int r, int g, int b) {
+    if ((r | g | b) == 0) return 0;
+    int first, second;
+    int s = sextant_of(r, g, b, &first, &second);
+    return host_slice_table()[((size_t)s * 256 + first) * 256 + second] + 1;
+}
+
+static int ensure_slice_lut(cds_context *ctx) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->d_slice_lut) return CDS_OK;
+    const std::vector<uint8_t> &t = host_slice_table();
+    CDS_HIP(hipMalloc(&ctx->d_slice_lut, t.size()));
+    CDS_HIP(hipMemcpy(ctx->d_slice_lut, t.data(), t.size(), hipMemcpyHostToDevice));
+    return CDS_OK;
+}
+
+// makeLineRadii -- ImageTransformation.java:549-572.  hw[dy + k] = half width of kernel row dy.
+static int line_radii(double radius_arg, std::vector<int> &hw) {
+    double radius = radius_arg;
+    if (radius_arg >= 1.5 && radius_arg < 1.75) radius = 1.75;
+    else if (radius_arg >= 2.5 && radius_arg < 2.85) radius = 2.85;
+    int r2 = (int)(radius * radius) + 1;
+    int k = (int)(std::sqrt(r2 + 1e-10));
+    hw.assign((size_t)2 * k + 1, 0);
+    hw[(size_t)k] = k;
+    for (int y = 1; y <= k; y++) {
+        int dx = (int)(std::sqrt(r2 - y * y + 1e-10));
+        hw[(size_t)(k - y)] = dx;
+        hw[(size_t)(k + y)] = dx;
+    }
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Circular max filter (per channel, out-of-image ignored) of a pitched RGB image, restricted to the
+// output box [bx0,bx1) x [by0,by1).  Optional pre-ops on the source: black out rectangles, black out
+// pixels whose channels are all <= thr (ColorTransformation.mask).  One thread per output pixel; the
+// source box + k fits L2, so this small helper is left un-tiled.
+// ---------------------------------------------------------------------------------------------
+struct MaxFilterParams {
+    const uint8_t *src;
+    uint8_t *dst;
+    int pitch, W, H, k;
+    int bx0, by0, bx1, by1;
+    int thr;  // < 0: no threshold masking
+    int nrects;
+    cds_rect rects[CDS_MAX_RECTS];
+    const int *hw;  // device, 2k+1
+};
+
+__device__ __forceinline__ bool dev_in_rects(const cds_rect *r, int n, int x, int y) {
+    for (int i = 0; i < n; i++)
+        if (x >= r[i].x0 && x < r[i].x1 && y >= r[i].y0 && y < r[i].y1) return true;
+    return false;
+}
+
+__global__ __launch_bounds__(256) void prefilter_kernel(MaxFilterParams p) {
+    // dst = src with rectangles and sub-threshold pixels blacked (whole image)
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= p.W) return;
+    const uint8_t *s = p.src + (size_t)y * p.pitch + 3 * x;
+    uint8_t *d = p.dst + (size_t)y * p.pitch + 3 * x;
+    int r = s[0], g = s[1], b = s[2];
+    bool kill = dev_in_rects(p.rects, p.nrects, x, y) || (p.thr >= 0 && r <= p.thr && g <= p.thr && b <= p.thr);
+    d[0] = kill ? 0 : r; d[1] = kill ? 0 : g; d[2] = kill ? 0 : b;
+}
+
+__global__ __launch_bounds__(256) void max_filter_kernel(MaxFilterParams p) {
+    int x = p.bx0 + blockIdx.x * blockDim.x + threadIdx.x, y = p.by0 + blockIdx.y;
+    if (x >= p.bx1) return;
+    int mr = 0, mg = 0, mb = 0;
+    for (int dy = -p.k; dy <= p.k; dy++) {
+        int yy = y + dy;
+        if (yy < 0 || yy >= p.H) continue;
+        int h = p.hw[dy + p.k];
+        int xa = x - h < 0 ? 0 : x - h, xb = x + h >= p.W ? p.W - 1 : x + h;
+        const uint8_t *s = p.src + (size_t)yy * p.pitch + 3 * xa;
+        for (int xx = xa; xx <= xb; xx++, s += 3) {
+            mr = max(mr, (int)s[0]); mg = max(mg, (int)s[1]); mb = max(mb, (int)s[2]);
+        }
+    }
+    uint8_t *d = p.dst + (size_t)y * p.pitch + 3 * x;
+    d[0] = mr; d[1] = mg; d[2] = mb;
+}
+
+// host image (pitch 3W) -> optional clear/threshold -> max filter -> host image.  Output outside the box
+// that can be non-black (source bbox grown by k) is black by construction.
+static int max_filter_host(cds_context *ctx, const uint8_t *src, int W, int H, double radius, int thr,
+                           const cds_rect *rects, int nrects, uint8_t *dst) {
+    CDS_HIP(hipSetDevice(ctx->device));
+    std::vector<int> hw;
+    const int k = line_radii(radius, hw);
+    const int pitch = rgb_pitch(W);
+    const size_t bytes = (size_t)pitch * H;
+    uint8_t *d_a = nullptr, *d_b = nullptr;
+    int *d_hw = nullptr;
+    hipStream_t st = ctx->stream;
+    int rc = CDS_OK;
+    auto cleanup = [&]() { if (d_a) hipFree(d_a); if (d_b) hipFree(d_b); if (d_hw) hipFree(d_hw); };
+#define MF_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); return hip_fail(_e, #call); } } while (0)
+    MF_HIP(hipMalloc(&d_a, bytes));
+    MF_HIP(hipMalloc(&d_b, bytes));
+    MF_HIP(hipMalloc(&d_hw, hw.size() * sizeof(int)));
+    MF_HIP(hipMemsetAsync(d_a, 0, bytes, st));
+    MF_HIP(hipMemsetAsync(d_b, 0, bytes, st));
+    MF_HIP(hipMemcpy2DAsync(d_a, pitch, src, (size_t)3 * W, (size_t)3 * W, H, hipMemcpyHostToDevice, st));
+    MF_HIP(hipMemcpyAsync(d_hw, hw.data(), hw.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    MaxFilterParams p{};
+    p.pitch = pitch; p.W = W; p.H = H; p.k = k; p.thr = thr; p.nrects = nrects; p.hw = d_hw;
+    for (int i = 0; i < nrects; i++) p.rects[i] = rects[i];
+    if (thr >= 0 || nrects > 0) {
+        p.src = d_a; p.dst = d_a;  // in place, pixel-wise
+        hipLaunchKernelGGL(prefilter_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, p);
+        MF_HIP(hipGetLastError());
+    }
+    // bounding box of the (pre-filtered) source on the host copy is cheap enough
+    int bx0 = W, by0 = H, bx1 = 0, by1 = 0;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const uint8_t *q = src + 3 * ((size_t)y * W + x);
+            if ((q[0] | q[1] | q[2]) == 0) continue;
+            bx0 = std::min(bx0, x); bx1 = std::max(bx1, x + 1); by0 = std::min(by0, y); by1 = std::max(by1, y + 1);
+        }
+    if (bx1 > bx0) {
+        p.bx0 = std::max(0, bx0 - k); p.bx1 = std::min(W, bx1 + k);
+        p.by0 = std::max(0, by0 - k); p.by1 = std::min(H, by1 + k);
+        p.src = d_a; p.dst = d_b;
+        hipLaunchKernelGGL(max_filter_kernel, dim3((p.bx1 - p.bx0 + 255) / 256, p.by1 - p.by0), dim3(256), 0, st, p);
+        MF_HIP(hipGetLastError());
+    }
+    MF_HIP(hipMemcpy2DAsync(dst, (size_t)3 * W, d_b, pitch, (size_t)3 * W, H, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+#undef MF_HIP
+    cleanup();
+    return rc;
+}
+
+// rgbToGrayNoGammaCorrection(pv, 255) -- ColorTransformation.java:40-54
+static inline int gray_nogamma(int r, int g, int b) {
+    if ((r | g | b) == 0) return 0;
+    double rw = 1 / 3., gw = 1 / 3., bw = 1 / 3.;
+    float maxGray = 255;
+    volatile double s = r * rw;
+    s = s + g * gw;
+    s = s + b * bw;
+    s = s + 0.5;
+    return (int)((maxGray / 255) * s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel 2
+// ---------------------------------------------------------------------------------------------
+constexpr int kPlaneS = 511, kPlaneQM = 1 << 9, kPlaneQH = 1 << 10;
+constexpr int kShapeRows = 8;  // rows per LDS batch
+
+struct ShapeParams {
+    const uint8_t *rgb, *zgap;
+    const uint16_t *grad;
+    size_t img_stride, grad_stride;
+    int pitch, gpitch, W, H, wp;  // wp: plane row length (u16 elements), multiple of 4
+    const uint16_t *planes;       // [n_masks][2][H][wp]
+    const int *boxes;             // [n_masks][2]: first row, end row with any plane bit
+    const uint8_t *slice_lut;
+    int thr, mirror, nrects;
+    cds_rect rects[CDS_MAX_RECTS];
+    const int32_t *pair_mask;
+    const int64_t *pair_slot;     // < 0: pair has no variants, skipped (host reports -1,-1)
+    int64_t n_pairs;
+    int64_t *out;                 // [n_pairs][4]: gap0, high0, gap1, high1
+};
+
+__device__ __forceinline__ int dev_slice(const uint8_t *lut, int r, int g, int b, int thr) {
+    // ColorTransformation.mask(thr): all channels <= thr -> black -> no slice
+    if (r <= thr && g <= thr && b <= thr) return 0;
+    if ((r | g | b) == 0) return 0;
+    int first, second, s;
+    if (r >= g && r >= b) { first = r; if (g >= b) { second = g; s = 0; } else { second = b; s = 1; } }
+    else if (g >= r && g >= b) { first = g; if (r >= b) { second = r; s = 2; } else { second = b; s = 3; } }
+    else { first = b; if (r >= g) { second = r; s = 4; } else { second = g; s = 5; } }
+    return lut[((s * 256 + first) << 8) + second] + 1;
+}
+
+__device__ __forceinline__ int gap_of(int pl, int sz, int g) {
+    const int sq = pl & kPlaneS;
+    const int d = sq > sz ? sq - sz : sz - sq;
+    int gap = (sq != 0 && sz != 0 && d >= 80) ? d - 40 : ((pl & kPlaneQM) ? g : 0);
+    return gap > 3 ? gap : 0;
+}
+
+__global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t zs[];  // [kShapeRows][wp]
+    __shared__ long long red[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+        const int64_t slot = p.pair_slot[pi];
+        if (slot < 0) continue;  // uniform per block
+        const int m = p.pair_mask[pi];
+        const uint8_t *timg = p.rgb + (size_t)slot * p.img_stride;
+        const uint8_t *zimg = p.zgap + (size_t)slot * p.img_stride;
+        const uint8_t *gimg = reinterpret_cast<const uint8_t *>(p.grad) + (size_t)slot * p.grad_stride;
+        const uint16_t *pl0 = p.planes + (size_t)m * 2 * p.H * p.wp;
+        const uint16_t *pl1 = pl0 + (size_t)p.H * p.wp;
+        const int ya = p.boxes[2 * m], yb = p.boxes[2 * m + 1];
+        const int gpr = p.wp / 4;
+        long long gap0 = 0, gap1 = 0;
+        int high0 = 0, high1 = 0;
+        for (int y0 = ya; y0 < yb; y0 += kShapeRows) {
+            const int nr = min(kShapeRows, yb - y0);
+            // phase 1: zgap rows -> slice numbers in LDS
+            for (int it = threadIdx.x; it < nr * gpr; it += blockDim.x) {
+                const int rr = it / gpr, gi = it - rr * gpr, y = y0 + rr, x0 = 4 * gi;
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(zimg + (size_t)y * p.pitch + (size_t)x0 * 3);
+                const uint32_t a = src[0], b = src[1], c = src[2];
+                ushort4 s;
+                s.x = dev_slice(p.slice_lut, a & 255, (a >> 8) & 255, (a >> 16) & 255, p.thr);
+                s.y = dev_slice(p.slice_lut, a >> 24, b & 255, (b >> 8) & 255, p.thr);
+                s.z = dev_slice(p.slice_lut, (b >> 16) & 255, b >> 24, c & 255, p.thr);
+                s.w = dev_slice(p.slice_lut, (c >> 8) & 255, (c >> 16) & 255, c >> 24, p.thr);
+                *reinterpret_cast<ushort4 *>(zs + rr * p.wp + x0) = s;
+            }
+            __syncthreads();
+            // phase 2: per-pixel gap and high-expression terms, both orientations
+            for (int it = threadIdx.x; it < nr * gpr; it += blockDim.x) {
+                const int rr = it / gpr, gi = it - rr * gpr, y = y0 + rr, x0 = 4 * gi;
+                const ushort4 q0 = *reinterpret_cast<const ushort4 *>(pl0 + (size_t)y * p.wp + x0);
+                ushort4 q1 = make_ushort4(0, 0, 0, 0);
+                if (p.mirror) q1 = *reinterpret_cast<const ushort4 *>(pl1 + (size_t)y * p.wp + x0);
+                if (((q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w)) == 0) continue;
+                const ushort4 g = *reinterpret_cast<const ushort4 *>(gimg + (size_t)y * p.gpitch + (size_t)x0 * 2);
+                const uint16_t *zr = zs + rr * p.wp;
+                const int qa[4] = {q0.x, q0.y, q0.z, q0.w}, qb[4] = {q1.x, q1.y, q1.z, q1.w}, gg[4] = {g.x, g.y, g.z, g.w};
+                int anyh = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int x = x0 + j;
+                    if (x >= p.W) break;
+                    gap0 += gap_of(qa[j], zr[x], gg[j]);
+                    if (p.mirror) gap1 += gap_of(qb[j], zr[p.W - 1 - x], gg[j]);
+                    anyh |= (qa[j] | qb[j]) & kPlaneQH;
+                }
+                if (anyh) {
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(timg + (size_t)y * p.pitch + (size_t)x0 * 3);
+                    const uint32_t a = src[0], b = src[1], c = src[2];
+                    const int mx[4] = {max(max((int)(a & 255), (int)((a >> 8) & 255)), (int)((a >> 16) & 255)),
+                                       max(max((int)(a >> 24), (int)(b & 255)), (int)((b >> 8) & 255)),
+                                       max(max((int)((b >> 16) & 255), (int)(b >> 24)), (int)(c & 255)),
+                                       max(max((int)((c >> 8) & 255), (int)((c >> 16) & 255)), (int)(c >> 24))};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int x = x0 + j;
+                        if (x >= p.W) break;
+                        const bool sig = mx[j] > p.thr && !dev_in_rects(p.rects, p.nrects, x, y);
+                        high0 += (sig && (qa[j] & kPlaneQH)) ? 1 : 0;
+                        high1 += (sig && (qb[j] & kPlaneQH)) ? 1 : 0;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        long long v[4] = {gap0, (long long)high0, gap1, (long long)high1};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            long long s = v[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) red[wave][k] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            long long s = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += red[w][threadIdx.x];
+            p.out[pi * 4 + threadIdx.x] = s;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace cds
+
+using namespace cds;
+
+struct cds_shapeset {
+    cds_context *ctx = nullptr;
+    int W = 0, H = 0, wp = 0, n_masks = 0, thr = 0, mirror = 0, nrects = 0;
+    cds_rect rects[CDS_MAX_RECTS];
+    uint16_t *d_planes = nullptr;
+    int *d_boxes = nullptr;
+    std::vector<int64_t> qm_sum, qh_sum;
+    mutable std::mutex mu;
+    mutable double last_ms = 0;
+    mutable int last_launches = 0;
+};
+
+extern "C" {
+
+int cds_make_zgap(cds_context *ctx, const uint8_t *target_rgb, int32_t W, int32_t H, int32_t threshold, double radius,
+                  const cds_rect *excluded, int32_t n_excluded, uint8_t *zgap_rgb) {
+    if (!ctx || !target_rgb || !zgap_rgb) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (W < 8 || H < 1 || W > kMaxW || H > kMaxH) return fail(CDS_ERR_UNSUPPORTED, "image size outside 8..2000 x 1..1000");
+    if (n_excluded < 0 || n_excluded > CDS_MAX_RECTS || (n_excluded > 0 && !excluded)) return fail(CDS_ERR_INVALID_ARGUMENT, "bad excluded-region list");
+    if (!(radius >= 0 && radius <= 200)) return fail(CDS_ERR_INVALID_ARGUMENT, "radius outside 0..200");
+    // the bbox shortcut in max_filter_host looks at the unfiltered source: harmless (a superset)
+    return max_filter_host(ctx, target_rgb, W, H, radius, threshold, excluded, n_excluded, zgap_rgb);
+}
+
+int cds_shapeset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_rgb, int32_t W, int32_t H,
+                        int32_t query_threshold, int32_t mirror, const uint8_t *roi, const cds_rect *excluded,
+                        int32_t n_excluded, cds_shapeset **out) {
+    if (!ctx || !out) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    if (n_masks <= 0 || !masks_rgb) return fail(CDS_ERR_INVALID_ARGUMENT, "no masks");
+    if (W < 8 || H < 1 || W > kMaxW || H > kMaxH) return fail(CDS_ERR_UNSUPPORTED, "image size outside 8..2000 x 1..1000");
+    if (n_excluded < 0 || n_excluded > CDS_MAX_RECTS || (n_excluded > 0 && !excluded)) return fail(CDS_ERR_INVALID_ARGUMENT, "bad excluded-region list");
+    int rc = ensure_slice_lut(ctx);
+    if (rc) return rc;
+    const size_t N = (size_t)W * H;
+    const int wp = round_up(W, 4);
+    std::vector<uint8_t> Q(3 * N), d60(3 * N), d20(3 * N);
+    std::vector<uint16_t> planes((size_t)n_masks * 2 * H * wp, 0);
+    std::vector<int> boxes((size_t)n_masks * 2);
+    cds_shapeset *ss = new cds_shapeset();
+    ss->ctx = ctx; ss->W = W; ss->H = H; ss->wp = wp; ss->n_masks = n_masks; ss->thr = query_threshold; ss->mirror = mirror != 0;
+    ss->nrects = n_excluded;
+    for (int i = 0; i < n_excluded; i++) ss->rects[i] = excluded[i];
+    ss->qm_sum.assign((size_t)n_masks, 0);
+    ss->qh_sum.assign((size_t)n_masks, 0);
+    for (int m = 0; m < n_masks; m++) {
+        const uint8_t *img = masks_rgb + (size_t)m * 3 * N;
+        // Q = clearRegion(mask)  (Factory:92,100)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                size_t i = 3 * ((size_t)y * W + x);
+                bool ex = in_rects_host(excluded, n_excluded, x, y);
+                Q[i] = ex ? 0 : img[i]; Q[i + 1] = ex ? 0 : img[i + 1]; Q[i + 2] = ex ? 0 : img[i + 2];
+            }
+        // unsafeMaxFilter(60) / (20) of Q on the GPU  (Factory:102-104)
+        rc = max_filter_host(ctx, Q.data(), W, H, 60, -1, nullptr, 0, d60.data());
+        if (rc == CDS_OK) rc = max_filter_host(ctx, Q.data(), W, H, 20, -1, nullptr, 0, d20.data());
+        if (rc) { delete ss; return rc; }
+        uint16_t *p0 = planes.data() + (size_t)m * 2 * H * wp, *p1 = p0 + (size_t)H * wp;
+        int ya = H, yb = 0;
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                size_t i = (size_t)y * W + x;
+                int r = Q[3 * i], g = Q[3 * i + 1], b = Q[3 * i + 2];
+                int qm = gray_nogamma(r, g, b) > 2;                                   // Factory:108
+                int p2black = (d20[3 * i] | d20[3 * i + 1] | d20[3 * i + 2]) == 0;
+                int qh = p2black ? (gray_nogamma(d60[3 * i], d60[3 * i + 1], d60[3 * i + 2]) > 0) : 0;  // Factory:101-106
+                ss->qm_sum[(size_t)m] += qm;
+                ss->qh_sum[(size_t)m] += qh;
+                uint16_t v = (uint16_t)(host_slice_number(r, g, b) | (qm ? kPlaneQM : 0) | (qh ? kPlaneQH : 0));
+                if (!v) continue;
+                // identity orientation: value at x; mirrored orientation: the same value seen at W-1-x;
+                // the ROI (already cleared in the excluded regions, Factory:96-100) is applied after mirroring
+                const int xm = W - 1 - x;
+                auto roi_in = [&](int xx) { return !roi || (roi[(size_t)y * W + xx] != 0 && !in_rects_host(excluded, n_excluded, xx, y)); };
+                if (roi_in(x)) { p0[(size_t)y * wp + x] = v; ya = std::min(ya, y); yb = std::max(yb, y + 1); }
+                if (mirror && roi_in(xm)) { p1[(size_t)y * wp + xm] = v; ya = std::min(ya, y); yb = std::max(yb, y + 1); }
+            }
+        if (yb <= ya) ya = yb = 0;
+        boxes[(size_t)2 * m] = ya; boxes[(size_t)2 * m + 1] = yb;
+    }
+    hipSetDevice(ctx->device);
+    hipError_t e = hipMalloc(&ss->d_planes, planes.size() * 2);
+    if (e == hipSuccess) e = hipMalloc(&ss->d_boxes, boxes.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(ss->d_planes, planes.data(), planes.size() * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ss->d_boxes, boxes.data(), boxes.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { cds_shapeset_destroy(ss); return hip_fail(e, "shapeset upload"); }
+    *out = ss;
+    return CDS_OK;
+}
+
+void cds_shapeset_destroy(cds_shapeset *ss) {
+    if (!ss) return;
+    hipSetDevice(ss->ctx->device);
+    if (ss->d_planes) hipFree(ss->d_planes);
+    if (ss->d_boxes) hipFree(ss->d_boxes);
+    delete ss;
+}
+
+int cds_shapeset_mask_stats(const cds_shapeset *ss, int64_t *mask_size, int64_t *high_expression_size) {
+    if (!ss) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (int m = 0; m < ss->n_masks; m++) {
+        if (mask_size) mask_size[m] = ss->qm_sum[(size_t)m];
+        if (high_expression_size) high_expression_size[m] = ss->qh_sum[(size_t)m];
+    }
+    return CDS_OK;
+}
+
+int64_t cds_shape_score_value(int64_t gap, int64_t high) {  // GradientAreaGapUtils.java:199-207
+    if (gap >= 0 && high >= 0) return gap + high / 3;
+    return -1;
+}
+
+double cds_normalized_score(int32_t pix, int64_t shape, int64_t max_pix, int64_t max_shape) {  // GradientAreaGapUtils.java:219-235
+    if (pix == 0 || max_pix == 0 || shape < 0 || max_shape <= 0) return pix;
+    double np = (double)pix / max_pix;
+    double ns = (double)shape / max_shape;
+    double bounded = std::fmin(std::fmax(ns * 2.5, 0.002), 1.);
+    return np / bounded * 100;
+}
+
+int cds_gradscore(const cds_shapeset *ss, const cds_library *lib, int64_t n_pairs, const int32_t *pair_mask,
+                  const int64_t *pair_slot, int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored) {
+    if (!ss || !lib) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_pairs < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "n_pairs < 0");
+    if (n_pairs == 0) return CDS_OK;
+    if (!pair_mask || !pair_slot || !gradient_area_gap || !high_expression_area || !mirrored) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (lib->ctx != ss->ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "shape set and library belong to different contexts");
+    if (lib->W != ss->W || lib->H != ss->H) return fail(CDS_ERR_INVALID_ARGUMENT, "target image size must match the query image size");
+    std::vector<int64_t> slots((size_t)n_pairs);
+    for (int64_t i = 0; i < n_pairs; i++) {
+        if (pair_mask[i] < 0 || pair_mask[i] >= ss->n_masks) return fail(CDS_ERR_INVALID_ARGUMENT, "pair mask index out of range");
+        if (pair_slot[i] < 0 || pair_slot[i] >= lib->capacity) return fail(CDS_ERR_INVALID_ARGUMENT, "pair slot out of range");
+        const bool ok = lib->d_grad && lib->d_zgap && lib->has_grad[(size_t)pair_slot[i]] && lib->has_zgap[(size_t)pair_slot[i]];
+        slots[(size_t)i] = ok ? pair_slot[i] : -1;  // Shape2DMatch...Algorithm.java:155-158
+    }
+    cds_context *ctx = ss->ctx;
+    CDS_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int32_t *d_pm = nullptr;
+    int64_t *d_ps = nullptr, *d_out = nullptr;
+    auto cleanup = [&]() { if (d_pm) hipFree(d_pm); if (d_ps) hipFree(d_ps); if (d_out) hipFree(d_out); };
+#define GS_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); return hip_fail(_e, #call); } } while (0)
+    GS_HIP(hipMalloc(&d_pm, (size_t)n_pairs * 4));
+    GS_HIP(hipMalloc(&d_ps, (size_t)n_pairs * 8));
+    GS_HIP(hipMalloc(&d_out, (size_t)n_pairs * 32));
+    GS_HIP(hipMemcpyAsync(d_pm, pair_mask, (size_t)n_pairs * 4, hipMemcpyHostToDevice, st));
+    GS_HIP(hipMemcpyAsync(d_ps, slots.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, st));
+    GS_HIP(hipMemsetAsync(d_out, 0, (size_t)n_pairs * 32, st));
+    ShapeParams p{};
+    p.rgb = lib->d_rgb; p.zgap = lib->d_zgap; p.grad = lib->d_grad;
+    p.img_stride = lib->img_stride; p.grad_stride = lib->grad_stride;
+    p.pitch = lib->pitch; p.gpitch = lib->gpitch; p.W = ss->W; p.H = ss->H; p.wp = ss->wp;
+    p.planes = ss->d_planes; p.boxes = ss->d_boxes; p.slice_lut = ctx->d_slice_lut;
+    p.thr = ss->thr; p.mirror = ss->mirror; p.nrects = ss->nrects;
+    for (int i = 0; i < ss->nrects; i++) p.rects[i] = ss->rects[i];
+    p.pair_mask = d_pm; p.pair_slot = d_ps; p.n_pairs = n_pairs; p.out = d_out;
+    const size_t lds = (size_t)kShapeRows * ss->wp * sizeof(uint16_t);
+    int64_t g64 = (int64_t)ctx->n_cus * 8;
+    int grid = (int)std::min<int64_t>(n_pairs, g64);
+    hipEvent_t ev0, ev1;
+    GS_HIP(hipEventCreate(&ev0));
+    GS_HIP(hipEventCreate(&ev1));
+    GS_HIP(hipEventRecord(ev0, st));
+    hipLaunchKernelGGL(gradscore_kernel, dim3(grid), dim3(256), lds, st, p);
+    GS_HIP(hipGetLastError());
+    GS_HIP(hipEventRecord(ev1, st));
+    std::vector<int64_t> res((size_t)n_pairs * 4);
+    GS_HIP(hipMemcpyAsync(res.data(), d_out, (size_t)n_pairs * 32, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    float t = 0;
+    hipEventElapsedTime(&t, ev0, ev1);
+    hipEventDestroy(ev0);
+    hipEventDestroy(ev1);
+#undef GS_HIP
+    cleanup();
+    {
+        std::lock_guard<std::mutex> lk(ss->mu);
+        ss->last_ms = t;
+        ss->last_launches = 1;
+    }
+    for (int64_t i = 0; i < n_pairs; i++) {
+        if (slots[(size_t)i] < 0) {
+            gradient_area_gap[i] = -1; high_expression_area[i] = -1; mirrored[i] = 0;
+            continue;
+        }
+        const int64_t *r = &res[(size_t)i * 4];
+        gradient_area_gap[i] = r[0]; high_expression_area[i] = r[1]; mirrored[i] = 0;
+        // keep the mirrored orientation iff its int-cast score is lower (Shape2DMatch...Algorithm.java:181-183)
+        if (ss->mirror && (int)cds_shape_score_value(r[2], r[3]) < (int)cds_shape_score_value(r[0], r[1])) {
+            gradient_area_gap[i] = r[2]; high_expression_area[i] = r[3]; mirrored[i] = 1;
+        }
+    }
+    return CDS_OK;
+}
+
+int cds_shape_score_pair(const cds_shapeset *ss, int32_t mask_index, const uint8_t *target_rgb, const uint16_t *grad,
+                         const uint8_t *zgap_rgb, int32_t W, int32_t H, int64_t *gradient_area_gap,
+                         int64_t *high_expression_area, uint8_t *mirrored) {
+    if (!ss || !target_rgb || !gradient_area_gap || !high_expression_area || !mirrored) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (mask_index < 0 || mask_index >= ss->n_masks) return fail(CDS_ERR_INVALID_ARGUMENT, "mask_index out of range");
+    if (!grad || !zgap_rgb) {  // Shape2DMatch...Algorithm.java:155-158
+        *gradient_area_gap = -1; *high_expression_area = -1; *mirrored = 0;
+        return CDS_OK;
+    }
+    if (W != ss->W || H != ss->H) return fail(CDS_ERR_INVALID_ARGUMENT, "target image size must match the query image size");
+    cds_library *lib = nullptr;
+    int rc = cds_library_create(ss->ctx, W, H, 1, &lib);
+    if (rc) return rc;
+    rc = cds_library_upload(lib, 0, 1, target_rgb);
+    if (rc == CDS_OK) rc = cds_library_upload_variants(lib, 0, 1, grad, zgap_rgb);
+    int64_t slot = 0;
+    if (rc == CDS_OK) rc = cds_gradscore(ss, lib, 1, &mask_index, &slot, gradient_area_gap, high_expression_area, mirrored);
+    cds_library_destroy(lib);
+    return rc;
+}
+
+int cds_shapeset_last_kernel_ms(const cds_shapeset *ss, double *avg_ms, int32_t *launches) {
+    if (!ss) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(ss->mu);
+    if (avg_ms) *avg_ms = ss->last_ms;
+    if (launches) *launches = ss->last_launches;
+    return CDS_OK;
+}
+
+}  // extern "C"

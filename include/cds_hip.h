@@ -1,0 +1,172 @@
+/*
+ * cds_hip.h -- C ABI of libcds_hip.so: the MI355X (gfx950) color-depth MIP search core.
+ *
+ * This is the drop-in boundary for ONE path of JaneliaSciComp/colormipsearch (v3.1.1): what its
+ * `ColorDepthSearchAlgorithm` plugin surface computes.  A JVM host binds these entry points through
+ * JNI / java.lang.foreign (INTEGRATION.md shows the stub); the Python mirror (colormipsearch_amd/cds.py)
+ * binds them through ctypes; the C++ mirror is include/cds_hip.hpp.
+ *
+ * Citations: API/ = colormipsearch-api/src/main/java/org/janelia/colormipsearch/ of the reference.
+ *
+ * Conventions: plain C, opaque handles, int status returns (0 = CDS_OK), caller-allocated outputs, no
+ * ownership transfer, no exceptions across the ABI.  cds_last_error() returns a thread-local message for
+ * the last failing call on the calling thread.  Handles are immutable after creation and may be used
+ * from several host threads at once (the reference shares one algorithm object between all worker
+ * threads: tools cmd/cdsprocess/LocalColorMIPSearchProcessor.java:88-105).
+ * There is NO CPU fallback: every call that computes fails with CDS_ERR_NO_DEVICE when no gfx950 GPU
+ * is usable.
+ *
+ * Images: packed RGB, uint8, R,G,B byte order, row-major, row pitch 3*W -- the byte layout of the
+ * reference's ColorImageArray (API/imageprocessing/ColorImageArray.java:4-38).  Gradient images:
+ * uint16 row-major (the reference's ShortImageArray; widen a GRAY8 gradient on the host).
+ */
+#ifndef CDS_HIP_H
+#define CDS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDS_OK 0
+#define CDS_ERR_INVALID_ARGUMENT (-1) /* the reference throws IllegalArgumentException here */
+#define CDS_ERR_NO_DEVICE (-2)
+#define CDS_ERR_HIP (-3)
+#define CDS_ERR_OUT_OF_MEMORY (-4)
+#define CDS_ERR_UNSUPPORTED (-5)
+
+#define CDS_MAX_RECTS 8
+#define CDS_N_TRANSFORMS 18 /* 9 xy-shifts x (plain, mirrored) */
+
+typedef struct cds_context cds_context;   /* one GPU: device, default stream, tables          */
+typedef struct cds_library cds_library;   /* a resident shard of target MIPs (+ variants)      */
+typedef struct cds_maskset cds_maskset;   /* n prepared PixelMatchColorDepthSearchAlgorithm    */
+typedef struct cds_shapeset cds_shapeset; /* n prepared Shape2DMatchColorDepthSearchAlgorithm  */
+
+/* Excluded ("label") region: half-open rectangle [x0,x1) x [y0,y1).  Replaces the predicate of
+ * API/imageprocessing/ImageRegionDefinition.java:5-13; every caller in the reference builds a union of
+ * rectangles (tools cmd/AbstractColorDepthMatchArgs.java:101-119). */
+typedef struct cds_rect {
+    int32_t x0, y0, x1, y1;
+} cds_rect;
+
+/* Parameters of ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider
+ * (API/cds/ColorDepthSearchAlgorithmProviderFactory.java:30-74) + the per-mask query threshold. */
+typedef struct cds_pixmatch_params {
+    int32_t mask_threshold; /* queryThreshold                                            */
+    int32_t data_threshold; /* targetThreshold                                           */
+    double z_tolerance;     /* pixColorFluctuation / 100  (Factory:55-56)                */
+    int32_t xy_shift;       /* 0 or 2; odd -> CDS_ERR_INVALID_ARGUMENT (Factory:58-60);  */
+                            /* >= 4 -> CDS_ERR_UNSUPPORTED (the reference overruns its   */
+                            /* own array there, PixelMatch...Algorithm.java:114-125)     */
+    int32_t mirror;         /* mirrorMask                                                */
+} cds_pixmatch_params;
+
+const char *cds_last_error(void);
+const char *cds_version(void);
+
+/* ---- context ------------------------------------------------------------------------------- */
+int cds_context_create(int device_id, cds_context **out);
+void cds_context_destroy(cds_context *ctx);
+/* Use an externally owned hipStream_t (e.g. torch's current stream) for all later launches; NULL
+ * restores the context's own stream. */
+int cds_context_set_stream(cds_context *ctx, void *hip_stream);
+int cds_context_synchronize(cds_context *ctx);
+
+/* ---- target library (replaces the host-side MIP cache, tools cmd/CachedMIPsUtils.java:60-100) -- */
+/* Device bytes for `capacity` targets of W x H (padded row pitch, see DESIGN.md "data layout"). */
+size_t cds_library_bytes(int32_t W, int32_t H, int64_t capacity);
+int cds_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t capacity, cds_library **out);
+/* Adopt caller-owned device memory (e.g. a torch tensor) of at least cds_library_bytes() bytes. */
+int cds_library_wrap(cds_context *ctx, int32_t W, int32_t H, int64_t capacity, void *device_ptr,
+                     size_t device_bytes, cds_library **out);
+void cds_library_destroy(cds_library *lib);
+/* Host -> device: `count` images, packed RGB pitch 3*W, into slots [first, first+count). */
+int cds_library_upload(cds_library *lib, int64_t first, int64_t count, const uint8_t *rgb);
+int cds_library_download(cds_library *lib, int64_t first, int64_t count, uint8_t *rgb);
+/* Variant images of the same slots for the shape scorer (ComputeFileType.GradientImage / ZGapImage,
+ * API/model/ComputeFileType.java:5-28).  Either pointer may be NULL to leave that variant unchanged. */
+int cds_library_upload_variants(cds_library *lib, int64_t first, int64_t count, const uint16_t *grad,
+                                const uint8_t *zgap_rgb);
+int cds_library_download_variants(cds_library *lib, int64_t first, int64_t count, uint16_t *grad, uint8_t *zgap_rgb);
+/* Fill slots [first_slot, first_slot+count) on the device with synthetic images number
+ * first_index.. of the stream `seed` (DESIGN.md "synthetic library").  kind: 0 sparse-lut target,
+ * 1 dense-uniform target, 2 arbor mask.  with_variants != 0 also generates gradient + zgap (kind 0). */
+int cds_library_generate_synthetic(cds_library *lib, uint64_t seed, int64_t first_index, int64_t first_slot,
+                                   int64_t count, int32_t kind, int32_t with_variants);
+
+/* ---- pixel-match scan (kernel 1) ----------------------------------------------------------------
+ * cds_maskset_create == n x `new PixelMatchColorDepthSearchAlgorithm(...)`
+ * (API/cds/PixelMatchColorDepthSearchAlgorithm.java:29-101 with getMaskPosArray
+ * API/cds/AbstractColorDepthSearchAlgorithm.java:96-126).  masks_rgb: n_masks x (3*W*H) bytes. */
+int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_rgb, int32_t W, int32_t H,
+                       const cds_pixmatch_params *params, const cds_rect *excluded, int32_t n_excluded,
+                       cds_maskset **out);
+void cds_maskset_destroy(cds_maskset *ms);
+/* getQuerySize() per mask (API/cds/ColorDepthSearchAlgorithm.java:27). */
+int cds_maskset_query_sizes(const cds_maskset *ms, int32_t *sizes);
+/* Scan slots [first, first+count) of the library with every mask of the set ==
+ * calculateMatchingScore per (mask,target) (PixelMatch...Algorithm.java:166-219).
+ * scores[m*count + t] = matching pixels, mirrored[...] = bestScoreMirrored.  Host outputs; blocks. */
+int cds_search(const cds_maskset *ms, const cds_library *lib, int64_t first, int64_t count, int32_t *scores,
+               uint8_t *mirrored);
+/* Same, asynchronous on the context's stream, result left on the device:
+ * d_scores[m*count + t] = score | (mirrored << 31)  (int32, device pointer). */
+int cds_search_device(const cds_maskset *ms, const cds_library *lib, int64_t first, int64_t count,
+                      int32_t *d_scores);
+/* Diagnostic: all CDS_N_TRANSFORMS match counts per pair, counts[(m*count+t)*18 + k]; k<9 plain
+ * shifts in the reference's order (dx,dy)=(-2,-2),(-2,0),(-2,2),(0,-2),...,(2,2), k>=9 mirrored.
+ * With xy_shift 0 only k=4 (and 13) are used. */
+int cds_search_counts(const cds_maskset *ms, const cds_library *lib, int64_t first, int64_t count, int32_t *counts);
+/* The reference's per-pair entry point: one host image against mask `mask_index`. */
+int cds_score_pair(const cds_maskset *ms, int32_t mask_index, const uint8_t *target_rgb, int32_t W, int32_t H,
+                   int32_t *score, uint8_t *mirrored);
+/* PixelMatchScore.getNormalizedScore (API/cds/PixelMatchScore.java:21-24) and
+ * ColorMIPSearch.isMatch (API/cds/ColorMIPSearch.java:42-45). Pure host arithmetic. */
+float cds_pixel_match_normalized(int32_t score, int32_t query_size);
+int cds_is_match(int32_t score, int32_t query_size, double pct_positive_pixels);
+
+/* Average device time (ms) of the scan kernel launches of the last cds_search*_ call on this mask
+ * set, measured with hipEvents on the launch stream, and the number of launches. */
+int cds_maskset_last_kernel_ms(const cds_maskset *ms, double *avg_ms, int32_t *launches);
+
+/* ---- GradientAreaGap scorer (kernel 2) ----------------------------------------------------------
+ * cds_shapeset_create == n x createShapeMatchCDSAlgorithmProvider(...).createColorDepthSearchAlgorithm
+ * (API/cds/ColorDepthSearchAlgorithmProviderFactory.java:76-127), queryBorderSize 0.
+ * roi: optional W*H byte plane (non-zero = inside), NULL for none. */
+int cds_shapeset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_rgb, int32_t W, int32_t H,
+                        int32_t query_threshold, int32_t mirror, const uint8_t *roi, const cds_rect *excluded,
+                        int32_t n_excluded, cds_shapeset **out);
+void cds_shapeset_destroy(cds_shapeset *ss);
+/* Sum of the query mask and of the high-expression mask per mask
+ * (the values Shape2DMatch...Test.java:53-54 checks). */
+int cds_shapeset_mask_stats(const cds_shapeset *ss, int64_t *mask_size, int64_t *high_expression_size);
+/* Score n_pairs (mask index, library slot) pairs == Shape2DMatch...Algorithm.calculateMatchingScore
+ * (API/cds/Shape2DMatchColorDepthSearchAlgorithm.java:150-186).  Slots must hold gradient and zgap
+ * variants, otherwise that pair returns (-1,-1,false) as the reference does (:155-158).
+ * Host outputs; blocks. */
+int cds_gradscore(const cds_shapeset *ss, const cds_library *lib, int64_t n_pairs, const int32_t *pair_mask,
+                  const int64_t *pair_slot, int64_t *gradient_area_gap, int64_t *high_expression_area,
+                  uint8_t *mirrored);
+/* Per-pair convenience with host images (grad/zgap may be NULL -> -1,-1). */
+int cds_shape_score_pair(const cds_shapeset *ss, int32_t mask_index, const uint8_t *target_rgb,
+                         const uint16_t *grad, const uint8_t *zgap_rgb, int32_t W, int32_t H,
+                         int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored);
+/* GradientAreaGapUtils.calculate2DShapeScore / calculateNormalizedScore
+ * (API/cds/GradientAreaGapUtils.java:199-235). Pure host arithmetic. */
+int64_t cds_shape_score_value(int64_t gradient_area_gap, int64_t high_expression_area);
+double cds_normalized_score(int32_t pixel_match_score, int64_t shape_score, int64_t max_pixel_match,
+                            int64_t max_shape_score);
+int cds_shapeset_last_kernel_ms(const cds_shapeset *ss, double *avg_ms, int32_t *launches);
+
+/* Host helper used by tests and by callers that have no ZGapImage file: clearRegion -> mask(thr) ->
+ * circular max filter (API/imageprocessing/ImageTransformation.java:353-572), computed on the GPU. */
+int cds_make_zgap(cds_context *ctx, const uint8_t *target_rgb, int32_t W, int32_t H, int32_t threshold,
+                  double radius, const cds_rect *excluded, int32_t n_excluded, uint8_t *zgap_rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDS_HIP_H */

@@ -1,0 +1,24 @@
+/*
+ * cds_hip_debug.h -- diagnostic entry points of libcds_hip.so used by the CPU-side tests of the host
+ * logic (tests/test_host_logic.py).  Not part of the plugin surface; they compute nothing on a GPU.
+ *
+ * The device encodes a target pixel as hue_code = class << 29 | bits(fl32(second) * rcp[max]) >> 1 and a
+ * mask pixel as two inclusive code intervals (lo, len); the device predicate is
+ *   (code - lo1 <= len1) || (code - lo2 <= len2)       (unsigned)
+ * which must equal the reference's  max(target) > dataThreshold && calculatePixelGap(mask, target) <= zTolerance
+ * (API/cds/PixelMatchColorDepthSearchAlgorithm.java:251-258).  `rcp_table` is any 256-entry reciprocal
+ * table (on a GPU it is that device's v_rcp_f32, see cds_debug_device_rcp).
+ */
+#ifndef CDS_HIP_DEBUG_H
+#define CDS_HIP_DEBUG_H
+#include "cds_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+int cds_debug_intervals(const float *rcp_table, int32_t r, int32_t g, int32_t b, double z_tolerance, uint32_t *out4);
+uint32_t cds_debug_hue_code(const float *rcp_table, int32_t r, int32_t g, int32_t b, int32_t threshold);
+int cds_debug_device_rcp(const cds_context *ctx, float *out256);
+#ifdef __cplusplus
+}
+#endif
+#endif

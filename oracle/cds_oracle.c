@@ -594,3 +594,17 @@ double cdso_normalized_score(int pix, int64_t shape, int64_t max_pix, int64_t ma
     double bounded = fmin(fmax(ns * 2.5, 0.002), 1.);
     return np / bounded * 100;
 }
+
+/* Test helper: out[i*m + j] = 1 iff target colour j passes the data threshold and
+ * calculatePixelGap(mask colour i, target colour j) <= ztol  (the body of PM:251-258). */
+void cdso_match_matrix(const uint8_t *mask_rgb, int n, const uint8_t *target_rgb, int m, int data_thr, double ztol,
+                       uint8_t *out) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < m; j++) {
+            int r2 = target_rgb[3 * j], g2 = target_rgb[3 * j + 1], b2 = target_rgb[3 * j + 2];
+            int ok = 0;
+            if (r2 > data_thr || g2 > data_thr || b2 > data_thr)
+                ok = cdso_pixel_gap(mask_rgb[3 * i], mask_rgb[3 * i + 1], mask_rgb[3 * i + 2], r2, g2, b2) <= ztol;
+            out[(size_t)i * m + j] = (uint8_t)ok;
+        }
+}

@@ -87,6 +87,7 @@ def lib():
                                    ctypes.c_int, rp, ctypes.c_int, i64p]
     L.cdso_normalized_score.restype = ctypes.c_double
     L.cdso_normalized_score.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+    L.cdso_match_matrix.argtypes = [u8p, ctypes.c_int, u8p, ctypes.c_int, ctypes.c_int, ctypes.c_double, u8p]
     L.cdso_synth_image.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p]
     L.cdso_synth_variants.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, u8p, u16p]
     _lib = L
@@ -105,6 +106,15 @@ def _img(a):
 
 def pixel_gap(m, t):
     return lib().cdso_pixel_gap(int(m[0]), int(m[1]), int(m[2]), int(t[0]), int(t[1]), int(t[2]))
+
+
+def match_matrix(mask_colors, target_colors, data_thr, ztol):
+    """bool[n,m]: does target colour j match mask colour i (threshold + pixel gap <= ztol)."""
+    mc = np.ascontiguousarray(mask_colors, dtype=np.uint8).reshape(-1, 3)
+    tc = np.ascontiguousarray(target_colors, dtype=np.uint8).reshape(-1, 3)
+    out = np.zeros((len(mc), len(tc)), dtype=np.uint8)
+    lib().cdso_match_matrix(_u8(mc), len(mc), _u8(tc), len(tc), int(data_thr), float(ztol), _u8(out))
+    return out.astype(bool)
 
 
 def mask_positions(mask, thr, rects=None):

@@ -22,11 +22,11 @@
  *     z(t)   = clamp(z0 + (((t-a0) * dz) >> 8), 0, 255); colour c = (LUT[z][c] * bright + 127) / 255
  *     pixel (x,y) belongs to stroke k iff a0 <= t < a1 and |o - f(t)| <= hw   (t,o = x,y or y,x by orient)
  *   pixel value = colour of the belonging stroke with the largest k, else black.
- *   kind 0 "sparse-lut" target: K = 3 + draw(i,255,0) % 10, hw_base 1, whole frame, len 200..999; the
+ *   kind 0 "sparse-lut" target: K = 3 + draw(i,255,0) % 10, hw_base 2, whole frame, len 300..1199; the
  *        reference's label regions (x<330&&y<100, x>=W-270&&y<90) are left black.
  *   kind 1 "dense-uniform" target: r,g,b = low three bytes of mix64(seed ^ (i+1)*0xD1B5.. ^ (pixel+1)*0x9E37..).
- *   kind 2 "arbor" mask: K = 5, hw_base 3, strokes and pixels confined to the box cols 316..893, rows 165..334
- *        (bbox of the reference fixture 12191_JRC2018U_FL.tif), len 150..449, plus four anchor dashes of LUT[128]
+ *   kind 2 "arbor" mask: K = 11, hw_base 4, strokes and pixels confined to the box cols 316..893, rows 165..334
+ *        (bbox of the reference fixture 12191_JRC2018U_FL.tif), len 200..499, plus four anchor dashes of LUT[128]
  *        that pin the bounding box: row 165 and row 334 at x 600..615, col 316 and col 893 at y 250..257.
  *   variants of a kind-0 target for the shape scorer:
  *     zgap : same strokes dilated by 10 px (|o - f(tc)| <= hw+10, a0-10 <= t < a1+10, tc = clamp(t,a0,a1-1)),
@@ -115,7 +115,7 @@ static void paint(uint8_t *img, int W, int H, const stroke *s, int K, int dil, i
 
 static int target_strokes(stroke *s, uint64_t seed, uint64_t i, int W, int H) {
     int K = 3 + (int)(draw(seed, i, 255, 0) % 10);
-    for (int k = 0; k < K; k++) make_stroke(&s[k], seed, i, k, 1, 0, W, 0, H, 200, 800);
+    for (int k = 0; k < K; k++) make_stroke(&s[k], seed, i, k, 2, 0, W, 0, H, 300, 900);
     return K;
 }
 
@@ -137,8 +137,8 @@ void cdso_synth_image(uint64_t seed, uint64_t index, int kind, int W, int H, uin
         paint(out, W, H, s, K, 0, 0, W, 0, H, 1);
     } else {
         const int lox = 316, hix = 894, loy = 165, hiy = 335;
-        for (int k = 0; k < 5; k++) make_stroke(&s[k], seed, index, k, 3, lox, hix, loy, hiy, 150, 300);
-        paint(out, W, H, s, 5, 0, lox, hix, loy, hiy, 0);
+        for (int k = 0; k < 11; k++) make_stroke(&s[k], seed, index, k, 4, lox, hix, loy, hiy, 200, 300);
+        paint(out, W, H, s, 11, 0, lox, hix, loy, hiy, 0);
         const uint8_t *lut = cdso_depth_lut();
         for (int x = 600; x < 616; x++) { put(out, W, x, 165, lut, 128, 255); put(out, W, x, 334, lut, 128, 255); }
         for (int y = 250; y < 258; y++) { put(out, W, 316, y, lut, 128, 255); put(out, W, 893, y, lut, 128, 255); }

@@ -1,0 +1,256 @@
+"""GPU parity tests of kernel 1 (pixel-match scan) through the C ABI: the reference's own known answers on
+its own fixture images, then oracle parity on seeded synthetic libraries and on the edge cases the
+reference's semantics define.  Bar: bit-exact integer counts and mirrored flags."""
+import numpy as np
+import pytest
+
+from tests.golden import expected as E
+
+pytestmark = pytest.mark.gpu
+
+W, H = 1210, 566
+
+
+@pytest.fixture(scope="module")
+def cds():
+    from colormipsearch_amd import cds as m
+    m.default_context()  # fails loudly without a gfx950 GPU
+    return m
+
+
+def test_loaded_native_library(cds):
+    from colormipsearch_amd import capi
+    assert b"gfx950" in capi.load().cds_version()
+    rcp = cds.default_context().device_rcp_table()
+    assert rcp[1] == 1.0 and abs(rcp[3] - 1 / 3) < 1e-6
+
+
+# ---- the reference's JUnit tests, restated over the mirror API -------------------------------------
+def test_pixelMatchScore(cds, fixtures):
+    # PixelMatchColorDepthSearchAlgorithmTest.pixelMatchScore (:33-53)
+    e = E.PIXEL_MATCH_DIRECT
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(fixtures[e["mask"]], 20, True, None, 0, False, 20, 0.01, 2, e["rects"])
+    score = alg.calculateMatchingScore(fixtures[e["target"]], {})
+    assert score.getScore() == 87
+    assert not score.isMirrored()
+
+
+@pytest.mark.parametrize("mask,target,expected,mirrored", E.PIXEL_MATCH_PROVIDER)
+def test_multiplePixelScores(cds, fixtures, mask, target, expected, mirrored):
+    # PixelMatchColorDepthSearchAlgorithmTest.multiplePixelScores (:56-153)
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(
+        True, 20, 1, 2, cds.label_regions)
+    alg = provider.createColorDepthQuerySearchAlgorithmWithDefaultParams(fixtures[mask], 20, 0)
+    s = alg.calculateMatchingScore(fixtures[target], {})
+    assert s.getScore() == expected
+    assert s.isMirrored() == mirrored
+    assert s.getNormalizedScore() == float(np.float32(expected / alg.getQuerySize()))
+
+
+def test_fixture_matrix_all_transforms(cds, fixtures, oracle):
+    """3 EM masks x 4 LM targets, every per-transform count, 4 parameter combinations, batched masks."""
+    masks = np.stack([fixtures[k] for k in ("em_12191", "em_12191_FL", "em_LPLC2")])
+    tkeys = ("lm_BJD", "lm_GMR", "lm_VT016795", "lm_VT033614")
+    targets = np.stack([fixtures[k] for k in tkeys])
+    lib = cds.Library(W, H, len(tkeys))
+    lib.upload(0, targets)
+    for xy, mirror in ((2, True), (2, False), (0, True), (0, False)):
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, mirror, None, 0, False, 20, 0.01, xy, E.STD_RECTS)
+        scores, mir = alg.searchLibrary(lib)
+        counts = alg.searchLibraryCounts(lib)
+        for m in range(3):
+            q = oracle.PixelMatchQuery(masks[m], 20, 20, 0.01, xy, mirror, E.STD_RECTS)
+            assert alg.getQuerySize(m) == q.size
+            for t in range(len(tkeys)):
+                s, mm, c = q.score(targets[t])
+                assert (int(scores[m, t]), bool(mir[m, t])) == (s, mm), (xy, mirror, m, t)
+                assert np.array_equal(counts[m, t], c), (xy, mirror, m, t, counts[m, t], c)
+        # single-mask kernel variant agrees with the batched one
+        one = cds.PixelMatchColorDepthSearchAlgorithm(masks[1], 20, mirror, None, 0, False, 20, 0.01, xy, E.STD_RECTS)
+        s1, m1 = one.searchLibrary(lib)
+        assert np.array_equal(s1[0], scores[1]) and np.array_equal(m1[0], mir[1])
+        assert np.array_equal(one.searchLibraryCounts(lib)[0], counts[1])
+
+
+# ---- synthetic libraries --------------------------------------------------------------------------
+def test_device_generator_equals_cpu_twin(cds, oracle):
+    lib = cds.Library(W, H, 6)
+    lib.generate_synthetic(0xC0FFEE, 5, 0, 3, kind=0)
+    lib.generate_synthetic(0xC0FFEE, 2, 3, 2, kind=1)
+    lib.generate_synthetic(0xBADC0DE, 7, 5, 1, kind=2)
+    got = lib.download(0, 6)
+    for i in range(3):
+        assert np.array_equal(got[i], oracle.synth_image(0xC0FFEE, 5 + i, 0))
+    for i in range(2):
+        assert np.array_equal(got[3 + i], oracle.synth_image(0xC0FFEE, 2 + i, 1))
+    assert np.array_equal(got[5], oracle.synth_image(0xBADC0DE, 7, 2))
+
+
+@pytest.mark.parametrize("kind,n", [(0, 48), (1, 6)])
+def test_synthetic_library_parity(cds, oracle, kind, n):
+    """BASELINE config 2 at a size the oracle finishes in seconds: 1 mask x n targets, xyShift 2, mirror."""
+    rects = cds.label_regions(W)
+    mask = oracle.synth_image(0xBADC0DE, 0, 2)
+    lib = cds.Library(W, H, n)
+    lib.generate_synthetic(0xC0FFEE, 0, 0, n, kind=kind)
+    targets = lib.download(0, n)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    scores, mir = alg.searchLibrary(lib)
+    q = oracle.PixelMatchQuery(mask, 20, 20, 0.01, 2, True, rects)
+    want_s, want_m = q.scan(targets, n_threads=8)
+    assert np.array_equal(scores[0], want_s)
+    assert np.array_equal(mir[0], want_m.astype(bool))
+    if kind == 1:
+        assert scores.max() > 0  # dense targets do hit
+
+
+def test_self_match_and_mirror(cds, oracle):
+    rects = cds.label_regions(W)
+    mask = oracle.synth_image(0xBADC0DE, 3, 2)
+    targets = np.stack([mask, np.fliplr(mask), np.roll(mask, 2, axis=1), np.roll(mask, -2, axis=0), np.zeros_like(mask)])
+    lib = cds.Library(W, H, len(targets))
+    lib.upload(0, targets)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    scores, mir = alg.searchLibrary(lib)
+    P = alg.getQuerySize()
+    q = oracle.PixelMatchQuery(mask, 20, 20, 0.01, 2, True, rects)
+    for t in range(len(targets)):
+        s, m, _ = q.score(targets[t])
+        assert (int(scores[0, t]), bool(mir[0, t])) == (s, m)
+    assert scores[0, 0] <= P and scores[0, 0] > 0.9 * P and not mir[0, 0]
+    assert mir[0, 1] and scores[0, 4] == 0
+
+
+def test_batched_masks_and_parameter_sweep(cds, oracle):
+    """BASELINE config 3 in miniature: a batch of masks shares one pass over the library."""
+    rects = cds.label_regions(W)
+    n_masks, n_t = 5, 12
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(n_masks)])
+    lib = cds.Library(W, H, n_t)
+    lib.generate_synthetic(0xC0FFEE, 100, 0, n_t - 2, kind=0)
+    lib.upload(n_t - 2, np.stack([masks[1], np.fliplr(masks[2])]))
+    targets = lib.download(0, n_t)
+    for (mthr, dthr, ztol, xy, mirror) in ((20, 20, 0.01, 2, True), (100, 100, 0.02, 0, False), (20, 50, 0.3, 2, False)):
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, mthr, mirror, None, 0, False, dthr, ztol, xy, rects)
+        scores, mir = alg.searchLibrary(lib)
+        for m in range(n_masks):
+            q = oracle.PixelMatchQuery(masks[m], mthr, dthr, ztol, xy, mirror, rects)
+            ws, wm = q.scan(targets, n_threads=8)
+            assert np.array_equal(scores[m], ws), (m, mthr, dthr, ztol, xy, mirror)
+            assert np.array_equal(mir[m], wm.astype(bool))
+
+
+def test_sub_ranges_and_slots(cds, oracle):
+    rects = cds.label_regions(W)
+    mask = oracle.synth_image(0xBADC0DE, 0, 2)
+    lib = cds.Library(W, H, 10)
+    lib.generate_synthetic(0xC0FFEE, 40, 0, 10, kind=0)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    full, fm = alg.searchLibrary(lib)
+    part, pm = alg.searchLibrary(lib, 3, 4)
+    assert np.array_equal(part, full[:, 3:7]) and np.array_equal(pm, fm[:, 3:7])
+    empty, _ = alg.searchLibrary(lib, 2, 0)
+    assert empty.shape == (1, 0)
+
+
+# ---- edge cases of the reference's semantics ------------------------------------------------------
+def test_mask_touching_every_border(cds, oracle):
+    """Shifted positions falling off the image are skipped (-1, PixelMatch...Algorithm.java:132-144,241-243),
+    mirrored columns use the full width; also a small non-standard geometry."""
+    w, h = 64, 40
+    rng = np.random.default_rng(7)
+    lut = oracle.depth_lut()
+    mask = np.zeros((h, w, 3), dtype=np.uint8)
+    for (y, x) in [(0, 0), (0, w - 1), (h - 1, 0), (h - 1, w - 1), (1, 1), (h // 2, w // 2)]:
+        mask[y, x] = lut[rng.integers(0, 256)]
+    mask[0, 5:40] = lut[40]
+    mask[h - 1, 10:60] = lut[200]
+    mask[5:35, 0] = lut[100]
+    mask[3:30, w - 1] = lut[150]
+    targets = np.stack([mask, np.fliplr(mask), np.roll(np.roll(mask, 2, 0), -2, 1),
+                        lut[rng.integers(0, 256, size=(h, w))].astype(np.uint8)])
+    lib = cds.Library(w, h, len(targets))
+    lib.upload(0, targets)
+    for xy, mirror in ((2, True), (0, True), (2, False)):
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, mirror, None, 0, False, 20, 0.01, xy, [])
+        counts = alg.searchLibraryCounts(lib)
+        q = oracle.PixelMatchQuery(mask, 20, 20, 0.01, xy, mirror, [])
+        for t in range(len(targets)):
+            assert np.array_equal(counts[0, t], q.score(targets[t])[2]), (xy, mirror, t)
+
+
+def test_empty_and_classless_masks(cds, oracle):
+    rects = cds.label_regions(W)
+    black = np.zeros((H, W, 3), dtype=np.uint8)
+    gray = black.copy()
+    gray[200:220, 400:500] = 128          # r == g == b: no hue class, never matches, but counts in the query size
+    in_label = black.copy()
+    in_label[10:50, 10:200] = (0, 200, 255)   # entirely inside the name-label region
+    target = oracle.synth_image(0xC0FFEE, 1, 0)
+    for mask, size in ((black, 0), (gray, 2000), (in_label, 0)):
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+        assert alg.getQuerySize() == size == oracle.PixelMatchQuery(mask, 20, 20, 0.01, 2, True, rects).size
+        s = alg.calculateMatchingScore(target, {})
+        assert (s.getScore(), s.getNormalizedScore(), s.isMirrored()) == (0, 0.0, False)
+
+
+def test_reference_error_behaviour(cds, fixtures):
+    mask = fixtures["em_12191"]
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(True, 20, 1, 3, cds.label_regions)
+    with pytest.raises(ValueError, match="XY shift parameter must be an even number"):   # Factory:58-60
+        provider.createColorDepthQuerySearchAlgorithmWithDefaultParams(mask, 20, 0)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, cds.label_regions)
+    with pytest.raises(ValueError, match="Invalid image size"):                           # PixelMatch...:171-175
+        alg.calculateMatchingScore(np.zeros((100, 200, 3), dtype=np.uint8), {})
+    with pytest.raises(cds.CdsError):                                                     # xyShift 4 overruns in the reference
+        cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 4, cds.label_regions)
+    # per-mask parameter overrides flow through ColorDepthSearchParams (Factory:39-43,55-68)
+    p = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(False, 100, 2, 0, cds.label_regions)
+    a = p.createColorDepthSearchAlgorithm(mask, 20, 0, cds.ColorDepthSearchParams().setParam("mirrorMask", True)
+                                          .setParam("dataThreshold", 20).setParam("pixColorFluctuation", 1.0).setParam("xyShift", 2))
+    assert a.calculateMatchingScore(fixtures["lm_VT016795"], {}).getScore() == 426
+
+
+def test_is_match_set(cds, oracle):
+    """The match set (ColorMIPSearch.isMatch, pctPositivePixels 1) equals the oracle's on a synthetic library."""
+    rects = cds.label_regions(W)
+    mask = oracle.synth_image(0xBADC0DE, 0, 2)
+    n = 16
+    lib = cds.Library(W, H, n)
+    lib.generate_synthetic(0xC0FFEE, 300, 0, n - 1, kind=0)
+    lib.upload(n - 1, mask[None])
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(True, 20, 1, 2, cds.label_regions)
+    search = cds.ColorMIPSearch(1.0, 20, provider)
+    alg = search.createQueryColorDepthSearchWithDefaultThreshold(mask)
+    scores, mir = alg.searchLibrary(lib)
+    got = search.isMatchArray(scores[0], alg.getQuerySize())
+    want = np.array([oracle.is_match(int(s), alg.getQuerySize(), 1.0) for s in scores[0]])
+    assert np.array_equal(got, want) and got[n - 1]
+    one = search.isMatch(cds.PixelMatchScore(int(scores[0, 0]), scores[0, 0] / alg.getQuerySize(), False))
+    assert one == bool(want[0])
+
+
+def test_size_independent_properties_large(cds, oracle):
+    """At a library size the oracle cannot check directly: sub-range consistency, permutation
+    equivariance and a checksum over repeated scans (determinism)."""
+    rects = cds.label_regions(W)
+    mask = oracle.synth_image(0xBADC0DE, 0, 2)
+    n = 2048
+    lib = cds.Library(W, H, n)
+    lib.generate_synthetic(0xC0FFEE, 0, 0, n, kind=0)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    s1, m1 = alg.searchLibrary(lib)
+    s2, m2 = alg.searchLibrary(lib)
+    assert np.array_equal(s1, s2) and np.array_equal(m1, m2)
+    assert (s1 >= 0).all() and (s1 <= alg.getQuerySize()).all()
+    # slots generated as a different index order give the permuted scores
+    lib2 = cds.Library(W, H, 64)
+    for k, idx in enumerate(range(1000, 1064)):
+        lib2.generate_synthetic(0xC0FFEE, idx, 63 - k, 1, kind=0)
+    s3, _ = alg.searchLibrary(lib2)
+    assert np.array_equal(s3[0][::-1], s1[0][1000:1064])
+    # spot-check a few against the oracle
+    q = oracle.PixelMatchQuery(mask, 20, 20, 0.01, 2, True, rects)
+    for t in (0, 777, 2047):
+        s, m, _ = q.score(oracle.synth_image(0xC0FFEE, t, 0))
+        assert (int(s1[0, t]), bool(m1[0, t])) == (s, m)

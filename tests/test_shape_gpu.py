@@ -1,0 +1,102 @@
+"""GPU parity tests of kernel 2 (GradientAreaGap scorer) and of the mask preparation / max filter it needs."""
+import numpy as np
+import pytest
+
+from tests.golden import expected as E
+
+pytestmark = pytest.mark.gpu
+
+W, H = 1210, 566
+
+
+@pytest.fixture(scope="module")
+def cds():
+    from colormipsearch_amd import cds as m
+    m.default_context()
+    return m
+
+
+def test_overExpressesMaskExpression(cds, fixtures):
+    # Shape2DMatchColorDepthSearchAlgorithmTest.overExpressesMaskExpression (:32-60)
+    alg = cds.Shape2DMatchColorDepthSearchAlgorithm(fixtures["em_12191_FL"], 20, True, None, cds.label_regions)
+    sizeMask, sizeHigh = alg.maskStats()
+    assert sizeMask[0] == 17340
+    assert sizeHigh[0] == 70640
+
+
+def test_gpu_max_filter_equals_oracle(cds, fixtures, oracle):
+    for key in ("lm_VT033614", "lm_GMR"):
+        got = cds.default_context().make_zgap(fixtures[key], 20, 10, cds.label_regions)
+        want = oracle.make_zgap(fixtures[key], 20, 10, E.STD_RECTS)
+        assert np.array_equal(got, want)
+
+
+@pytest.fixture(scope="module")
+def shape_algs(cds, fixtures):
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createShapeMatchCDSAlgorithmProvider(True, None, cds.label_regions)
+    return {k: provider.createColorDepthQuerySearchAlgorithmWithDefaultParams(fixtures[k], 20, 0) for k in ("em_12191", "em_12191_FL")}
+
+
+@pytest.mark.parametrize("mask,target,grad,zgap,gaps,high,score,mirrored", E.SHAPE_SCORES)
+def test_computeShapeScore(cds, fixtures, shape_algs, mask, target, grad, zgap, gaps, high, score, mirrored):
+    # Shape2DMatchColorDepthSearchAlgorithmTest.computeShapeScoreUsing{AlgorithmProvider,DirectAlgorithmConstructor}
+    targetImageArray = fixtures[target]
+    variantSuppliers = {
+        cds.ComputeFileType.GradientImage: lambda: fixtures[grad],
+        cds.ComputeFileType.ZGapImage: (lambda: fixtures[zgap]) if zgap else
+        (lambda: cds.default_context().make_zgap(targetImageArray, 20, 10, cds.label_regions)),
+    }
+    s = shape_algs[mask].calculateMatchingScore(targetImageArray, variantSuppliers)
+    assert s.getGradientAreaGap() == gaps
+    assert s.getHighExpressionArea() == high
+    assert s.getScore() == score
+    assert s.isMirrored() == mirrored
+
+
+def test_missing_variants_give_minus_one(cds, fixtures, shape_algs):
+    # Shape2DMatchColorDepthSearchAlgorithm.java:155-158
+    s = shape_algs["em_12191"].calculateMatchingScore(fixtures["lm_BJD"], {cds.ComputeFileType.GradientImage: lambda: fixtures["grad_BJD"]})
+    assert (s.getGradientAreaGap(), s.getHighExpressionArea(), s.getScore(), s.isMirrored()) == (-1, -1, -1, False)
+    assert shape_algs["em_12191"].getRequiredTargetVariantTypes() == {cds.ComputeFileType.GradientImage, cds.ComputeFileType.ZGapImage}
+
+
+def test_synthetic_pairs_parity(cds, oracle):
+    """BASELINE config 5 in miniature: several masks x several resident targets with generated variants;
+    mirror on/off and an ROI mask."""
+    rects = cds.label_regions(W)
+    n_masks, n_t = 3, 6
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(n_masks)])
+    lib = cds.Library(W, H, n_t + 1)
+    lib.generate_synthetic(0xC0FFEE, 10, 0, n_t, kind=0, with_variants=True)
+    targets = lib.download(0, n_t)
+    grads, zgaps = lib.download_variants(0, n_t)
+    for i in range(2):  # device generator of the variants == CPU twin
+        z, g = oracle.synth_variants(0xC0FFEE, 10 + i)
+        assert np.array_equal(zgaps[i], z) and np.array_equal(grads[i], g)
+    roi = np.zeros((H, W), dtype=np.uint8)
+    roi[150:300, 300:800] = 1
+    pm = np.repeat(np.arange(n_masks), n_t).astype(np.int32)
+    ps = np.tile(np.arange(n_t), n_masks).astype(np.int64)
+    for mirror, use_roi in ((True, False), (False, False), (True, True)):
+        alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, 20, mirror, roi if use_roi else None, rects)
+        gap, high, mir = alg.scoreLibraryPairs(lib, pm, ps)
+        for m in range(n_masks):
+            sq = oracle.ShapeQuery(masks[m], 20, mirror, rects, roi if use_roi else None)
+            for t in range(n_t):
+                want = sq.score(targets[t], grads[t], zgaps[t])
+                k = m * n_t + t
+                assert (int(gap[k]), int(high[k]), bool(mir[k])) == (want[0], want[1], want[3]), (mirror, use_roi, m, t)
+    # a slot without variants reports (-1,-1,false); it does not poison its neighbours
+    lib.upload(n_t, targets[:1])
+    alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks[0], 20, True, None, rects)
+    gap, high, mir = alg.scoreLibraryPairs(lib, [0, 0], [n_t, 0])
+    assert (gap[0], high[0], mir[0]) == (-1, -1, False) and gap[1] >= 0
+
+
+def test_normalized_scores_per_mask(cds, oracle):
+    # GradientAreaGapUtils.calculateNormalizedScore applied per mask as CalculateGradientScoresCmd.java:616-645 does
+    pix = np.array([636, 500, 0, 679])
+    shape = np.array([788, 1114361, 50, -1])
+    got = [cds.calculateNormalizedScore(int(p), int(s), int(pix.max()), int(shape.max())) for p, s in zip(pix, shape)]
+    want = [oracle.normalized_score(int(p), int(s), int(pix.max()), int(shape.max())) for p, s in zip(pix, shape)]
+    assert got == want
