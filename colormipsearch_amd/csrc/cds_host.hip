@@ -568,8 +568,10 @@ static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t fi
     cds_context *ctx = ms->ctx;
     CDS_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    CDS_HIP(hipMemsetAsync(d_scores, 0, (size_t)ms->n_masks * count * sizeof(int32_t), st));
-    if (d_counts) CDS_HIP(hipMemsetAsync(d_counts, 0, (size_t)ms->n_masks * count * CDS_N_TRANSFORMS * sizeof(int32_t), st));
+    if (ms->n_px == 0) {  // no mask pixel can match: all-zero result without a launch (the kernel writes every output otherwise)
+        CDS_HIP(hipMemsetAsync(d_scores, 0, (size_t)ms->n_masks * count * sizeof(int32_t), st));
+        if (d_counts) CDS_HIP(hipMemsetAsync(d_counts, 0, (size_t)ms->n_masks * count * CDS_N_TRANSFORMS * sizeof(int32_t), st));
+    }
     double ms_sum = 0;
     int launches = 0;
     if (ms->n_px > 0) {
