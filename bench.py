@@ -33,6 +33,18 @@ MASK_THR, DATA_THR, ZTOL, XY_SHIFT, MIRROR = 20, 20, 0.01, 2, True
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask and cgroup CPU quota, not the machine total."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,7 +188,7 @@ def main():
     # ---- CPU baseline: the C oracle (a restatement of the reference's Java loops), bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cds_oracle as O
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         n_s = args.cpu_sample or 512
         n_s = min(n_s, chunk)
         sample = lib.download(0, n_s)

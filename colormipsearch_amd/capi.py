@@ -59,6 +59,7 @@ SIGNATURES = {
     "cds_context_create": (_i, [_i, ctypes.POINTER(_vp)]),
     "cds_context_destroy": (None, [_vp]),
     "cds_context_set_stream": (_i, [_vp, _vp]),
+    "cds_context_reset_stream": (_i, [_vp]),
     "cds_context_synchronize": (_i, [_vp]),
     "cds_library_bytes": (ctypes.c_size_t, [_i32, _i32, _i64]),
     "cds_library_create": (_i, [_vp, _i32, _i32, _i64, ctypes.POINTER(_vp)]),

@@ -85,6 +85,9 @@ class Context:
         """Launch on an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
         capi.check(self._lib.cds_context_set_stream(self._h, ctypes.c_void_p(int(hip_stream) if hip_stream else None)))
 
+    def reset_stream(self):
+        capi.check(self._lib.cds_context_reset_stream(self._h))
+
     def synchronize(self):
         capi.check(self._lib.cds_context_synchronize(self._h))
 

@@ -265,7 +265,13 @@ void cds_context_destroy(cds_context *ctx) {
 
 int cds_context_set_stream(cds_context *ctx, void *hip_stream) {
     if (!ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "ctx is NULL");
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;
+    return CDS_OK;
+}
+
+int cds_context_reset_stream(cds_context *ctx) {
+    if (!ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    ctx->stream = ctx->own_stream;
     return CDS_OK;
 }
 

@@ -70,9 +70,10 @@ const char *cds_version(void);
 /* ---- context ------------------------------------------------------------------------------- */
 int cds_context_create(int device_id, cds_context **out);
 void cds_context_destroy(cds_context *ctx);
-/* Use an externally owned hipStream_t (e.g. torch's current stream) for all later launches; NULL
- * restores the context's own stream. */
+/* Use an externally owned hipStream_t (e.g. torch's current stream) for all later launches; NULL is
+ * HIP's legacy default stream.  cds_context_reset_stream goes back to the context's own stream. */
 int cds_context_set_stream(cds_context *ctx, void *hip_stream);
+int cds_context_reset_stream(cds_context *ctx);
 int cds_context_synchronize(cds_context *ctx);
 
 /* ---- target library (replaces the host-side MIP cache, tools cmd/CachedMIPsUtils.java:60-100) -- */
@@ -118,7 +119,7 @@ int cds_search_device(const cds_maskset *ms, const cds_library *lib, int64_t fir
                       int32_t *d_scores);
 /* Diagnostic: all CDS_N_TRANSFORMS match counts per pair, counts[(m*count+t)*18 + k]; k<9 plain
  * shifts in the reference's order (dx,dy)=(-2,-2),(-2,0),(-2,2),(0,-2),...,(2,2), k>=9 mirrored.
- * With xy_shift 0 only k=4 (and 13) are used. */
+ * With xy_shift 0 only k=0 (and 9) are used. */
 int cds_search_counts(const cds_maskset *ms, const cds_library *lib, int64_t first, int64_t count, int32_t *counts);
 /* The reference's per-pair entry point: one host image against mask `mask_index`. */
 int cds_score_pair(const cds_maskset *ms, int32_t mask_index, const uint8_t *target_rgb, int32_t W, int32_t H,
