@@ -1,0 +1,130 @@
+"""Target-sharded multi-GPU search: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
+
+The reference's only parallel strategy is data parallelism over target partitions
+(tools cmd/cdsprocess/LocalColorMIPSearchProcessor.java:93-97, SparkColorMIPSearchProcessor.java:50-73: partitions of
+targets, results `collect()`-ed).  Here every (mask, target) score depends on that pair alone, so the library is cut
+into `world` contiguous index ranges, each resident in one GPU's HBM; a search is a local scan per rank followed by
+ONE gather of the per-target score arrays (int32, score | mirrored << 31) to rank 0 -- the only collective on the path
+(4 MB per GPU per million targets: latency-, not bandwidth-bound on xGMI; no reduction, no ring).  The mask set is tiny
+and replicated by the host.
+
+torch is plumbing here (process group + device buffers); the scan itself is the HIP kernel behind the C ABI.
+The functions take the local scan as a callable so that the sharding / gather logic is testable on CPU with gloo.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [begin, end) of rank: GPU g owns [g*n/world, (g+1)*n/world)."""
+    return (n_items * rank) // world, (n_items * (rank + 1)) // world
+
+
+def owner_of(index, n_items, world):
+    """Rank owning library index `index` under shard_range (vectorised)."""
+    index = np.asarray(index, dtype=np.int64)
+    ends = np.array([(n_items * (r + 1)) // world for r in range(world)], dtype=np.int64)
+    return np.searchsorted(ends, index, side="right")
+
+
+def unpack_scores(packed):
+    """int32 score | mirrored<<31  ->  (scores int32, mirrored bool)."""
+    packed = np.asarray(packed).astype(np.int64) & 0xFFFFFFFF
+    return (packed & 0x7FFFFFFF).astype(np.int32), ((packed >> 31) & 1).astype(bool)
+
+
+def gather_scores(local_packed, n_total, group=None, dst=0):
+    """local_packed: int32 tensor [n_masks, n_local] of THIS rank's shard (on the group's device type).
+    Returns on rank `dst` an int32 tensor [n_masks, n_total] in library order, None elsewhere.
+    One collective: a gather of equal-sized (padded) buffers."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_masks = local_packed.shape[0]
+    sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    pad = max(sizes)
+    assert local_packed.shape[1] == sizes[rank], (local_packed.shape, sizes[rank])
+    send = local_packed
+    if sizes[rank] != pad:
+        send = torch.zeros((n_masks, pad), dtype=local_packed.dtype, device=local_packed.device)
+        send[:, : sizes[rank]] = local_packed
+    send = send.contiguous()
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([recv[r][:, : sizes[r]] for r in range(world)], dim=1)
+
+
+def sharded_search(local_scan, n_masks, n_total, device, group=None, dst=0):
+    """local_scan(out): fills the int32 tensor out[n_masks, n_local] (on `device`) with this rank's packed scores,
+    asynchronously on the current stream.  Returns the gathered [n_masks, n_total] tensor on rank dst."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    b, e = shard_range(n_total, rank, world)
+    out = torch.empty((n_masks, e - b), dtype=torch.int32, device=device)
+    local_scan(out)
+    return gather_scores(out, n_total, group=group, dst=dst)
+
+
+class ShardedLibrary:
+    """This rank's shard of an n_total-target library, resident in its GPU's HBM (cds.Library over torch memory)."""
+
+    def __init__(self, width, height, n_total, context=None, group=None):
+        from . import cds
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.n_total = int(n_total)
+        self.begin, self.end = shard_range(self.n_total, self.rank, self.world)
+        self.ctx = context or cds.default_context()
+        self.device = torch.device("cuda", self.ctx.device)
+        n_local = max(1, self.end - self.begin)
+        self._buf = torch.zeros(cds.Library.bytes_required(width, height, n_local), dtype=torch.uint8, device=self.device)
+        self.library = cds.Library(width, height, n_local, context=self.ctx, device_buffer=self._buf)
+
+    @property
+    def n_local(self):
+        return self.end - self.begin
+
+    def generate_synthetic(self, seed, kind=0, with_variants=False):
+        """Every rank regenerates its own index range of the same global stream."""
+        if self.n_local:
+            self.library.generate_synthetic(seed, self.begin, 0, self.n_local, kind=kind, with_variants=with_variants)
+
+    def search(self, algorithm, dst=0):
+        """All masks of `algorithm` x the whole sharded library: gathered packed scores on rank dst."""
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+        def local_scan(out):
+            if self.n_local:
+                algorithm.searchLibraryDevice(self.library, 0, self.n_local, out.data_ptr())
+
+        return sharded_search(local_scan, algorithm.n_masks, self.n_total, self.device, group=self.group, dst=dst)
+
+
+def sharded_pair_scores(local_score, pair_mask, pair_target, n_total, device, group=None, dst=0):
+    """GradientAreaGap over a (mask, global target index) pair list: each rank scores the pairs whose target it owns
+    (local_score(mask_idx, local_slots) -> int64 tensor [k, 3] = gap, high, mirrored), results gathered to rank dst in
+    the original pair order as an int64 tensor [n_pairs, 3]."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    pair_mask = np.asarray(pair_mask, dtype=np.int32)
+    pair_target = np.asarray(pair_target, dtype=np.int64)
+    own = owner_of(pair_target, n_total, world)
+    counts = [int((own == r).sum()) for r in range(world)]
+    pad = max(1, max(counts))
+    mine = np.flatnonzero(own == rank)
+    b, _ = shard_range(n_total, rank, world)
+    send = torch.zeros((pad, 3), dtype=torch.int64, device=device)
+    if len(mine):
+        send[: len(mine)] = local_score(pair_mask[mine], pair_target[mine] - b).to(device)
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = torch.zeros((len(pair_mask), 3), dtype=torch.int64, device=device)
+    for r in range(world):
+        idx = np.flatnonzero(own == r)
+        if len(idx):
+            out[torch.as_tensor(idx, device=device)] = recv[r][: len(idx)]
+    return out

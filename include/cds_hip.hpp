@@ -1,0 +1,271 @@
+// cds_hip.hpp -- header-only C++17 mirror of the reference's `cds` plugin surface over the C ABI (cds_hip.h).
+//
+// The reference is Java; this image has no JDK, so the compiled-language host side above the C ABI is C++.
+// Same names / argument meaning / error behaviour as
+//   ColorDepthSearchAlgorithm            API/cds/ColorDepthSearchAlgorithm.java:17-62
+//   ColorDepthSearchAlgorithmProvider    API/cds/ColorDepthSearchAlgorithmProvider.java:12-38
+//   ColorDepthSearchAlgorithmProviderFactory  API/cds/ColorDepthSearchAlgorithmProviderFactory.java:30-127
+//   ColorMIPSearch                       API/cds/ColorMIPSearch.java:12-47
+//   PixelMatchScore / ShapeMatchScore    API/cds/PixelMatchScore.java:3-31, API/cds/ShapeMatchScore.java:5-65
+// (API/ = colormipsearch-api/src/main/java/org/janelia/colormipsearch/).  IllegalArgumentException maps to
+// std::invalid_argument, every other failure to std::runtime_error.  Link with -lcds_hip.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <optional>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "cds_hip.h"
+
+namespace cds {
+
+inline void check(int rc) {
+    if (rc == CDS_OK) return;
+    std::string msg = cds_last_error();
+    if (rc == CDS_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+    throw std::runtime_error("[cds " + std::to_string(rc) + "] " + msg);
+}
+
+enum class ComputeFileType { InputColorDepthImage, GradientImage, ZGapImage };  // API/model/ComputeFileType.java:5-28
+
+// ImageArray<?> of the reference: type + width + height + pixels (API/imageprocessing/ImageArray.java:12-68).
+struct ImageArray {
+    int width = 0, height = 0;
+    std::vector<uint8_t> rgb;    // packed R,G,B (ColorImageArray) -- or
+    std::vector<uint16_t> gray;  // GRAY16 / widened GRAY8 (ShortImageArray / ByteImageArray)
+    bool isColor() const { return !rgb.empty(); }
+};
+
+// ImageRegionDefinition as rectangles; labelRegions == AbstractColorDepthMatchArgs.getRegionGeneratorForTextLabels
+// (colormipsearch-tools/.../cmd/AbstractColorDepthMatchArgs.java:101-119).
+using Regions = std::vector<cds_rect>;
+inline Regions labelRegions(int width, bool nameLabel = true, bool colorScaleLabel = true) {
+    Regions r;
+    if (colorScaleLabel && width > 270) r.push_back({width - 270, 0, width, 90});
+    if (nameLabel) r.push_back({0, 0, 330, 100});
+    return r;
+}
+
+class Context {
+public:
+    explicit Context(int device = 0) { check(cds_context_create(device, &h_)); }
+    ~Context() { cds_context_destroy(h_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    cds_context *handle() const { return h_; }
+    void setStream(void *hipStream) { check(cds_context_set_stream(h_, hipStream)); }
+    void synchronize() { check(cds_context_synchronize(h_)); }
+private:
+    cds_context *h_ = nullptr;
+};
+
+// Resident shard of targets (counterpart of the host-side MIP cache, CachedMIPsUtils.java:60-100).
+class Library {
+public:
+    Library(Context &ctx, int width, int height, int64_t capacity) : w_(width), h_(height), cap_(capacity) {
+        check(cds_library_create(ctx.handle(), width, height, capacity, &lib_));
+    }
+    ~Library() { cds_library_destroy(lib_); }
+    Library(const Library &) = delete;
+    Library &operator=(const Library &) = delete;
+    cds_library *handle() const { return lib_; }
+    int64_t capacity() const { return cap_; }
+    void upload(int64_t first, int64_t count, const uint8_t *rgb) { check(cds_library_upload(lib_, first, count, rgb)); }
+    void uploadVariants(int64_t first, int64_t count, const uint16_t *grad, const uint8_t *zgap) {
+        check(cds_library_upload_variants(lib_, first, count, grad, zgap));
+    }
+    void generateSynthetic(uint64_t seed, int64_t firstIndex, int64_t firstSlot, int64_t count, int kind, bool variants = false) {
+        check(cds_library_generate_synthetic(lib_, seed, firstIndex, firstSlot, count, kind, variants ? 1 : 0));
+    }
+private:
+    cds_library *lib_ = nullptr;
+    int w_, h_;
+    int64_t cap_;
+};
+
+struct ColorDepthMatchScore {  // API/cds/ColorDepthMatchScore.java:5-22
+    virtual ~ColorDepthMatchScore() = default;
+    virtual int getScore() const = 0;
+    virtual float getNormalizedScore() const = 0;
+    virtual bool isMirrored() const = 0;
+};
+
+class PixelMatchScore : public ColorDepthMatchScore {
+public:
+    PixelMatchScore(int n, double ratio, bool mirrored) : n_(n), ratio_(ratio), mirrored_(mirrored) {}
+    int getScore() const override { return n_; }
+    float getNormalizedScore() const override { return (float)ratio_; }
+    bool isMirrored() const override { return mirrored_; }
+private:
+    int n_;
+    double ratio_;
+    bool mirrored_;
+};
+
+class ShapeMatchScore : public ColorDepthMatchScore {
+public:
+    ShapeMatchScore(int64_t gap, int64_t high, int64_t maxGap, bool mirrored) : gap_(gap), high_(high), max_(maxGap), mirrored_(mirrored) {}
+    int getScore() const override { return (int)cds_shape_score_value(gap_, high_); }
+    float getNormalizedScore() const override { long s = getScore(); return max_ > 0 ? s / (float)max_ : (float)s; }
+    bool isMirrored() const override { return mirrored_; }
+    int64_t getGradientAreaGap() const { return gap_; }
+    int64_t getHighExpressionArea() const { return high_; }
+private:
+    int64_t gap_, high_, max_;
+    bool mirrored_;
+};
+
+using VariantSuppliers = std::map<ComputeFileType, std::function<const ImageArray *()>>;
+
+template <class S>
+class ColorDepthSearchAlgorithm {  // API/cds/ColorDepthSearchAlgorithm.java:17-62
+public:
+    virtual ~ColorDepthSearchAlgorithm() = default;
+    virtual const ImageArray &getQueryImage() const = 0;
+    virtual int getQuerySize() const = 0;
+    virtual std::set<ComputeFileType> getRequiredTargetVariantTypes() const = 0;
+    virtual S calculateMatchingScore(const ImageArray &target, const VariantSuppliers &variantImageSuppliers) const = 0;
+};
+
+class PixelMatchColorDepthSearchAlgorithm : public ColorDepthSearchAlgorithm<PixelMatchScore> {
+public:
+    PixelMatchColorDepthSearchAlgorithm(Context &ctx, const ImageArray &query, int queryThreshold, bool mirrorQuery,
+                                        int targetThreshold, double zTolerance, int xyShift, const Regions &excluded)
+        : query_(query) {
+        cds_pixmatch_params p{queryThreshold, targetThreshold, zTolerance, xyShift, mirrorQuery ? 1 : 0};
+        check(cds_maskset_create(ctx.handle(), 1, query.rgb.data(), query.width, query.height, &p, excluded.data(),
+                                 (int32_t)excluded.size(), &ms_));
+        check(cds_maskset_query_sizes(ms_, &size_));
+    }
+    ~PixelMatchColorDepthSearchAlgorithm() override { cds_maskset_destroy(ms_); }
+    const ImageArray &getQueryImage() const override { return query_; }
+    int getQuerySize() const override { return size_; }
+    std::set<ComputeFileType> getRequiredTargetVariantTypes() const override { return {}; }
+    PixelMatchScore calculateMatchingScore(const ImageArray &target, const VariantSuppliers &) const override {
+        if (size_ == 0) return PixelMatchScore(0, 0, false);
+        int32_t s = 0;
+        uint8_t m = 0;
+        check(cds_score_pair(ms_, 0, target.rgb.data(), target.width, target.height, &s, &m));
+        return PixelMatchScore(s, (double)s / (double)size_, m != 0);
+    }
+    // GPU-native granularity: the whole resident library in one launch
+    void searchLibrary(const Library &lib, int64_t first, int64_t count, std::vector<int32_t> &scores, std::vector<uint8_t> &mirrored) const {
+        scores.assign((size_t)count, 0);
+        mirrored.assign((size_t)count, 0);
+        check(cds_search(ms_, lib.handle(), first, count, scores.data(), mirrored.data()));
+    }
+private:
+    ImageArray query_;
+    cds_maskset *ms_ = nullptr;
+    int32_t size_ = 0;
+};
+
+class Shape2DMatchColorDepthSearchAlgorithm : public ColorDepthSearchAlgorithm<ShapeMatchScore> {
+public:
+    Shape2DMatchColorDepthSearchAlgorithm(Context &ctx, const ImageArray &query, int queryThreshold, bool mirrorQuery,
+                                          const uint8_t *roiMask, const Regions &excluded)
+        : query_(query), thr_(queryThreshold) {
+        check(cds_shapeset_create(ctx.handle(), 1, query.rgb.data(), query.width, query.height, queryThreshold,
+                                  mirrorQuery ? 1 : 0, roiMask, excluded.data(), (int32_t)excluded.size(), &ss_));
+    }
+    ~Shape2DMatchColorDepthSearchAlgorithm() override { cds_shapeset_destroy(ss_); }
+    const ImageArray &getQueryImage() const override { return query_; }
+    int getQuerySize() const override {
+        int n = 0;
+        for (size_t i = 0; i + 2 < query_.rgb.size(); i += 3)
+            n += (query_.rgb[i] > thr_ || query_.rgb[i + 1] > thr_ || query_.rgb[i + 2] > thr_) ? 1 : 0;
+        return n;
+    }
+    std::set<ComputeFileType> getRequiredTargetVariantTypes() const override { return {ComputeFileType::GradientImage, ComputeFileType::ZGapImage}; }
+    ShapeMatchScore calculateMatchingScore(const ImageArray &target, const VariantSuppliers &sup) const override {
+        auto g = sup.find(ComputeFileType::GradientImage), z = sup.find(ComputeFileType::ZGapImage);
+        const ImageArray *grad = g != sup.end() ? g->second() : nullptr, *zgap = z != sup.end() ? z->second() : nullptr;
+        if (!grad || !zgap) return ShapeMatchScore(-1, -1, -1, false);  // Shape2DMatch...Algorithm.java:155-158
+        int64_t gap = 0, high = 0;
+        uint8_t m = 0;
+        check(cds_shape_score_pair(ss_, 0, target.rgb.data(), grad->gray.data(), zgap->rgb.data(), target.width, target.height, &gap, &high, &m));
+        return ShapeMatchScore(gap, high, -1, m != 0);
+    }
+    void maskStats(int64_t &maskSize, int64_t &highExpressionSize) const { check(cds_shapeset_mask_stats(ss_, &maskSize, &highExpressionSize)); }
+private:
+    ImageArray query_;
+    int thr_;
+    cds_shapeset *ss_ = nullptr;
+};
+
+// ColorDepthSearchParams: the four keys the factory reads (Factory:39-43,55-68)
+struct ColorDepthSearchParams {
+    std::optional<bool> mirrorMask;
+    std::optional<int> dataThreshold, xyShift;
+    std::optional<double> pixColorFluctuation;
+};
+
+template <class S>
+class ColorDepthSearchAlgorithmProvider {  // API/cds/ColorDepthSearchAlgorithmProvider.java:12-38
+public:
+    virtual ~ColorDepthSearchAlgorithmProvider() = default;
+    virtual ColorDepthSearchParams getDefaultCDSParams() const = 0;
+    virtual std::unique_ptr<ColorDepthSearchAlgorithm<S>> createColorDepthSearchAlgorithm(const ImageArray &query, int queryThreshold,
+                                                                                         int queryBorderSize, const ColorDepthSearchParams &p) const = 0;
+    std::unique_ptr<ColorDepthSearchAlgorithm<S>> createColorDepthQuerySearchAlgorithmWithDefaultParams(const ImageArray &query, int queryThreshold,
+                                                                                                       int queryBorderSize) const {
+        return createColorDepthSearchAlgorithm(query, queryThreshold, queryBorderSize, ColorDepthSearchParams{});
+    }
+};
+
+class ColorDepthSearchAlgorithmProviderFactory {  // API/cds/ColorDepthSearchAlgorithmProviderFactory.java:30-127
+public:
+    static std::unique_ptr<ColorDepthSearchAlgorithmProvider<PixelMatchScore>> createPixMatchCDSAlgorithmProvider(
+        Context &ctx, bool mirrorMask, int targetThreshold, double pixColorFluctuation, int xyShiftParam, const Regions &ignored) {
+        struct P : ColorDepthSearchAlgorithmProvider<PixelMatchScore> {
+            Context &ctx; bool m; int t; double f; int s; Regions r;
+            P(Context &c, bool m_, int t_, double f_, int s_, Regions r_) : ctx(c), m(m_), t(t_), f(f_), s(s_), r(std::move(r_)) {}
+            ColorDepthSearchParams getDefaultCDSParams() const override { return {m, t, s, f}; }
+            std::unique_ptr<ColorDepthSearchAlgorithm<PixelMatchScore>> createColorDepthSearchAlgorithm(const ImageArray &q, int thr, int, const ColorDepthSearchParams &p) const override {
+                double zTolerance = p.pixColorFluctuation.value_or(f) / 100;  // Factory:55-56
+                int xy = p.xyShift.value_or(s);
+                if ((xy & 1) == 1) throw std::invalid_argument("XY shift parameter must be an even number.");  // Factory:58-60
+                return std::make_unique<PixelMatchColorDepthSearchAlgorithm>(ctx, q, thr, p.mirrorMask.value_or(m), p.dataThreshold.value_or(t), zTolerance, xy, r);
+            }
+        };
+        return std::make_unique<P>(ctx, mirrorMask, targetThreshold, pixColorFluctuation, xyShiftParam, ignored);
+    }
+    static std::unique_ptr<ColorDepthSearchAlgorithmProvider<ShapeMatchScore>> createShapeMatchCDSAlgorithmProvider(
+        Context &ctx, bool mirrorMask, const uint8_t *roiMask, const Regions &excluded) {
+        struct P : ColorDepthSearchAlgorithmProvider<ShapeMatchScore> {
+            Context &ctx; bool m; const uint8_t *roi; Regions r;
+            P(Context &c, bool m_, const uint8_t *roi_, Regions r_) : ctx(c), m(m_), roi(roi_), r(std::move(r_)) {}
+            ColorDepthSearchParams getDefaultCDSParams() const override { ColorDepthSearchParams p; p.mirrorMask = m; return p; }
+            std::unique_ptr<ColorDepthSearchAlgorithm<ShapeMatchScore>> createColorDepthSearchAlgorithm(const ImageArray &q, int thr, int border, const ColorDepthSearchParams &p) const override {
+                if (border != 0) throw std::runtime_error("queryBorderSize != 0 is not supported");
+                return std::make_unique<Shape2DMatchColorDepthSearchAlgorithm>(ctx, q, thr, p.mirrorMask.value_or(m), roi, r);
+            }
+        };
+        return std::make_unique<P>(ctx, mirrorMask, roiMask, excluded);
+    }
+};
+
+class ColorMIPSearch {  // API/cds/ColorMIPSearch.java:12-47
+public:
+    ColorMIPSearch(std::optional<double> pctPositivePixels, std::optional<int> defaultQueryThreshold,
+                   std::shared_ptr<ColorDepthSearchAlgorithmProvider<PixelMatchScore>> provider)
+        : pct_(pctPositivePixels), thr_(defaultQueryThreshold), provider_(std::move(provider)) {}
+    std::unique_ptr<ColorDepthSearchAlgorithm<PixelMatchScore>> createQueryColorDepthSearchWithDefaultThreshold(const ImageArray &query) const {
+        return provider_->createColorDepthQuerySearchAlgorithmWithDefaultParams(query, thr_.value_or(0), 0);
+    }
+    bool isMatch(const PixelMatchScore &s) const {
+        double t = pct_ ? *pct_ / 100 : 0.;
+        return s.getScore() > 0 && s.getNormalizedScore() > t;
+    }
+private:
+    std::optional<double> pct_;
+    std::optional<int> thr_;
+    std::shared_ptr<ColorDepthSearchAlgorithmProvider<PixelMatchScore>> provider_;
+};
+
+}  // namespace cds

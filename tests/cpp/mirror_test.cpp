@@ -1,0 +1,53 @@
+// Exercises the C++ mirror (include/cds_hip.hpp) the way the reference's JUnit tests exercise the Java plugin
+// surface: provider factory -> algorithm -> calculateMatchingScore, plus the library-level entry point.
+// Prints "OK <self score> <mirrored score> <mirrored flag>" on success.
+#include <cstdio>
+#include <cstdlib>
+
+#include "cds_hip.hpp"
+
+int main() {
+    const int W = 1210, H = 566;
+    try {
+        cds::Context ctx(0);
+        cds::Library lib(ctx, W, H, 4);
+        lib.generateSynthetic(0xBADC0DEull, 0, 0, 1, 2);     // slot 0: the benchmark mask
+        lib.generateSynthetic(0xC0FFEEull, 0, 1, 2, 0);      // slots 1,2: sparse targets
+        cds::ImageArray mask;
+        mask.width = W; mask.height = H; mask.rgb.resize((size_t)3 * W * H);
+        cds::check(cds_library_download(lib.handle(), 0, 1, mask.rgb.data()));
+        cds::ImageArray flipped = mask;
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++)
+                for (int c = 0; c < 3; c++) flipped.rgb[3 * ((size_t)y * W + x) + c] = mask.rgb[3 * ((size_t)y * W + (W - 1 - x)) + c];
+        lib.upload(3, 1, flipped.rgb.data());
+
+        auto provider = cds::ColorDepthSearchAlgorithmProviderFactory::createPixMatchCDSAlgorithmProvider(ctx, true, 20, 1.0, 2, cds::labelRegions(W));
+        auto alg = provider->createColorDepthQuerySearchAlgorithmWithDefaultParams(mask, 20, 0);
+        cds::PixelMatchScore self = alg->calculateMatchingScore(mask, {});
+        cds::PixelMatchScore mir = alg->calculateMatchingScore(flipped, {});
+        if (self.getScore() <= 0 || self.getScore() > alg->getQuerySize() || self.isMirrored()) return 2;
+        if (!mir.isMirrored() || mir.getScore() != self.getScore()) return 3;
+
+        auto *pm = dynamic_cast<cds::PixelMatchColorDepthSearchAlgorithm *>(alg.get());
+        std::vector<int32_t> scores;
+        std::vector<uint8_t> mirrored;
+        pm->searchLibrary(lib, 0, 4, scores, mirrored);
+        if (scores[0] != self.getScore() || scores[3] != mir.getScore() || !mirrored[3] || mirrored[0]) return 4;
+
+        cds::ColorMIPSearch search(1.0, 20, std::move(provider));
+        if (!search.isMatch(self)) return 5;
+
+        bool threw = false;
+        try {
+            auto bad = cds::ColorDepthSearchAlgorithmProviderFactory::createPixMatchCDSAlgorithmProvider(ctx, true, 20, 1.0, 3, cds::labelRegions(W));
+            bad->createColorDepthQuerySearchAlgorithmWithDefaultParams(mask, 20, 0);
+        } catch (const std::invalid_argument &) { threw = true; }
+        if (!threw) return 6;
+        std::printf("OK %d %d %d %d\n", self.getScore(), mir.getScore(), (int)mir.isMirrored(), alg->getQuerySize());
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "exception: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
