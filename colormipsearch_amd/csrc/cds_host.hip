@@ -609,6 +609,7 @@ static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t fi
             p.counts = d_counts ? d_counts + (size_t)g0 * count * CDS_N_TRANSFORMS : nullptr;
             p.out_stride = count;
             p.out_offset = 0;
+            if (const char *e = getenv("CDS_SCAN_DEBUG")) p.debug = atoi(e);
             if (timed_sync) CDS_HIP(hipEventRecord(ev0, st));
             rc = launch_scan(ctx, p, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
             if (rc) return rc;

@@ -95,6 +95,7 @@ struct ScanParams {
     int32_t *counts;         // optional [n_masks][count][18]
     int64_t out_stride;      // elements between masks in out (== total count of the call)
     int64_t out_offset;      // offset of this launch's first target in out
+    int debug;               // timing-only ablations (CDS_SCAN_DEBUG): 1 = skip probes, 2 = skip conversion
 };
 
 int launch_scan(cds_context *ctx, const ScanParams &p, bool xy2, bool mirror, hipStream_t stream);

@@ -81,10 +81,50 @@ __device__ __forceinline__ void stage_rows(const ScanParams &p, const uint8_t *i
         for (int u = 0; u < U; u++) {
             if (dst[u] >= 0) {
                 uint4 codes = make_uint4(0, 0, 0, 0);
-                if (__any((v[u].a | v[u].b | v[u].c) != 0)) codes = convert4(v[u], p.data_thr);
+                if (!(p.debug & 2) && __any((v[u].a | v[u].b | v[u].c) != 0)) codes = convert4(v[u], p.data_thr);
                 *reinterpret_cast<uint4 *>(ring + dst[u]) = codes;
             }
         }
+    }
+}
+
+// Software-pipelined staging: issue_loads() puts the raw 12-byte groups of rows [ra, rb) into registers
+// (the loads stay in flight while the previous band is probed), commit() converts them and writes the ring.
+template <int RR, int NT, int UP>
+__device__ __forceinline__ void issue_loads(const ScanParams &p, const uint8_t *img, int ra, int rb, u3 (&v)[UP], int (&dst)[UP]) {
+    const int items = (rb - ra) * p.gpr;
+    const int rowbase = p.m0 - p.halo;
+#pragma unroll
+    for (int u = 0; u < UP; u++) {
+        const int it = threadIdx.x + u * NT;
+        v[u].a = v[u].b = v[u].c = 0;
+        dst[u] = -1;
+        if (it < items) {
+            const int rr = (int)__umulhi((uint32_t)it, p.gpr_magic);
+            const int gi = it - rr * p.gpr;
+            const int rel = ra + rr;
+            const int row = rel + rowbase;
+            const int x0 = p.cx0 + 4 * gi;
+            dst[u] = (rel & (RR - 1)) * p.wc + 4 * gi;
+            if (row >= 0 && row < p.H && x0 >= 0 && x0 + 4 <= p.wpad) {
+                const u32x3_a4 *src = reinterpret_cast<const u32x3_a4 *>(img + (size_t)row * p.pitch + (size_t)x0 * 3);
+                const u32x3 w = __builtin_nontemporal_load(src);
+                v[u].a = w.x; v[u].b = w.y; v[u].c = w.z;
+            }
+        }
+    }
+}
+
+template <int UP>
+__device__ __forceinline__ void commit(const ScanParams &p, uint32_t *ring, const u3 (&v)[UP], const int (&dst)[UP]) {
+#pragma unroll
+    for (int u = 0; u < UP; u++) {
+        if (dst[u] >= 0) {
+            uint4 codes = make_uint4(0, 0, 0, 0);
+            if (!(p.debug & 2) && __any((v[u].a | v[u].b | v[u].c) != 0)) codes = convert4(v[u], p.data_thr);
+            *reinterpret_cast<uint4 *>(ring + dst[u]) = codes;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one group at a time: keeps the live ranges (VGPRs) short
     }
 }
 
@@ -97,7 +137,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 // XY2: xyShift == 2 (9 shifts) else 0 (1 shift).  MIRROR: also the mirrored orientation.
 // MULTI: several masks share the staged rows (counts by wave ballot into LDS) else one mask with
 // per-lane counters kept in registers for the whole target.
-template <bool XY2, bool MIRROR, bool MULTI, int BH, int RR, int NT>
+template <bool XY2, bool MIRROR, bool MULTI, int BH, int RR, int NT, int UP>
 __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr int NS = XY2 ? 9 : 1;
@@ -118,14 +158,24 @@ __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
 #pragma unroll
         for (int k = 0; k < NC; k++) acc[k] = 0;
 
-        int staged = 0;  // rows [0, staged) relative to (m0 - halo) are in the ring (or were)
+        // Band k = mask rows [k*BH, (k+1)*BH) needs ring rows up to (k+1)*BH + 2*halo (relative to m0-halo).
+        // The first band is staged directly; every later band is loaded into registers one band ahead
+        // (pipelined when it fits UP*NT groups) and committed to the ring after the previous band's probes.
+        constexpr int UPA = UP > 0 ? UP : 1;
+        const bool pipelined = UP > 0 && BH * p.gpr <= UP * NT;
+        u3 pv[UPA];
+        int pdst[UPA];
+        int staged = ((BH < m1rel) ? BH : m1rel) + 2 * halo;
+        stage_rows<RR, NT>(p, img, ring, 0, staged);
+        int pre_end = staged;  // rows [staged, pre_end) are in flight in pv
+        if (pipelined && BH < m1rel) {
+            pre_end = ((2 * BH < m1rel) ? 2 * BH : m1rel) + 2 * halo;
+            issue_loads<RR, NT, UPA>(p, img, staged, pre_end, pv, pdst);
+        }
+        __syncthreads();
         for (int y0 = 0; y0 < m1rel; y0 += BH) {
             const int y1 = (y0 + BH < m1rel) ? y0 + BH : m1rel;
-            const int need = y1 + 2 * halo;  // relative to m0-halo: mask row y needs rows y .. y+2*halo
-            stage_rows<RR, NT>(p, img, ring, staged, need);
-            staged = need;
-            __syncthreads();
-            const int nm = MULTI ? p.n_masks : 1;
+            const int nm = (p.debug & 1) ? 0 : (MULTI ? p.n_masks : 1);
             for (int g = 0; g < nm; g++) {
                 const uint32_t *rp = p.rowptr + (size_t)g * (p.nrows + 1);
                 const uint32_t s = rp[y0], e = rp[y1];
@@ -169,6 +219,22 @@ __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
                     }
                 }
             }
+            if (y1 < m1rel) {  // make the next band's rows available
+                if (pipelined) {
+                    commit<UPA>(p, ring, pv, pdst);
+                    staged = pre_end;
+                    const int y2 = (y1 + BH < m1rel) ? y1 + BH : m1rel;
+                    if (y2 < m1rel) {
+                        pre_end = ((y2 + BH < m1rel) ? y2 + BH : m1rel) + 2 * halo;
+                        issue_loads<RR, NT, UPA>(p, img, staged, pre_end, pv, pdst);
+                    }
+                } else {
+                    const int need = ((y1 + BH < m1rel) ? y1 + BH : m1rel) + 2 * halo;
+                    stage_rows<RR, NT>(p, img, ring, staged, need);
+                    staged = need;
+                }
+                __syncthreads();
+            }
         }
         if (!MULTI) {
 #pragma unroll
@@ -204,9 +270,9 @@ __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
     }
 }
 
-template <bool XY2, bool MIRROR, bool MULTI, int BH, int RR, int NT>
+template <bool XY2, bool MIRROR, bool MULTI, int BH, int RR, int NT, int UP>
 static int launch_cfg(const ScanParams &p, int grid, size_t lds_bytes, hipStream_t stream) {
-    auto kern = scan_kernel<XY2, MIRROR, MULTI, BH, RR, NT>;
+    auto kern = scan_kernel<XY2, MIRROR, MULTI, BH, RR, NT, UP>;
     CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds_bytes, stream, p);
@@ -221,17 +287,24 @@ static int launch_shape(cds_context *ctx, const ScanParams &p, hipStream_t strea
     const size_t ring32 = (size_t)32 * p.wc * 4, ring16 = (size_t)16 * p.wc * 4;
     const size_t lds_max = ctx->lds_per_block;
     int cfg = 0;  // 0: RR=16/BH=6, 1: RR=32/BH=12
-    if (ring32 + cnt_bytes <= 80 * 1024) cfg = 1;
+    (void)ring32;
     if (const char *e = getenv("CDS_SCAN_CFG")) cfg = atoi(e);
-    if (cfg == 1 && ring32 + cnt_bytes > lds_max) cfg = 0;
-    if (cfg == 0 && ring16 + cnt_bytes > lds_max) return fail(CDS_ERR_UNSUPPORTED, "column window too wide for LDS");
+    const bool big = (cfg == 1 || cfg == 3);
+    if (big && ring32 + cnt_bytes > lds_max) cfg = 0;
+    if (!(cfg == 1 || cfg == 3) && ring16 + cnt_bytes > lds_max) return fail(CDS_ERR_UNSUPPORTED, "column window too wide for LDS");
     int per_cu = 8;
     if (const char *e = getenv("CDS_SCAN_WGS_PER_CU")) per_cu = atoi(e);
     int64_t g64 = (int64_t)ctx->n_cus * per_cu;
     int grid = (int)(p.count < g64 ? p.count : g64);
     if (grid < 1) grid = 1;
-    if (cfg == 1) return launch_cfg<XY2, MIRROR, MULTI, 12, 32, 256>(p, grid, ring32 + cnt_bytes, stream);
-    return launch_cfg<XY2, MIRROR, MULTI, 6, 16, 256>(p, grid, ring16 + cnt_bytes, stream);
+    switch (cfg) {
+        case 1: return launch_cfg<XY2, MIRROR, MULTI, 12, 32, 512, 0>(p, grid, ring32 + cnt_bytes, stream);
+        case 2: return launch_cfg<XY2, MIRROR, MULTI, 6, 16, 512, 0>(p, grid, ring16 + cnt_bytes, stream);
+        case 3: return launch_cfg<XY2, MIRROR, MULTI, 12, 32, 1024, 0>(p, grid, ring32 + cnt_bytes, stream);
+        case 4: return launch_cfg<XY2, MIRROR, MULTI, 6, 16, 512, 2>(p, grid, ring16 + cnt_bytes, stream);
+        case 5: return launch_cfg<XY2, MIRROR, MULTI, 6, 16, 256, 4>(p, grid, ring16 + cnt_bytes, stream);
+        default: return launch_cfg<XY2, MIRROR, MULTI, 6, 16, 256, 0>(p, grid, ring16 + cnt_bytes, stream);
+    }
 }
 
 int launch_scan(cds_context *ctx, const ScanParams &p, bool xy2, bool mirror, hipStream_t stream) {

@@ -1,7 +1,8 @@
 #!/bin/bash
-# usage: tools_sweep.sh  (runs on the GPU box) -- scan kernel configuration sweep
-for cfg in 0 1; do for w in 2 4 8 16; do
-  CDS_SCAN_CFG=$cfg CDS_SCAN_WGS_PER_CU=$w python bench.py --chunk 8192 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/o.json
+# usage: tools/sweep.sh  (runs on the GPU box) -- scan kernel configuration sweep
+CH=${CHUNK:-16384}
+for cfg in ${CFGS:-0 1 2}; do for w in ${WGS:-8 16}; do
+  CDS_SCAN_CFG=$cfg CDS_SCAN_WGS_PER_CU=$w python bench.py --chunk $CH --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/o.json
   python - "$cfg" "$w" <<'PY'
 import sys, json
 d = json.loads(open('/tmp/o.json').read())
