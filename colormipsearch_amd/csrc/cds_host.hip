@@ -503,36 +503,73 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
         clo = std::min(clo, W - xhi - shift);
         chi = std::max(chi, W - xlo + shift);
     }
-    ms->cx0 = floor4(clo);
-    ms->wc = std::max(8, ceil4(chi) - ms->cx0);
+    ms->cx0 = floor4(clo) & ~15;                       // floor to a multiple of 16 pixels (also for negatives)
+    ms->wc = std::max(32, ((ceil4(chi) - ms->cx0) + 15) & ~15);   // >= 2 items per row (32-bit magic division)
     ms->m0 = m0; ms->m1 = m1;
     if (ms->wc > 2047) {
         delete ms;
         return fail(CDS_ERR_UNSUPPORTED, "column window too wide");
     }
     const int nrows = m1 - m0;
-    std::vector<uint32_t> rowptr((size_t)n_masks * (nrows + 1));
-    std::vector<uint32_t> pos(total);
-    std::vector<uint4> ivs(total);
-    size_t k = 0;
+    const int nbands = (nrows + kScanBandRows - 1) / kScanBandRows;
+    ms->nbands = nbands;
+    // Pixels are regrouped per band of kScanBandRows mask rows, sorted by (x, y) inside a band so that 64
+    // consecutive pixels form a spatially compact chunk; each chunk carries the staging blocks / rows its probes
+    // can touch, which lets a wave skip an orientation whose neighbourhood is all black (cds_scan.hip).
+    std::vector<uint32_t> bandptr((size_t)n_masks * (nbands + 1));
+    std::vector<uint4> chunks;
+    std::vector<uint32_t> pos;
+    std::vector<uint4> ivs;
+    pos.reserve(total + total / 4 + 64);
+    ivs.reserve(total + total / 4 + 64);
+    auto desc = [&](int cmin, int cmax, int nr) -> uint32_t {   // columns are window-relative pixels
+        const int g0 = (cmin - shift) >> 2, g1 = (cmax + shift) >> 2;
+        if ((g1 >> 5) - (g0 >> 5) > 1 || nr > 31) return 0;   // spans more than two occupancy words: never skip
+        return (uint32_t)g0 | ((uint32_t)g1 << 9) | (1u << 31);
+    };
     for (int m = 0; m < n_masks; m++) {
-        uint32_t *rp = rowptr.data() + (size_t)m * (nrows + 1);
-        int row = 0;
-        rp[0] = (uint32_t)k;
-        for (const Px &p : per_mask[(size_t)m]) {  // already in row-major order
-            while (row < p.y - m0) rp[++row] = (uint32_t)k;
-            uint32_t cpl = (uint32_t)(p.x - ms->cx0), cmi = (uint32_t)(W - 1 - p.x - ms->cx0);
-            pos[k] = cpl | (cmi << 11) | ((uint32_t)(p.y - m0) << 22);
-            ivs[k] = make_uint4(p.iv.lo1, p.iv.len1, p.iv.lo2, p.iv.len2);
-            k++;
+        std::vector<Px> &list = per_mask[(size_t)m];
+        std::vector<std::vector<Px>> bands((size_t)nbands);
+        for (const Px &p : list) bands[(size_t)((p.y - m0) / kScanBandRows)].push_back(p);
+        for (int b = 0; b < nbands; b++) {
+            bandptr[(size_t)m * (nbands + 1) + b] = (uint32_t)chunks.size();
+            std::vector<Px> &bl = bands[(size_t)b];
+            std::sort(bl.begin(), bl.end(), [](const Px &a, const Px &c) { return a.x < c.x || (a.x == c.x && a.y < c.y); });
+            for (size_t s0 = 0; s0 < bl.size(); s0 += 64) {
+                const size_t s1 = std::min(bl.size(), s0 + 64);
+                int xmin = W, xmax = -1, ymin = H, ymax = -1;
+                for (size_t i = s0; i < s1; i++) {
+                    const Px &p = bl[i];
+                    xmin = std::min(xmin, p.x); xmax = std::max(xmax, p.x);
+                    ymin = std::min(ymin, p.y); ymax = std::max(ymax, p.y);
+                    uint32_t cpl = (uint32_t)(p.x - ms->cx0), cmi = (uint32_t)(W - 1 - p.x - ms->cx0);
+                    pos.push_back(cpl | (cmi << 11) | ((uint32_t)(p.y - m0) << 22));
+                    ivs.push_back(make_uint4(p.iv.lo1, p.iv.len1, p.iv.lo2, p.iv.len2));
+                }
+                for (size_t i = s1; i < s0 + 64; i++) {  // pad the chunk: a pixel that can never match, at a valid position
+                    pos.push_back(pos[pos.size() - (i - s0)]);
+                    ivs.push_back(make_uint4(kEmptyIv.lo1, kEmptyIv.len1, kEmptyIv.lo2, kEmptyIv.len2));
+                }
+                const int r0 = ymin - m0, nr = (ymax - ymin) + 1 + 2 * shift;  // ring rows r0 .. r0+nr-1 (relative to m0-halo)
+                uint4 ch;
+                ch.x = (uint32_t)(s1 - s0);
+                ch.y = (uint32_t)r0 | ((uint32_t)nr << 10);
+                ch.z = desc(xmin - ms->cx0, xmax - ms->cx0, nr);
+                ch.w = mirror ? desc(W - 1 - xmax - ms->cx0, W - 1 - xmin - ms->cx0, nr) : 0;
+                chunks.push_back(ch);
+            }
         }
-        while (row < nrows) rp[++row] = (uint32_t)k;
+        bandptr[(size_t)m * (nbands + 1) + nbands] = (uint32_t)chunks.size();
     }
+    total = pos.size();
+    if (chunks.empty()) chunks.push_back(make_uint4(0, 0, 0, 0));
     hipSetDevice(ctx->device);
-    hipError_t e = hipMalloc(&ms->d_rowptr, rowptr.size() * 4);
+    hipError_t e = hipMalloc(&ms->d_bandptr, bandptr.size() * 4);
+    if (e == hipSuccess) e = hipMalloc(&ms->d_chunks, chunks.size() * sizeof(uint4));
     if (e == hipSuccess) e = hipMalloc(&ms->d_px_pos, total * 4);
     if (e == hipSuccess) e = hipMalloc(&ms->d_px_iv, total * sizeof(uint4));
-    if (e == hipSuccess) e = hipMemcpy(ms->d_rowptr, rowptr.data(), rowptr.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ms->d_bandptr, bandptr.data(), bandptr.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ms->d_chunks, chunks.data(), chunks.size() * sizeof(uint4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ms->d_px_pos, pos.data(), total * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ms->d_px_iv, ivs.data(), total * sizeof(uint4), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -546,7 +583,8 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
 void cds_maskset_destroy(cds_maskset *ms) {
     if (!ms) return;
     hipSetDevice(ms->ctx->device);
-    if (ms->d_rowptr) hipFree(ms->d_rowptr);
+    if (ms->d_bandptr) hipFree(ms->d_bandptr);
+    if (ms->d_chunks) hipFree(ms->d_chunks);
     if (ms->d_px_pos) hipFree(ms->d_px_pos);
     if (ms->d_px_iv) hipFree(ms->d_px_iv);
     delete ms;
@@ -600,9 +638,12 @@ static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t fi
             p.m0 = ms->m0;
             p.halo = ms->params.xy_shift;
             p.cx0 = ms->cx0; p.wc = ms->wc; p.gpr = ms->wc / 4;
-            p.gpr_magic = (uint32_t)(((1ull << 32) + p.gpr - 1) / p.gpr);
+            p.nseg = (p.gpr + 63) / 64;
+            p.occw = 2 * p.nseg;
+            p.nbands = ms->nbands;
             p.data_thr = (float)ms->params.data_threshold;
-            p.rowptr = ms->d_rowptr + (size_t)g0 * (p.nrows + 1);
+            p.bandptr = ms->d_bandptr + (size_t)g0 * (ms->nbands + 1);
+            p.chunks = ms->d_chunks;
             p.px_pos = ms->d_px_pos;
             p.px_iv = ms->d_px_iv;
             p.out = d_scores + (size_t)g0 * count;

@@ -21,6 +21,9 @@ int hip_fail(hipError_t e, const char *what);
         if (_e != hipSuccess) return cds::hip_fail(_e, #call); \
     } while (0)
 
+// ---- scan kernel geometry shared by host preparation and device code (cds_scan.hip) ----
+constexpr int kScanBandRows = 12;  // mask rows per band
+
 // ---- geometry limits (bit-packing of the mask pixel records, see cds_scan.hip) ----
 constexpr int kMaxW = 2000;
 constexpr int kMaxH = 1000;
@@ -84,13 +87,16 @@ struct ScanParams {
     int nrows;            // m1 - m0
     int m0;               // first mask row of the union span
     int halo;             // 0 or 2
-    int cx0, wc;          // column window [cx0, cx0+wc), both multiples of 4 (cx0 may be negative)
-    int gpr;              // wc / 4
-    uint32_t gpr_magic;   // ceil(2^32 / gpr)
+    int cx0, wc;          // column window [cx0, cx0+wc), both multiples of 16 (cx0 may be negative)
+    int gpr;              // wc / 4 : 4-pixel groups per staged row
+    int nseg;             // ceil(gpr / 64): 64-group segments per staged row
+    int occw;             // occupancy words (u32, one bit per group) per ring row = 2 * nseg
+    int nbands;           // ceil(nrows / kScanBandRows)
     float data_thr;
-    const uint32_t *rowptr;  // [n_masks][nrows+1]
-    const uint32_t *px_pos;  // cplain | cmir << 11 | yrel << 22
-    const uint4 *px_iv;      // lo1, len1, lo2, len2
+    const uint32_t *bandptr;  // [n_masks][nbands+1] -> chunk index
+    const uint4 *chunks;      // y: r0 | nr<<10, z/w: plain/mirror g0 | g1<<9 | testable<<31 (64 pixels per chunk)
+    const uint32_t *px_pos;   // cplain | cmir << 11 | yrel << 22   (sorted by mask, band, x, y; chunks padded to 64)
+    const uint4 *px_iv;       // lo1, len1, lo2, len2
     int32_t *out;            // [n_masks][count]  score | mirrored << 31
     int32_t *counts;         // optional [n_masks][count][18]
     int64_t out_stride;      // elements between masks in out (== total count of the call)
@@ -109,7 +115,9 @@ struct cds_maskset {
     int W = 0, H = 0, n_masks = 0;
     std::vector<int32_t> sizes;  // query size P per mask (includes class-less pixels)
     int m0 = 0, m1 = 0, cx0 = 0, wc = 0;
-    uint32_t *d_rowptr = nullptr;
+    uint32_t *d_bandptr = nullptr;
+    uint4 *d_chunks = nullptr;
+    int nbands = 0;
     uint32_t *d_px_pos = nullptr;
     uint4 *d_px_iv = nullptr;
     size_t n_px = 0;

@@ -7,26 +7,72 @@
 // then max over shifts, mirrored only if strictly greater.
 //
 // How (MI355X-first, not the reference's gather loops):
-//   * one workgroup streams ONE target: the rows the mask can touch, and of those only the column
-//     window the mask (and its mirror image) can touch, as 12-byte (4 pixel) coalesced loads;
-//   * every loaded pixel is converted ONCE to a 32-bit "hue code" = class<<29 | bits(med/max)>>1 (0 for
-//     below-threshold / class-less pixels) and written to an LDS ring of rows;  med/max is computed as
-//     fl32(med) * v_rcp_f32(max); the host builds its acceptance intervals from the very same
-//     v_rcp_f32 table (read back from this device at context creation), so the device predicate is an
-//     integer range test that is bit-exact with the reference's double arithmetic by construction
-//     (cds_host.hip: build_ratio_table / intervals_for);
-//   * each mask pixel (two code intervals: own hue class + at most one adjacent class) probes the 18
-//     transformed positions in LDS; per-lane counters (one mask) or wave ballots (mask batches) count;
-//   * no MFMA: byte compare / integer count, HBM- and VALU-bound.
+//   * one workgroup streams ONE target at a time: only the rows the mask can touch, and of those only the
+//     column window the mask (and its mirror image) can touch, as 12-byte (4 pixel) non-temporal loads;
+//   * staging is sparse-aware.  Phase A writes the raw 12 bytes of every group into a 16-row LDS ring (an
+//     all-black group is already its own all-zero code), records one occupancy bit per group and appends the
+//     ring index of every non-black group to a small queue; phase B converts only the queued groups, in
+//     place, to 32-bit "hue codes" = class<<29 | bits(med * v_rcp_f32(max))>>1 (0 = below threshold / no hue
+//     class).  The host builds its acceptance intervals from this device's own v_rcp_f32 table, so the
+//     device predicate is an integer range test that is bit-exact with the reference's double arithmetic by
+//     construction (cds_host.hip: build_ratio_table / intervals_for);
+//   * mask pixels are pre-sorted into spatially compact chunks of <= 64 per 6-row band; a wave takes one
+//     chunk, and skips an orientation's 9 probes when the occupancy bits of the chunk's neighbourhood are
+//     all clear (one ballot); otherwise every lane probes its 9 (18) transformed positions in LDS against its
+//     two code intervals (own hue class + at most one adjacent class); per-lane counters (one mask) or wave
+//     ballots (mask batches) count;
+//   * no MFMA: byte compare / integer count; the kernel is VALU-issue- and HBM-bound.
 #include "cds_internal.hpp"
 
 namespace cds {
 
-struct u3 {
-    uint32_t a, b, c;
-};
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef u32x3 u32x3_a4 __attribute__((aligned(4)));  // 12-byte groups are only 4-byte aligned
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Asynchronous loads with MANUAL waits.  hipcc's own s_waitcnt placement treats vmcnt conservatively (vector-memory
+// operations retire in order, and it waits with vmcnt(0) as soon as any register with a pending load is touched),
+// which would make the probes wait for the HBM rows of the NEXT band.  The band loop therefore issues its loads --
+// first the (L2-resident) mask data of this band, then the rows of the next band -- through these asm statements
+// and waits explicitly: vmcnt(KMAX) before the probes (mask data arrived, rows still in flight), vmcnt(0) before
+// the rows are committed.  No asm-loaded value is loop-carried or read before its wait statement, which names it
+// as an in/out operand (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ u32x3 async_ld12_nt(const void *ptr) {
+    u32x3 v;
+    asm volatile("global_load_dwordx3 %0, %1, off nt" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ u32x4 async_ld16(const void *ptr) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+template <int KMAX>
+__device__ __forceinline__ void wait_rows(u32x3 (&w)[KMAX]) {  // all outstanding loads have landed; names w as in/out
+    if (KMAX == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[KMAX - 1]) :: "memory");
+    else if (KMAX == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[KMAX - 1]) :: "memory");
+    else if (KMAX == 5) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[KMAX - 1]) :: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[KMAX - 1]) :: "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_mask(u32x4 &ch, uint32_t &pos, u32x4 &iv) {  // at most N loads still outstanding
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(ch), "+v"(pos), "+v"(iv) : "n"(N) : "memory");
+}
+__device__ __forceinline__ uint32_t async_ld4(const void *ptr) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+
+constexpr int BH = kScanBandRows;  // mask rows per band
+constexpr int RR = 16;             // code ring rows = BH + 4: exactly what one band's probes touch
+constexpr int RO = 16;             // occupancy ring rows
+constexpr int NT = 256;
+constexpr int NW = NT / 64;
+constexpr int QCAP = 512;  // queue entries (one per non-black group); overflow falls back to in-place conversion
+constexpr int MAXC = 4;    // chunks per wave and band whose mask data is fetched asynchronously at the top of the band
+constexpr int RPW = BH / NW;  // new rows per wave and band
+static_assert(RR >= BH + 4 && (RR & (RR - 1)) == 0 && RO >= RR && BH % NW == 0, "ring geometry");
 
 // class lookup by the three strict comparisons: idx = 4*(r>g) + 8*(g>b) + 16*(b>r) selects a nibble.
 // 1 BR, 2 BG, 3 GB, 4 GR, 5 RG, 6 RB (AbstractColorDepthSearchAlgorithm.java:195-225); 0 = none.
@@ -40,91 +86,112 @@ __device__ __forceinline__ uint32_t hue_code(float r, float g, float b, float th
     return (mx > thr && mx > md) ? c : 0u;
 }
 
-__device__ __forceinline__ uint4 convert4(u3 v, float thr) {
+__device__ __forceinline__ uint4 convert4(uint32_t a, uint32_t b, uint32_t c, float thr) {
     uint4 o;
-    o.x = hue_code((float)(v.a & 255), (float)((v.a >> 8) & 255), (float)((v.a >> 16) & 255), thr);
-    o.y = hue_code((float)(v.a >> 24), (float)(v.b & 255), (float)((v.b >> 8) & 255), thr);
-    o.z = hue_code((float)((v.b >> 16) & 255), (float)(v.b >> 24), (float)(v.c & 255), thr);
-    o.w = hue_code((float)((v.c >> 8) & 255), (float)((v.c >> 16) & 255), (float)(v.c >> 24), thr);
+    o.x = hue_code((float)(a & 255), (float)((a >> 8) & 255), (float)((a >> 16) & 255), thr);
+    o.y = hue_code((float)(a >> 24), (float)(b & 255), (float)((b >> 8) & 255), thr);
+    o.z = hue_code((float)((b >> 16) & 255), (float)(b >> 24), (float)(c & 255), thr);
+    o.w = hue_code((float)((c >> 8) & 255), (float)((c >> 16) & 255), (float)(c >> 24), thr);
     return o;
 }
 
-// Stage target rows [ra, rb) (relative to row m0-halo) of the column window into the LDS ring.
-template <int RR, int NT>
-__device__ __forceinline__ void stage_rows(const ScanParams &p, const uint8_t *img, uint32_t *ring, int ra, int rb) {
-    const int items = (rb - ra) * p.gpr;
-    const int rowbase = p.m0 - p.halo;
-    constexpr int U = 4;
-    for (int it0 = threadIdx.x; it0 < items; it0 += NT * U) {
-        u3 v[U];
-        int dst[U];
+struct Lds {
+    uint32_t *ring;   // [RR][wc]   codes (or raw groups between phase A and phase B)
+    uint32_t *occ;    // [RR][occw] one bit per 4-pixel group (32 groups per word): group non-black
+    uint16_t *queue;  // [QCAP]     ring index / 4 of the groups phase B must convert
+    int *qcount;      // [2]        double-buffered by band parity
+    int *cnt;         // counters
+};
+
+// Phase A for rows [ra, ra+n) (rows relative to m0-halo): wave w stages rows ra+w, ra+w+NW, ...  A row is
+// K = ceil(gpr/64) segments of 64 groups (12 bytes each): lane l of segment k loads group 64k+l, so every load
+// instruction reads 768 contiguous bytes from a wave-uniform row pointer; all K loads of a row are in flight
+// together (the lane offsets are clamped, not branched, for the lanes beyond the window).  The raw group goes to
+// the ring as (a,b,c,0) -- a black group is already its all-zero code --, the segment's ballot IS its two
+// occupancy words, and every non-black group is queued for phase B.
+// a_issue: the K loads of ring row r into registers.  a_commit: registers -> ring / occupancy / queue.
+template <int KMAX, bool ASYNC>  // KMAX: compile-time bound of K.  ASYNC: all KMAX loads are issued by asm (manual wait)
+__device__ __forceinline__ void a_issue(const ScanParams &p, const uint8_t *img, int r, int lane, u32x3 (&w)[KMAX]) {
+    const int K = p.nseg;
+    int row = r + p.m0 - p.halo;
+    row = row < 0 ? 0 : (row >= p.H ? p.H - 1 : row);  // rows outside the image are loaded (clamped) and ignored
+    const uint8_t *rowp = img + (uint32_t)(row * p.pitch);
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            int it = it0 + u * NT;
-            v[u].a = v[u].b = v[u].c = 0;
-            dst[u] = -1;
-            if (it < items) {
-                int rr = (int)__umulhi((uint32_t)it, p.gpr_magic);
-                int gi = it - rr * p.gpr;
-                int rel = ra + rr;
-                int row = rel + rowbase;
-                int x0 = p.cx0 + 4 * gi;
-                dst[u] = (rel & (RR - 1)) * p.wc + 4 * gi;
-                if (row >= 0 && row < p.H && x0 >= 0 && x0 + 4 <= p.wpad) {
-                    const u32x3_a4 *src = reinterpret_cast<const u32x3_a4 *>(img + (size_t)row * p.pitch + (size_t)x0 * 3);
-                    const u32x3 w = __builtin_nontemporal_load(src);
-                    v[u].a = w.x; v[u].b = w.y; v[u].c = w.z;
+    for (int k = 0; k < KMAX; k++) {
+        if (ASYNC || k < K) {  // wave-uniform
+            // byte offset of group 64k+lane inside the row; lanes beyond the window or the image columns re-read the
+            // window's first in-image group (no extra traffic, data never used)
+            const int gi = 64 * k + lane;
+            const int x0 = p.cx0 + 4 * gi;
+            const bool incol = gi < p.gpr && x0 >= 0 && x0 + 4 <= p.wpad;
+            const int xs = p.cx0 < 0 ? 0 : p.cx0;
+            const uint8_t *src = rowp + (incol ? x0 : xs) * 3;
+            if (ASYNC) w[k] = async_ld12_nt(src);
+            else w[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4 *>(src));
+        }
+    }
+}
+
+template <int KMAX>
+__device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, int r, int qsel, int lane, const u32x3 (&w)[KMAX]) {
+    const int K = p.nseg;
+    const int row = r + p.m0 - p.halo;
+    const bool rowok = row >= 0 && row < p.H;  // wave-uniform
+    uint32_t *ringrow = L.ring + (r & (RR - 1)) * p.wc;
+    uint32_t *occrow = L.occ + (r & (RO - 1)) * p.occw;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        if (k < K) {  // wave-uniform
+            const int gi = 64 * k + lane;
+            const int x0 = p.cx0 + 4 * gi;
+            const bool inwin = gi < p.gpr;
+            const bool incol = rowok && inwin && x0 >= 0 && x0 + 4 <= p.wpad;
+            const uint32_t a = w[k].x, b = w[k].y, c = w[k].z;
+            const bool nz = incol && (a | b | c) != 0;
+            if (inwin) *reinterpret_cast<uint4 *>(ringrow + 4 * gi) = incol ? make_uint4(a, b, c, 0) : make_uint4(0, 0, 0, 0);
+            const unsigned long long bal = __ballot(nz);
+            if (lane == 0) *reinterpret_cast<uint2 *>(occrow + 2 * k) = make_uint2((uint32_t)bal, (uint32_t)(bal >> 32));
+            if (bal != 0 && !(p.debug & 8)) {  // wave-uniform
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&L.qcount[qsel], __popcll(bal));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (nz) {
+                    const int dst = (r & (RR - 1)) * p.wc + 4 * gi;
+                    const int my = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+                    if (my < QCAP) {
+                        L.queue[my] = (uint16_t)(dst >> 2);
+                    } else {  // queue full (dense target): convert in place now
+                        *reinterpret_cast<uint4 *>(L.ring + dst) = convert4(a, b, c, p.data_thr);
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (dst[u] >= 0) {
-                uint4 codes = make_uint4(0, 0, 0, 0);
-                if (!(p.debug & 2) && __any((v[u].a | v[u].b | v[u].c) != 0)) codes = convert4(v[u], p.data_thr);
-                *reinterpret_cast<uint4 *>(ring + dst[u]) = codes;
-            }
-        }
     }
 }
 
-// Software-pipelined staging: issue_loads() puts the raw 12-byte groups of rows [ra, rb) into registers
-// (the loads stay in flight while the previous band is probed), commit() converts them and writes the ring.
-template <int RR, int NT, int UP>
-__device__ __forceinline__ void issue_loads(const ScanParams &p, const uint8_t *img, int ra, int rb, u3 (&v)[UP], int (&dst)[UP]) {
-    const int items = (rb - ra) * p.gpr;
-    const int rowbase = p.m0 - p.halo;
-#pragma unroll
-    for (int u = 0; u < UP; u++) {
-        const int it = threadIdx.x + u * NT;
-        v[u].a = v[u].b = v[u].c = 0;
-        dst[u] = -1;
-        if (it < items) {
-            const int rr = (int)__umulhi((uint32_t)it, p.gpr_magic);
-            const int gi = it - rr * p.gpr;
-            const int rel = ra + rr;
-            const int row = rel + rowbase;
-            const int x0 = p.cx0 + 4 * gi;
-            dst[u] = (rel & (RR - 1)) * p.wc + 4 * gi;
-            if (row >= 0 && row < p.H && x0 >= 0 && x0 + 4 <= p.wpad) {
-                const u32x3_a4 *src = reinterpret_cast<const u32x3_a4 *>(img + (size_t)row * p.pitch + (size_t)x0 * 3);
-                const u32x3 w = __builtin_nontemporal_load(src);
-                v[u].a = w.x; v[u].b = w.y; v[u].c = w.z;
-            }
-        }
+// Phase A for rows [ra, ra+n) (rows relative to m0-halo): wave w stages rows ra+w, ra+w+NW, ...  A row is
+// K = ceil(gpr/64) segments of 64 groups (12 bytes each): lane l of segment k loads group 64k+l, so every load
+// instruction reads 768 contiguous bytes from a wave-uniform row pointer and all K loads of a row are in flight
+// together.  The raw group goes to the ring as (a,b,c,0) -- a black group is already its all-zero code --, the
+// segment's ballot IS its two occupancy words, and every non-black group is queued for phase B.
+template <int KMAX>
+__device__ __forceinline__ void stage_a(const ScanParams &p, const uint8_t *img, const Lds &L, int ra, int n, int qsel,
+                                        int wave, int lane) {
+    for (int r = ra + wave; r < ra + n; r += NW) {  // wave-uniform
+        u32x3 w[KMAX];
+        a_issue<KMAX, false>(p, img, r, lane, w);
+        a_commit<KMAX>(p, L, r, qsel, lane, w);
     }
 }
 
-template <int UP>
-__device__ __forceinline__ void commit(const ScanParams &p, uint32_t *ring, const u3 (&v)[UP], const int (&dst)[UP]) {
-#pragma unroll
-    for (int u = 0; u < UP; u++) {
-        if (dst[u] >= 0) {
-            uint4 codes = make_uint4(0, 0, 0, 0);
-            if (!(p.debug & 2) && __any((v[u].a | v[u].b | v[u].c) != 0)) codes = convert4(v[u], p.data_thr);
-            *reinterpret_cast<uint4 *>(ring + dst[u]) = codes;
-        }
-        __builtin_amdgcn_sched_barrier(0);  // one group at a time: keeps the live ranges (VGPRs) short
+// Phase B: convert the queued groups in place.
+__device__ __forceinline__ void stage_b(const ScanParams &p, const Lds &L, int qsel) {
+    int n = L.qcount[qsel];
+    n = n < QCAP ? n : QCAP;
+    for (int e = threadIdx.x; e < n; e += NT) {
+        const int idx = (int)L.queue[e] << 2;
+        const uint4 raw = *reinterpret_cast<const uint4 *>(L.ring + idx);
+        *reinterpret_cast<uint4 *>(L.ring + idx) = convert4(raw.x, raw.y, raw.z, p.data_thr);
     }
 }
 
@@ -134,119 +201,193 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// True when no group of the chunk's neighbourhood -- groups [g0, g1] x ring rows [r0, r0+nr) -- is occupied.
+// desc = g0 | g1 << 9 | testable << 31 (the host only marks regions spanning <= 2 occupancy words per row as
+// testable).  Lane l tests word (row l>>1, word (g0>>5) + (l&1)).
+__device__ __forceinline__ bool region_empty(const Lds &L, int occw, uint32_t desc, int r0, int nr, int lane) {
+    if (!(desc >> 31)) return false;
+    const int g0 = desc & 511, g1 = (desc >> 9) & 511;
+    const int wd = (g0 >> 5) + (lane & 1);
+    const int q = lane >> 1;
+    bool hit = false;
+    if (q < nr && wd <= (g1 >> 5)) {
+        const uint32_t w = L.occ[((r0 + q) & (RO - 1)) * occw + wd];
+        const int lo = g0 - 32 * wd, hi = g1 - 32 * wd;
+        uint32_t m = ~0u;
+        if (lo > 0) m &= ~0u << lo;
+        if (hi < 31) m &= ~(~0u << (hi + 1));
+        hit = (w & m) != 0;
+    }
+    return __ballot(hit) == 0;
+}
+
 // XY2: xyShift == 2 (9 shifts) else 0 (1 shift).  MIRROR: also the mirrored orientation.
 // MULTI: several masks share the staged rows (counts by wave ballot into LDS) else one mask with
 // per-lane counters kept in registers for the whole target.
-template <bool XY2, bool MIRROR, bool MULTI, int BH, int RR, int NT, int UP>
+//
+// Per band of BH mask rows the workgroup runs three phases separated by barriers -- A: stage the band's new target
+// rows (raw) and queue the non-black groups; B: convert the queued groups; P: probe.  The code ring holds exactly
+// the BH + 4 rows one band needs (18.9 KB for the benchmark window), so that 7-8 workgroups share a CU and cover
+// each other's memory latency and barrier waits; the (tiny) occupancy ring is twice as deep so that phase A of the
+// next band can set bits while nobody reads the rows it replaces.
+template <bool XY2, bool MIRROR, bool MULTI, int KMAX>
 __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr int NS = XY2 ? 9 : 1;
     constexpr int NSX = XY2 ? 3 : 1;
     constexpr int NO = MIRROR ? 2 : 1;
     constexpr int NC = NS * NO;
-    uint32_t *ring = lds;
-    int *cnt = reinterpret_cast<int *>(ring + RR * p.wc);  // MULTI: [n_masks][NC]; single: [NC]
+    Lds L;
+    L.ring = lds;
+    L.occ = L.ring + RR * p.wc;
+    L.queue = reinterpret_cast<uint16_t *>(L.occ + RO * p.occw);
+    L.qcount = reinterpret_cast<int *>(L.queue + QCAP);
+    L.cnt = L.qcount + 2;  // MULTI: [n_masks][NC]; single: [NC]
     const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int halo = XY2 ? 2 : 0;
     const int m1rel = p.nrows;  // mask rows are [0, nrows) relative to m0
 
     for (int64_t t = blockIdx.x; t < p.count; t += gridDim.x) {
         const uint8_t *img = p.lib + (size_t)t * p.img_stride;
         const int ncnt = MULTI ? p.n_masks * NC : NC;
-        for (int i = threadIdx.x; i < ncnt; i += NT) cnt[i] = 0;
+        for (int i = threadIdx.x; i < ncnt; i += NT) L.cnt[i] = 0;
+        if (threadIdx.x < 2) L.qcount[threadIdx.x] = 0;
+        for (int i = threadIdx.x; i < RO * p.occw; i += NT) L.occ[i] = 0;
         int acc[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) acc[k] = 0;
-
-        // Band k = mask rows [k*BH, (k+1)*BH) needs ring rows up to (k+1)*BH + 2*halo (relative to m0-halo).
-        // The first band is staged directly; every later band is loaded into registers one band ahead
-        // (pipelined when it fits UP*NT groups) and committed to the ring after the previous band's probes.
-        constexpr int UPA = UP > 0 ? UP : 1;
-        const bool pipelined = UP > 0 && BH * p.gpr <= UP * NT;
-        u3 pv[UPA];
-        int pdst[UPA];
-        int staged = ((BH < m1rel) ? BH : m1rel) + 2 * halo;
-        stage_rows<RR, NT>(p, img, ring, 0, staged);
-        int pre_end = staged;  // rows [staged, pre_end) are in flight in pv
-        if (pipelined && BH < m1rel) {
-            pre_end = ((2 * BH < m1rel) ? 2 * BH : m1rel) + 2 * halo;
-            issue_loads<RR, NT, UPA>(p, img, staged, pre_end, pv, pdst);
-        }
         __syncthreads();
-        for (int y0 = 0; y0 < m1rel; y0 += BH) {
+
+        // band b = mask rows [b*BH, (b+1)*BH) needs target rows [b*BH, (b+1)*BH + 2*halo) (relative to m0-halo).
+        // Band 0 is staged directly.  Every later band adds BH = NW new rows, one per wave: at the top of band b the
+        // wave issues (asynchronously) the mask data of band b and then the loads of ITS row of band b+1, which stay
+        // in flight during phases B and P of band b; after the band's last barrier the row is committed to the ring.
+        int staged = ((BH < m1rel) ? BH : m1rel) + 2 * halo;
+        stage_a<KMAX>(p, img, L, 0, staged, 0, wave, lane);
+        int band = 0;
+        for (int y0 = 0; y0 < m1rel; y0 += BH, band++) {
             const int y1 = (y0 + BH < m1rel) ? y0 + BH : m1rel;
+            const int qsel = band & 1;
+            // mask data of this wave's first MAXC chunks of the band (chunks are padded to 64 pixels: pixel index =
+            // chunk * 64 + lane); a wave without a chunk re-reads the band's first chunk and ignores it
+            const uint32_t cbeg0 = p.bandptr[band], cend0 = p.bandptr[band + 1];
+            u32x4 pch[MAXC], piv[MAXC];
+            uint32_t ppos[MAXC];
+#pragma unroll
+            for (int k = 0; k < MAXC; k++) {
+                uint32_t ci = cbeg0 + wave + k * NW;
+                ci = ci < cend0 ? ci : cbeg0;
+                pch[k] = async_ld16(p.chunks + ci);
+                ppos[k] = async_ld4(p.px_pos + (size_t)ci * 64 + lane);
+                piv[k] = async_ld16(p.px_iv + (size_t)ci * 64 + lane);
+            }
+            // this wave's RPW rows of the next band (clamped and ignored where there is none)
+            const int next_end = (y1 < m1rel) ? ((y1 + BH < m1rel) ? y1 + BH : m1rel) + 2 * halo : staged;
+            u32x3 pw[RPW][KMAX];
+#pragma unroll
+            for (int j = 0; j < RPW; j++) {
+                const int my_row = staged + wave + j * NW;
+                a_issue<KMAX, true>(p, img, my_row < next_end ? my_row : staged - 1, lane, pw[j]);
+            }
+            __syncthreads();  // phase A of this band is complete
+            // ---- phase B (+ the next band's queue counter)
+            if (threadIdx.x == 0) L.qcount[qsel ^ 1] = 0;
+            if (!(p.debug & 2)) stage_b(p, L, qsel);
+            __syncthreads();
+            // ---- phase P: the mask data has arrived when at most the RPW*KMAX row loads are outstanding
+#pragma unroll
+            for (int k = 0; k < MAXC; k++) wait_mask<RPW * KMAX>(pch[k], ppos[k], piv[k]);
+            auto probe_chunk = [&](const uint4 ch, const uint32_t pos, const uint4 iv, int *ctr) {
+                const int r0 = ch.y & 1023, nr = (ch.y >> 10) & 31;
+                const bool do_plain = (p.debug & 4) || !region_empty(L, p.occw, ch.z, r0, nr, lane);
+                const bool do_mirror = MIRROR && ((p.debug & 4) || !region_empty(L, p.occw, ch.w, r0, nr, lane));
+                if (!(do_plain || do_mirror)) return;
+                const int cpl = pos & 2047, cmi = (pos >> 11) & 2047, yrel = pos >> 22;
+#pragma unroll
+                for (int iy = 0; iy < NSX; iy++) {
+                    const int rel = yrel + (XY2 ? 2 * iy : 0);  // = yrel + halo + dy
+                    const uint32_t *rowp = L.ring + (rel & (RR - 1)) * p.wc;
+                    if (do_plain) {
+#pragma unroll
+                        for (int ix = 0; ix < NSX; ix++) {
+                            const int dx = XY2 ? 2 * (ix - 1) : 0;
+                            const int k = ix * NSX + iy;
+                            const uint32_t c = rowp[cpl + dx];
+                            const bool hit = ((c - iv.x) <= iv.y) | ((c - iv.z) <= iv.w);
+                            if (MULTI) ctr[k] += __popcll(__ballot(hit));
+                            else ctr[k] += hit ? 1 : 0;
+                        }
+                    }
+                    if (do_mirror) {
+#pragma unroll
+                        for (int ix = 0; ix < NSX; ix++) {
+                            const int dx = XY2 ? 2 * (ix - 1) : 0;
+                            const int k = ix * NSX + iy;
+                            const uint32_t c = rowp[cmi - dx];
+                            const bool hit = ((c - iv.x) <= iv.y) | ((c - iv.z) <= iv.w);
+                            if (MULTI) ctr[NS + k] += __popcll(__ballot(hit));
+                            else ctr[NS + k] += hit ? 1 : 0;
+                        }
+                    }
+                }
+            };
             const int nm = (p.debug & 1) ? 0 : (MULTI ? p.n_masks : 1);
             for (int g = 0; g < nm; g++) {
-                const uint32_t *rp = p.rowptr + (size_t)g * (p.nrows + 1);
-                const uint32_t s = rp[y0], e = rp[y1];
+                // (mask 0 reuses the values loaded at the top of the band: a compiler-issued load here would carry an
+                // s_waitcnt vmcnt(0) and with it wait for the next band's rows)
+                uint32_t cbeg = cbeg0, cend = cend0;
+                if (MULTI && g > 0) {
+                    const uint32_t *bp = p.bandptr + (size_t)g * (p.nbands + 1) + band;
+                    cbeg = bp[0];
+                    cend = bp[1];
+                }
                 int sacc[NC];
                 if (MULTI) {
 #pragma unroll
                     for (int k = 0; k < NC; k++) sacc[k] = 0;
                 }
-                for (uint32_t i = s + threadIdx.x; i < e; i += NT) {
-                    const uint32_t pos = p.px_pos[i];
-                    const uint4 iv = p.px_iv[i];
-                    const int cpl = pos & 2047, cmi = (pos >> 11) & 2047, yrel = pos >> 22;
+                uint32_t ci = cbeg + wave;
+                if (g == 0) {
 #pragma unroll
-                    for (int iy = 0; iy < NSX; iy++) {
-                        const int rel = yrel + (XY2 ? 2 * iy : 0);  // = yrel + halo + dy
-                        const uint32_t *rowp = ring + (rel & (RR - 1)) * p.wc;
-#pragma unroll
-                        for (int ix = 0; ix < NSX; ix++) {
-                            const int dx = XY2 ? 2 * (ix - 1) : 0;
-                            const int k = ix * NSX + iy;
-                            {
-                                const uint32_t c = rowp[cpl + dx];
-                                const bool hit = ((c - iv.x) <= iv.y) | ((c - iv.z) <= iv.w);
-                                if (MULTI) sacc[k] += __popcll(__ballot(hit));
-                                else acc[k] += hit ? 1 : 0;
-                            }
-                            if (MIRROR) {
-                                const uint32_t c = rowp[cmi - dx];
-                                const bool hit = ((c - iv.x) <= iv.y) | ((c - iv.z) <= iv.w);
-                                if (MULTI) sacc[NS + k] += __popcll(__ballot(hit));
-                                else acc[NS + k] += hit ? 1 : 0;
-                            }
-                        }
+                    for (int k = 0; k < MAXC; k++) {
+                        if (ci < cend)
+                            probe_chunk(make_uint4(pch[k].x, pch[k].y, pch[k].z, pch[k].w), ppos[k],
+                                        make_uint4(piv[k].x, piv[k].y, piv[k].z, piv[k].w), MULTI ? sacc : acc);
+                        ci += NW;
                     }
                 }
+                for (; ci < cend; ci += NW)
+                    probe_chunk(p.chunks[ci], p.px_pos[ci * 64 + lane], p.px_iv[ci * 64 + lane], MULTI ? sacc : acc);
                 if (MULTI) {
                     if (lane == 0) {
 #pragma unroll
                         for (int k = 0; k < NC; k++)
-                            if (sacc[k]) atomicAdd(&cnt[g * NC + k], sacc[k]);
+                            if (sacc[k]) atomicAdd(&L.cnt[g * NC + k], sacc[k]);
                     }
                 }
             }
-            if (y1 < m1rel) {  // make the next band's rows available
-                if (pipelined) {
-                    commit<UPA>(p, ring, pv, pdst);
-                    staged = pre_end;
-                    const int y2 = (y1 + BH < m1rel) ? y1 + BH : m1rel;
-                    if (y2 < m1rel) {
-                        pre_end = ((y2 + BH < m1rel) ? y2 + BH : m1rel) + 2 * halo;
-                        issue_loads<RR, NT, UPA>(p, img, staged, pre_end, pv, pdst);
-                    }
-                } else {
-                    const int need = ((y1 + BH < m1rel) ? y1 + BH : m1rel) + 2 * halo;
-                    stage_rows<RR, NT>(p, img, ring, staged, need);
-                    staged = need;
-                }
-                __syncthreads();
+            __syncthreads();  // the next band's phase A overwrites the oldest BH rows of the ring
+            // ---- phase A of the next band: the rows loaded at the top of this band
+#pragma unroll
+            for (int j = 0; j < RPW; j++) {
+                const int my_row = staged + wave + j * NW;
+                wait_rows<KMAX>(pw[j]);
+                if (my_row < next_end) a_commit<KMAX>(p, L, my_row, qsel ^ 1, lane, pw[j]);
             }
+            staged = next_end;
         }
         if (!MULTI) {
 #pragma unroll
             for (int k = 0; k < NC; k++) {
                 int v = wave_sum(acc[k]);
-                if (lane == 0 && v) atomicAdd(&cnt[k], v);
+                if (lane == 0 && v) atomicAdd(&L.cnt[k], v);
             }
         }
         __syncthreads();
         const int nm = MULTI ? p.n_masks : 1;
         for (int g = threadIdx.x; g < nm; g += NT) {
-            const int *c = cnt + g * NC;
+            const int *c = L.cnt + g * NC;
             int best = 0, bm = 0;
 #pragma unroll
             for (int k = 0; k < NS; k++) best = c[k] > best ? c[k] : best;
@@ -266,55 +407,41 @@ __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
                 }
             }
         }
-        __syncthreads();  // cnt and ring are reused by the next target
+        __syncthreads();  // cnt, queue and ring are reused by the next target
     }
 }
 
-template <bool XY2, bool MIRROR, bool MULTI, int BH, int RR, int NT, int UP>
-static int launch_cfg(const ScanParams &p, int grid, size_t lds_bytes, hipStream_t stream) {
-    auto kern = scan_kernel<XY2, MIRROR, MULTI, BH, RR, NT, UP>;
-    CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes));
+size_t scan_lds_bytes(const ScanParams &p, bool xy2, bool mirror) {
+    const int nc = (xy2 ? 9 : 1) * (mirror ? 2 : 1);
+    return (size_t)RR * p.wc * 4 + (size_t)RO * p.occw * 4 + (size_t)QCAP * 2 + 2 * sizeof(int) +
+           (size_t)(p.n_masks > 1 ? p.n_masks : 1) * nc * sizeof(int);
+}
+
+template <bool XY2, bool MIRROR, bool MULTI>
+static int launch_one(cds_context *ctx, const ScanParams &p, hipStream_t stream) {
+    const size_t lds_bytes = scan_lds_bytes(p, XY2, MIRROR);
+    if (lds_bytes > ctx->lds_per_block) return fail(CDS_ERR_UNSUPPORTED, "column window too wide for LDS");
+    int per_cu = 32;
+    if (const char *e = getenv("CDS_SCAN_WGS_PER_CU")) per_cu = atoi(e);
+    const int64_t g64 = (int64_t)ctx->n_cus * per_cu;
+    int grid = (int)(p.count < g64 ? p.count : g64);
+    if (grid < 1) grid = 1;
+    auto kern = p.nseg <= 2 ? scan_kernel<XY2, MIRROR, MULTI, 2> : p.nseg <= 3 ? scan_kernel<XY2, MIRROR, MULTI, 3>
+                : p.nseg <= 5 ? scan_kernel<XY2, MIRROR, MULTI, 5> : scan_kernel<XY2, MIRROR, MULTI, 8>;
+    CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds_bytes, stream, p);
     CDS_HIP(hipGetLastError());
     return CDS_OK;
 }
 
-template <bool XY2, bool MIRROR, bool MULTI>
-static int launch_shape(cds_context *ctx, const ScanParams &p, hipStream_t stream) {
-    constexpr int NC = (XY2 ? 9 : 1) * (MIRROR ? 2 : 1);
-    const size_t cnt_bytes = (size_t)(MULTI ? p.n_masks : 1) * NC * sizeof(int);
-    const size_t ring32 = (size_t)32 * p.wc * 4, ring16 = (size_t)16 * p.wc * 4;
-    const size_t lds_max = ctx->lds_per_block;
-    int cfg = 0;  // 0: RR=16/BH=6, 1: RR=32/BH=12
-    (void)ring32;
-    if (const char *e = getenv("CDS_SCAN_CFG")) cfg = atoi(e);
-    const bool big = (cfg == 1 || cfg == 3);
-    if (big && ring32 + cnt_bytes > lds_max) cfg = 0;
-    if (!(cfg == 1 || cfg == 3) && ring16 + cnt_bytes > lds_max) return fail(CDS_ERR_UNSUPPORTED, "column window too wide for LDS");
-    int per_cu = 8;
-    if (const char *e = getenv("CDS_SCAN_WGS_PER_CU")) per_cu = atoi(e);
-    int64_t g64 = (int64_t)ctx->n_cus * per_cu;
-    int grid = (int)(p.count < g64 ? p.count : g64);
-    if (grid < 1) grid = 1;
-    switch (cfg) {
-        case 1: return launch_cfg<XY2, MIRROR, MULTI, 12, 32, 512, 0>(p, grid, ring32 + cnt_bytes, stream);
-        case 2: return launch_cfg<XY2, MIRROR, MULTI, 6, 16, 512, 0>(p, grid, ring16 + cnt_bytes, stream);
-        case 3: return launch_cfg<XY2, MIRROR, MULTI, 12, 32, 1024, 0>(p, grid, ring32 + cnt_bytes, stream);
-        case 4: return launch_cfg<XY2, MIRROR, MULTI, 6, 16, 512, 2>(p, grid, ring16 + cnt_bytes, stream);
-        case 5: return launch_cfg<XY2, MIRROR, MULTI, 6, 16, 256, 4>(p, grid, ring16 + cnt_bytes, stream);
-        default: return launch_cfg<XY2, MIRROR, MULTI, 6, 16, 256, 0>(p, grid, ring16 + cnt_bytes, stream);
-    }
-}
-
 int launch_scan(cds_context *ctx, const ScanParams &p, bool xy2, bool mirror, hipStream_t stream) {
     const bool multi = p.n_masks > 1;
     if (xy2) {
-        if (mirror) return multi ? launch_shape<true, true, true>(ctx, p, stream) : launch_shape<true, true, false>(ctx, p, stream);
-        return multi ? launch_shape<true, false, true>(ctx, p, stream) : launch_shape<true, false, false>(ctx, p, stream);
+        if (mirror) return multi ? launch_one<true, true, true>(ctx, p, stream) : launch_one<true, true, false>(ctx, p, stream);
+        return multi ? launch_one<true, false, true>(ctx, p, stream) : launch_one<true, false, false>(ctx, p, stream);
     }
-    if (mirror) return multi ? launch_shape<false, true, true>(ctx, p, stream) : launch_shape<false, true, false>(ctx, p, stream);
-    return multi ? launch_shape<false, false, true>(ctx, p, stream) : launch_shape<false, false, false>(ctx, p, stream);
+    if (mirror) return multi ? launch_one<false, true, true>(ctx, p, stream) : launch_one<false, true, false>(ctx, p, stream);
+    return multi ? launch_one<false, false, true>(ctx, p, stream) : launch_one<false, false, false>(ctx, p, stream);
 }
 
 // v_rcp_f32 of 0..255 as this device computes it -- the host's interval builder uses the same values.
