@@ -201,16 +201,19 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
-// True when no group of the chunk's neighbourhood -- groups [g0, g1] x ring rows [r0, r0+nr) -- is occupied.
-// desc = g0 | g1 << 9 | testable << 31 (the host only marks regions spanning <= 2 occupancy words per row as
-// testable).  Lane l tests word (row l>>1, word (g0>>5) + (l&1)).
-__device__ __forceinline__ bool region_empty(const Lds &L, int occw, uint32_t desc, int r0, int nr, int lane) {
-    if (!(desc >> 31)) return false;
+// Occupancy test of a chunk's neighbourhoods, both orientations in one ballot: lanes 0..31 look at the plain
+// region, lanes 32..63 at the mirrored one.  A region = groups [g0, g1] x ring rows [r0, r0+nr) with nr <= 16; its
+// descriptor is g0 | g1 << 9 | testable << 31 (the host marks a region testable when it spans <= 2 occupancy words
+// per row).  Lane l of a half tests word (row l>>1, word (g0>>5) + (l&1)).  Returns bit 0: plain region has an
+// occupied group (or is not testable), bit 1: same for the mirrored region.
+__device__ __forceinline__ uint32_t regions_occupied(const Lds &L, int occw, uint32_t dplain, uint32_t dmirror, int r0, int nr, int lane) {
+    const uint32_t desc = lane < 32 ? dplain : dmirror;
+    const int l = lane & 31;
     const int g0 = desc & 511, g1 = (desc >> 9) & 511;
-    const int wd = (g0 >> 5) + (lane & 1);
-    const int q = lane >> 1;
-    bool hit = false;
-    if (q < nr && wd <= (g1 >> 5)) {
+    const int wd = (g0 >> 5) + (l & 1);
+    const int q = l >> 1;
+    bool hit = !(desc >> 31);  // untestable: treat as occupied
+    if ((desc >> 31) && q < nr && wd <= (g1 >> 5)) {
         const uint32_t w = L.occ[((r0 + q) & (RO - 1)) * occw + wd];
         const int lo = g0 - 32 * wd, hi = g1 - 32 * wd;
         uint32_t m = ~0u;
@@ -218,7 +221,8 @@ __device__ __forceinline__ bool region_empty(const Lds &L, int occw, uint32_t de
         if (hi < 31) m &= ~(~0u << (hi + 1));
         hit = (w & m) != 0;
     }
-    return __ballot(hit) == 0;
+    const unsigned long long bal = __ballot(hit);
+    return ((uint32_t)bal != 0 ? 1u : 0u) | ((uint32_t)(bal >> 32) != 0 ? 2u : 0u);
 }
 
 // XY2: xyShift == 2 (9 shifts) else 0 (1 shift).  MIRROR: also the mirrored orientation.
@@ -300,8 +304,8 @@ __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
             for (int k = 0; k < MAXC; k++) wait_mask<RPW * KMAX>(pch[k], ppos[k], piv[k]);
             auto probe_chunk = [&](const uint4 ch, const uint32_t pos, const uint4 iv, int *ctr) {
                 const int r0 = ch.y & 1023, nr = (ch.y >> 10) & 31;
-                const bool do_plain = (p.debug & 4) || !region_empty(L, p.occw, ch.z, r0, nr, lane);
-                const bool do_mirror = MIRROR && ((p.debug & 4) || !region_empty(L, p.occw, ch.w, r0, nr, lane));
+                const uint32_t occ2 = (p.debug & 4) ? 3u : regions_occupied(L, p.occw, ch.z, MIRROR ? ch.w : (1u << 31), r0, nr, lane);
+                const bool do_plain = occ2 & 1, do_mirror = MIRROR && (occ2 & 2);
                 if (!(do_plain || do_mirror)) return;
                 const int cpl = pos & 2047, cmi = (pos >> 11) & 2047, yrel = pos >> 22;
 #pragma unroll
@@ -315,8 +319,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
                             const int k = ix * NSX + iy;
                             const uint32_t c = rowp[cpl + dx];
                             const bool hit = ((c - iv.x) <= iv.y) | ((c - iv.z) <= iv.w);
-                            if (MULTI) ctr[k] += __popcll(__ballot(hit));
-                            else ctr[k] += hit ? 1 : 0;
+                            ctr[k] += hit ? 1 : 0;
                         }
                     }
                     if (do_mirror) {
@@ -326,44 +329,51 @@ __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
                             const int k = ix * NSX + iy;
                             const uint32_t c = rowp[cmi - dx];
                             const bool hit = ((c - iv.x) <= iv.y) | ((c - iv.z) <= iv.w);
-                            if (MULTI) ctr[NS + k] += __popcll(__ballot(hit));
-                            else ctr[NS + k] += hit ? 1 : 0;
+                            ctr[NS + k] += hit ? 1 : 0;
                         }
                     }
                 }
             };
-            const int nm = (p.debug & 1) ? 0 : (MULTI ? p.n_masks : 1);
-            for (int g = 0; g < nm; g++) {
-                // (mask 0 reuses the values loaded at the top of the band: a compiler-issued load here would carry an
-                // s_waitcnt vmcnt(0) and with it wait for the next band's rows)
-                uint32_t cbeg = cbeg0, cend = cend0;
-                if (MULTI && g > 0) {
-                    const uint32_t *bp = p.bandptr + (size_t)g * (p.nbands + 1) + band;
-                    cbeg = bp[0];
-                    cend = bp[1];
-                }
-                int sacc[NC];
-                if (MULTI) {
-#pragma unroll
-                    for (int k = 0; k < NC; k++) sacc[k] = 0;
-                }
-                uint32_t ci = cbeg + wave;
-                if (g == 0) {
+            if (!MULTI) {
+                // one mask: the band's chunks are dealt to the waves; counters stay in registers for the whole target
+                if (!(p.debug & 1)) {
+                    uint32_t ci = cbeg0 + wave;
 #pragma unroll
                     for (int k = 0; k < MAXC; k++) {
-                        if (ci < cend)
+                        if (ci < cend0)
                             probe_chunk(make_uint4(pch[k].x, pch[k].y, pch[k].z, pch[k].w), ppos[k],
-                                        make_uint4(piv[k].x, piv[k].y, piv[k].z, piv[k].w), MULTI ? sacc : acc);
+                                        make_uint4(piv[k].x, piv[k].y, piv[k].z, piv[k].w), acc);
                         ci += NW;
                     }
+                    for (; ci < cend0; ci += NW)  // (compiler-issued loads: also wait for the rows in flight; rare)
+                        probe_chunk(p.chunks[ci], p.px_pos[ci * 64 + lane], p.px_iv[ci * 64 + lane], acc);
                 }
-                for (; ci < cend; ci += NW)
-                    probe_chunk(p.chunks[ci], p.px_pos[ci * 64 + lane], p.px_iv[ci * 64 + lane], MULTI ? sacc : acc);
-                if (MULTI) {
-                    if (lane == 0) {
+            } else {
+                // mask batch: every wave owns whole masks (g = wave, wave+NW, ...), keeps per-lane counters over all
+                // chunks of (band, mask) with the next chunk's data prefetched, and adds the wave sums to its own LDS
+                // counters -- no atomics, nobody else touches cnt[g].
+                for (int g = wave; g < p.n_masks && !(p.debug & 1); g += NW) {
+                    const uint32_t *bp = p.bandptr + (size_t)g * (p.nbands + 1) + band;
+                    const uint32_t cbeg = bp[0], cend = bp[1];
+                    if (cbeg >= cend) continue;
+                    int lacc[NC];
 #pragma unroll
-                        for (int k = 0; k < NC; k++)
-                            if (sacc[k]) atomicAdd(&L.cnt[g * NC + k], sacc[k]);
+                    for (int k = 0; k < NC; k++) lacc[k] = 0;
+                    uint4 nch = p.chunks[cbeg], niv = p.px_iv[(size_t)cbeg * 64 + lane];
+                    uint32_t npos = p.px_pos[(size_t)cbeg * 64 + lane];
+                    for (uint32_t ci = cbeg; ci < cend; ci++) {
+                        const uint4 ch = nch, iv = niv;
+                        const uint32_t pos = npos;
+                        const uint32_t cn = ci + 1 < cend ? ci + 1 : ci;
+                        nch = p.chunks[cn];
+                        niv = p.px_iv[(size_t)cn * 64 + lane];
+                        npos = p.px_pos[(size_t)cn * 64 + lane];
+                        probe_chunk(ch, pos, iv, lacc);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NC; k++) {
+                        const int v = wave_sum(lacc[k]);
+                        if (lane == 0 && v) L.cnt[g * NC + k] += v;
                     }
                 }
             }
