@@ -13,6 +13,7 @@
 // mirrored orientation can read them reversed; both orientations are reduced in the same pass.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "cds_internal.hpp"
@@ -228,7 +229,6 @@ static inline int gray_nogamma(int r, int g, int b) {
 // kernel 2
 // ---------------------------------------------------------------------------------------------
 constexpr int kPlaneS = 511, kPlaneQM = 1 << 9, kPlaneQH = 1 << 10;
-constexpr int kShapeRows = 8;  // rows per LDS batch
 
 struct ShapeParams {
     const uint8_t *rgb, *zgap;
@@ -236,7 +236,8 @@ struct ShapeParams {
     size_t img_stride, grad_stride;
     int pitch, gpitch, W, H, wp;  // wp: plane row length (u16 elements), multiple of 4
     const uint16_t *planes;       // [n_masks][2][H][wp]
-    const int *boxes;             // [n_masks][2]: first row, end row with any plane bit
+    const int *boxes;             // [n_masks][8]: ya, yb (rows with any plane bit), gap columns [gx0,gx1), QH columns [hx0,hx1)
+    const uint8_t *rowflags;      // [n_masks][H]: bit0 row has gap bits (S(q) or queryMask), bit1 row has high-expression bits
     const uint8_t *slice_lut;
     int thr, mirror, nrects;
     cds_rect rects[CDS_MAX_RECTS];
@@ -264,7 +265,12 @@ __device__ __forceinline__ int gap_of(int pl, int sz, int g) {
     return gap > 3 ? gap : 0;
 }
 
+template <int kShapeRows>
 __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
+    // One workgroup scores one (mask, target) pair, 8 rows per batch, one row per wave at a time.
+    // Phase 1 (rows with gap bits only): zgap groups of the gap window and of its mirror image -> slice numbers in
+    // LDS (black groups are skipped by a wave vote).  Phase 2: per 4-pixel group the two orientation planes decide
+    // what else is needed -- gradient + S(z) when a gap bit is set, the target pixels when a high-expression bit is.
     extern __shared__ __attribute__((aligned(16))) uint16_t zs[];  // [kShapeRows][wp]
     __shared__ long long red[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -277,64 +283,89 @@ __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
         const uint8_t *gimg = reinterpret_cast<const uint8_t *>(p.grad) + (size_t)slot * p.grad_stride;
         const uint16_t *pl0 = p.planes + (size_t)m * 2 * p.H * p.wp;
         const uint16_t *pl1 = pl0 + (size_t)p.H * p.wp;
-        const int ya = p.boxes[2 * m], yb = p.boxes[2 * m + 1];
-        const int gpr = p.wp / 4;
-        long long gap0 = 0, gap1 = 0;
+        const int *bx = p.boxes + 8 * m;
+        const int ya = bx[0], yb = bx[1];
+        // gap window and the zgap columns both orientations read (the window and its mirror image), in groups of 4
+        const int gq0 = bx[2] >> 2, gq1 = (bx[3] + 3) >> 2;
+        const int zlo = min(bx[2], p.W - bx[3]), zhi = max(bx[3], p.W - bx[2]);
+        const int zq0 = (zlo < 0 ? 0 : zlo) >> 2, zq1 = ((zhi > p.W ? p.W : zhi) + 3) >> 2;
+        // columns phase 2 visits: gap window U high-expression window
+        const int aq0 = min(bx[2], bx[4]) >> 2, aq1 = (max(bx[3], bx[5]) + 3) >> 2;
+        const uint8_t *rf = p.rowflags + (size_t)m * p.H;
+        unsigned gap0 = 0, gap1 = 0;  // per lane < 2^31 for H*W <= 2M pixels (gap <= 65535 per pixel)
         int high0 = 0, high1 = 0;
         for (int y0 = ya; y0 < yb; y0 += kShapeRows) {
-            const int nr = min(kShapeRows, yb - y0);
-            // phase 1: zgap rows -> slice numbers in LDS
-            for (int it = threadIdx.x; it < nr * gpr; it += blockDim.x) {
-                const int rr = it / gpr, gi = it - rr * gpr, y = y0 + rr, x0 = 4 * gi;
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(zimg + (size_t)y * p.pitch + (size_t)x0 * 3);
-                const uint32_t a = src[0], b = src[1], c = src[2];
-                ushort4 s;
-                s.x = dev_slice(p.slice_lut, a & 255, (a >> 8) & 255, (a >> 16) & 255, p.thr);
-                s.y = dev_slice(p.slice_lut, a >> 24, b & 255, (b >> 8) & 255, p.thr);
-                s.z = dev_slice(p.slice_lut, (b >> 16) & 255, b >> 24, c & 255, p.thr);
-                s.w = dev_slice(p.slice_lut, (c >> 8) & 255, (c >> 16) & 255, c >> 24, p.thr);
-                *reinterpret_cast<ushort4 *>(zs + rr * p.wp + x0) = s;
+            // ---- phase 1
+            for (int rr = wave; rr < kShapeRows; rr += 4) {
+                const int y = y0 + rr;
+                if (y >= yb || !(rf[y] & 1)) continue;  // wave-uniform
+                const uint8_t *zrow = zimg + (size_t)y * p.pitch;
+                uint16_t *zr = zs + rr * p.wp;
+                for (int gi = zq0 + lane; gi < ((zq1 - zq0 + 63) & ~63) + zq0; gi += 64) {
+                    uint32_t a = 0, b = 0, c = 0;
+                    if (gi < zq1) {
+                        const uint32_t *src = reinterpret_cast<const uint32_t *>(zrow + (size_t)gi * 12);
+                        a = src[0]; b = src[1]; c = src[2];
+                    }
+                    ushort4 s4 = make_ushort4(0, 0, 0, 0);
+                    if (__any((a | b | c) != 0)) {
+                        s4.x = dev_slice(p.slice_lut, a & 255, (a >> 8) & 255, (a >> 16) & 255, p.thr);
+                        s4.y = dev_slice(p.slice_lut, a >> 24, b & 255, (b >> 8) & 255, p.thr);
+                        s4.z = dev_slice(p.slice_lut, (b >> 16) & 255, b >> 24, c & 255, p.thr);
+                        s4.w = dev_slice(p.slice_lut, (c >> 8) & 255, (c >> 16) & 255, c >> 24, p.thr);
+                    }
+                    if (gi < zq1) *reinterpret_cast<ushort4 *>(zr + 4 * gi) = s4;
+                }
             }
             __syncthreads();
-            // phase 2: per-pixel gap and high-expression terms, both orientations
-            for (int it = threadIdx.x; it < nr * gpr; it += blockDim.x) {
-                const int rr = it / gpr, gi = it - rr * gpr, y = y0 + rr, x0 = 4 * gi;
-                const ushort4 q0 = *reinterpret_cast<const ushort4 *>(pl0 + (size_t)y * p.wp + x0);
-                ushort4 q1 = make_ushort4(0, 0, 0, 0);
-                if (p.mirror) q1 = *reinterpret_cast<const ushort4 *>(pl1 + (size_t)y * p.wp + x0);
-                if (((q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w)) == 0) continue;
-                const ushort4 g = *reinterpret_cast<const ushort4 *>(gimg + (size_t)y * p.gpitch + (size_t)x0 * 2);
+            // ---- phase 2
+            for (int rr = wave; rr < kShapeRows; rr += 4) {
+                const int y = y0 + rr;
+                if (y >= yb) continue;
+                const int flags = rf[y];
+                if (!flags) continue;  // wave-uniform
                 const uint16_t *zr = zs + rr * p.wp;
-                const int qa[4] = {q0.x, q0.y, q0.z, q0.w}, qb[4] = {q1.x, q1.y, q1.z, q1.w}, gg[4] = {g.x, g.y, g.z, g.w};
-                int anyh = 0;
+                const int q0 = (flags & 2) ? aq0 : gq0, q1 = (flags & 2) ? aq1 : gq1;
+                for (int gi = q0 + lane; gi < q1; gi += 64) {
+                    const int x0 = 4 * gi;
+                    const ushort4 qa = *reinterpret_cast<const ushort4 *>(pl0 + (size_t)y * p.wp + x0);
+                    ushort4 qb = make_ushort4(0, 0, 0, 0);
+                    if (p.mirror) qb = *reinterpret_cast<const ushort4 *>(pl1 + (size_t)y * p.wp + x0);
+                    const int all = qa.x | qa.y | qa.z | qa.w | qb.x | qb.y | qb.z | qb.w;
+                    if (!all) continue;
+                    const int pa[4] = {qa.x, qa.y, qa.z, qa.w}, pb[4] = {qb.x, qb.y, qb.z, qb.w};
+                    if (all & (kPlaneS | kPlaneQM)) {
+                        const ushort4 g = *reinterpret_cast<const ushort4 *>(gimg + (size_t)y * p.gpitch + (size_t)x0 * 2);
+                        const int gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int x = x0 + j;
-                    if (x >= p.W) break;
-                    gap0 += gap_of(qa[j], zr[x], gg[j]);
-                    if (p.mirror) gap1 += gap_of(qb[j], zr[p.W - 1 - x], gg[j]);
-                    anyh |= (qa[j] | qb[j]) & kPlaneQH;
-                }
-                if (anyh) {
-                    const uint32_t *src = reinterpret_cast<const uint32_t *>(timg + (size_t)y * p.pitch + (size_t)x0 * 3);
-                    const uint32_t a = src[0], b = src[1], c = src[2];
-                    const int mx[4] = {max(max((int)(a & 255), (int)((a >> 8) & 255)), (int)((a >> 16) & 255)),
-                                       max(max((int)(a >> 24), (int)(b & 255)), (int)((b >> 8) & 255)),
-                                       max(max((int)((b >> 16) & 255), (int)(b >> 24)), (int)(c & 255)),
-                                       max(max((int)((c >> 8) & 255), (int)((c >> 16) & 255)), (int)(c >> 24))};
+                        for (int j = 0; j < 4; j++) {
+                            const int x = x0 + j;
+                            if (x >= p.W) break;
+                            gap0 += gap_of(pa[j], zr[x], gg[j]);
+                            if (p.mirror) gap1 += gap_of(pb[j], zr[p.W - 1 - x], gg[j]);
+                        }
+                    }
+                    if (all & kPlaneQH) {
+                        const uint32_t *src = reinterpret_cast<const uint32_t *>(timg + (size_t)y * p.pitch + (size_t)x0 * 3);
+                        const uint32_t a = src[0], b = src[1], c = src[2];
+                        const int mx[4] = {max(max((int)(a & 255), (int)((a >> 8) & 255)), (int)((a >> 16) & 255)),
+                                           max(max((int)(a >> 24), (int)(b & 255)), (int)((b >> 8) & 255)),
+                                           max(max((int)((b >> 16) & 255), (int)(b >> 24)), (int)(c & 255)),
+                                           max(max((int)((c >> 8) & 255), (int)((c >> 16) & 255)), (int)(c >> 24))};
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int x = x0 + j;
-                        if (x >= p.W) break;
-                        const bool sig = mx[j] > p.thr && !dev_in_rects(p.rects, p.nrects, x, y);
-                        high0 += (sig && (qa[j] & kPlaneQH)) ? 1 : 0;
-                        high1 += (sig && (qb[j] & kPlaneQH)) ? 1 : 0;
+                        for (int j = 0; j < 4; j++) {
+                            const int x = x0 + j;
+                            if (x >= p.W) break;
+                            const bool sig = mx[j] > p.thr && !dev_in_rects(p.rects, p.nrects, x, y);
+                            high0 += (sig && (pa[j] & kPlaneQH)) ? 1 : 0;
+                            high1 += (sig && (pb[j] & kPlaneQH)) ? 1 : 0;
+                        }
                     }
                 }
             }
             __syncthreads();
         }
-        long long v[4] = {gap0, (long long)high0, gap1, (long long)high1};
+        long long v[4] = {(long long)gap0, (long long)high0, (long long)gap1, (long long)high1};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             long long s = v[k];
@@ -362,6 +393,7 @@ struct cds_shapeset {
     cds_rect rects[CDS_MAX_RECTS];
     uint16_t *d_planes = nullptr;
     int *d_boxes = nullptr;
+    uint8_t *d_rowflags = nullptr;
     std::vector<int64_t> qm_sum, qh_sum;
     mutable std::mutex mu;
     mutable double last_ms = 0;
@@ -394,7 +426,8 @@ int cds_shapeset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_
     const int wp = round_up(W, 4);
     std::vector<uint8_t> Q(3 * N), d60(3 * N), d20(3 * N);
     std::vector<uint16_t> planes((size_t)n_masks * 2 * H * wp, 0);
-    std::vector<int> boxes((size_t)n_masks * 2);
+    std::vector<int> boxes((size_t)n_masks * 8, 0);
+    std::vector<uint8_t> rowflags((size_t)n_masks * H, 0);
     cds_shapeset *ss = new cds_shapeset();
     ss->ctx = ctx; ss->W = W; ss->H = H; ss->wp = wp; ss->n_masks = n_masks; ss->thr = query_threshold; ss->mirror = mirror != 0;
     ss->nrects = n_excluded;
@@ -415,7 +448,13 @@ int cds_shapeset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_
         if (rc == CDS_OK) rc = max_filter_host(ctx, Q.data(), W, H, 20, -1, nullptr, 0, d20.data());
         if (rc) { delete ss; return rc; }
         uint16_t *p0 = planes.data() + (size_t)m * 2 * H * wp, *p1 = p0 + (size_t)H * wp;
-        int ya = H, yb = 0;
+        int ya = H, yb = 0, gx0 = W, gx1 = 0, hx0 = W, hx1 = 0;
+        uint8_t *rfl = rowflags.data() + (size_t)m * H;
+        auto mark = [&](int x, int y, uint16_t v) {
+            ya = std::min(ya, y); yb = std::max(yb, y + 1);
+            if (v & (kPlaneS | kPlaneQM)) { gx0 = std::min(gx0, x); gx1 = std::max(gx1, x + 1); rfl[y] |= 1; }
+            if (v & kPlaneQH) { hx0 = std::min(hx0, x); hx1 = std::max(hx1, x + 1); rfl[y] |= 2; }
+        };
         for (int y = 0; y < H; y++)
             for (int x = 0; x < W; x++) {
                 size_t i = (size_t)y * W + x;
@@ -431,15 +470,22 @@ int cds_shapeset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_
                 // the ROI (already cleared in the excluded regions, Factory:96-100) is applied after mirroring
                 const int xm = W - 1 - x;
                 auto roi_in = [&](int xx) { return !roi || (roi[(size_t)y * W + xx] != 0 && !in_rects_host(excluded, n_excluded, xx, y)); };
-                if (roi_in(x)) { p0[(size_t)y * wp + x] = v; ya = std::min(ya, y); yb = std::max(yb, y + 1); }
-                if (mirror && roi_in(xm)) { p1[(size_t)y * wp + xm] = v; ya = std::min(ya, y); yb = std::max(yb, y + 1); }
+                if (roi_in(x)) { p0[(size_t)y * wp + x] = v; mark(x, y, v); }
+                if (mirror && roi_in(xm)) { p1[(size_t)y * wp + xm] = v; mark(xm, y, v); }
             }
         if (yb <= ya) ya = yb = 0;
-        boxes[(size_t)2 * m] = ya; boxes[(size_t)2 * m + 1] = yb;
+        if (gx1 <= gx0) gx0 = gx1 = 0;
+        if (hx1 <= hx0) hx0 = hx1 = 0;
+        if (hx1 == 0 && gx1 > 0) { hx0 = gx0; hx1 = gx0; }   // empty QH window inside the gap window
+        if (gx1 == 0 && hx1 > 0) { gx0 = hx0; gx1 = hx0; }
+        int *bxm = boxes.data() + (size_t)8 * m;
+        bxm[0] = ya; bxm[1] = yb; bxm[2] = gx0; bxm[3] = gx1; bxm[4] = hx0; bxm[5] = hx1;
     }
     hipSetDevice(ctx->device);
     hipError_t e = hipMalloc(&ss->d_planes, planes.size() * 2);
     if (e == hipSuccess) e = hipMalloc(&ss->d_boxes, boxes.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&ss->d_rowflags, rowflags.size());
+    if (e == hipSuccess) e = hipMemcpy(ss->d_rowflags, rowflags.data(), rowflags.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ss->d_planes, planes.data(), planes.size() * 2, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ss->d_boxes, boxes.data(), boxes.size() * sizeof(int), hipMemcpyHostToDevice);
     if (e != hipSuccess) { cds_shapeset_destroy(ss); return hip_fail(e, "shapeset upload"); }
@@ -452,6 +498,7 @@ void cds_shapeset_destroy(cds_shapeset *ss) {
     hipSetDevice(ss->ctx->device);
     if (ss->d_planes) hipFree(ss->d_planes);
     if (ss->d_boxes) hipFree(ss->d_boxes);
+    if (ss->d_rowflags) hipFree(ss->d_rowflags);
     delete ss;
 }
 
@@ -509,18 +556,28 @@ int cds_gradscore(const cds_shapeset *ss, const cds_library *lib, int64_t n_pair
     p.rgb = lib->d_rgb; p.zgap = lib->d_zgap; p.grad = lib->d_grad;
     p.img_stride = lib->img_stride; p.grad_stride = lib->grad_stride;
     p.pitch = lib->pitch; p.gpitch = lib->gpitch; p.W = ss->W; p.H = ss->H; p.wp = ss->wp;
-    p.planes = ss->d_planes; p.boxes = ss->d_boxes; p.slice_lut = ctx->d_slice_lut;
+    p.planes = ss->d_planes; p.boxes = ss->d_boxes; p.rowflags = ss->d_rowflags; p.slice_lut = ctx->d_slice_lut;
     p.thr = ss->thr; p.mirror = ss->mirror; p.nrects = ss->nrects;
     for (int i = 0; i < ss->nrects; i++) p.rects[i] = ss->rects[i];
     p.pair_mask = d_pm; p.pair_slot = d_ps; p.n_pairs = n_pairs; p.out = d_out;
-    const size_t lds = (size_t)kShapeRows * ss->wp * sizeof(uint16_t);
-    int64_t g64 = (int64_t)ctx->n_cus * 8;
+    int rows = 8;  // rows per LDS batch (19 KB of LDS: 8 workgroups per CU)
+    if (const char *e = getenv("CDS_SHAPE_ROWS")) rows = atoi(e);
+    rows = rows <= 8 ? 8 : (rows <= 16 ? 16 : 32);
+    const size_t lds = (size_t)rows * ss->wp * sizeof(uint16_t);
+    int per_cu = 32;
+    if (const char *e = getenv("CDS_SHAPE_WGS_PER_CU")) per_cu = atoi(e);
+    int64_t g64 = (int64_t)ctx->n_cus * per_cu;
     int grid = (int)std::min<int64_t>(n_pairs, g64);
     hipEvent_t ev0, ev1;
     GS_HIP(hipEventCreate(&ev0));
     GS_HIP(hipEventCreate(&ev1));
     GS_HIP(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(gradscore_kernel, dim3(grid), dim3(256), lds, st, p);
+    if (rows == 8) hipLaunchKernelGGL(gradscore_kernel<8>, dim3(grid), dim3(256), lds, st, p);
+    else if (rows == 16) hipLaunchKernelGGL(gradscore_kernel<16>, dim3(grid), dim3(256), lds, st, p);
+    else {
+        GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gradscore_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gradscore_kernel<32>, dim3(grid), dim3(256), lds, st, p);
+    }
     GS_HIP(hipGetLastError());
     GS_HIP(hipEventRecord(ev1, st));
     std::vector<int64_t> res((size_t)n_pairs * 4);
