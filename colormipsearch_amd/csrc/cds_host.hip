@@ -503,6 +503,10 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
         clo = std::min(clo, W - xhi - shift);
         chi = std::max(chi, W - xlo + shift);
     }
+    if (getenv("CDS_SCAN_FULLWINDOW")) {  // experiment: stage whole rows instead of the column window
+        clo = std::min(clo, 0);
+        chi = std::max(chi, W);
+    }
     ms->cx0 = floor4(clo) & ~15;                       // floor to a multiple of 16 pixels (also for negatives)
     ms->wc = std::max(32, ((ceil4(chi) - ms->cx0) + 15) & ~15);   // >= 2 items per row (32-bit magic division)
     ms->m0 = m0; ms->m1 = m1;

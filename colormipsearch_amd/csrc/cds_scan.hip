@@ -42,6 +42,11 @@ __device__ __forceinline__ u32x3 async_ld12_nt(const void *ptr) {
     asm volatile("global_load_dwordx3 %0, %1, off nt" : "=v"(v) : "v"(ptr) : "memory");
     return v;
 }
+__device__ __forceinline__ u32x3 async_ld12(const void *ptr) {
+    u32x3 v;
+    asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
 __device__ __forceinline__ u32x4 async_ld16(const void *ptr) {
     u32x4 v;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
@@ -109,78 +114,112 @@ struct Lds {
 // together (the lane offsets are clamped, not branched, for the lanes beyond the window).  The raw group goes to
 // the ring as (a,b,c,0) -- a black group is already its all-zero code --, the segment's ballot IS its two
 // occupancy words, and every non-black group is queued for phase B.
-// a_issue: the K loads of ring row r into registers.  a_commit: registers -> ring / occupancy / queue.
-template <int KMAX, bool ASYNC>  // KMAX: compile-time bound of K.  ASYNC: all KMAX loads are issued by asm (manual wait)
-__device__ __forceinline__ void a_issue(const ScanParams &p, const uint8_t *img, int r, int lane, u32x3 (&w)[KMAX]) {
-    const int K = p.nseg;
-    int row = r + p.m0 - p.halo;
-    row = row < 0 ? 0 : (row >= p.H ? p.H - 1 : row);  // rows outside the image are loaded (clamped) and ignored
-    const uint8_t *rowp = img + (uint32_t)(row * p.pitch);
-#pragma unroll
-    for (int k = 0; k < KMAX; k++) {
-        if (ASYNC || k < K) {  // wave-uniform
-            // byte offset of group 64k+lane inside the row; lanes beyond the window or the image columns re-read the
-            // window's first in-image group (no extra traffic, data never used)
-            const int gi = 64 * k + lane;
-            const int x0 = p.cx0 + 4 * gi;
-            const bool incol = gi < p.gpr && x0 >= 0 && x0 + 4 <= p.wpad;
-            const int xs = p.cx0 < 0 ? 0 : p.cx0;
-            const uint8_t *src = rowp + (incol ? x0 : xs) * 3;
-            if (ASYNC) w[k] = async_ld12_nt(src);
-            else w[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4 *>(src));
-        }
-    }
-}
+// Per-lane constants of phase A, computed once per kernel: for segment k the byte offset of this lane's group inside
+// an image row, the dword offset of its slot inside a ring row, and whether the lane's data is real.
+// Lanes beyond the window (or beyond the image columns) re-read the window's first in-image group: no extra traffic;
+// lanes beyond the window also re-write that group's slot with the same value (a benign duplicate), lanes inside the
+// window but outside the image columns write zeros.
+template <int KMAX>
+struct LaneConst {
+    uint32_t ldoff[KMAX];  // byte offset inside the image row
+    int wr4[KMAX];         // dword offset inside the ring row
+    uint32_t own;          // bit k: group 64k+lane is inside window and image (data counts)
+    uint32_t zero;         // bit k: inside the window but outside the image columns (write zeros)
+};
 
 template <int KMAX>
-__device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, int r, int qsel, int lane, const u32x3 (&w)[KMAX]) {
+__device__ __forceinline__ LaneConst<KMAX> make_lane_const(const ScanParams &p, int lane) {
+    LaneConst<KMAX> lc;
+    lc.own = lc.zero = 0;
+    const int gfirst = p.cx0 < 0 ? (-p.cx0) >> 2 : 0;  // first window group inside the image
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        const int gi = 64 * k + lane;
+        const int x0 = p.cx0 + 4 * gi;
+        const bool inwin = gi < p.gpr;
+        const bool incol = inwin && x0 >= 0 && x0 + 4 <= p.wpad;
+        lc.ldoff[k] = (uint32_t)((incol ? x0 : p.cx0 + 4 * gfirst) * 3);
+        lc.wr4[k] = 4 * (inwin ? gi : gfirst);
+        lc.own |= incol ? (1u << k) : 0u;
+        lc.zero |= (inwin && !incol) ? (1u << k) : 0u;
+    }
+    return lc;
+}
+
+// a_issue: the KMAX loads of ring row r (asm: the caller waits with wait_rows before reading w).
+template <int KMAX>
+__device__ __forceinline__ void a_issue(const ScanParams &p, const uint8_t *img, const LaneConst<KMAX> &lc, int r, u32x3 (&w)[KMAX]) {
+    int row = r + p.m0 - p.halo;
+    row = row < 0 ? 0 : (row >= p.H ? p.H - 1 : row);  // rows outside the image are loaded (clamped) and ignored
+    const uint8_t *rowp = img + (uint32_t)(row * p.pitch);  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        asm volatile("global_load_dwordx3 %0, %1, %2 nt" : "=v"(w[k]) : "v"(lc.ldoff[k]), "s"(rowp) : "memory");
+}
+
+// a_commit: registers -> ring (raw) / occupancy words / queue of non-black groups.
+template <int KMAX>
+__device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, const LaneConst<KMAX> &lc, int r, int qsel, int lane,
+                                         const u32x3 (&w)[KMAX]) {
     const int K = p.nseg;
     const int row = r + p.m0 - p.halo;
     const bool rowok = row >= 0 && row < p.H;  // wave-uniform
-    uint32_t *ringrow = L.ring + (r & (RR - 1)) * p.wc;
-    uint32_t *occrow = L.occ + (r & (RO - 1)) * p.occw;
+    const int slot = r & (RR - 1);
+    uint32_t *ringrow = L.ring + slot * p.wc;
+    unsigned long long bal[KMAX];
+    int total = 0;
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
+        bal[k] = 0;
         if (k < K) {  // wave-uniform
-            const int gi = 64 * k + lane;
-            const int x0 = p.cx0 + 4 * gi;
-            const bool inwin = gi < p.gpr;
-            const bool incol = rowok && inwin && x0 >= 0 && x0 + 4 <= p.wpad;
-            const uint32_t a = w[k].x, b = w[k].y, c = w[k].z;
-            const bool nz = incol && (a | b | c) != 0;
-            if (inwin) *reinterpret_cast<uint4 *>(ringrow + 4 * gi) = incol ? make_uint4(a, b, c, 0) : make_uint4(0, 0, 0, 0);
-            const unsigned long long bal = __ballot(nz);
-            if (lane == 0) *reinterpret_cast<uint2 *>(occrow + 2 * k) = make_uint2((uint32_t)bal, (uint32_t)(bal >> 32));
-            if (bal != 0 && !(p.debug & 8)) {  // wave-uniform
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&L.qcount[qsel], __popcll(bal));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (nz) {
-                    const int dst = (r & (RR - 1)) * p.wc + 4 * gi;
-                    const int my = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+            const bool keep = rowok && !((lc.zero >> k) & 1);
+            const uint32_t a = keep ? w[k].x : 0u, b = keep ? w[k].y : 0u, c = keep ? w[k].z : 0u;
+            *reinterpret_cast<uint4 *>(ringrow + lc.wr4[k]) = make_uint4(a, b, c, 0);  // black group == zero codes
+            bal[k] = __ballot(((lc.own >> k) & 1) && (a | b | c) != 0);
+            total += __popcll(bal[k]);
+        }
+    }
+    // the segments' ballots ARE the occupancy words of the row: lane k stores segment k's
+    {
+        unsigned long long mine = bal[0];
+#pragma unroll
+        for (int k = 1; k < KMAX; k++) mine = lane == k ? bal[k] : mine;
+        if (lane < K) *reinterpret_cast<uint2 *>(L.occ + (r & (RO - 1)) * p.occw + 2 * lane) = make_uint2((uint32_t)mine, (uint32_t)(mine >> 32));
+    }
+    if (total != 0 && !(p.debug & 8)) {  // wave-uniform: one queue reservation per row
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&L.qcount[qsel], total);
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) {
+            if (k < K && bal[k] != 0) {  // wave-uniform
+                if ((bal[k] >> lane) & 1) {
+                    const int my = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[k], 0));
+                    const int dst = slot * p.wc + lc.wr4[k];
                     if (my < QCAP) {
                         L.queue[my] = (uint16_t)(dst >> 2);
                     } else {  // queue full (dense target): convert in place now
-                        *reinterpret_cast<uint4 *>(L.ring + dst) = convert4(a, b, c, p.data_thr);
+                        *reinterpret_cast<uint4 *>(L.ring + dst) = convert4(w[k].x, w[k].y, w[k].z, p.data_thr);
                     }
                 }
+                base += __popcll(bal[k]);
             }
         }
     }
 }
 
-// Phase A for rows [ra, ra+n) (rows relative to m0-halo): wave w stages rows ra+w, ra+w+NW, ...  A row is
-// K = ceil(gpr/64) segments of 64 groups (12 bytes each): lane l of segment k loads group 64k+l, so every load
-// instruction reads 768 contiguous bytes from a wave-uniform row pointer and all K loads of a row are in flight
-// together.  The raw group goes to the ring as (a,b,c,0) -- a black group is already its all-zero code --, the
-// segment's ballot IS its two occupancy words, and every non-black group is queued for phase B.
+// Phase A for rows [ra, ra+n) (rows relative to m0-halo) without prefetch (band 0): wave w stages rows ra+w, ra+w+NW, ...
+// A row is K = ceil(gpr/64) segments of 64 groups (12 bytes each): lane l of segment k loads group 64k+l, so every
+// load instruction reads 768 contiguous bytes from a wave-uniform row pointer and all loads of a row are in flight
+// together.
 template <int KMAX>
-__device__ __forceinline__ void stage_a(const ScanParams &p, const uint8_t *img, const Lds &L, int ra, int n, int qsel,
-                                        int wave, int lane) {
+__device__ __forceinline__ void stage_a(const ScanParams &p, const uint8_t *img, const Lds &L, const LaneConst<KMAX> &lc, int ra, int n,
+                                        int qsel, int wave, int lane) {
     for (int r = ra + wave; r < ra + n; r += NW) {  // wave-uniform
         u32x3 w[KMAX];
-        a_issue<KMAX, false>(p, img, r, lane, w);
-        a_commit<KMAX>(p, L, r, qsel, lane, w);
+        a_issue<KMAX>(p, img, lc, r, w);
+        wait_rows<KMAX>(w);
+        a_commit<KMAX>(p, L, lc, r, qsel, lane, w);
     }
 }
 
@@ -235,7 +274,7 @@ __device__ __forceinline__ uint32_t regions_occupied(const Lds &L, int occw, uin
 // each other's memory latency and barrier waits; the (tiny) occupancy ring is twice as deep so that phase A of the
 // next band can set bits while nobody reads the rows it replaces.
 template <bool XY2, bool MIRROR, bool MULTI, int KMAX>
-__global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
+__global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams p) {  // 4 waves/SIMD: <= 128 VGPRs
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr int NS = XY2 ? 9 : 1;
     constexpr int NSX = XY2 ? 3 : 1;
@@ -251,6 +290,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int halo = XY2 ? 2 : 0;
     const int m1rel = p.nrows;  // mask rows are [0, nrows) relative to m0
+    const LaneConst<KMAX> lc = make_lane_const<KMAX>(p, lane);
 
     for (int64_t t = blockIdx.x; t < p.count; t += gridDim.x) {
         const uint8_t *img = p.lib + (size_t)t * p.img_stride;
@@ -268,7 +308,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
         // wave issues (asynchronously) the mask data of band b and then the loads of ITS row of band b+1, which stay
         // in flight during phases B and P of band b; after the band's last barrier the row is committed to the ring.
         int staged = ((BH < m1rel) ? BH : m1rel) + 2 * halo;
-        stage_a<KMAX>(p, img, L, 0, staged, 0, wave, lane);
+        stage_a<KMAX>(p, img, L, lc, 0, staged, 0, wave, lane);
         int band = 0;
         for (int y0 = 0; y0 < m1rel; y0 += BH, band++) {
             const int y1 = (y0 + BH < m1rel) ? y0 + BH : m1rel;
@@ -292,7 +332,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
 #pragma unroll
             for (int j = 0; j < RPW; j++) {
                 const int my_row = staged + wave + j * NW;
-                a_issue<KMAX, true>(p, img, my_row < next_end ? my_row : staged - 1, lane, pw[j]);
+                a_issue<KMAX>(p, img, lc, my_row < next_end ? my_row : staged - 1, pw[j]);
             }
             __syncthreads();  // phase A of this band is complete
             // ---- phase B (+ the next band's queue counter)
@@ -383,7 +423,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
             for (int j = 0; j < RPW; j++) {
                 const int my_row = staged + wave + j * NW;
                 wait_rows<KMAX>(pw[j]);
-                if (my_row < next_end) a_commit<KMAX>(p, L, my_row, qsel ^ 1, lane, pw[j]);
+                if (my_row < next_end) a_commit<KMAX>(p, L, lc, my_row, qsel ^ 1, lane, pw[j]);
             }
             staged = next_end;
         }
@@ -431,7 +471,7 @@ template <bool XY2, bool MIRROR, bool MULTI>
 static int launch_one(cds_context *ctx, const ScanParams &p, hipStream_t stream) {
     const size_t lds_bytes = scan_lds_bytes(p, XY2, MIRROR);
     if (lds_bytes > ctx->lds_per_block) return fail(CDS_ERR_UNSUPPORTED, "column window too wide for LDS");
-    int per_cu = 32;
+    int per_cu = 128;  // many short workgroups: targets differ in sparsity, the tail balances itself
     if (const char *e = getenv("CDS_SCAN_WGS_PER_CU")) per_cu = atoi(e);
     const int64_t g64 = (int64_t)ctx->n_cus * per_cu;
     int grid = (int)(p.count < g64 ? p.count : g64);
