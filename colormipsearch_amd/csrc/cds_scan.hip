@@ -471,7 +471,7 @@ template <bool XY2, bool MIRROR, bool MULTI>
 static int launch_one(cds_context *ctx, const ScanParams &p, hipStream_t stream) {
     const size_t lds_bytes = scan_lds_bytes(p, XY2, MIRROR);
     if (lds_bytes > ctx->lds_per_block) return fail(CDS_ERR_UNSUPPORTED, "column window too wide for LDS");
-    int per_cu = 128;  // many short workgroups: targets differ in sparsity, the tail balances itself
+    int per_cu = 64;  // many short workgroups: targets differ in sparsity, the tail balances itself
     if (const char *e = getenv("CDS_SCAN_WGS_PER_CU")) per_cu = atoi(e);
     const int64_t g64 = (int64_t)ctx->n_cus * per_cu;
     int grid = (int)(p.count < g64 ? p.count : g64);

@@ -1,0 +1,40 @@
+"""The sharded search on a real GPU through RCCL (world size 1 on the one-GPU box: the gather degenerates, the
+plumbing -- torch memory, torch's stream, device score buffers, nccl process group -- is the multi-GPU one)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H = 1210, 566
+
+
+def test_sharded_library_search_single_rank(oracle):
+    import torch
+    import torch.distributed as dist
+    from colormipsearch_amd import cds
+    from colormipsearch_amd import dist as cdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rects = cds.label_regions(W)
+        n = 24
+        shard = cdist.ShardedLibrary(W, H, n)
+        assert (shard.begin, shard.end) == (0, n)
+        shard.generate_synthetic(0xC0FFEE, kind=1)
+        masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(2)])
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects, context=shard.ctx)
+        packed = shard.search(alg)
+        torch.cuda.synchronize()
+        scores, mirrored = cdist.unpack_scores(packed.cpu().numpy())
+        targets = shard.library.download(0, n)
+        for m in range(2):
+            ws, wm = oracle.PixelMatchQuery(masks[m], 20, 20, 0.01, 2, True, rects).scan(targets, n_threads=8)
+            assert np.array_equal(scores[m], ws) and np.array_equal(mirrored[m], wm.astype(bool))
+        assert scores.max() > 0
+    finally:
+        shard.ctx.reset_stream()
+        dist.destroy_process_group()

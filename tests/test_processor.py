@@ -1,0 +1,107 @@
+"""The caller side: match filter, top-N selection, gradient scores, normalisation.
+CPU part: selectTopRankedElements restated from the reference's ItemsHandlingTest.  GPU part: the whole
+colorDepthSearch -> gradientScores pipeline on a synthetic library equals the same pipeline over the oracle."""
+import numpy as np
+import pytest
+
+from colormipsearch_amd import processor as P
+
+W, H = 1210, 566
+
+
+def _test_data():
+    # same shape as ItemsHandlingTest.createTestData: several lines, several matches per line, distinct scores
+    out = []
+    k = 0
+    for line in ("l1", "l2", "l3", "l4"):
+        for j in range(3):
+            out.append(P.CDMatch(0, k, matchingPixels=10 * (k % 5) + j + (7 if line == "l3" else 0), matchingPixelsRatio=0.1, mirrored=False))
+            k += 1
+    names = [f"l{1 + i // 3}" for i in range(12)]
+    return out, names
+
+
+def test_selectAllElementsWithAllSubResults():
+    data, names = _test_data()
+    ranked = P.selectTopRankedElements(data, lambda m: names[m.targetIndex], lambda m: m.matchingPixels, -1, -1)
+    assert len(ranked) == 4
+    assert all(len(items) == 3 for _, _, items in ranked)
+
+
+def test_selectAllElementsWithLimitedSubResults():
+    data, names = _test_data()
+    for top_sub in (1, 2, 3):
+        ranked = P.selectTopRankedElements(data, lambda m: names[m.targetIndex], lambda m: m.matchingPixels, -1, top_sub)
+        assert len(ranked) == 4 and all(len(items) == top_sub for _, _, items in ranked)
+
+
+def test_selectTopRankedElements_order_and_cut():
+    data, names = _test_data()
+    for top in (1, 2, 3):
+        ranked = P.selectTopRankedElements(data, lambda m: names[m.targetIndex], lambda m: m.matchingPixels, top, -1)
+        assert len(ranked) == top
+        best = [s for _, s, _ in ranked]
+        assert best == sorted(best, reverse=True)
+        for _, s, items in ranked:
+            scores = [m.matchingPixels for m in items]
+            assert scores == sorted(scores, reverse=True) and s == scores[0]
+    # blank group names fall into "UNKNOWN"
+    ranked = P.selectTopRankedElements(data, lambda m: " ", lambda m: m.matchingPixels, -1, -1)
+    assert [k for k, _, _ in ranked] == ["UNKNOWN"]
+
+
+def test_normalizeScores_matches_reference_formula(oracle):
+    ms = [P.CDMatch(0, 0, 636, 0.1, False, 156, 1897), P.CDMatch(0, 1, 679, 0.1, False, 1114361, 0),
+          P.CDMatch(0, 2, 10, 0.1, False, None, None), P.CDMatch(1, 3, 5, 0.1, False, -1, -1)]
+    P.GpuColorMIPSearchProcessor.normalizeScores(ms)
+    assert abs(ms[0].normalizedScore - 46833.58) <= 0.1            # GradientAreaGapUtilsTest.java:31-32
+    assert ms[2].normalizedScore == 10.0 and ms[3].normalizedScore == 5.0   # no shape score: the pixel score itself
+
+
+@pytest.mark.gpu
+def test_pipeline_equals_oracle_pipeline(oracle):
+    from colormipsearch_amd import cds
+    rects = cds.label_regions(W)
+    n_masks, n_t = 2, 40
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(n_masks)])
+    lib = cds.Library(W, H, n_t)
+    lib.generate_synthetic(0xC0FFEE, 500, 0, n_t - 4, kind=0, with_variants=True)
+    # a few targets that really match: the masks themselves (plain / mirrored) with generated variants of another image
+    extra = np.stack([masks[0], np.fliplr(masks[0]), masks[1], np.roll(masks[1], 2, axis=1)])
+    lib.upload(n_t - 4, extra)
+    g, z = lib.download_variants(0, 4)
+    lib.upload_variants(n_t - 4, g, z)
+    targets = lib.download(0, n_t)
+    grads, zgaps = lib.download_variants(0, n_t)
+    infos = [P.NeuronInfo(str(i), f"line{i % 7}", f"sample{i % 11}") for i in range(n_t)]
+
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(True, 20, 1, 2, cds.label_regions)
+    search = cds.ColorMIPSearch(0.01, 20, provider)     # low pctPositivePixels so that sparse synthetic targets match too
+    proc = P.GpuColorMIPSearchProcessor(search, lib, infos)
+    matches = proc.findAllColorDepthMatches(masks)
+
+    want = []
+    for m in range(n_masks):
+        q = oracle.PixelMatchQuery(masks[m], 20, 20, 0.01, 2, True, rects)
+        s, mir = q.scan(targets, n_threads=8)
+        for t in range(n_t):
+            if oracle.is_match(int(s[t]), q.size, 0.01):
+                want.append((m, t, int(s[t]), bool(mir[t])))
+    assert [(mt.maskIndex, mt.targetIndex, mt.matchingPixels, mt.mirrored) for mt in matches] == want
+    assert len(want) >= 4
+
+    best = proc.selectBestMatches(matches, 3, 2, 1)
+    assert 0 < len(best) <= n_masks * 3 * 2
+    for m in range(n_masks):
+        lines = {infos[mt.targetIndex].publishedName for mt in best if mt.maskIndex == m}
+        assert len(lines) <= 3
+    scored = proc.calculateGradientScores(masks, best, 20, True, None, cds.label_regions)
+    for mt in scored:
+        sq = oracle.ShapeQuery(masks[mt.maskIndex], 20, True, rects)
+        gap, high, _, _ = sq.score(targets[mt.targetIndex], grads[mt.targetIndex], zgaps[mt.targetIndex])
+        assert (mt.gradientAreaGap, mt.highExpressionArea) == (gap, high)
+    for m in range(n_masks):
+        items = [mt for mt in scored if mt.maskIndex == m]
+        mp, mg = max(mt.matchingPixels for mt in items), max(mt.getGradScore() for mt in items)
+        for mt in items:
+            assert mt.normalizedScore == float(np.float32(oracle.normalized_score(mt.matchingPixels, mt.getGradScore(), mp, mg)))
