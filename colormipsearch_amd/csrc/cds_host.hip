@@ -343,6 +343,7 @@ void cds_library_destroy(cds_library *lib) {
     if (lib->owns_rgb && lib->d_rgb) hipFree(lib->d_rgb);
     if (lib->d_grad) hipFree(lib->d_grad);
     if (lib->d_zgap) hipFree(lib->d_zgap);
+    if (lib->d_zslice) hipFree(lib->d_zslice);
     delete lib;
 }
 
@@ -390,6 +391,11 @@ int cds_library_ensure_variants(cds_library *lib) {
         CDS_HIP(hipMalloc(&lib->d_zgap, bytes));
         CDS_HIP(hipMemsetAsync(lib->d_zgap, 0, bytes, lib->ctx->stream));
     }
+    if (!lib->d_zslice) {
+        size_t bytes = (size_t)lib->capacity * lib->grad_stride;
+        CDS_HIP(hipMalloc(&lib->d_zslice, bytes));
+        CDS_HIP(hipMemsetAsync(lib->d_zslice, 0, bytes, lib->ctx->stream));
+    }
     return CDS_OK;
 }
 
@@ -410,6 +416,8 @@ int cds_library_upload_variants(cds_library *lib, int64_t first, int64_t count, 
         CDS_HIP(hipMemcpy2DAsync(lib->d_zgap + (size_t)first * lib->img_stride, lib->pitch, zgap_rgb, (size_t)3 * lib->W,
                                  (size_t)3 * lib->W, (size_t)lib->H * count, hipMemcpyHostToDevice, lib->ctx->stream));
         for (int64_t i = 0; i < count; i++) lib->has_zgap[(size_t)(first + i)] = 1;
+        rc = refresh_zslice(lib, first, count);
+        if (rc) return rc;
     }
     CDS_HIP(hipStreamSynchronize(lib->ctx->stream));
     return CDS_OK;

@@ -71,6 +71,7 @@ struct cds_library {
     bool owns_rgb = false;
     uint16_t *d_grad = nullptr;  // lazily allocated
     uint8_t *d_zgap = nullptr;   // lazily allocated, same layout as d_rgb
+    uint16_t *d_zslice = nullptr;  // derived from d_zgap, gradient layout: (slice number - 1) | max channel << 8
     std::vector<uint8_t> has_grad, has_zgap;  // per slot
     std::mutex mu;
 };
@@ -105,6 +106,7 @@ struct ScanParams {
 };
 
 int launch_scan(cds_context *ctx, const ScanParams &p, bool xy2, bool mirror, hipStream_t stream);
+int refresh_zslice(cds_library *lib, int64_t first, int64_t count);  // cds_shape.hip: zgap RGB -> zslice plane
 int init_rcp_table(cds_context *ctx);
 
 }  // namespace cds

@@ -231,14 +231,13 @@ static inline int gray_nogamma(int r, int g, int b) {
 constexpr int kPlaneS = 511, kPlaneQM = 1 << 9, kPlaneQH = 1 << 10;
 
 struct ShapeParams {
-    const uint8_t *rgb, *zgap;
-    const uint16_t *grad;
+    const uint8_t *rgb;
+    const uint16_t *grad, *zslice;  // zslice: (slice number - 1) | max channel << 8 per zgap pixel (gradient layout)
     size_t img_stride, grad_stride;
     int pitch, gpitch, W, H, wp;  // wp: plane row length (u16 elements), multiple of 4
     const uint16_t *planes;       // [n_masks][2][H][wp]
     const int *boxes;             // [n_masks][8]: ya, yb (rows with any plane bit), gap columns [gx0,gx1), QH columns [hx0,hx1)
     const uint8_t *rowflags;      // [n_masks][H]: bit0 row has gap bits (S(q) or queryMask), bit1 row has high-expression bits
-    const uint8_t *slice_lut;
     int thr, mirror, nrects;
     cds_rect rects[CDS_MAX_RECTS];
     const int32_t *pair_mask;
@@ -265,105 +264,124 @@ __device__ __forceinline__ int gap_of(int pl, int sz, int g) {
     return gap > 3 ? gap : 0;
 }
 
-template <int kShapeRows>
+// zgap RGB -> zslice plane, once per uploaded / generated variant image: the colour-LUT search of
+// GradientAreaGapUtils.calculateSliceGap becomes one table gather here and a byte compare in the scorer.
+struct ZsliceParams {
+    const uint8_t *zgap;
+    uint16_t *zslice;
+    const uint8_t *slice_lut;
+    size_t img_stride, grad_stride;
+    int pitch, gpitch, H, gpr;  // gpr: 4-pixel groups per row (covers the padded row)
+    int64_t count;
+};
+
+__global__ __launch_bounds__(256) void zslice_kernel(ZsliceParams p) {
+    const int64_t items = (int64_t)p.count * p.H * p.gpr;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+        const int gi = (int)(it % p.gpr);
+        const int64_t rowi = it / p.gpr;
+        const int y = (int)(rowi % p.H);
+        const int64_t img = rowi / p.H;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.zgap + (size_t)img * p.img_stride + (size_t)y * p.pitch + (size_t)gi * 12);
+        const uint32_t a = src[0], b = src[1], c = src[2];
+        const int px[4][3] = {{(int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255)},
+                              {(int)(a >> 24), (int)(b & 255), (int)((b >> 8) & 255)},
+                              {(int)((b >> 16) & 255), (int)(b >> 24), (int)(c & 255)},
+                              {(int)((c >> 8) & 255), (int)((c >> 16) & 255), (int)(c >> 24)}};
+        uint16_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int mx = max(px[j][0], max(px[j][1], px[j][2]));
+            const int s = mx ? dev_slice(p.slice_lut, px[j][0], px[j][1], px[j][2], -1) : 1;  // 1..256
+            o[j] = (uint16_t)((s - 1) | (mx << 8));
+        }
+        uint16_t *dst = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(p.zslice) + (size_t)img * p.grad_stride + (size_t)y * p.gpitch) + 4 * gi;
+        *reinterpret_cast<ushort4 *>(dst) = make_ushort4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// S(z) of a zslice entry under ColorTransformation.mask(thr): black if all channels <= thr.
+__device__ __forceinline__ int zs_of(int e, int thr) {
+    const int mx = e >> 8;
+    return (mx > thr && mx > 0) ? (e & 255) + 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
-    // One workgroup scores one (mask, target) pair, 8 rows per batch, one row per wave at a time.
-    // Phase 1 (rows with gap bits only): zgap groups of the gap window and of its mirror image -> slice numbers in
-    // LDS (black groups are skipped by a wave vote).  Phase 2: per 4-pixel group the two orientation planes decide
-    // what else is needed -- gradient + S(z) when a gap bit is set, the target pixels when a high-expression bit is.
-    extern __shared__ __attribute__((aligned(16))) uint16_t zs[];  // [kShapeRows][wp]
+    // One workgroup scores one (mask, target) pair; one row per wave at a time, lanes over 4-pixel groups, no LDS and
+    // no barriers in the row loop.  The two orientation planes of a group decide what else is fetched: gradient +
+    // zslice (plain and reversed) when a gap bit is set, the target pixels when a high-expression bit is.
     __shared__ long long red[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool even_w = (p.W & 1) == 0;
     for (int64_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
         const int64_t slot = p.pair_slot[pi];
         if (slot < 0) continue;  // uniform per block
         const int m = p.pair_mask[pi];
         const uint8_t *timg = p.rgb + (size_t)slot * p.img_stride;
-        const uint8_t *zimg = p.zgap + (size_t)slot * p.img_stride;
+        const uint8_t *zimg = reinterpret_cast<const uint8_t *>(p.zslice) + (size_t)slot * p.grad_stride;
         const uint8_t *gimg = reinterpret_cast<const uint8_t *>(p.grad) + (size_t)slot * p.grad_stride;
         const uint16_t *pl0 = p.planes + (size_t)m * 2 * p.H * p.wp;
         const uint16_t *pl1 = pl0 + (size_t)p.H * p.wp;
         const int *bx = p.boxes + 8 * m;
         const int ya = bx[0], yb = bx[1];
-        // gap window and the zgap columns both orientations read (the window and its mirror image), in groups of 4
-        const int gq0 = bx[2] >> 2, gq1 = (bx[3] + 3) >> 2;
-        const int zlo = min(bx[2], p.W - bx[3]), zhi = max(bx[3], p.W - bx[2]);
-        const int zq0 = (zlo < 0 ? 0 : zlo) >> 2, zq1 = ((zhi > p.W ? p.W : zhi) + 3) >> 2;
-        // columns phase 2 visits: gap window U high-expression window
-        const int aq0 = min(bx[2], bx[4]) >> 2, aq1 = (max(bx[3], bx[5]) + 3) >> 2;
+        const int gq0 = bx[2] >> 2, gq1 = (bx[3] + 3) >> 2;                             // gap window, in groups
+        const int aq0 = min(bx[2], bx[4]) >> 2, aq1 = (max(bx[3], bx[5]) + 3) >> 2;     // gap U high-expression window
         const uint8_t *rf = p.rowflags + (size_t)m * p.H;
         unsigned gap0 = 0, gap1 = 0;  // per lane < 2^31 for H*W <= 2M pixels (gap <= 65535 per pixel)
         int high0 = 0, high1 = 0;
-        for (int y0 = ya; y0 < yb; y0 += kShapeRows) {
-            // ---- phase 1
-            for (int rr = wave; rr < kShapeRows; rr += 4) {
-                const int y = y0 + rr;
-                if (y >= yb || !(rf[y] & 1)) continue;  // wave-uniform
-                const uint8_t *zrow = zimg + (size_t)y * p.pitch;
-                uint16_t *zr = zs + rr * p.wp;
-                for (int gi = zq0 + lane; gi < ((zq1 - zq0 + 63) & ~63) + zq0; gi += 64) {
-                    uint32_t a = 0, b = 0, c = 0;
-                    if (gi < zq1) {
-                        const uint32_t *src = reinterpret_cast<const uint32_t *>(zrow + (size_t)gi * 12);
-                        a = src[0]; b = src[1]; c = src[2];
+        for (int y = ya + wave; y < yb; y += 4) {  // wave-uniform
+            const int flags = rf[y];
+            if (!flags) continue;
+            const int q0 = (flags & 2) ? aq0 : gq0, q1 = (flags & 2) ? aq1 : gq1;
+            const uint16_t *zrow = reinterpret_cast<const uint16_t *>(zimg + (size_t)y * p.gpitch);
+            for (int gi = q0 + lane; gi < q1; gi += 64) {
+                const int x0 = 4 * gi;
+                const ushort4 qa = *reinterpret_cast<const ushort4 *>(pl0 + (size_t)y * p.wp + x0);
+                ushort4 qb = make_ushort4(0, 0, 0, 0);
+                if (p.mirror) qb = *reinterpret_cast<const ushort4 *>(pl1 + (size_t)y * p.wp + x0);
+                const int all = qa.x | qa.y | qa.z | qa.w | qb.x | qb.y | qb.z | qb.w;
+                if (!all) continue;
+                const int pa[4] = {qa.x, qa.y, qa.z, qa.w}, pb[4] = {qb.x, qb.y, qb.z, qb.w};
+                if (all & (kPlaneS | kPlaneQM)) {
+                    const ushort4 g = *reinterpret_cast<const ushort4 *>(gimg + (size_t)y * p.gpitch + (size_t)x0 * 2);
+                    const ushort4 z = *reinterpret_cast<const ushort4 *>(zrow + x0);
+                    const int gg[4] = {g.x, g.y, g.z, g.w}, zz[4] = {z.x, z.y, z.z, z.w};
+                    int zm[4] = {0, 0, 0, 0};  // zslice at W-1-x for x = x0 .. x0+3
+                    if (p.mirror) {
+                        const int xm = p.W - 4 - x0;  // element index of the reversed run (may be < 0 at the far right)
+                        if (even_w && xm >= 0) {
+                            const uint2 r = *reinterpret_cast<const uint2 *>(zrow + xm);  // xm even: 4-byte aligned
+                            zm[3] = r.x & 0xffff; zm[2] = r.x >> 16; zm[1] = r.y & 0xffff; zm[0] = r.y >> 16;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if (p.W - 1 - x0 - j >= 0) zm[j] = zrow[p.W - 1 - x0 - j];
+                        }
                     }
-                    ushort4 s4 = make_ushort4(0, 0, 0, 0);
-                    if (__any((a | b | c) != 0)) {
-                        s4.x = dev_slice(p.slice_lut, a & 255, (a >> 8) & 255, (a >> 16) & 255, p.thr);
-                        s4.y = dev_slice(p.slice_lut, a >> 24, b & 255, (b >> 8) & 255, p.thr);
-                        s4.z = dev_slice(p.slice_lut, (b >> 16) & 255, b >> 24, c & 255, p.thr);
-                        s4.w = dev_slice(p.slice_lut, (c >> 8) & 255, (c >> 16) & 255, c >> 24, p.thr);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (x0 + j >= p.W) break;
+                        gap0 += gap_of(pa[j], zs_of(zz[j], p.thr), gg[j]);
+                        if (p.mirror) gap1 += gap_of(pb[j], zs_of(zm[j], p.thr), gg[j]);
                     }
-                    if (gi < zq1) *reinterpret_cast<ushort4 *>(zr + 4 * gi) = s4;
                 }
-            }
-            __syncthreads();
-            // ---- phase 2
-            for (int rr = wave; rr < kShapeRows; rr += 4) {
-                const int y = y0 + rr;
-                if (y >= yb) continue;
-                const int flags = rf[y];
-                if (!flags) continue;  // wave-uniform
-                const uint16_t *zr = zs + rr * p.wp;
-                const int q0 = (flags & 2) ? aq0 : gq0, q1 = (flags & 2) ? aq1 : gq1;
-                for (int gi = q0 + lane; gi < q1; gi += 64) {
-                    const int x0 = 4 * gi;
-                    const ushort4 qa = *reinterpret_cast<const ushort4 *>(pl0 + (size_t)y * p.wp + x0);
-                    ushort4 qb = make_ushort4(0, 0, 0, 0);
-                    if (p.mirror) qb = *reinterpret_cast<const ushort4 *>(pl1 + (size_t)y * p.wp + x0);
-                    const int all = qa.x | qa.y | qa.z | qa.w | qb.x | qb.y | qb.z | qb.w;
-                    if (!all) continue;
-                    const int pa[4] = {qa.x, qa.y, qa.z, qa.w}, pb[4] = {qb.x, qb.y, qb.z, qb.w};
-                    if (all & (kPlaneS | kPlaneQM)) {
-                        const ushort4 g = *reinterpret_cast<const ushort4 *>(gimg + (size_t)y * p.gpitch + (size_t)x0 * 2);
-                        const int gg[4] = {g.x, g.y, g.z, g.w};
+                if (all & kPlaneQH) {
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(timg + (size_t)y * p.pitch + (size_t)x0 * 3);
+                    const uint32_t a = src[0], b = src[1], c = src[2];
+                    const int mx[4] = {max(max((int)(a & 255), (int)((a >> 8) & 255)), (int)((a >> 16) & 255)),
+                                       max(max((int)(a >> 24), (int)(b & 255)), (int)((b >> 8) & 255)),
+                                       max(max((int)((b >> 16) & 255), (int)(b >> 24)), (int)(c & 255)),
+                                       max(max((int)((c >> 8) & 255), (int)((c >> 16) & 255)), (int)(c >> 24))};
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int x = x0 + j;
-                            if (x >= p.W) break;
-                            gap0 += gap_of(pa[j], zr[x], gg[j]);
-                            if (p.mirror) gap1 += gap_of(pb[j], zr[p.W - 1 - x], gg[j]);
-                        }
-                    }
-                    if (all & kPlaneQH) {
-                        const uint32_t *src = reinterpret_cast<const uint32_t *>(timg + (size_t)y * p.pitch + (size_t)x0 * 3);
-                        const uint32_t a = src[0], b = src[1], c = src[2];
-                        const int mx[4] = {max(max((int)(a & 255), (int)((a >> 8) & 255)), (int)((a >> 16) & 255)),
-                                           max(max((int)(a >> 24), (int)(b & 255)), (int)((b >> 8) & 255)),
-                                           max(max((int)((b >> 16) & 255), (int)(b >> 24)), (int)(c & 255)),
-                                           max(max((int)((c >> 8) & 255), (int)((c >> 16) & 255)), (int)(c >> 24))};
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int x = x0 + j;
-                            if (x >= p.W) break;
-                            const bool sig = mx[j] > p.thr && !dev_in_rects(p.rects, p.nrects, x, y);
-                            high0 += (sig && (pa[j] & kPlaneQH)) ? 1 : 0;
-                            high1 += (sig && (pb[j] & kPlaneQH)) ? 1 : 0;
-                        }
+                    for (int j = 0; j < 4; j++) {
+                        const int x = x0 + j;
+                        if (x >= p.W) break;
+                        const bool sig = mx[j] > p.thr && !dev_in_rects(p.rects, p.nrects, x, y);
+                        high0 += (sig && (pa[j] & kPlaneQH)) ? 1 : 0;
+                        high1 += (sig && (pb[j] & kPlaneQH)) ? 1 : 0;
                     }
                 }
             }
-            __syncthreads();
         }
         long long v[4] = {(long long)gap0, (long long)high0, (long long)gap1, (long long)high1};
 #pragma unroll
@@ -381,6 +399,25 @@ __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
         }
         __syncthreads();
     }
+}
+
+int refresh_zslice(cds_library *lib, int64_t first, int64_t count) {
+    if (count <= 0) return CDS_OK;
+    int rc = ensure_slice_lut(lib->ctx);
+    if (rc) return rc;
+    ZsliceParams p{};
+    p.zgap = lib->d_zgap + (size_t)first * lib->img_stride;
+    p.zslice = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(lib->d_zslice) + (size_t)first * lib->grad_stride);
+    p.slice_lut = lib->ctx->d_slice_lut;
+    p.img_stride = lib->img_stride; p.grad_stride = lib->grad_stride;
+    p.pitch = lib->pitch; p.gpitch = lib->gpitch; p.H = lib->H;
+    p.gpr = std::min(lib->pitch / 12, lib->gpitch / 8);
+    p.count = count;
+    const int64_t items = count * p.H * p.gpr;
+    const int grid = (int)std::min<int64_t>((items + 255) / 256, (int64_t)lib->ctx->n_cus * 64);
+    hipLaunchKernelGGL(zslice_kernel, dim3(grid), dim3(256), 0, lib->ctx->stream, p);
+    CDS_HIP(hipGetLastError());
+    return CDS_OK;
 }
 
 }  // namespace cds
@@ -553,17 +590,13 @@ int cds_gradscore(const cds_shapeset *ss, const cds_library *lib, int64_t n_pair
     GS_HIP(hipMemcpyAsync(d_ps, slots.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, st));
     GS_HIP(hipMemsetAsync(d_out, 0, (size_t)n_pairs * 32, st));
     ShapeParams p{};
-    p.rgb = lib->d_rgb; p.zgap = lib->d_zgap; p.grad = lib->d_grad;
+    p.rgb = lib->d_rgb; p.zslice = lib->d_zslice; p.grad = lib->d_grad;
     p.img_stride = lib->img_stride; p.grad_stride = lib->grad_stride;
     p.pitch = lib->pitch; p.gpitch = lib->gpitch; p.W = ss->W; p.H = ss->H; p.wp = ss->wp;
-    p.planes = ss->d_planes; p.boxes = ss->d_boxes; p.rowflags = ss->d_rowflags; p.slice_lut = ctx->d_slice_lut;
+    p.planes = ss->d_planes; p.boxes = ss->d_boxes; p.rowflags = ss->d_rowflags;
     p.thr = ss->thr; p.mirror = ss->mirror; p.nrects = ss->nrects;
     for (int i = 0; i < ss->nrects; i++) p.rects[i] = ss->rects[i];
     p.pair_mask = d_pm; p.pair_slot = d_ps; p.n_pairs = n_pairs; p.out = d_out;
-    int rows = 8;  // rows per LDS batch (19 KB of LDS: 8 workgroups per CU)
-    if (const char *e = getenv("CDS_SHAPE_ROWS")) rows = atoi(e);
-    rows = rows <= 8 ? 8 : (rows <= 16 ? 16 : 32);
-    const size_t lds = (size_t)rows * ss->wp * sizeof(uint16_t);
     int per_cu = 32;
     if (const char *e = getenv("CDS_SHAPE_WGS_PER_CU")) per_cu = atoi(e);
     int64_t g64 = (int64_t)ctx->n_cus * per_cu;
@@ -572,12 +605,7 @@ int cds_gradscore(const cds_shapeset *ss, const cds_library *lib, int64_t n_pair
     GS_HIP(hipEventCreate(&ev0));
     GS_HIP(hipEventCreate(&ev1));
     GS_HIP(hipEventRecord(ev0, st));
-    if (rows == 8) hipLaunchKernelGGL(gradscore_kernel<8>, dim3(grid), dim3(256), lds, st, p);
-    else if (rows == 16) hipLaunchKernelGGL(gradscore_kernel<16>, dim3(grid), dim3(256), lds, st, p);
-    else {
-        GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gradscore_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(gradscore_kernel<32>, dim3(grid), dim3(256), lds, st, p);
-    }
+    hipLaunchKernelGGL(gradscore_kernel, dim3(grid), dim3(256), 0, st, p);
     GS_HIP(hipGetLastError());
     GS_HIP(hipEventRecord(ev1, st));
     std::vector<int64_t> res((size_t)n_pairs * 4);

@@ -198,8 +198,11 @@ extern "C" int cds_library_generate_synthetic(cds_library *lib, uint64_t seed, i
         hipLaunchKernelGGL(synth_kernel, dim3((unsigned)(n * p.blocks_per_image)), dim3(256), 0, lib->ctx->stream, q);
         CDS_HIP(hipGetLastError());
     }
-    if (with_variants)
+    if (with_variants) {
         for (int64_t i = 0; i < count; i++) lib->has_grad[(size_t)(first_slot + i)] = lib->has_zgap[(size_t)(first_slot + i)] = 1;
+        int rc = refresh_zslice(lib, first_slot, count);
+        if (rc) return rc;
+    }
     CDS_HIP(hipStreamSynchronize(lib->ctx->stream));
     return CDS_OK;
 }
