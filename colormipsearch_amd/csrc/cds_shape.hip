@@ -334,6 +334,8 @@ __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
             if (!flags) continue;
             const int q0 = (flags & 2) ? aq0 : gq0, q1 = (flags & 2) ? aq1 : gq1;
             const uint16_t *zrow = reinterpret_cast<const uint16_t *>(zimg + (size_t)y * p.gpitch);
+            bool row_in_rects = false;  // wave-uniform: does any excluded rectangle intersect this row at all?
+            for (int i = 0; i < p.nrects; i++) row_in_rects |= (y >= p.rects[i].y0 && y < p.rects[i].y1);
             for (int gi = q0 + lane; gi < q1; gi += 64) {
                 const int x0 = 4 * gi;
                 const ushort4 qa = *reinterpret_cast<const ushort4 *>(pl0 + (size_t)y * p.wp + x0);
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
                     for (int j = 0; j < 4; j++) {
                         const int x = x0 + j;
                         if (x >= p.W) break;
-                        const bool sig = mx[j] > p.thr && !dev_in_rects(p.rects, p.nrects, x, y);
+                        const bool sig = mx[j] > p.thr && !(row_in_rects && dev_in_rects(p.rects, p.nrects, x, y));
                         high0 += (sig && (pa[j] & kPlaneQH)) ? 1 : 0;
                         high1 += (sig && (pb[j] & kPlaneQH)) ? 1 : 0;
                     }
