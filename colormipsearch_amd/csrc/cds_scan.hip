@@ -348,31 +348,21 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                 const bool do_plain = occ2 & 1, do_mirror = MIRROR && (occ2 & 2);
                 if (!(do_plain || do_mirror)) return;
                 const int cpl = pos & 2047, cmi = (pos >> 11) & 2047, yrel = pos >> 22;
+                // all LDS reads of one orientation are issued before the first compare (one wait instead of one per row)
+                auto probe9 = [&](int col, int sgn, int *c9) {
+                    uint32_t cv[NS];
 #pragma unroll
-                for (int iy = 0; iy < NSX; iy++) {
-                    const int rel = yrel + (XY2 ? 2 * iy : 0);  // = yrel + halo + dy
-                    const uint32_t *rowp = L.ring + (rel & (RR - 1)) * p.wc;
-                    if (do_plain) {
+                    for (int iy = 0; iy < NSX; iy++) {
+                        const int rel = yrel + (XY2 ? 2 * iy : 0);  // = yrel + halo + dy
+                        const uint32_t *rowp = L.ring + (rel & (RR - 1)) * p.wc + col;
 #pragma unroll
-                        for (int ix = 0; ix < NSX; ix++) {
-                            const int dx = XY2 ? 2 * (ix - 1) : 0;
-                            const int k = ix * NSX + iy;
-                            const uint32_t c = rowp[cpl + dx];
-                            const bool hit = ((c - iv.x) <= iv.y) | ((c - iv.z) <= iv.w);
-                            ctr[k] += hit ? 1 : 0;
-                        }
+                        for (int ix = 0; ix < NSX; ix++) cv[ix * NSX + iy] = rowp[XY2 ? sgn * 2 * (ix - 1) : 0];
                     }
-                    if (do_mirror) {
 #pragma unroll
-                        for (int ix = 0; ix < NSX; ix++) {
-                            const int dx = XY2 ? 2 * (ix - 1) : 0;
-                            const int k = ix * NSX + iy;
-                            const uint32_t c = rowp[cmi - dx];
-                            const bool hit = ((c - iv.x) <= iv.y) | ((c - iv.z) <= iv.w);
-                            ctr[NS + k] += hit ? 1 : 0;
-                        }
-                    }
-                }
+                    for (int k = 0; k < NS; k++) c9[k] += (((cv[k] - iv.x) <= iv.y) | ((cv[k] - iv.z) <= iv.w)) ? 1 : 0;
+                };
+                if (do_plain) probe9(cpl, 1, ctr);
+                if (do_mirror) probe9(cmi, -1, ctr + NS);
             };
             if (!MULTI) {
                 // one mask: the band's chunks are dealt to the waves; counters stay in registers for the whole target
