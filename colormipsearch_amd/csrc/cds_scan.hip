@@ -6,22 +6,25 @@
 // transformed target pixel passes the data threshold and lies within zTolerance in hue-ratio space;
 // then max over shifts, mirrored only if strictly greater.
 //
-// How (MI355X-first, not the reference's gather loops):
+// How (MI355X-first, not the reference's gather loops) -- see DESIGN.md section 4 for the measurements behind it:
 //   * one workgroup streams ONE target at a time: only the rows the mask can touch, and of those only the
-//     column window the mask (and its mirror image) can touch, as 12-byte (4 pixel) non-temporal loads;
-//   * staging is sparse-aware.  Phase A writes the raw 12 bytes of every group into a 16-row LDS ring (an
-//     all-black group is already its own all-zero code), records one occupancy bit per group and appends the
-//     ring index of every non-black group to a small queue; phase B converts only the queued groups, in
-//     place, to 32-bit "hue codes" = class<<29 | bits(med * v_rcp_f32(max))>>1 (0 = below threshold / no hue
-//     class).  The host builds its acceptance intervals from this device's own v_rcp_f32 table, so the
-//     device predicate is an integer range test that is bit-exact with the reference's double arithmetic by
-//     construction (cds_host.hip: build_ratio_table / intervals_for);
-//   * mask pixels are pre-sorted into spatially compact chunks of <= 64 per 6-row band; a wave takes one
-//     chunk, and skips an orientation's 9 probes when the occupancy bits of the chunk's neighbourhood are
-//     all clear (one ballot); otherwise every lane probes its 9 (18) transformed positions in LDS against its
-//     two code intervals (own hue class + at most one adjacent class); per-lane counters (one mask) or wave
-//     ballots (mask batches) count;
-//   * no MFMA: byte compare / integer count; the kernel is VALU-issue- and HBM-bound.
+//     column window the mask (and its mirror image) can touch, as 12-byte (4 pixel) non-temporal loads, 768
+//     contiguous bytes per wave-instruction;
+//   * the mask's rows are cut into bands of 12; per band three phases separated by barriers:
+//     A  stage: raw 12-byte groups into a 16-row LDS ring as (a,b,c,0) (an all-black group is already its all-zero
+//        code), the segment ballots become occupancy words, non-black groups are queued.  The loads of band b+1 are
+//        issued at the top of band b by asm with manual s_waitcnt, so HBM requests stay in flight during B and P;
+//     B  convert only the queued groups, in place, to 32-bit "hue codes" = class<<29 | bits(med * v_rcp_f32(max))>>1
+//        (0 = below threshold / no hue class).  The host builds its acceptance intervals from this device's own
+//        v_rcp_f32 table, so the device predicate is an integer range test that is bit-exact with the reference's
+//        double arithmetic by construction (cds_host.hip: build_ratio_table / intervals_for);
+//     P  probe: mask pixels are pre-sorted into spatially compact chunks of 64 per band; a wave takes one chunk and
+//        skips an orientation's 9 probes when the occupancy bits of the chunk's neighbourhood are all clear (one
+//        ballot for both orientations); otherwise every lane probes its 9 (18) transformed positions in LDS against
+//        its two code intervals (own hue class + at most one adjacent class) with per-lane counters;
+//   * no MFMA: byte compare / integer count; the kernel is instruction-issue- and HBM-bound.
+//   * CDS_SCAN_DEBUG bits (timing-only ablations, results are wrong with them): 1 skip probes, 2 skip phase B,
+//     4 never skip by occupancy, 8 no queue.
 #include "cds_internal.hpp"
 
 namespace cds {
@@ -37,16 +40,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // and waits explicitly: vmcnt(KMAX) before the probes (mask data arrived, rows still in flight), vmcnt(0) before
 // the rows are committed.  No asm-loaded value is loop-carried or read before its wait statement, which names it
 // as an in/out operand (cdna_hip_programming.md section 5.7).
-__device__ __forceinline__ u32x3 async_ld12_nt(const void *ptr) {
-    u32x3 v;
-    asm volatile("global_load_dwordx3 %0, %1, off nt" : "=v"(v) : "v"(ptr) : "memory");
-    return v;
-}
-__device__ __forceinline__ u32x3 async_ld12(const void *ptr) {
-    u32x3 v;
-    asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-    return v;
-}
 __device__ __forceinline__ u32x4 async_ld16(const void *ptr) {
     u32x4 v;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
