@@ -140,6 +140,48 @@ def test_batched_masks_and_parameter_sweep(cds, oracle):
             assert np.array_equal(mir[m], wm.astype(bool))
 
 
+def test_wide_windows_and_many_masks(cds, oracle):
+    """Kernel variants the benchmark mask does not reach: a full-width window (5 load segments per row), a very wide
+    image (8 segments), and a mask batch larger than one launch (> 32 masks)."""
+    rects = cds.label_regions(W)
+    # (a) a sparse-lut TARGET image used as the mask: strokes all over the frame -> window = whole rows
+    mask = oracle.synth_image(0xC0FFEE, 9001, 0)
+    targets = np.stack([oracle.synth_image(0xC0FFEE, i, 0) for i in (9001, 9002, 9003)] + [np.fliplr(mask), oracle.synth_image(0xC0FFEE, 3, 1)])
+    lib = cds.Library(W, H, len(targets))
+    lib.upload(0, targets)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    counts = alg.searchLibraryCounts(lib)
+    q = oracle.PixelMatchQuery(mask, 20, 20, 0.01, 2, True, rects)
+    for t in range(len(targets)):
+        assert np.array_equal(counts[0, t], q.score(targets[t])[2]), t
+    # (b) 1600 x 64 image, mask pixels near both ends -> 8 segments
+    w2, h2 = 1600, 64
+    rng = np.random.default_rng(11)
+    lut = oracle.depth_lut()
+    m2 = np.zeros((h2, w2, 3), dtype=np.uint8)
+    for x0 in (3, 700, 1500):
+        m2[10:50, x0:x0 + 40] = lut[rng.integers(0, 256, size=(40, 40))]
+    t2 = np.stack([m2, np.fliplr(m2), lut[rng.integers(0, 256, size=(h2, w2))].astype(np.uint8)])
+    lib2 = cds.Library(w2, h2, len(t2))
+    lib2.upload(0, t2)
+    a2 = cds.PixelMatchColorDepthSearchAlgorithm(m2, 20, True, None, 0, False, 20, 0.01, 2, [])
+    c2 = a2.searchLibraryCounts(lib2)
+    q2 = oracle.PixelMatchQuery(m2, 20, 20, 0.01, 2, True, [])
+    for t in range(len(t2)):
+        assert np.array_equal(c2[0, t], q2.score(t2[t])[2]), t
+    # (c) 34 masks in one set: two launches
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(34)])
+    tg = np.stack([masks[33], np.fliplr(masks[5]), oracle.synth_image(0xC0FFEE, 77, 1)])
+    lib3 = cds.Library(W, H, len(tg))
+    lib3.upload(0, tg)
+    a3 = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    s3, m3 = a3.searchLibrary(lib3)
+    for m in (0, 5, 31, 32, 33):
+        ws, wm = oracle.PixelMatchQuery(masks[m], 20, 20, 0.01, 2, True, rects).scan(tg, n_threads=4)
+        assert np.array_equal(s3[m], ws) and np.array_equal(m3[m], wm.astype(bool)), m
+    assert m3[5, 1] and s3[33, 0] > 0.9 * a3.getQuerySize(33)
+
+
 def test_sub_ranges_and_slots(cds, oracle):
     rects = cds.label_regions(W)
     mask = oracle.synth_image(0xBADC0DE, 0, 2)
