@@ -90,6 +90,7 @@ SIGNATURES = {
     "cds_normalized_score": (ctypes.c_double, [_i32, _i64, _i64, _i64]),
     "cds_shapeset_last_kernel_ms": (_i, [_vp, ctypes.POINTER(ctypes.c_double), _i32p]),
     "cds_make_zgap": (_i, [_vp, _u8p, _i32, _i32, _i32, ctypes.c_double, _rp, _i32, _u8p]),
+    "cds_library_make_zgap_variants": (_i, [_vp, _i64, _i64, _i32, ctypes.c_double, _rp, _i32]),
     # include/cds_hip_debug.h
     "cds_debug_intervals": (_i, [_f32p, _i32, _i32, _i32, ctypes.c_double, _u32p]),
     "cds_debug_hue_code": (ctypes.c_uint32, [_f32p, _i32, _i32, _i32, _i32]),

@@ -186,6 +186,11 @@ class Library:
         capi.check(self._lib.cds_library_download_variants(self._h, int(first), int(count), capi.as_u16p(g), capi.as_u8p(z)))
         return g, z
 
+    def make_zgap_variants(self, first, count, threshold, radius=10, excluded_regions=None):
+        """ZGapImage variants of resident slots, computed on the device: clearRegion -> mask(threshold) -> max filter."""
+        r, n = capi.rect_array(_resolve_regions(excluded_regions, self.width))
+        capi.check(self._lib.cds_library_make_zgap_variants(self._h, int(first), int(count), int(threshold), float(radius), r, n))
+
     def generate_synthetic(self, seed, first_index, first_slot, count, kind=0, with_variants=False):
         capi.check(self._lib.cds_library_generate_synthetic(self._h, ctypes.c_uint64(int(seed)), int(first_index),
                                                             int(first_slot), int(count), int(kind), int(bool(with_variants))))

@@ -451,6 +451,52 @@ int cds_make_zgap(cds_context *ctx, const uint8_t *target_rgb, int32_t W, int32_
     return max_filter_host(ctx, target_rgb, W, H, radius, threshold, excluded, n_excluded, zgap_rgb);
 }
 
+int cds_library_ensure_variants(cds_library *lib);
+
+int cds_library_make_zgap_variants(cds_library *lib, int64_t first, int64_t count, int32_t threshold, double radius,
+                                   const cds_rect *excluded, int32_t n_excluded) {
+    if (!lib) return fail(CDS_ERR_INVALID_ARGUMENT, "library is NULL");
+    if (first < 0 || count < 0 || first + count > lib->capacity) return fail(CDS_ERR_INVALID_ARGUMENT, "slot range outside the library");
+    if (n_excluded < 0 || n_excluded > CDS_MAX_RECTS || (n_excluded > 0 && !excluded)) return fail(CDS_ERR_INVALID_ARGUMENT, "bad excluded-region list");
+    if (!(radius >= 0 && radius <= 200)) return fail(CDS_ERR_INVALID_ARGUMENT, "radius outside 0..200");
+    if (count == 0) return CDS_OK;
+    int rc = cds_library_ensure_variants(lib);
+    if (rc) return rc;
+    cds_context *ctx = lib->ctx;
+    CDS_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<int> hw;
+    const int k = line_radii(radius, hw);
+    uint8_t *d_tmp = nullptr;
+    int *d_hw = nullptr;
+    CDS_HIP(hipMalloc(&d_tmp, lib->img_stride));
+    hipError_t e = hipMalloc(&d_hw, hw.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_hw, hw.data(), hw.size() * sizeof(int), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_tmp, 0, lib->img_stride, st);
+    MaxFilterParams p{};
+    p.pitch = lib->pitch; p.W = lib->W; p.H = lib->H; p.k = k; p.thr = threshold; p.nrects = n_excluded; p.hw = d_hw;
+    for (int i = 0; i < n_excluded; i++) p.rects[i] = excluded[i];
+    p.bx0 = 0; p.by0 = 0; p.bx1 = lib->W; p.by1 = lib->H;
+    for (int64_t i = 0; i < count && e == hipSuccess; i++) {
+        p.src = lib->d_rgb + (size_t)(first + i) * lib->img_stride;
+        p.dst = d_tmp;
+        hipLaunchKernelGGL(prefilter_kernel, dim3((lib->W + 255) / 256, lib->H), dim3(256), 0, st, p);
+        p.src = d_tmp;
+        p.dst = lib->d_zgap + (size_t)(first + i) * lib->img_stride;
+        hipLaunchKernelGGL(max_filter_kernel, dim3((lib->W + 255) / 256, lib->H), dim3(256), 0, st, p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d_tmp);
+    if (d_hw) hipFree(d_hw);
+    if (e != hipSuccess) return hip_fail(e, "make_zgap_variants");
+    for (int64_t i = 0; i < count; i++) lib->has_zgap[(size_t)(first + i)] = 1;
+    rc = refresh_zslice(lib, first, count);
+    if (rc) return rc;
+    CDS_HIP(hipStreamSynchronize(st));
+    return CDS_OK;
+}
+
 int cds_shapeset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_rgb, int32_t W, int32_t H,
                         int32_t query_threshold, int32_t mirror, const uint8_t *roi, const cds_rect *excluded,
                         int32_t n_excluded, cds_shapeset **out) {

@@ -166,6 +166,11 @@ int cds_shapeset_last_kernel_ms(const cds_shapeset *ss, double *avg_ms, int32_t 
  * circular max filter (API/imageprocessing/ImageTransformation.java:353-572), computed on the GPU. */
 int cds_make_zgap(cds_context *ctx, const uint8_t *target_rgb, int32_t W, int32_t H, int32_t threshold,
                   double radius, const cds_rect *excluded, int32_t n_excluded, uint8_t *zgap_rgb);
+/* The same transformation for resident library slots, entirely on the device: fills the ZGapImage variant of slots
+ * [first, first+count) from their targets (for libraries that come without ZGapImage files; the reference's tests do
+ * this per image on the CPU, Shape2DMatch...Test.java:171-174). */
+int cds_library_make_zgap_variants(cds_library *lib, int64_t first, int64_t count, int32_t threshold, double radius,
+                                   const cds_rect *excluded, int32_t n_excluded);
 
 #ifdef __cplusplus
 }

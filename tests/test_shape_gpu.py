@@ -93,6 +93,23 @@ def test_synthetic_pairs_parity(cds, oracle):
     assert (gap[0], high[0], mir[0]) == (-1, -1, False) and gap[1] >= 0
 
 
+def test_device_side_zgap_variants(cds, fixtures, oracle):
+    """ZGapImage variants generated on the device from resident targets equal the reference's CPU construction, and
+    scoring through them reproduces the goldens (12191 x VT033614 -> 21365 / 731, Shape2DMatch...Test.java:86-94)."""
+    keys = ("lm_VT033614", "lm_BJD")
+    lib = cds.Library(W, H, len(keys))
+    lib.upload(0, np.stack([fixtures[k] for k in keys]))
+    lib.upload_variants(0, gradients=np.stack([fixtures["grad_VT033614"], fixtures["grad_BJD"]]))
+    lib.make_zgap_variants(0, len(keys), 20, 10, cds.label_regions)
+    _, z = lib.download_variants(0, len(keys))
+    for i, k in enumerate(keys):
+        assert np.array_equal(z[i], oracle.make_zgap(fixtures[k], 20, 10, E.STD_RECTS))
+    alg = cds.Shape2DMatchColorDepthSearchAlgorithm(fixtures["em_12191"], 20, True, None, cds.label_regions)
+    gap, high, mir = alg.scoreLibraryPairs(lib, [0, 0], [0, 1])
+    assert (int(gap[0]), int(high[0]), bool(mir[0])) == (21365, 731, False)
+    assert (int(gap[1]), int(high[1]), bool(mir[1])) == (23359, 523, False)
+
+
 def test_normalized_scores_per_mask(cds, oracle):
     # GradientAreaGapUtils.calculateNormalizedScore applied per mask as CalculateGradientScoresCmd.java:616-645 does
     pix = np.array([636, 500, 0, 679])
