@@ -182,6 +182,8 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_target": alg_bytes_per_target,
                 "kernel_ms_per_launch": kern_ms,
+                # the kernel fetches only the column window of each row, so real traffic < algorithmic bytes
+                "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
             },
         }
 
@@ -203,6 +205,14 @@ def main():
         t0 = time.perf_counter()
         ws, wm = q.scan(sample, n_threads=cores, partition=100)   # partitions of 100 like LocalColorMIPSearchProcessor
         dt = time.perf_counter() - t0
+        n1 = max(16, min(n_s, int(n_s / max(cores, 1) / 4)))      # single-thread leg on a slice of the sample
+        t0 = time.perf_counter()
+        q.scan(sample[:n1], n_threads=1, partition=100)
+        dt1 = time.perf_counter() - t0
+        try:
+            cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            cpu_model = "unknown CPU"
         ok = bool(np.array_equal(ws, sc[:n_s]) and np.array_equal(wm.astype(np.int64), mir[:n_s].astype(np.int64)))
         out["cpu_baseline"] = {
             "value": n_s / dt,
@@ -210,7 +220,9 @@ def main():
             "cores": cores,
             "kind": "port",
             "sample": f"first {n_s} targets of the same chunk, same mask and parameters, C oracle (-O2, f64 predicate, "
-                      f"18 gather passes per pair) on {cores} threads, target partitions of 100; scores equal to the GPU's: {ok}",
+                      f"18 gather passes per pair) on {cores} threads of {cpu_model}, target partitions of 100: {dt:.2f} s wall = "
+                      f"{dt * cores:.0f} core-seconds; scores equal to the GPU's: {ok}",
+            "single_thread_value": n1 / dt1,
         }
         if not ok:
             out["cpu_baseline"]["parity_failure"] = True
