@@ -1,0 +1,121 @@
+"""Data formats on either side of the hot path -- host I/O glue only.
+
+* reading MIPs: the reference decodes TIFF (PackBits / LZW / raw) and PNG/JPG files or zip entries into ImageArrays
+  (API/imageprocessing/ImageArrayUtils.java:98-121, API/mips/NeuronMIPUtils.java:177-199); here Pillow does the decode
+  (pixel-identical to ImageJ for the reference's fixtures) and yields the arrays the C ABI takes;
+* a packed shard format: one header line (JSON) + the raw uint8[n,H,W,3] pixels, written once and memory-mapped for
+  large sequential uploads into a `cds.Library` -- for real libraries decode + PCIe dominate, not the scan;
+* match results as JSON records with the field names of the reference's CDMatchEntity files
+  (PERSIST/dataio/fs/JSONNeuronMatchesWriter.java; API/model/CDMatchEntity.java:13-20), one file per mask, sorted by
+  descending matchingPixels (tools cmd/ColorDepthSearchCmd.java:403-409).
+"""
+import io
+import json
+import os
+import zipfile
+
+import numpy as np
+
+SHARD_MAGIC = "cds-mip-shard-v1"
+
+
+def _pil():
+    try:
+        from PIL import Image
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("reading MIP image files needs Pillow") from e
+    return Image
+
+
+def _open(file_data):
+    """file_data: a path, or (zip_path, entry_name) like the reference's FileData zipEntry."""
+    if isinstance(file_data, (tuple, list)):
+        zpath, entry = file_data
+        with zipfile.ZipFile(zpath) as z:
+            return io.BytesIO(z.read(entry))
+    return file_data
+
+
+def read_mip(file_data):
+    """-> uint8[H,W,3] (R,G,B), the byte layout of the reference's ColorImageArray."""
+    with _pil().open(_open(file_data)) as im:
+        return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
+
+
+def read_gradient(file_data):
+    """-> uint16[H,W]: GRAY16 as is, GRAY8 widened (ImageArray.get semantics)."""
+    with _pil().open(_open(file_data)) as im:
+        a = np.asarray(im)
+    if a.ndim != 2:
+        raise ValueError(f"gradient image must be grayscale, got shape {a.shape}")
+    return np.ascontiguousarray(a.astype(np.uint16))
+
+
+# ---- packed shards ------------------------------------------------------------------------------------
+def write_shard(path, images, meta=None):
+    images = np.ascontiguousarray(images, dtype=np.uint8)
+    if images.ndim != 4 or images.shape[3] != 3:
+        raise ValueError(f"expected uint8[n,H,W,3], got {images.shape}")
+    n, h, w, _ = images.shape
+    header = json.dumps({"magic": SHARD_MAGIC, "n": n, "height": h, "width": w, "meta": meta or []}).encode() + b"\n"
+    with open(path, "wb") as f:
+        f.write(header)
+        f.write(images.tobytes())
+
+
+def open_shard(path):
+    """-> (memory-mapped uint8[n,H,W,3], meta list). The pixels are not read until they are uploaded."""
+    with open(path, "rb") as f:
+        header = f.readline()
+    hd = json.loads(header)
+    if hd.get("magic") != SHARD_MAGIC:
+        raise ValueError(f"{path} is not a {SHARD_MAGIC} file")
+    arr = np.memmap(path, dtype=np.uint8, mode="r", offset=len(header), shape=(hd["n"], hd["height"], hd["width"], 3))
+    return arr, hd.get("meta", [])
+
+
+def upload_shard(library, shard_pixels, first_slot=0, batch=256):
+    """Stream a (memory-mapped) shard into a resident library in batches."""
+    n = shard_pixels.shape[0]
+    for a in range(0, n, batch):
+        b = min(n, a + batch)
+        library.upload(first_slot + a, np.ascontiguousarray(shard_pixels[a:b]))
+    return n
+
+
+# ---- results ------------------------------------------------------------------------------------------
+def match_records(matches, mask_infos, target_infos):
+    out = []
+    for m in matches:
+        rec = {
+            "class": "org.janelia.colormipsearch.model.CDMatchEntity",
+            "maskImage": dict(mask_infos[m.maskIndex]),
+            "image": dict(target_infos[m.targetIndex]),
+            "mirrored": bool(m.mirrored),
+            "matchingPixels": int(m.matchingPixels),
+            "matchingPixelsRatio": float(m.matchingPixelsRatio),
+        }
+        if m.gradientAreaGap is not None:
+            rec["gradientAreaGap"] = int(m.gradientAreaGap)
+        if m.highExpressionArea is not None:
+            rec["highExpressionArea"] = int(m.highExpressionArea)
+        if m.normalizedScore is not None:
+            rec["normalizedScore"] = float(m.normalizedScore)
+        out.append(rec)
+    return out
+
+
+def write_matches_per_mask(out_dir, matches, mask_infos, target_infos):
+    """One `<mask mipId>.json` per mask, records sorted by descending matchingPixels."""
+    os.makedirs(out_dir, exist_ok=True)
+    by_mask = {}
+    for m in matches:
+        by_mask.setdefault(m.maskIndex, []).append(m)
+    paths = []
+    for mi, items in by_mask.items():
+        items = sorted(items, key=lambda v: -v.matchingPixels)
+        path = os.path.join(out_dir, f"{mask_infos[mi].get('mipId', mi)}.json")
+        with open(path, "w") as f:
+            json.dump(match_records(items, mask_infos, target_infos), f, indent=1)
+        paths.append(path)
+    return paths
