@@ -110,6 +110,40 @@ def test_device_side_zgap_variants(cds, fixtures, oracle):
     assert (int(gap[1]), int(high[1]), bool(mir[1])) == (23359, 523, False)
 
 
+@pytest.mark.parametrize("w,h", [(131, 70), (200, 64)])
+def test_small_and_odd_geometry(cds, oracle, w, h):
+    """Non-standard image sizes (odd width: the reversed zslice run is unaligned), one custom excluded rectangle."""
+    rng = np.random.default_rng(w)
+    lut = oracle.depth_lut()
+    mask = np.zeros((h, w, 3), dtype=np.uint8)
+    mask[20:45, 30:90] = lut[rng.integers(0, 256, size=(25, 60))]
+    mask[rng.random((h, w)) < 0.5] = 0
+    rects = [(0, 0, 25, 12)]
+    n = 4
+    targets = np.zeros((n, h, w, 3), dtype=np.uint8)
+    for i in range(n):
+        t = lut[rng.integers(0, 256, size=(h, w))].astype(np.uint8)
+        t[rng.random((h, w)) < 0.7] = 0
+        targets[i] = t
+    targets[1] = np.fliplr(mask)
+    grads = rng.integers(0, 600, size=(n, h, w)).astype(np.uint16)
+    zgaps = np.stack([oracle.make_zgap(targets[i], 20, 3, rects) for i in range(n)])
+    lib = cds.Library(w, h, n)
+    lib.upload(0, targets)
+    lib.upload_variants(0, grads, zgaps)
+    for mirror in (True, False):
+        alg = cds.Shape2DMatchColorDepthSearchAlgorithm(mask, 20, mirror, None, rects)
+        gap, high, mir = alg.scoreLibraryPairs(lib, [0] * n, list(range(n)))
+        sq = oracle.ShapeQuery(mask, 20, mirror, rects)
+        for i in range(n):
+            want = sq.score(targets[i], grads[i], zgaps[i])
+            assert (int(gap[i]), int(high[i]), bool(mir[i])) == (want[0], want[1], want[3]), (w, mirror, i)
+    # device-side zgap generation at this geometry
+    lib.make_zgap_variants(0, n, 20, 3, rects)
+    _, z = lib.download_variants(0, n)
+    assert np.array_equal(z, zgaps)
+
+
 def test_normalized_scores_per_mask(cds, oracle):
     # GradientAreaGapUtils.calculateNormalizedScore applied per mask as CalculateGradientScoresCmd.java:616-645 does
     pix = np.array([636, 500, 0, 679])
