@@ -528,50 +528,65 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
     // Pixels are regrouped per band of kScanBandRows mask rows, sorted by (x, y) inside a band so that 64
     // consecutive pixels form a spatially compact chunk; each chunk carries the staging blocks / rows its probes
     // can touch, which lets a wave skip an orientation whose neighbourhood is all black (cds_scan.hip).
-    std::vector<uint32_t> bandptr((size_t)n_masks * (nbands + 1));
+    // Masks are scanned in launches ("groups") of ms->group masks sharing one pass over the library; the chunks of a
+    // group are stored band-major (band, mask, chunk) so that one band's work of the whole group is one contiguous
+    // chunk range: bandptr[group][band] .. bandptr[group][band + 1].
+    int group = 32;
+    if (const char *e = getenv("CDS_SCAN_MASKS_PER_LAUNCH")) group = std::max(2, std::min(128, atoi(e)));
+    if (n_masks == 1) group = 1;
+    ms->group = group;
+    const int ngroups = (n_masks + group - 1) / group;
+    std::vector<uint32_t> bandptr((size_t)ngroups * (nbands + 1));
     std::vector<uint4> chunks;
     std::vector<uint32_t> pos;
     std::vector<uint4> ivs;
     pos.reserve(total + total / 4 + 64);
     ivs.reserve(total + total / 4 + 64);
-    auto desc = [&](int cmin, int cmax, int nr) -> uint32_t {   // columns are window-relative pixels
+    auto desc = [&](int cmin, int cmax) -> uint32_t {   // columns are window-relative pixels
         const int g0 = (cmin - shift) >> 2, g1 = (cmax + shift) >> 2;
-        if ((g1 >> 5) - (g0 >> 5) > 1 || nr > 31) return 0;   // spans more than two occupancy words: never skip
+        if ((g1 >> 5) - (g0 >> 5) > 1) return 0;   // spans more than two occupancy words: never skip
         return (uint32_t)g0 | ((uint32_t)g1 << 9) | (1u << 31);
     };
+    std::vector<std::vector<std::vector<Px>>> bands((size_t)n_masks);
     for (int m = 0; m < n_masks; m++) {
-        std::vector<Px> &list = per_mask[(size_t)m];
-        std::vector<std::vector<Px>> bands((size_t)nbands);
-        for (const Px &p : list) bands[(size_t)((p.y - m0) / kScanBandRows)].push_back(p);
+        bands[(size_t)m].resize((size_t)nbands);
+        for (const Px &p : per_mask[(size_t)m]) bands[(size_t)m][(size_t)((p.y - m0) / kScanBandRows)].push_back(p);
+        std::vector<Px>().swap(per_mask[(size_t)m]);
+    }
+    for (int q = 0; q < ngroups; q++) {
         for (int b = 0; b < nbands; b++) {
-            bandptr[(size_t)m * (nbands + 1) + b] = (uint32_t)chunks.size();
-            std::vector<Px> &bl = bands[(size_t)b];
-            std::sort(bl.begin(), bl.end(), [](const Px &a, const Px &c) { return a.x < c.x || (a.x == c.x && a.y < c.y); });
-            for (size_t s0 = 0; s0 < bl.size(); s0 += 64) {
-                const size_t s1 = std::min(bl.size(), s0 + 64);
-                int xmin = W, xmax = -1, ymin = H, ymax = -1;
-                for (size_t i = s0; i < s1; i++) {
-                    const Px &p = bl[i];
-                    xmin = std::min(xmin, p.x); xmax = std::max(xmax, p.x);
-                    ymin = std::min(ymin, p.y); ymax = std::max(ymax, p.y);
-                    uint32_t cpl = (uint32_t)(p.x - ms->cx0), cmi = (uint32_t)(W - 1 - p.x - ms->cx0);
-                    pos.push_back(cpl | (cmi << 11) | ((uint32_t)(p.y - m0) << 22));
-                    ivs.push_back(make_uint4(p.iv.lo1, p.iv.len1, p.iv.lo2, p.iv.len2));
+            bandptr[(size_t)q * (nbands + 1) + b] = (uint32_t)chunks.size();
+            for (int m = q * group; m < std::min(n_masks, (q + 1) * group); m++) {
+                std::vector<Px> &bl = bands[(size_t)m][(size_t)b];
+                std::sort(bl.begin(), bl.end(), [](const Px &a, const Px &c) { return a.x < c.x || (a.x == c.x && a.y < c.y); });
+                for (size_t s0 = 0; s0 < bl.size(); s0 += 64) {
+                    const size_t s1 = std::min(bl.size(), s0 + 64);
+                    int xmin = W, xmax = -1, ymin = H, ymax = -1;
+                    bool two = false;
+                    for (size_t i = s0; i < s1; i++) {
+                        const Px &p = bl[i];
+                        xmin = std::min(xmin, p.x); xmax = std::max(xmax, p.x);
+                        ymin = std::min(ymin, p.y); ymax = std::max(ymax, p.y);
+                        uint32_t cpl = (uint32_t)(p.x - ms->cx0), cmi = (uint32_t)(W - 1 - p.x - ms->cx0);
+                        pos.push_back(cpl | (cmi << 11) | ((uint32_t)(p.y - m0) << 22));
+                        ivs.push_back(make_uint4(p.iv.lo1, p.iv.len1, p.iv.lo2, p.iv.len2));
+                        two = two || !(p.iv.lo2 == kEmptyIv.lo2 && p.iv.len2 == kEmptyIv.len2);
+                    }
+                    for (size_t i = s1; i < s0 + 64; i++) {  // pad the chunk: a pixel that can never match, at a valid position
+                        pos.push_back(pos[pos.size() - (i - s0)]);
+                        ivs.push_back(make_uint4(kEmptyIv.lo1, kEmptyIv.len1, kEmptyIv.lo2, kEmptyIv.len2));
+                    }
+                    const int r0 = ymin - m0, nr = (ymax - ymin) + 1 + 2 * shift;  // ring rows r0 .. r0+nr-1 (relative to m0-halo)
+                    uint4 ch;
+                    ch.x = (uint32_t)(s1 - s0) | ((uint32_t)(m - q * group) << 8) | (two ? 1u << 16 : 0u);
+                    ch.y = (uint32_t)r0 | ((uint32_t)nr << 10);
+                    ch.z = desc(xmin - ms->cx0, xmax - ms->cx0);
+                    ch.w = mirror ? desc(W - 1 - xmax - ms->cx0, W - 1 - xmin - ms->cx0) : 0;
+                    chunks.push_back(ch);
                 }
-                for (size_t i = s1; i < s0 + 64; i++) {  // pad the chunk: a pixel that can never match, at a valid position
-                    pos.push_back(pos[pos.size() - (i - s0)]);
-                    ivs.push_back(make_uint4(kEmptyIv.lo1, kEmptyIv.len1, kEmptyIv.lo2, kEmptyIv.len2));
-                }
-                const int r0 = ymin - m0, nr = (ymax - ymin) + 1 + 2 * shift;  // ring rows r0 .. r0+nr-1 (relative to m0-halo)
-                uint4 ch;
-                ch.x = (uint32_t)(s1 - s0);
-                ch.y = (uint32_t)r0 | ((uint32_t)nr << 10);
-                ch.z = desc(xmin - ms->cx0, xmax - ms->cx0, nr);
-                ch.w = mirror ? desc(W - 1 - xmax - ms->cx0, W - 1 - xmin - ms->cx0, nr) : 0;
-                chunks.push_back(ch);
             }
         }
-        bandptr[(size_t)m * (nbands + 1) + nbands] = (uint32_t)chunks.size();
+        bandptr[(size_t)q * (nbands + 1) + nbands] = (uint32_t)chunks.size();
     }
     total = pos.size();
     if (chunks.empty()) chunks.push_back(make_uint4(0, 0, 0, 0));
@@ -631,9 +646,7 @@ static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t fi
     double ms_sum = 0;
     int launches = 0;
     if (ms->n_px > 0) {
-        int chunk = 32;  // masks per launch when batching
-        if (const char *e = getenv("CDS_SCAN_MASKS_PER_LAUNCH")) chunk = std::max(2, atoi(e));
-        if (ms->n_masks == 1) chunk = 1;
+        const int chunk = ms->group;  // masks per launch (fixed when the mask set was laid out)
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (timed_sync) {
             CDS_HIP(hipEventCreate(&ev0));
@@ -650,11 +663,12 @@ static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t fi
             p.m0 = ms->m0;
             p.halo = ms->params.xy_shift;
             p.cx0 = ms->cx0; p.wc = ms->wc; p.gpr = ms->wc / 4;
+            p.rp = ms->wc + (getenv("CDS_SCAN_RINGPAD") ? atoi(getenv("CDS_SCAN_RINGPAD")) : 4);
             p.nseg = (p.gpr + 63) / 64;
             p.occw = 2 * p.nseg;
             p.nbands = ms->nbands;
             p.data_thr = (float)ms->params.data_threshold;
-            p.bandptr = ms->d_bandptr + (size_t)g0 * (ms->nbands + 1);
+            p.bandptr = ms->d_bandptr + (size_t)(g0 / chunk) * (ms->nbands + 1);
             p.chunks = ms->d_chunks;
             p.px_pos = ms->d_px_pos;
             p.px_iv = ms->d_px_iv;

@@ -90,12 +90,15 @@ struct ScanParams {
     int halo;             // 0 or 2
     int cx0, wc;          // column window [cx0, cx0+wc), both multiples of 16 (cx0 may be negative)
     int gpr;              // wc / 4 : 4-pixel groups per staged row
+    int rp;               // LDS ring row pitch in dwords = wc + 4: wc is a multiple of 16, so rp = 4 (mod 8) and the 12 rows
+                          // of a band start 4 banks apart (a chunk of 64 x-sorted mask pixels is ~5 columns x 12 rows)
     int nseg;             // ceil(gpr / 64): 64-group segments per staged row
     int occw;             // occupancy words (u32, one bit per group) per ring row = 2 * nseg
     int nbands;           // ceil(nrows / kScanBandRows)
     float data_thr;
-    const uint32_t *bandptr;  // [n_masks][nbands+1] -> chunk index
-    const uint4 *chunks;      // y: r0 | nr<<10, z/w: plain/mirror g0 | g1<<9 | testable<<31 (64 pixels per chunk)
+    const uint32_t *bandptr;  // [nbands+1] of this launch's mask group -> chunk index (chunks are stored band, mask, chunk)
+    const uint4 *chunks;      // x: pixels | mask-in-group << 8 | has-second-interval << 16, y: r0 | nr<<10,
+                              // z/w: plain/mirror g0 | g1<<9 | testable<<31 (64 pixels per chunk)
     const uint32_t *px_pos;   // cplain | cmir << 11 | yrel << 22   (sorted by mask, band, x, y; chunks padded to 64)
     const uint4 *px_iv;       // lo1, len1, lo2, len2
     int32_t *out;            // [n_masks][count]  score | mirrored << 31
@@ -115,6 +118,7 @@ struct cds_maskset {
     cds_context *ctx = nullptr;
     cds_pixmatch_params params{};
     int W = 0, H = 0, n_masks = 0;
+    int group = 1;               // masks per launch; the chunk arrays are laid out per group (cds_maskset_create)
     std::vector<int32_t> sizes;  // query size P per mask (includes class-less pixels)
     int m0 = 0, m1 = 0, cx0 = 0, wc = 0;
     uint32_t *d_bandptr = nullptr;

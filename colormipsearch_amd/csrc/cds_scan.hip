@@ -94,10 +94,11 @@ __device__ __forceinline__ uint4 convert4(uint32_t a, uint32_t b, uint32_t c, fl
 }
 
 struct Lds {
-    uint32_t *ring;   // [RR][wc]   codes (or raw groups between phase A and phase B)
+    uint32_t *ring;   // [RR][rp]   codes (or raw groups between phase A and phase B); row pitch rp = wc + 4, see ScanParams
     uint32_t *occ;    // [RR][occw] one bit per 4-pixel group (32 groups per word): group non-black
     uint16_t *queue;  // [QCAP]     ring index / 4 of the groups phase B must convert
     int *qcount;      // [2]        double-buffered by band parity
+    int *next;        // [2]        mask batches: next block of chunks to hand out, double-buffered by band parity
     int *cnt;         // counters
 };
 
@@ -158,7 +159,7 @@ __device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, cons
     const int row = r + p.m0 - p.halo;
     const bool rowok = row >= 0 && row < p.H;  // wave-uniform
     const int slot = r & (RR - 1);
-    uint32_t *ringrow = L.ring + slot * p.wc;
+    uint32_t *ringrow = L.ring + slot * p.rp;
     unsigned long long bal[KMAX];
     int total = 0;
 #pragma unroll
@@ -188,7 +189,7 @@ __device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, cons
             if (k < K && bal[k] != 0) {  // wave-uniform
                 if ((bal[k] >> lane) & 1) {
                     const int my = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[k], 0));
-                    const int dst = slot * p.wc + lc.wr4[k];
+                    const int dst = slot * p.rp + lc.wr4[k];
                     if (my < QCAP) {
                         L.queue[my] = (uint16_t)(dst >> 2);
                     } else {  // queue full (dense target): convert in place now
@@ -275,10 +276,11 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
     constexpr int NC = NS * NO;
     Lds L;
     L.ring = lds;
-    L.occ = L.ring + RR * p.wc;
+    L.occ = L.ring + RR * p.rp;
     L.queue = reinterpret_cast<uint16_t *>(L.occ + RO * p.occw);
     L.qcount = reinterpret_cast<int *>(L.queue + QCAP);
-    L.cnt = L.qcount + 2;  // MULTI: [n_masks][NC]; single: [NC]
+    L.next = L.qcount + 2;
+    L.cnt = L.next + 2;  // MULTI: [n_masks][NC]; single: [NC]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int halo = XY2 ? 2 : 0;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
         const uint8_t *img = p.lib + (size_t)t * p.img_stride;
         const int ncnt = MULTI ? p.n_masks * NC : NC;
         for (int i = threadIdx.x; i < ncnt; i += NT) L.cnt[i] = 0;
-        if (threadIdx.x < 2) L.qcount[threadIdx.x] = 0;
+        if (threadIdx.x < 4) L.qcount[threadIdx.x] = 0;  // qcount[2] and next[2]
         for (int i = threadIdx.x; i < RO * p.occw; i += NT) L.occ[i] = 0;
         int acc[NC];
 #pragma unroll
@@ -311,13 +313,15 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
             const uint32_t cbeg0 = p.bandptr[band], cend0 = p.bandptr[band + 1];
             u32x4 pch[MAXC], piv[MAXC];
             uint32_t ppos[MAXC];
+            if (!MULTI) {
 #pragma unroll
-            for (int k = 0; k < MAXC; k++) {
-                uint32_t ci = cbeg0 + wave + k * NW;
-                ci = ci < cend0 ? ci : cbeg0;
-                pch[k] = async_ld16(p.chunks + ci);
-                ppos[k] = async_ld4(p.px_pos + (size_t)ci * 64 + lane);
-                piv[k] = async_ld16(p.px_iv + (size_t)ci * 64 + lane);
+                for (int k = 0; k < MAXC; k++) {
+                    uint32_t ci = cbeg0 + wave + k * NW;
+                    ci = ci < cend0 ? ci : cbeg0;
+                    pch[k] = async_ld16(p.chunks + ci);
+                    ppos[k] = async_ld4(p.px_pos + (size_t)ci * 64 + lane);
+                    piv[k] = async_ld16(p.px_iv + (size_t)ci * 64 + lane);
+                }
             }
             // this wave's RPW rows of the next band (clamped and ignored where there is none)
             const int next_end = (y1 < m1rel) ? ((y1 + BH < m1rel) ? y1 + BH : m1rel) + 2 * halo : staged;
@@ -329,12 +333,17 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
             }
             __syncthreads();  // phase A of this band is complete
             // ---- phase B (+ the next band's queue counter)
-            if (threadIdx.x == 0) L.qcount[qsel ^ 1] = 0;
+            if (threadIdx.x == 0) {
+                L.qcount[qsel ^ 1] = 0;
+                L.next[qsel ^ 1] = 0;
+            }
             if (!(p.debug & 2)) stage_b(p, L, qsel);
             __syncthreads();
             // ---- phase P: the mask data has arrived when at most the RPW*KMAX row loads are outstanding
+            if (!MULTI) {
 #pragma unroll
-            for (int k = 0; k < MAXC; k++) wait_mask<RPW * KMAX>(pch[k], ppos[k], piv[k]);
+                for (int k = 0; k < MAXC; k++) wait_mask<RPW * KMAX>(pch[k], ppos[k], piv[k]);
+            }
             auto probe_chunk = [&](const uint4 ch, const uint32_t pos, const uint4 iv, int *ctr) {
                 const int r0 = ch.y & 1023, nr = (ch.y >> 10) & 31;
                 const uint32_t occ2 = (p.debug & 4) ? 3u : regions_occupied(L, p.occw, ch.z, MIRROR ? ch.w : (1u << 31), r0, nr, lane);
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
 #pragma unroll
                     for (int iy = 0; iy < NSX; iy++) {
                         const int rel = yrel + (XY2 ? 2 * iy : 0);  // = yrel + halo + dy
-                        const uint32_t *rowp = L.ring + (rel & (RR - 1)) * p.wc + col;
+                        const uint32_t *rowp = L.ring + (rel & (RR - 1)) * p.rp + col;
 #pragma unroll
                         for (int ix = 0; ix < NSX; ix++) cv[ix * NSX + iy] = rowp[XY2 ? sgn * 2 * (ix - 1) : 0];
                     }
@@ -371,34 +380,98 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                     for (; ci < cend0; ci += NW)  // (compiler-issued loads: also wait for the rows in flight; rare)
                         probe_chunk(p.chunks[ci], p.px_pos[ci * 64 + lane], p.px_iv[ci * 64 + lane], acc);
                 }
-            } else {
-                // mask batch: every wave owns whole masks (g = wave, wave+NW, ...), keeps per-lane counters over all
-                // chunks of (band, mask) with the next chunk's data prefetched, and adds the wave sums to its own LDS
-                // counters -- no atomics, nobody else touches cnt[g].
-                for (int g = wave; g < p.n_masks && !(p.debug & 1); g += NW) {
-                    const uint32_t *bp = p.bandptr + (size_t)g * (p.nbands + 1) + band;
-                    const uint32_t cbeg = bp[0], cend = bp[1];
-                    if (cbeg >= cend) continue;
-                    int lacc[NC];
+            } else if (!(p.debug & 1)) {
+                // Mask batch.  The chunks of ALL masks of the launch are stored band-major (band, mask, chunk), so one
+                // band's work is the contiguous chunk range [cbeg0, cend0).  Waves draw blocks of 32 chunks from an
+                // LDS counter; lane l tests chunk l's plain region, lane 32+l its mirrored region, against the BAND's
+                // occupancy (the OR of the 16 ring rows' occupancy words, one word per lane, fetched by ds_bpermute)
+                // -- one ballot tells which chunks and orientations need probing at all.  Only those chunks' pixel
+                // records are loaded (the next occupied chunk's while the current one is probed), matches are
+                // counted with s_bcnt1 of the compare masks into wave-uniform (SGPR) counters, which are flushed to the
+                // mask's LDS counters when the mask changes.
+                uint32_t bo = 0;
+                if (lane < p.occw) {
 #pragma unroll
-                    for (int k = 0; k < NC; k++) lacc[k] = 0;
-                    uint4 nch = p.chunks[cbeg], niv = p.px_iv[(size_t)cbeg * 64 + lane];
-                    uint32_t npos = p.px_pos[(size_t)cbeg * 64 + lane];
-                    for (uint32_t ci = cbeg; ci < cend; ci++) {
-                        const uint4 ch = nch, iv = niv;
-                        const uint32_t pos = npos;
-                        const uint32_t cn = ci + 1 < cend ? ci + 1 : ci;
-                        nch = p.chunks[cn];
-                        niv = p.px_iv[(size_t)cn * 64 + lane];
-                        npos = p.px_pos[(size_t)cn * 64 + lane];
-                        probe_chunk(ch, pos, iv, lacc);
+                    for (int r = 0; r < RO; r++) bo |= L.occ[r * p.occw + lane];
+                }
+                int sacc[NC];
+#pragma unroll
+                for (int k = 0; k < NC; k++) sacc[k] = 0;
+                int curmask = -1;
+                auto flush = [&]() {
+                    if (curmask >= 0) {
+                        int v = 0;
+#pragma unroll
+                        for (int k = 0; k < NC; k++) v = lane == k ? sacc[k] : v;
+                        if (lane < NC && v) atomicAdd(&L.cnt[curmask * NC + lane], v);
+#pragma unroll
+                        for (int k = 0; k < NC; k++) sacc[k] = 0;
                     }
+                };
+                const int l32 = lane & 31;
+                for (;;) {
+                    int blk = 0;
+                    if (lane == 0) blk = atomicAdd(&L.next[qsel], 1);
+                    blk = __builtin_amdgcn_readfirstlane(blk);
+                    const uint32_t base = cbeg0 + 32u * (uint32_t)blk;
+                    if (base >= cend0) break;
+                    const uint32_t ci = base + l32;
+                    const bool valid = ci < cend0;
+                    const uint4 d = p.chunks[valid ? ci : cend0 - 1];
+                    // region [g0, g1] of the band: at most 2 occupancy words (else the host cleared bit 31: never skip)
+                    const uint32_t desc = (lane < 32 || !MIRROR) ? d.z : d.w;
+                    const int g0 = desc & 511, g1 = (desc >> 9) & 511;
+                    const uint32_t wlo = __shfl(bo, g0 >> 5, 64), whi = __shfl(bo, (g0 >> 5) + 1, 64);
+                    const unsigned long long bits = (((unsigned long long)whi << 32) | wlo) >> (g0 & 31);
+                    const int width = g1 - g0 + 1;
+                    const unsigned long long wm = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
+                    const bool hit = valid && (MIRROR || lane < 32) && (!(desc >> 31) || (bits & wm) != 0 || (p.debug & 4));
+                    const unsigned long long bal = __ballot(hit);
+                    const uint32_t bpl = (uint32_t)bal, bmi = (uint32_t)(bal >> 32);
+                    uint32_t todo = bpl | bmi;
+                    if (!todo) continue;
+                    int i = __builtin_ctz(todo);
+                    uint32_t pos = p.px_pos[(size_t)(base + i) * 64 + lane];
+                    uint4 iv = p.px_iv[(size_t)(base + i) * 64 + lane];
+                    while (todo) {
+                        todo &= todo - 1;
+                        const int inext = todo ? __builtin_ctz(todo) : i;
+                        const uint32_t npos = p.px_pos[(size_t)(base + inext) * 64 + lane];  // next occupied chunk (or this one again)
+                        const uint4 niv = p.px_iv[(size_t)(base + inext) * 64 + lane];
+                        const uint32_t dx = (uint32_t)__builtin_amdgcn_readlane((int)d.x, i);
+                        const int g = (dx >> 8) & 255;
+                        if (g != curmask) {
+                            flush();
+                            curmask = g;
+                        }
+                        const bool two = (dx >> 16) & 1;  // some pixel of the chunk has a second interval
+                        const int cpl = pos & 2047, cmi = (pos >> 11) & 2047, yrel = pos >> 22;
+                        auto probe9s = [&](int col, int sgn, int *sc) {
+                            uint32_t cv[NS];
 #pragma unroll
-                    for (int k = 0; k < NC; k++) {
-                        const int v = wave_sum(lacc[k]);
-                        if (lane == 0 && v) L.cnt[g * NC + k] += v;
+                            for (int iy = 0; iy < NSX; iy++) {
+                                const int rel = yrel + (XY2 ? 2 * iy : 0);
+                                const uint32_t *rowp = L.ring + (rel & (RR - 1)) * p.rp + col;
+#pragma unroll
+                                for (int ix = 0; ix < NSX; ix++) cv[ix * NSX + iy] = rowp[XY2 ? sgn * 2 * (ix - 1) : 0];
+                            }
+                            if (two) {
+#pragma unroll
+                                for (int k = 0; k < NS; k++)
+                                    sc[k] += __popcll(__ballot(((cv[k] - iv.x) <= iv.y) | ((cv[k] - iv.z) <= iv.w)));
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < NS; k++) sc[k] += __popcll(__ballot((cv[k] - iv.x) <= iv.y));
+                            }
+                        };
+                        if ((bpl >> i) & 1) probe9s(cpl, 1, sacc);
+                        if (MIRROR && ((bmi >> i) & 1)) probe9s(cmi, -1, sacc + NS);
+                        i = inext;
+                        pos = npos;
+                        iv = niv;
                     }
                 }
+                flush();
             }
             __syncthreads();  // the next band's phase A overwrites the oldest BH rows of the ring
             // ---- phase A of the next band: the rows loaded at the top of this band
@@ -446,7 +519,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
 
 size_t scan_lds_bytes(const ScanParams &p, bool xy2, bool mirror) {
     const int nc = (xy2 ? 9 : 1) * (mirror ? 2 : 1);
-    return (size_t)RR * p.wc * 4 + (size_t)RO * p.occw * 4 + (size_t)QCAP * 2 + 2 * sizeof(int) +
+    return (size_t)RR * p.rp * 4 + (size_t)RO * p.occw * 4 + (size_t)QCAP * 2 + 4 * sizeof(int) +
            (size_t)(p.n_masks > 1 ? p.n_masks : 1) * nc * sizeof(int);
 }
 
