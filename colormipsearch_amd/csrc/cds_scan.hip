@@ -70,6 +70,7 @@ constexpr int NW = NT / 64;
 constexpr int QCAP = 512;  // queue entries (one per non-black group); overflow falls back to in-place conversion
 constexpr int MAXC = 4;    // chunks per wave and band whose mask data is fetched asynchronously at the top of the band
 constexpr int RPW = BH / NW;  // new rows per wave and band
+constexpr int BLKC = 32;     // mask batches: chunks per block of work drawn from the LDS counter (<= 32)
 static_assert(RR >= BH + 4 && (RR & (RR - 1)) == 0 && RO >= RR && BH % NW == 0, "ring geometry");
 
 // class lookup by the three strict comparisons: idx = 4*(r>g) + 8*(g>b) + 16*(b>r) selects a nibble.
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
 #pragma unroll
                     for (int iy = 0; iy < NSX; iy++) {
                         const int rel = yrel + (XY2 ? 2 * iy : 0);  // = yrel + halo + dy
-                        const uint32_t *rowp = L.ring + (rel & (RR - 1)) * p.rp + col;
+                        const uint32_t *rowp = L.ring + __umul24((uint32_t)(rel & (RR - 1)), (uint32_t)p.rp) + col;  // v_mul_u32_u24: full rate
 #pragma unroll
                         for (int ix = 0; ix < NSX; ix++) cv[ix * NSX + iy] = rowp[XY2 ? sgn * 2 * (ix - 1) : 0];
                     }
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                 }
             } else if (!(p.debug & 1)) {
                 // Mask batch.  The chunks of ALL masks of the launch are stored band-major (band, mask, chunk), so one
-                // band's work is the contiguous chunk range [cbeg0, cend0).  Waves draw blocks of 32 chunks from an
+                // band's work is the contiguous chunk range [cbeg0, cend0).  Waves draw blocks of BLKC chunks from an
                 // LDS counter; lane l tests chunk l's plain region, lane 32+l its mirrored region, against the BAND's
                 // occupancy (the OR of the 16 ring rows' occupancy words, one word per lane, fetched by ds_bpermute)
                 // -- one ballot tells which chunks and orientations need probing at all.  Only those chunks' pixel
@@ -402,21 +403,21 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                     if (curmask >= 0) {
                         int v = 0;
 #pragma unroll
-                        for (int k = 0; k < NC; k++) v = lane == k ? sacc[k] : v;
+                        for (int k = 0; k < NC; k++) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(sacc[k])), "n"(k));
                         if (lane < NC && v) atomicAdd(&L.cnt[curmask * NC + lane], v);
 #pragma unroll
                         for (int k = 0; k < NC; k++) sacc[k] = 0;
                     }
                 };
-                const int l32 = lane & 31;
+                const int l32 = lane & 31;  // lanes 0..31 test plain regions, lanes 32..63 mirrored ones
                 for (;;) {
                     int blk = 0;
                     if (lane == 0) blk = atomicAdd(&L.next[qsel], 1);
                     blk = __builtin_amdgcn_readfirstlane(blk);
-                    const uint32_t base = cbeg0 + 32u * (uint32_t)blk;
+                    const uint32_t base = cbeg0 + (uint32_t)BLKC * (uint32_t)blk;
                     if (base >= cend0) break;
                     const uint32_t ci = base + l32;
-                    const bool valid = ci < cend0;
+                    const bool valid = l32 < BLKC && ci < cend0;
                     const uint4 d = p.chunks[valid ? ci : cend0 - 1];
                     // region [g0, g1] of the band: at most 2 occupancy words (else the host cleared bit 31: never skip)
                     const uint32_t desc = (lane < 32 || !MIRROR) ? d.z : d.w;
@@ -430,14 +431,9 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                     const uint32_t bpl = (uint32_t)bal, bmi = (uint32_t)(bal >> 32);
                     uint32_t todo = bpl | bmi;
                     if (!todo) continue;
-                    int i = __builtin_ctz(todo);
-                    uint32_t pos = p.px_pos[(size_t)(base + i) * 64 + lane];
-                    uint4 iv = p.px_iv[(size_t)(base + i) * 64 + lane];
-                    while (todo) {
-                        todo &= todo - 1;
-                        const int inext = todo ? __builtin_ctz(todo) : i;
-                        const uint32_t npos = p.px_pos[(size_t)(base + inext) * 64 + lane];  // next occupied chunk (or this one again)
-                        const uint4 niv = p.px_iv[(size_t)(base + inext) * 64 + lane];
+                    // two register sets (A/B) alternate so that the next occupied chunk's records are in flight while the
+                    // current chunk is probed, without a register copy (which would wait for the load just issued)
+                    auto process = [&](int i, uint32_t pos, const uint4 &iv) {
                         const uint32_t dx = (uint32_t)__builtin_amdgcn_readlane((int)d.x, i);
                         const int g = (dx >> 8) & 255;
                         if (g != curmask) {
@@ -446,19 +442,24 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                         }
                         const bool two = (dx >> 16) & 1;  // some pixel of the chunk has a second interval
                         const int cpl = pos & 2047, cmi = (pos >> 11) & 2047, yrel = pos >> 22;
+                        const uint32_t *rowp[NSX];  // the (up to) three ring rows of this lane's probes, shared by both orientations
+#pragma unroll
+                        for (int iy = 0; iy < NSX; iy++)
+                            rowp[iy] = L.ring + __umul24((uint32_t)((yrel + (XY2 ? 2 * iy : 0)) & (RR - 1)), (uint32_t)p.rp);  // full-rate multiply
                         auto probe9s = [&](int col, int sgn, int *sc) {
                             uint32_t cv[NS];
 #pragma unroll
                             for (int iy = 0; iy < NSX; iy++) {
-                                const int rel = yrel + (XY2 ? 2 * iy : 0);
-                                const uint32_t *rowp = L.ring + (rel & (RR - 1)) * p.rp + col;
 #pragma unroll
-                                for (int ix = 0; ix < NSX; ix++) cv[ix * NSX + iy] = rowp[XY2 ? sgn * 2 * (ix - 1) : 0];
+                                for (int ix = 0; ix < NSX; ix++) cv[ix * NSX + iy] = rowp[iy][col + (XY2 ? sgn * 2 * (ix - 1) : 0)];
                             }
-                            if (two) {
+                            if (two) {  // rare: keep its compares out of the common path (no hoisting across the branch)
 #pragma unroll
-                                for (int k = 0; k < NS; k++)
-                                    sc[k] += __popcll(__ballot(((cv[k] - iv.x) <= iv.y) | ((cv[k] - iv.z) <= iv.w)));
+                                for (int k = 0; k < NS; k++) {
+                                    uint32_t c = cv[k];
+                                    asm volatile("" : "+v"(c));
+                                    sc[k] += __popcll(__ballot(((c - iv.x) <= iv.y) | ((c - iv.z) <= iv.w)));
+                                }
                             } else {
 #pragma unroll
                                 for (int k = 0; k < NS; k++) sc[k] += __popcll(__ballot((cv[k] - iv.x) <= iv.y));
@@ -466,9 +467,23 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                         };
                         if ((bpl >> i) & 1) probe9s(cpl, 1, sacc);
                         if (MIRROR && ((bmi >> i) & 1)) probe9s(cmi, -1, sacc + NS);
-                        i = inext;
-                        pos = npos;
-                        iv = niv;
+                    };
+                    int iA = __builtin_ctz(todo), iB;
+                    uint32_t posA = p.px_pos[(size_t)(base + iA) * 64 + lane], posB;
+                    uint4 ivA = p.px_iv[(size_t)(base + iA) * 64 + lane], ivB;
+                    for (;;) {
+                        todo &= todo - 1;
+                        iB = todo ? __builtin_ctz(todo) : iA;  // next occupied chunk (or this one again: no branch around the loads)
+                        posB = p.px_pos[(size_t)(base + iB) * 64 + lane];
+                        ivB = p.px_iv[(size_t)(base + iB) * 64 + lane];
+                        process(iA, posA, ivA);
+                        if (!todo) break;
+                        todo &= todo - 1;
+                        iA = todo ? __builtin_ctz(todo) : iB;
+                        posA = p.px_pos[(size_t)(base + iA) * 64 + lane];
+                        ivA = p.px_iv[(size_t)(base + iA) * 64 + lane];
+                        process(iB, posB, ivB);
+                        if (!todo) break;
                     }
                 }
                 flush();
