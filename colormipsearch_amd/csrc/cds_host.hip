@@ -532,8 +532,12 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
     // group are stored band-major (band, mask, chunk) so that one band's work of the whole group is one contiguous
     // chunk range: bandptr[group][band] .. bandptr[group][band + 1].
     int group = 32;
-    if (const char *e = getenv("CDS_SCAN_MASKS_PER_LAUNCH")) group = std::max(2, std::min(128, atoi(e)));
+    if (const char *e = getenv("CDS_SCAN_MASKS_PER_LAUNCH")) group = std::max(1, std::min(128, atoi(e)));
     if (n_masks == 1) group = 1;
+    group = std::min(group, n_masks);
+    // the batch kernel keeps 4 more ring rows and the masks' counters in LDS: a window too wide for that is scanned
+    // mask by mask with the single-mask kernel (same results)
+    if (group > 1 && scan_lds_bytes(ms->wc, group, true, shift == 2, mirror) > ctx->lds_per_block) group = 1;
     ms->group = group;
     const int ngroups = (n_masks + group - 1) / group;
     std::vector<uint32_t> bandptr((size_t)ngroups * (nbands + 1));
@@ -568,7 +572,12 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
                         xmin = std::min(xmin, p.x); xmax = std::max(xmax, p.x);
                         ymin = std::min(ymin, p.y); ymax = std::max(ymax, p.y);
                         uint32_t cpl = (uint32_t)(p.x - ms->cx0), cmi = (uint32_t)(W - 1 - p.x - ms->cx0);
-                        pos.push_back(cpl | (cmi << 11) | ((uint32_t)(p.y - m0) << 22));
+                        if (group == 1) {
+                            pos.push_back(cpl | (cmi << 11) | ((uint32_t)(p.y - m0) << 22));
+                        } else {  // mask batches: dword offsets of the first probe inside the (non-wrapping) LDS ring
+                            const uint32_t row0 = (uint32_t)((p.y - m0) & 15) * (uint32_t)ring_pitch(ms->wc);
+                            pos.push_back((row0 + cpl - shift) | ((row0 + cmi - shift) << 16));
+                        }
                         ivs.push_back(make_uint4(p.iv.lo1, p.iv.len1, p.iv.lo2, p.iv.len2));
                         two = two || !(p.iv.lo2 == kEmptyIv.lo2 && p.iv.len2 == kEmptyIv.len2);
                     }
@@ -659,11 +668,12 @@ static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t fi
             p.pitch = lib->pitch; p.W = lib->W; p.H = lib->H; p.wpad = lib->pitch / 3;
             p.count = count;
             p.n_masks = std::min(chunk, ms->n_masks - g0);
+            p.batch = chunk > 1;
             p.nrows = ms->m1 - ms->m0;
             p.m0 = ms->m0;
             p.halo = ms->params.xy_shift;
             p.cx0 = ms->cx0; p.wc = ms->wc; p.gpr = ms->wc / 4;
-            p.rp = ms->wc + (getenv("CDS_SCAN_RINGPAD") ? atoi(getenv("CDS_SCAN_RINGPAD")) : 4);
+            p.rp = ring_pitch(ms->wc);
             p.nseg = (p.gpr + 63) / 64;
             p.occw = 2 * p.nseg;
             p.nbands = ms->nbands;

@@ -37,6 +37,9 @@ inline int ceil4(int v) { return -floor4(-v); }
 // whole number of 12-byte (4 pixel) load groups.
 inline int rgb_pitch(int W) { return round_up(3 * W, 48); }
 inline int grad_pitch(int W) { return round_up(2 * W, 16); }
+// LDS ring row pitch (dwords) of the scan kernel for a column window of wc pixels (a multiple of 16): wc + 4 = 4 (mod 8),
+// so the 12 rows of a band start 4 banks apart (a chunk of 64 x-sorted mask pixels is ~5 columns x 12 rows).
+inline int ring_pitch(int wc) { return wc + 4; }
 
 // One distinct value of second/max (a fraction n/d, 0 <= n < d <= 255) as the reference computes it in
 // double, with the range of device codes its (n,d) representatives map to.
@@ -85,13 +88,13 @@ struct ScanParams {
     int pitch, W, H, wpad;
     int64_t count;
     int n_masks;          // masks in this launch
+    int batch;            // records are in the mask-batch layout (mask set laid out for > 1 mask per launch)
     int nrows;            // m1 - m0
     int m0;               // first mask row of the union span
     int halo;             // 0 or 2
     int cx0, wc;          // column window [cx0, cx0+wc), both multiples of 16 (cx0 may be negative)
     int gpr;              // wc / 4 : 4-pixel groups per staged row
-    int rp;               // LDS ring row pitch in dwords = wc + 4: wc is a multiple of 16, so rp = 4 (mod 8) and the 12 rows
-                          // of a band start 4 banks apart (a chunk of 64 x-sorted mask pixels is ~5 columns x 12 rows)
+    int rp;               // LDS ring row pitch in dwords = ring_pitch(wc)
     int nseg;             // ceil(gpr / 64): 64-group segments per staged row
     int occw;             // occupancy words (u32, one bit per group) per ring row = 2 * nseg
     int nbands;           // ceil(nrows / kScanBandRows)
@@ -99,7 +102,8 @@ struct ScanParams {
     const uint32_t *bandptr;  // [nbands+1] of this launch's mask group -> chunk index (chunks are stored band, mask, chunk)
     const uint4 *chunks;      // x: pixels | mask-in-group << 8 | has-second-interval << 16, y: r0 | nr<<10,
                               // z/w: plain/mirror g0 | g1<<9 | testable<<31 (64 pixels per chunk)
-    const uint32_t *px_pos;   // cplain | cmir << 11 | yrel << 22   (sorted by mask, band, x, y; chunks padded to 64)
+    const uint32_t *px_pos;   // one mask: cplain | cmir << 11 | yrel << 22; mask batches: LDS dword offsets plain | mirrored << 16
+                              // (64 records per chunk, padded)
     const uint4 *px_iv;       // lo1, len1, lo2, len2
     int32_t *out;            // [n_masks][count]  score | mirrored << 31
     int32_t *counts;         // optional [n_masks][count][18]
@@ -109,6 +113,7 @@ struct ScanParams {
 };
 
 int launch_scan(cds_context *ctx, const ScanParams &p, bool xy2, bool mirror, hipStream_t stream);
+size_t scan_lds_bytes(int wc, int n_masks, bool batch, bool xy2, bool mirror);  // dynamic LDS of one workgroup
 int refresh_zslice(cds_library *lib, int64_t first, int64_t count);  // cds_shape.hip: zgap RGB -> zslice plane
 int init_rcp_table(cds_context *ctx);
 

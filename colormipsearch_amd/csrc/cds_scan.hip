@@ -70,6 +70,8 @@ constexpr int NW = NT / 64;
 constexpr int QCAP = 512;  // queue entries (one per non-black group); overflow falls back to in-place conversion
 constexpr int MAXC = 4;    // chunks per wave and band whose mask data is fetched asynchronously at the top of the band
 constexpr int RPW = BH / NW;  // new rows per wave and band
+constexpr int RDUP = 4;      // mask batches: ring slots 0..3 are mirrored in slots RR..RR+3, so that a probe's three rows
+                             // (slot, slot+2, slot+4) never wrap and the host can precompute LDS offsets per mask pixel
 constexpr int BLKC = 32;     // mask batches: chunks per block of work drawn from the LDS counter (<= 32)
 static_assert(RR >= BH + 4 && (RR & (RR - 1)) == 0 && RO >= RR && BH % NW == 0, "ring geometry");
 
@@ -153,7 +155,7 @@ __device__ __forceinline__ void a_issue(const ScanParams &p, const uint8_t *img,
 }
 
 // a_commit: registers -> ring (raw) / occupancy words / queue of non-black groups.
-template <int KMAX>
+template <int KMAX, bool DUP>
 __device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, const LaneConst<KMAX> &lc, int r, int qsel, int lane,
                                          const u32x3 (&w)[KMAX]) {
     const int K = p.nseg;
@@ -161,6 +163,8 @@ __device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, cons
     const bool rowok = row >= 0 && row < p.H;  // wave-uniform
     const int slot = r & (RR - 1);
     uint32_t *ringrow = L.ring + slot * p.rp;
+    const bool dup = DUP && slot < RDUP;  // wave-uniform: this row is also kept in slot RR + slot
+    const int dupoff = RR * p.rp;
     unsigned long long bal[KMAX];
     int total = 0;
 #pragma unroll
@@ -170,6 +174,7 @@ __device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, cons
             const bool keep = rowok && !((lc.zero >> k) & 1);
             const uint32_t a = keep ? w[k].x : 0u, b = keep ? w[k].y : 0u, c = keep ? w[k].z : 0u;
             *reinterpret_cast<uint4 *>(ringrow + lc.wr4[k]) = make_uint4(a, b, c, 0);  // black group == zero codes
+            if (dup) *reinterpret_cast<uint4 *>(ringrow + dupoff + lc.wr4[k]) = make_uint4(a, b, c, 0);
             bal[k] = __ballot(((lc.own >> k) & 1) && (a | b | c) != 0);
             total += __popcll(bal[k]);
         }
@@ -192,9 +197,11 @@ __device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, cons
                     const int my = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[k], 0));
                     const int dst = slot * p.rp + lc.wr4[k];
                     if (my < QCAP) {
-                        L.queue[my] = (uint16_t)(dst >> 2);
+                        L.queue[my] = (uint16_t)((dst >> 2) | (dup ? 0x8000 : 0));
                     } else {  // queue full (dense target): convert in place now
-                        *reinterpret_cast<uint4 *>(L.ring + dst) = convert4(w[k].x, w[k].y, w[k].z, p.data_thr);
+                        const uint4 cv = convert4(w[k].x, w[k].y, w[k].z, p.data_thr);
+                        *reinterpret_cast<uint4 *>(L.ring + dst) = cv;
+                        if (dup) *reinterpret_cast<uint4 *>(L.ring + dst + dupoff) = cv;
                     }
                 }
                 base += __popcll(bal[k]);
@@ -207,14 +214,14 @@ __device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, cons
 // A row is K = ceil(gpr/64) segments of 64 groups (12 bytes each): lane l of segment k loads group 64k+l, so every
 // load instruction reads 768 contiguous bytes from a wave-uniform row pointer and all loads of a row are in flight
 // together.
-template <int KMAX>
+template <int KMAX, bool DUP>
 __device__ __forceinline__ void stage_a(const ScanParams &p, const uint8_t *img, const Lds &L, const LaneConst<KMAX> &lc, int ra, int n,
                                         int qsel, int wave, int lane) {
     for (int r = ra + wave; r < ra + n; r += NW) {  // wave-uniform
         u32x3 w[KMAX];
         a_issue<KMAX>(p, img, lc, r, w);
         wait_rows<KMAX>(w);
-        a_commit<KMAX>(p, L, lc, r, qsel, lane, w);
+        a_commit<KMAX, DUP>(p, L, lc, r, qsel, lane, w);
     }
 }
 
@@ -223,9 +230,12 @@ __device__ __forceinline__ void stage_b(const ScanParams &p, const Lds &L, int q
     int n = L.qcount[qsel];
     n = n < QCAP ? n : QCAP;
     for (int e = threadIdx.x; e < n; e += NT) {
-        const int idx = (int)L.queue[e] << 2;
+        const uint32_t q = L.queue[e];
+        const int idx = (int)(q & 0x7fffu) << 2;
         const uint4 raw = *reinterpret_cast<const uint4 *>(L.ring + idx);
-        *reinterpret_cast<uint4 *>(L.ring + idx) = convert4(raw.x, raw.y, raw.z, p.data_thr);
+        const uint4 cv = convert4(raw.x, raw.y, raw.z, p.data_thr);
+        *reinterpret_cast<uint4 *>(L.ring + idx) = cv;
+        if (q & 0x8000u) *reinterpret_cast<uint4 *>(L.ring + idx + RR * p.rp) = cv;  // mirrored slot (mask batches)
     }
 }
 
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
     constexpr int NC = NS * NO;
     Lds L;
     L.ring = lds;
-    L.occ = L.ring + RR * p.rp;
+    L.occ = L.ring + (RR + (MULTI ? RDUP : 0)) * p.rp;
     L.queue = reinterpret_cast<uint16_t *>(L.occ + RO * p.occw);
     L.qcount = reinterpret_cast<int *>(L.queue + QCAP);
     L.next = L.qcount + 2;
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
         // wave issues (asynchronously) the mask data of band b and then the loads of ITS row of band b+1, which stay
         // in flight during phases B and P of band b; after the band's last barrier the row is committed to the ring.
         int staged = ((BH < m1rel) ? BH : m1rel) + 2 * halo;
-        stage_a<KMAX>(p, img, L, lc, 0, staged, 0, wave, lane);
+        stage_a<KMAX, MULTI>(p, img, L, lc, 0, staged, 0, wave, lane);
         int band = 0;
         for (int y0 = 0; y0 < m1rel; y0 += BH, band++) {
             const int y1 = (y0 + BH < m1rel) ? y0 + BH : m1rel;
@@ -441,17 +451,17 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                             curmask = g;
                         }
                         const bool two = (dx >> 16) & 1;  // some pixel of the chunk has a second interval
-                        const int cpl = pos & 2047, cmi = (pos >> 11) & 2047, yrel = pos >> 22;
-                        const uint32_t *rowp[NSX];  // the (up to) three ring rows of this lane's probes, shared by both orientations
-#pragma unroll
-                        for (int iy = 0; iy < NSX; iy++)
-                            rowp[iy] = L.ring + __umul24((uint32_t)((yrel + (XY2 ? 2 * iy : 0)) & (RR - 1)), (uint32_t)p.rp);  // full-rate multiply
-                        auto probe9s = [&](int col, int sgn, int *sc) {
+                        // pos = two 16-bit dword offsets into the ring (plain | mirrored << 16) of the lane's first probe:
+                        // (slot of its first row) * rp + column - shift; the other probes are +2, +4 dwords and +2, +4 rows
+                        // (no wrap: slots 0..3 are mirrored behind the ring)
+                        auto probe9s = [&](uint32_t off, bool mirrored, int *sc) {
+                            const uint32_t *b0 = L.ring + off;
                             uint32_t cv[NS];
 #pragma unroll
                             for (int iy = 0; iy < NSX; iy++) {
 #pragma unroll
-                                for (int ix = 0; ix < NSX; ix++) cv[ix * NSX + iy] = rowp[iy][col + (XY2 ? sgn * 2 * (ix - 1) : 0)];
+                                for (int ix = 0; ix < NSX; ix++)
+                                    cv[ix * NSX + iy] = b0[(XY2 ? 2 * iy : 0) * p.rp + (XY2 ? 2 * (mirrored ? 2 - ix : ix) : 0)];
                             }
                             if (two) {  // rare: keep its compares out of the common path (no hoisting across the branch)
 #pragma unroll
@@ -465,23 +475,26 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                                 for (int k = 0; k < NS; k++) sc[k] += __popcll(__ballot((cv[k] - iv.x) <= iv.y));
                             }
                         };
-                        if ((bpl >> i) & 1) probe9s(cpl, 1, sacc);
-                        if (MIRROR && ((bmi >> i) & 1)) probe9s(cmi, -1, sacc + NS);
+                        if ((bpl >> i) & 1) probe9s(pos & 0xffffu, false, sacc);
+                        if (MIRROR && ((bmi >> i) & 1)) probe9s(pos >> 16, true, sacc + NS);
                     };
+                    // wave-uniform chunk base (kept in SGPRs) + lane: global_load with a scalar base address
+                    auto ld_pos = [&](int i) { return (p.px_pos + (size_t)(base + (uint32_t)i) * 64)[(uint32_t)lane]; };
+                    auto ld_iv = [&](int i) { return (p.px_iv + (size_t)(base + (uint32_t)i) * 64)[(uint32_t)lane]; };
                     int iA = __builtin_ctz(todo), iB;
-                    uint32_t posA = p.px_pos[(size_t)(base + iA) * 64 + lane], posB;
-                    uint4 ivA = p.px_iv[(size_t)(base + iA) * 64 + lane], ivB;
+                    uint32_t posA = ld_pos(iA), posB;
+                    uint4 ivA = ld_iv(iA), ivB;
                     for (;;) {
                         todo &= todo - 1;
                         iB = todo ? __builtin_ctz(todo) : iA;  // next occupied chunk (or this one again: no branch around the loads)
-                        posB = p.px_pos[(size_t)(base + iB) * 64 + lane];
-                        ivB = p.px_iv[(size_t)(base + iB) * 64 + lane];
+                        posB = ld_pos(iB);
+                        ivB = ld_iv(iB);
                         process(iA, posA, ivA);
                         if (!todo) break;
                         todo &= todo - 1;
                         iA = todo ? __builtin_ctz(todo) : iB;
-                        posA = p.px_pos[(size_t)(base + iA) * 64 + lane];
-                        ivA = p.px_iv[(size_t)(base + iA) * 64 + lane];
+                        posA = ld_pos(iA);
+                        ivA = ld_iv(iA);
                         process(iB, posB, ivB);
                         if (!todo) break;
                     }
@@ -494,7 +507,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
             for (int j = 0; j < RPW; j++) {
                 const int my_row = staged + wave + j * NW;
                 wait_rows<KMAX>(pw[j]);
-                if (my_row < next_end) a_commit<KMAX>(p, L, lc, my_row, qsel ^ 1, lane, pw[j]);
+                if (my_row < next_end) a_commit<KMAX, MULTI>(p, L, lc, my_row, qsel ^ 1, lane, pw[j]);
             }
             staged = next_end;
         }
@@ -532,15 +545,16 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
     }
 }
 
-size_t scan_lds_bytes(const ScanParams &p, bool xy2, bool mirror) {
+size_t scan_lds_bytes(int wc, int n_masks, bool batch, bool xy2, bool mirror) {
     const int nc = (xy2 ? 9 : 1) * (mirror ? 2 : 1);
-    return (size_t)RR * p.rp * 4 + (size_t)RO * p.occw * 4 + (size_t)QCAP * 2 + 4 * sizeof(int) +
-           (size_t)(p.n_masks > 1 ? p.n_masks : 1) * nc * sizeof(int);
+    const int rp = ring_pitch(wc), occw = 2 * ((wc / 4 + 63) / 64);
+    return (size_t)(RR + (batch ? RDUP : 0)) * rp * 4 + (size_t)RO * occw * 4 + (size_t)QCAP * 2 + 4 * sizeof(int) +
+           (size_t)(n_masks > 1 ? n_masks : 1) * nc * sizeof(int);
 }
 
 template <bool XY2, bool MIRROR, bool MULTI>
 static int launch_one(cds_context *ctx, const ScanParams &p, hipStream_t stream) {
-    const size_t lds_bytes = scan_lds_bytes(p, XY2, MIRROR);
+    const size_t lds_bytes = scan_lds_bytes(p.wc, p.n_masks, MULTI, XY2, MIRROR);
     if (lds_bytes > ctx->lds_per_block) return fail(CDS_ERR_UNSUPPORTED, "column window too wide for LDS");
     int per_cu = 64;  // many short workgroups: targets differ in sparsity, the tail balances itself
     if (const char *e = getenv("CDS_SCAN_WGS_PER_CU")) per_cu = atoi(e);
@@ -556,7 +570,7 @@ static int launch_one(cds_context *ctx, const ScanParams &p, hipStream_t stream)
 }
 
 int launch_scan(cds_context *ctx, const ScanParams &p, bool xy2, bool mirror, hipStream_t stream) {
-    const bool multi = p.n_masks > 1;
+    const bool multi = p.batch != 0;  // the mask set's records are in the batch layout (even if this launch holds one mask)
     if (xy2) {
         if (mirror) return multi ? launch_one<true, true, true>(ctx, p, stream) : launch_one<true, true, false>(ctx, p, stream);
         return multi ? launch_one<true, false, true>(ctx, p, stream) : launch_one<true, false, false>(ctx, p, stream);

@@ -1,6 +1,8 @@
 """GPU parity tests of kernel 1 (pixel-match scan) through the C ABI: the reference's own known answers on
 its own fixture images, then oracle parity on seeded synthetic libraries and on the edge cases the
 reference's semantics define.  Bar: bit-exact integer counts and mirrored flags."""
+import os
+
 import numpy as np
 import pytest
 
@@ -180,6 +182,33 @@ def test_wide_windows_and_many_masks(cds, oracle):
         ws, wm = oracle.PixelMatchQuery(masks[m], 20, 20, 0.01, 2, True, rects).scan(tg, n_threads=4)
         assert np.array_equal(s3[m], ws) and np.array_equal(m3[m], wm.astype(bool)), m
     assert m3[5, 1] and s3[33, 0] > 0.9 * a3.getQuerySize(33)
+    # (d) 33 masks: the second launch holds ONE mask in the batch layout
+    a4 = cds.PixelMatchColorDepthSearchAlgorithm(masks[:33], 20, True, None, 0, False, 20, 0.01, 2, rects)
+    s4, m4 = a4.searchLibrary(lib3)
+    assert np.array_equal(s4, s3[:33]) and np.array_equal(m4, m3[:33])
+    # (e) the per-mask fallback of a batch (used when the window is too wide for the batch kernel's LDS)
+    os.environ["CDS_SCAN_MASKS_PER_LAUNCH"] = "1"
+    try:
+        a5 = cds.PixelMatchColorDepthSearchAlgorithm(masks[:3], 20, True, None, 0, False, 20, 0.01, 2, rects)
+    finally:
+        del os.environ["CDS_SCAN_MASKS_PER_LAUNCH"]
+    s5, m5 = a5.searchLibrary(lib3)
+    assert np.array_equal(s5, s3[:3]) and np.array_equal(m5, m3[:3])
+    # (f) batches over wide windows: whole-frame masks (5 segments) and the 1600-pixel image (8 segments)
+    wm = np.stack([oracle.synth_image(0xC0FFEE, i, 0) for i in (9001, 9002, 9003)])
+    a6 = cds.PixelMatchColorDepthSearchAlgorithm(wm, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    c6 = a6.searchLibraryCounts(lib)
+    for m in range(3):
+        q6 = oracle.PixelMatchQuery(wm[m], 20, 20, 0.01, 2, True, rects)
+        for t in range(len(targets)):
+            assert np.array_equal(c6[m, t], q6.score(targets[t])[2]), (m, t)
+    mm2 = np.stack([m2, np.roll(m2, 7, axis=1)])
+    a7 = cds.PixelMatchColorDepthSearchAlgorithm(mm2, 20, True, None, 0, False, 20, 0.01, 2, [])
+    c7 = a7.searchLibraryCounts(lib2)
+    for m in range(2):
+        q7 = oracle.PixelMatchQuery(mm2[m], 20, 20, 0.01, 2, True, [])
+        for t in range(len(t2)):
+            assert np.array_equal(c7[m, t], q7.score(t2[t])[2]), (m, t)
 
 
 def test_sub_ranges_and_slots(cds, oracle):
