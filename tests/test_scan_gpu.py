@@ -144,7 +144,7 @@ def test_batched_masks_and_parameter_sweep(cds, oracle):
 
 def test_wide_windows_and_many_masks(cds, oracle):
     """Kernel variants the benchmark mask does not reach: a full-width window (5 load segments per row), a very wide
-    image (8 segments), and a mask batch larger than one launch (> 32 masks)."""
+    image (8 segments), and mask batches larger than one launch."""
     rects = cds.label_regions(W)
     # (a) a sparse-lut TARGET image used as the mask: strokes all over the frame -> window = whole rows
     mask = oracle.synth_image(0xC0FFEE, 9001, 0)
@@ -171,7 +171,8 @@ def test_wide_windows_and_many_masks(cds, oracle):
     q2 = oracle.PixelMatchQuery(m2, 20, 20, 0.01, 2, True, [])
     for t in range(len(t2)):
         assert np.array_equal(c2[0, t], q2.score(t2[t])[2]), t
-    # (c) 34 masks in one set: two launches
+    # (c) 34 masks in one set, 32 per launch: two launches
+    os.environ["CDS_SCAN_MASKS_PER_LAUNCH"] = "32"
     masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(34)])
     tg = np.stack([masks[33], np.fliplr(masks[5]), oracle.synth_image(0xC0FFEE, 77, 1)])
     lib3 = cds.Library(W, H, len(tg))
@@ -184,6 +185,7 @@ def test_wide_windows_and_many_masks(cds, oracle):
     assert m3[5, 1] and s3[33, 0] > 0.9 * a3.getQuerySize(33)
     # (d) 33 masks: the second launch holds ONE mask in the batch layout
     a4 = cds.PixelMatchColorDepthSearchAlgorithm(masks[:33], 20, True, None, 0, False, 20, 0.01, 2, rects)
+    del os.environ["CDS_SCAN_MASKS_PER_LAUNCH"]
     s4, m4 = a4.searchLibrary(lib3)
     assert np.array_equal(s4, s3[:33]) and np.array_equal(m4, m3[:33])
     # (e) the per-mask fallback of a batch (used when the window is too wide for the batch kernel's LDS)
@@ -194,6 +196,9 @@ def test_wide_windows_and_many_masks(cds, oracle):
         del os.environ["CDS_SCAN_MASKS_PER_LAUNCH"]
     s5, m5 = a5.searchLibrary(lib3)
     assert np.array_equal(s5, s3[:3]) and np.array_equal(m5, m3[:3])
+    a5b = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects)   # default: one launch of 34
+    s5b, m5b = a5b.searchLibrary(lib3)
+    assert np.array_equal(s5b, s3) and np.array_equal(m5b, m3)
     # (f) batches over wide windows: whole-frame masks (5 segments) and the 1600-pixel image (8 segments)
     wm = np.stack([oracle.synth_image(0xC0FFEE, i, 0) for i in (9001, 9002, 9003)])
     a6 = cds.PixelMatchColorDepthSearchAlgorithm(wm, 20, True, None, 0, False, 20, 0.01, 2, rects)
