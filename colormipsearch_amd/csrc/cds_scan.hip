@@ -68,6 +68,7 @@ constexpr int RO = 16;             // occupancy ring rows
 constexpr int NT = 256;
 constexpr int NW = NT / 64;
 constexpr int QCAP = 512;  // queue entries (one per non-black group); overflow falls back to in-place conversion
+constexpr int QW = QCAP / (NT / 64);  // ... per wave
 constexpr int MAXC = 4;    // chunks per wave and band whose mask data is fetched asynchronously at the top of the band
 constexpr int RPW = BH / NW;  // new rows per wave and band
 constexpr int RDUP = 4;      // mask batches: ring slots 0..3 are mirrored in slots RR..RR+3, so that a probe's three rows
@@ -99,8 +100,7 @@ __device__ __forceinline__ uint4 convert4(uint32_t a, uint32_t b, uint32_t c, fl
 struct Lds {
     uint32_t *ring;   // [RR][rp]   codes (or raw groups between phase A and phase B); row pitch rp = wc + 4, see ScanParams
     uint32_t *occ;    // [RR][occw] one bit per 4-pixel group (32 groups per word): group non-black
-    uint16_t *queue;  // [QCAP]     ring index / 4 of the groups phase B must convert
-    int *qcount;      // [2]        double-buffered by band parity
+    uint16_t *queue;  // [NW][QW]   per wave: ring index / 4 of the non-black groups it staged and still has to convert
     int *next;        // [2]        mask batches: next block of chunks to hand out, double-buffered by band parity
     int *cnt;         // counters
 };
@@ -122,6 +122,8 @@ struct LaneConst {
     int wr4[KMAX];         // dword offset inside the ring row
     uint32_t own;          // bit k: group 64k+lane is inside window and image (data counts)
     uint32_t zero;         // bit k: inside the window but outside the image columns (write zeros)
+    unsigned long long ownmask[KMAX];  // wave-uniform: ballot of the own bits of segment k
+    bool anyzero;                      // wave-uniform: some lane of some segment has its zero bit set
 };
 
 template <int KMAX>
@@ -140,6 +142,9 @@ __device__ __forceinline__ LaneConst<KMAX> make_lane_const(const ScanParams &p, 
         lc.own |= incol ? (1u << k) : 0u;
         lc.zero |= (inwin && !incol) ? (1u << k) : 0u;
     }
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) lc.ownmask[k] = __ballot((lc.own >> k) & 1);
+    lc.anyzero = __ballot(lc.zero != 0) != 0;
     return lc;
 }
 
@@ -154,10 +159,10 @@ __device__ __forceinline__ void a_issue(const ScanParams &p, const uint8_t *img,
         asm volatile("global_load_dwordx3 %0, %1, %2 nt" : "=v"(w[k]) : "v"(lc.ldoff[k]), "s"(rowp) : "memory");
 }
 
-// a_commit: registers -> ring (raw) / occupancy words / queue of non-black groups.
+// a_commit: registers -> ring (raw) / occupancy words / this wave's queue of non-black groups (qn = entries so far).
 template <int KMAX, bool DUP>
-__device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, const LaneConst<KMAX> &lc, int r, int qsel, int lane,
-                                         const u32x3 (&w)[KMAX]) {
+__device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, const LaneConst<KMAX> &lc, int r, int wave, int lane,
+                                         const u32x3 (&w)[KMAX], int &qn) {
     const int K = p.nseg;
     const int row = r + p.m0 - p.halo;
     const bool rowok = row >= 0 && row < p.H;  // wave-uniform
@@ -171,11 +176,14 @@ __device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, cons
     for (int k = 0; k < KMAX; k++) {
         bal[k] = 0;
         if (k < K) {  // wave-uniform
-            const bool keep = rowok && !((lc.zero >> k) & 1);
-            const uint32_t a = keep ? w[k].x : 0u, b = keep ? w[k].y : 0u, c = keep ? w[k].z : 0u;
+            uint32_t a = w[k].x, b = w[k].y, c = w[k].z;
+            if (!rowok || lc.anyzero) {  // wave-uniform and rare: rows / columns outside the image are black
+                const bool keep = rowok && !((lc.zero >> k) & 1);
+                a = keep ? a : 0u, b = keep ? b : 0u, c = keep ? c : 0u;
+            }
             *reinterpret_cast<uint4 *>(ringrow + lc.wr4[k]) = make_uint4(a, b, c, 0);  // black group == zero codes
             if (dup) *reinterpret_cast<uint4 *>(ringrow + dupoff + lc.wr4[k]) = make_uint4(a, b, c, 0);
-            bal[k] = __ballot(((lc.own >> k) & 1) && (a | b | c) != 0);
+            bal[k] = __ballot((a | b | c) != 0) & lc.ownmask[k];
             total += __popcll(bal[k]);
         }
     }
@@ -186,18 +194,17 @@ __device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, cons
         for (int k = 1; k < KMAX; k++) mine = lane == k ? bal[k] : mine;
         if (lane < K) *reinterpret_cast<uint2 *>(L.occ + (r & (RO - 1)) * p.occw + 2 * lane) = make_uint2((uint32_t)mine, (uint32_t)(mine >> 32));
     }
-    if (total != 0 && !(p.debug & 8)) {  // wave-uniform: one queue reservation per row
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&L.qcount[qsel], total);
-        base = __builtin_amdgcn_readfirstlane(base);
+    if (total != 0 && !(p.debug & 8)) {  // wave-uniform
+        uint16_t *wq = L.queue + wave * QW;
+        int base = qn;
 #pragma unroll
         for (int k = 0; k < KMAX; k++) {
             if (k < K && bal[k] != 0) {  // wave-uniform
                 if ((bal[k] >> lane) & 1) {
                     const int my = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[k], 0));
                     const int dst = slot * p.rp + lc.wr4[k];
-                    if (my < QCAP) {
-                        L.queue[my] = (uint16_t)((dst >> 2) | (dup ? 0x8000 : 0));
+                    if (my < QW) {
+                        wq[my] = (uint16_t)((dst >> 2) | (dup ? 0x8000 : 0));
                     } else {  // queue full (dense target): convert in place now
                         const uint4 cv = convert4(w[k].x, w[k].y, w[k].z, p.data_thr);
                         *reinterpret_cast<uint4 *>(L.ring + dst) = cv;
@@ -207,36 +214,46 @@ __device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, cons
                 base += __popcll(bal[k]);
             }
         }
+        qn = base;
     }
 }
 
-// Phase A for rows [ra, ra+n) (rows relative to m0-halo) without prefetch (band 0): wave w stages rows ra+w, ra+w+NW, ...
-// A row is K = ceil(gpr/64) segments of 64 groups (12 bytes each): lane l of segment k loads group 64k+l, so every
-// load instruction reads 768 contiguous bytes from a wave-uniform row pointer and all loads of a row are in flight
-// together.
-template <int KMAX, bool DUP>
-__device__ __forceinline__ void stage_a(const ScanParams &p, const uint8_t *img, const Lds &L, const LaneConst<KMAX> &lc, int ra, int n,
-                                        int qsel, int wave, int lane) {
-    for (int r = ra + wave; r < ra + n; r += NW) {  // wave-uniform
-        u32x3 w[KMAX];
-        a_issue<KMAX>(p, img, lc, r, w);
-        wait_rows<KMAX>(w);
-        a_commit<KMAX, DUP>(p, L, lc, r, qsel, lane, w);
-    }
-}
-
-// Phase B: convert the queued groups in place.
-__device__ __forceinline__ void stage_b(const ScanParams &p, const Lds &L, int qsel) {
-    int n = L.qcount[qsel];
-    n = n < QCAP ? n : QCAP;
-    for (int e = threadIdx.x; e < n; e += NT) {
-        const uint32_t q = L.queue[e];
+// convert_own: the wave converts, in place, the groups it queued itself (its LDS writes and reads execute in order, so no
+// barrier is needed between a_commit and this; the workgroup barrier that follows publishes the codes to the probes).
+__device__ __forceinline__ void convert_own(const ScanParams &p, const Lds &L, int wave, int lane, int qn) {
+    const uint16_t *wq = L.queue + wave * QW;
+    const int n = qn < QW ? qn : QW;
+    for (int e = lane; e < n; e += 64) {
+        const uint32_t q = wq[e];
         const int idx = (int)(q & 0x7fffu) << 2;
         const uint4 raw = *reinterpret_cast<const uint4 *>(L.ring + idx);
         const uint4 cv = convert4(raw.x, raw.y, raw.z, p.data_thr);
         *reinterpret_cast<uint4 *>(L.ring + idx) = cv;
         if (q & 0x8000u) *reinterpret_cast<uint4 *>(L.ring + idx + RR * p.rp) = cv;  // mirrored slot (mask batches)
     }
+}
+
+// Staging without prefetch (band 0): wave w loads, commits and converts rows ra+w, ra+w+NW, ...; two rows' loads
+// are in flight together (band 0 is BH + 4 = 16 rows = 4 per wave; four together would spill).
+template <int KMAX, bool DUP>
+__device__ __forceinline__ void stage_a(const ScanParams &p, const uint8_t *img, const Lds &L, const LaneConst<KMAX> &lc, int ra, int n,
+                                        int wave, int lane) {
+    int qn = 0;
+    for (int r0 = ra + wave; r0 < ra + n; r0 += 2 * NW) {  // wave-uniform
+        u32x3 w[2][KMAX];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int r = r0 + j * NW;
+            a_issue<KMAX>(p, img, lc, r < ra + n ? r : r0, w[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int r = r0 + j * NW;
+            wait_rows<KMAX>(w[j]);
+            if (r < ra + n) a_commit<KMAX, DUP>(p, L, lc, r, wave, lane, w[j], qn);
+        }
+    }
+    if (!(p.debug & 2)) convert_own(p, L, wave, lane, qn);
 }
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -289,8 +306,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
     L.ring = lds;
     L.occ = L.ring + (RR + (MULTI ? RDUP : 0)) * p.rp;
     L.queue = reinterpret_cast<uint16_t *>(L.occ + RO * p.occw);
-    L.qcount = reinterpret_cast<int *>(L.queue + QCAP);
-    L.next = L.qcount + 2;
+    L.next = reinterpret_cast<int *>(L.queue + QCAP);
     L.cnt = L.next + 2;  // MULTI: [n_masks][NC]; single: [NC]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
         const uint8_t *img = p.lib + (size_t)t * p.img_stride;
         const int ncnt = MULTI ? p.n_masks * NC : NC;
         for (int i = threadIdx.x; i < ncnt; i += NT) L.cnt[i] = 0;
-        if (threadIdx.x < 4) L.qcount[threadIdx.x] = 0;  // qcount[2] and next[2]
+        if (threadIdx.x < 2) L.next[threadIdx.x] = 0;
         for (int i = threadIdx.x; i < RO * p.occw; i += NT) L.occ[i] = 0;
         int acc[NC];
 #pragma unroll
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
         // wave issues (asynchronously) the mask data of band b and then the loads of ITS row of band b+1, which stay
         // in flight during phases B and P of band b; after the band's last barrier the row is committed to the ring.
         int staged = ((BH < m1rel) ? BH : m1rel) + 2 * halo;
-        stage_a<KMAX, MULTI>(p, img, L, lc, 0, staged, 0, wave, lane);
+        stage_a<KMAX, MULTI>(p, img, L, lc, 0, staged, wave, lane);
         int band = 0;
         for (int y0 = 0; y0 < m1rel; y0 += BH, band++) {
             const int y1 = (y0 + BH < m1rel) ? y0 + BH : m1rel;
@@ -342,14 +358,8 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                 const int my_row = staged + wave + j * NW;
                 a_issue<KMAX>(p, img, lc, my_row < next_end ? my_row : staged - 1, pw[j]);
             }
-            __syncthreads();  // phase A of this band is complete
-            // ---- phase B (+ the next band's queue counter)
-            if (threadIdx.x == 0) {
-                L.qcount[qsel ^ 1] = 0;
-                L.next[qsel ^ 1] = 0;
-            }
-            if (!(p.debug & 2)) stage_b(p, L, qsel);
-            __syncthreads();
+            __syncthreads();  // the band's rows are staged and converted (by the waves that loaded them)
+            if (MULTI && threadIdx.x == 0) L.next[qsel ^ 1] = 0;
             // ---- phase P: the mask data has arrived when at most the RPW*KMAX row loads are outstanding
             if (!MULTI) {
 #pragma unroll
@@ -502,12 +512,16 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                 flush();
             }
             __syncthreads();  // the next band's phase A overwrites the oldest BH rows of the ring
-            // ---- phase A of the next band: the rows loaded at the top of this band
+            // ---- staging of the next band: commit the rows loaded at the top of this band, convert their non-black groups
+            {
+                int qn = 0;
 #pragma unroll
-            for (int j = 0; j < RPW; j++) {
-                const int my_row = staged + wave + j * NW;
-                wait_rows<KMAX>(pw[j]);
-                if (my_row < next_end) a_commit<KMAX, MULTI>(p, L, lc, my_row, qsel ^ 1, lane, pw[j]);
+                for (int j = 0; j < RPW; j++) {
+                    const int my_row = staged + wave + j * NW;
+                    wait_rows<KMAX>(pw[j]);
+                    if (my_row < next_end && !(p.debug & 16)) a_commit<KMAX, MULTI>(p, L, lc, my_row, wave, lane, pw[j], qn);
+                }
+                if (!(p.debug & 2)) convert_own(p, L, wave, lane, qn);
             }
             staged = next_end;
         }
@@ -548,7 +562,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
 size_t scan_lds_bytes(int wc, int n_masks, bool batch, bool xy2, bool mirror) {
     const int nc = (xy2 ? 9 : 1) * (mirror ? 2 : 1);
     const int rp = ring_pitch(wc), occw = 2 * ((wc / 4 + 63) / 64);
-    return (size_t)(RR + (batch ? RDUP : 0)) * rp * 4 + (size_t)RO * occw * 4 + (size_t)QCAP * 2 + 4 * sizeof(int) +
+    return (size_t)(RR + (batch ? RDUP : 0)) * rp * 4 + (size_t)RO * occw * 4 + (size_t)QCAP * 2 + 2 * sizeof(int) +
            (size_t)(n_masks > 1 ? n_masks : 1) * nc * sizeof(int);
 }
 
