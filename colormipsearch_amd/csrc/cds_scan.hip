@@ -163,7 +163,7 @@ __device__ __forceinline__ void a_issue(const ScanParams &p, const uint8_t *img,
 template <int KMAX, bool DUP>
 __device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, const LaneConst<KMAX> &lc, int r, int wave, int lane,
                                          const u32x3 (&w)[KMAX], int &qn) {
-    const int K = p.nseg;
+    constexpr int OCCW = 2 * KMAX;  // occupancy words per ring row (segments beyond the window stay zero)
     const int row = r + p.m0 - p.halo;
     const bool rowok = row >= 0 && row < p.H;  // wave-uniform
     const int slot = r & (RR - 1);
@@ -173,33 +173,30 @@ __device__ __forceinline__ void a_commit(const ScanParams &p, const Lds &L, cons
     unsigned long long bal[KMAX];
     int total = 0;
 #pragma unroll
-    for (int k = 0; k < KMAX; k++) {
-        bal[k] = 0;
-        if (k < K) {  // wave-uniform
-            uint32_t a = w[k].x, b = w[k].y, c = w[k].z;
-            if (!rowok || lc.anyzero) {  // wave-uniform and rare: rows / columns outside the image are black
-                const bool keep = rowok && !((lc.zero >> k) & 1);
-                a = keep ? a : 0u, b = keep ? b : 0u, c = keep ? c : 0u;
-            }
-            *reinterpret_cast<uint4 *>(ringrow + lc.wr4[k]) = make_uint4(a, b, c, 0);  // black group == zero codes
-            if (dup) *reinterpret_cast<uint4 *>(ringrow + dupoff + lc.wr4[k]) = make_uint4(a, b, c, 0);
-            bal[k] = __ballot((a | b | c) != 0) & lc.ownmask[k];
-            total += __popcll(bal[k]);
+    for (int k = 0; k < KMAX; k++) {  // (a segment wholly beyond the window re-writes the window's first group: benign)
+        uint32_t a = w[k].x, b = w[k].y, c = w[k].z;
+        if (!rowok || lc.anyzero) {  // wave-uniform and rare: rows / columns outside the image are black
+            const bool keep = rowok && !((lc.zero >> k) & 1);
+            a = keep ? a : 0u, b = keep ? b : 0u, c = keep ? c : 0u;
         }
+        *reinterpret_cast<uint4 *>(ringrow + lc.wr4[k]) = make_uint4(a, b, c, 0);  // black group == zero codes
+        if (dup) *reinterpret_cast<uint4 *>(ringrow + dupoff + lc.wr4[k]) = make_uint4(a, b, c, 0);
+        bal[k] = __ballot((a | b | c) != 0) & lc.ownmask[k];
+        total += __popcll(bal[k]);
     }
     // the segments' ballots ARE the occupancy words of the row: lane k stores segment k's
     {
         unsigned long long mine = bal[0];
 #pragma unroll
         for (int k = 1; k < KMAX; k++) mine = lane == k ? bal[k] : mine;
-        if (lane < K) *reinterpret_cast<uint2 *>(L.occ + (r & (RO - 1)) * p.occw + 2 * lane) = make_uint2((uint32_t)mine, (uint32_t)(mine >> 32));
+        if (lane < KMAX) *reinterpret_cast<uint2 *>(L.occ + (r & (RO - 1)) * OCCW + 2 * lane) = make_uint2((uint32_t)mine, (uint32_t)(mine >> 32));
     }
     if (total != 0 && !(p.debug & 8)) {  // wave-uniform
         uint16_t *wq = L.queue + wave * QW;
         int base = qn;
 #pragma unroll
         for (int k = 0; k < KMAX; k++) {
-            if (k < K && bal[k] != 0) {  // wave-uniform
+            if (bal[k] != 0) {  // wave-uniform
                 if ((bal[k] >> lane) & 1) {
                     const int my = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[k], 0));
                     const int dst = slot * p.rp + lc.wr4[k];
@@ -305,7 +302,8 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
     Lds L;
     L.ring = lds;
     L.occ = L.ring + (RR + (MULTI ? RDUP : 0)) * p.rp;
-    L.queue = reinterpret_cast<uint16_t *>(L.occ + RO * p.occw);
+    constexpr int OCCW = 2 * KMAX;
+    L.queue = reinterpret_cast<uint16_t *>(L.occ + RO * OCCW);
     L.next = reinterpret_cast<int *>(L.queue + QCAP);
     L.cnt = L.next + 2;  // MULTI: [n_masks][NC]; single: [NC]
     const int lane = threadIdx.x & 63;
@@ -319,7 +317,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
         const int ncnt = MULTI ? p.n_masks * NC : NC;
         for (int i = threadIdx.x; i < ncnt; i += NT) L.cnt[i] = 0;
         if (threadIdx.x < 2) L.next[threadIdx.x] = 0;
-        for (int i = threadIdx.x; i < RO * p.occw; i += NT) L.occ[i] = 0;
+        for (int i = threadIdx.x; i < RO * OCCW; i += NT) L.occ[i] = 0;
         int acc[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) acc[k] = 0;
@@ -365,9 +363,8 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
 #pragma unroll
                 for (int k = 0; k < MAXC; k++) wait_mask<RPW * KMAX>(pch[k], ppos[k], piv[k]);
             }
-            auto probe_chunk = [&](const uint4 ch, const uint32_t pos, const uint4 iv, int *ctr) {
-                const int r0 = ch.y & 1023, nr = (ch.y >> 10) & 31;
-                const uint32_t occ2 = (p.debug & 4) ? 3u : regions_occupied(L, p.occw, ch.z, MIRROR ? ch.w : (1u << 31), r0, nr, lane);
+            // occ2: bit 0 = the chunk's plain neighbourhood holds a non-black group (or cannot be tested), bit 1 = mirrored
+            auto probe_chunk = [&](const uint32_t occ2, const uint32_t pos, const uint4 iv, int *ctr) {
                 const bool do_plain = occ2 & 1, do_mirror = MIRROR && (occ2 & 2);
                 if (!(do_plain || do_mirror)) return;
                 const int cpl = pos & 2047, cmi = (pos >> 11) & 2047, yrel = pos >> 22;
@@ -390,16 +387,42 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
             if (!MULTI) {
                 // one mask: the band's chunks are dealt to the waves; counters stay in registers for the whole target
                 if (!(p.debug & 1)) {
+                    // occupancy of this wave's (up to MAXC) prefetched chunks in ONE test: lane k looks at the plain region of
+                    // chunk k, lane 32+k at its mirrored region, against the band's occupancy = the OR of the ring rows'
+                    // occupancy words (lane w holds word w; the two words a region spans come by ds_bpermute)
+                    uint32_t bo = 0;
+                    if (lane < OCCW) {
+#pragma unroll
+                        for (int r = 0; r < RO; r++) bo |= L.occ[r * OCCW + lane];
+                    }
+                    const int kk = lane & 31;
+                    uint32_t dz = pch[0].z, dw = pch[0].w;
+#pragma unroll
+                    for (int k = 1; k < MAXC; k++) {
+                        dz = kk == k ? pch[k].z : dz;
+                        dw = kk == k ? pch[k].w : dw;
+                    }
+                    const uint32_t desc = (lane < 32 || !MIRROR) ? dz : dw;
+                    const int g0 = desc & 511, g1 = (desc >> 9) & 511;
+                    const uint32_t wlo = __shfl(bo, g0 >> 5, 64), whi = __shfl(bo, (g0 >> 5) + 1, 64);
+                    const unsigned long long bits = (((unsigned long long)whi << 32) | wlo) >> (g0 & 31);
+                    const int width = g1 - g0 + 1;
+                    const unsigned long long wm = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
+                    const bool hit = kk < MAXC && (MIRROR || lane < 32) && (!(desc >> 31) || (bits & wm) != 0 || (p.debug & 4));
+                    const unsigned long long bal = __ballot(hit);
                     uint32_t ci = cbeg0 + wave;
 #pragma unroll
                     for (int k = 0; k < MAXC; k++) {
                         if (ci < cend0)
-                            probe_chunk(make_uint4(pch[k].x, pch[k].y, pch[k].z, pch[k].w), ppos[k],
+                            probe_chunk((uint32_t)((bal >> k) & 1) | (uint32_t)(((bal >> (32 + k)) & 1) << 1), ppos[k],
                                         make_uint4(piv[k].x, piv[k].y, piv[k].z, piv[k].w), acc);
                         ci += NW;
                     }
-                    for (; ci < cend0; ci += NW)  // (compiler-issued loads: also wait for the rows in flight; rare)
-                        probe_chunk(p.chunks[ci], p.px_pos[ci * 64 + lane], p.px_iv[ci * 64 + lane], acc);
+                    for (; ci < cend0; ci += NW) {  // (compiler-issued loads: also wait for the rows in flight; rare)
+                        const uint4 ch = p.chunks[ci];
+                        const uint32_t occ2 = (p.debug & 4) ? 3u : regions_occupied(L, OCCW, ch.z, MIRROR ? ch.w : (1u << 31), ch.y & 1023, (ch.y >> 10) & 31, lane);
+                        probe_chunk(occ2, p.px_pos[ci * 64 + lane], p.px_iv[ci * 64 + lane], acc);
+                    }
                 }
             } else if (!(p.debug & 1)) {
                 // Mask batch.  The chunks of ALL masks of the launch are stored band-major (band, mask, chunk), so one
@@ -411,9 +434,9 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                 // counted with s_bcnt1 of the compare masks into wave-uniform (SGPR) counters, which are flushed to the
                 // mask's LDS counters when the mask changes.
                 uint32_t bo = 0;
-                if (lane < p.occw) {
+                if (lane < OCCW) {
 #pragma unroll
-                    for (int r = 0; r < RO; r++) bo |= L.occ[r * p.occw + lane];
+                    for (int r = 0; r < RO; r++) bo |= L.occ[r * OCCW + lane];
                 }
                 int sacc[NC];
 #pragma unroll
@@ -559,9 +582,12 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
     }
 }
 
+// kernel instantiations exist for 2, 3, 5 and 8 segments (64 groups = 256 pixels each) per staged row
+static int scan_kmax(int nseg) { return nseg <= 2 ? 2 : nseg <= 3 ? 3 : nseg <= 5 ? 5 : 8; }
+
 size_t scan_lds_bytes(int wc, int n_masks, bool batch, bool xy2, bool mirror) {
     const int nc = (xy2 ? 9 : 1) * (mirror ? 2 : 1);
-    const int rp = ring_pitch(wc), occw = 2 * ((wc / 4 + 63) / 64);
+    const int rp = ring_pitch(wc), occw = 2 * scan_kmax((wc / 4 + 63) / 64);
     return (size_t)(RR + (batch ? RDUP : 0)) * rp * 4 + (size_t)RO * occw * 4 + (size_t)QCAP * 2 + 2 * sizeof(int) +
            (size_t)(n_masks > 1 ? n_masks : 1) * nc * sizeof(int);
 }
