@@ -531,8 +531,8 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
     // Masks are scanned in launches ("groups") of ms->group masks sharing one pass over the library; the chunks of a
     // group are stored band-major (band, mask, chunk) so that one band's work of the whole group is one contiguous
     // chunk range: bandptr[group][band] .. bandptr[group][band + 1].
-    int group = 64;
-    if (const char *e = getenv("CDS_SCAN_MASKS_PER_LAUNCH")) group = std::max(1, std::min(128, atoi(e)));
+    int group = 128;
+    if (const char *e = getenv("CDS_SCAN_MASKS_PER_LAUNCH")) group = std::max(1, std::min(256, atoi(e)));
     if (n_masks == 1) group = 1;
     group = std::min(group, n_masks);
     // the batch kernel keeps 4 more ring rows and the masks' counters in LDS: a window too wide for that is scanned

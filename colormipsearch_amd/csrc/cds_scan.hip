@@ -65,8 +65,9 @@ __device__ __forceinline__ uint32_t async_ld4(const void *ptr) {
 constexpr int BH = kScanBandRows;  // mask rows per band
 constexpr int RR = 16;             // code ring rows = BH + 4: exactly what one band's probes touch
 constexpr int RO = 16;             // occupancy ring rows
-constexpr int NT = 256;
+constexpr int NT = 256;     // threads of the single-mask kernel = the waves that stage rows
 constexpr int NW = NT / 64;
+constexpr int NT_BATCH = 512;  // the batch kernel adds 4 waves that only probe (its LDS footprint allows 2-3 workgroups per CU)
 constexpr int QCAP = 512;  // queue entries (one per non-black group); overflow falls back to in-place conversion
 constexpr int QW = QCAP / (NT / 64);  // ... per wave
 constexpr int MAXC = 4;    // chunks per wave and band whose mask data is fetched asynchronously at the top of the band
@@ -293,7 +294,7 @@ __device__ __forceinline__ uint32_t regions_occupied(const Lds &L, int occw, uin
 // each other's memory latency and barrier waits; the (tiny) occupancy ring is twice as deep so that phase A of the
 // next band can set bits while nobody reads the rows it replaces.
 template <bool XY2, bool MIRROR, bool MULTI, int KMAX>
-__global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams p) {  // 4 waves/SIMD: <= 128 VGPRs
+__global__ __launch_bounds__(MULTI ? NT_BATCH : NT, (!MULTI && KMAX <= 3) ? 4 : 1) void scan_kernel(ScanParams p) {  // one mask: 4 waves/SIMD, <= 128 VGPRs
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr int NS = XY2 ? 9 : 1;
     constexpr int NSX = XY2 ? 3 : 1;
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
     L.ring = lds;
     L.occ = L.ring + (RR + (MULTI ? RDUP : 0)) * p.rp;
     constexpr int OCCW = 2 * KMAX;
+    constexpr int NTH = MULTI ? NT_BATCH : NT;
     L.queue = reinterpret_cast<uint16_t *>(L.occ + RO * OCCW);
     L.next = reinterpret_cast<int *>(L.queue + QCAP);
     L.cnt = L.next + 2;  // MULTI: [n_masks][NC]; single: [NC]
@@ -315,9 +317,9 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
     for (int64_t t = blockIdx.x; t < p.count; t += gridDim.x) {
         const uint8_t *img = p.lib + (size_t)t * p.img_stride;
         const int ncnt = MULTI ? p.n_masks * NC : NC;
-        for (int i = threadIdx.x; i < ncnt; i += NT) L.cnt[i] = 0;
+        for (int i = threadIdx.x; i < ncnt; i += NTH) L.cnt[i] = 0;
         if (threadIdx.x < 2) L.next[threadIdx.x] = 0;
-        for (int i = threadIdx.x; i < RO * OCCW; i += NT) L.occ[i] = 0;
+        for (int i = threadIdx.x; i < RO * OCCW; i += NTH) L.occ[i] = 0;
         int acc[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) acc[k] = 0;
@@ -328,7 +330,8 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
         // wave issues (asynchronously) the mask data of band b and then the loads of ITS row of band b+1, which stay
         // in flight during phases B and P of band b; after the band's last barrier the row is committed to the ring.
         int staged = ((BH < m1rel) ? BH : m1rel) + 2 * halo;
-        stage_a<KMAX, MULTI>(p, img, L, lc, 0, staged, wave, lane);
+        const bool stager = !MULTI || wave < NW;  // wave-uniform: the batch kernel's extra waves only probe
+        if (stager) stage_a<KMAX, MULTI>(p, img, L, lc, 0, staged, wave, lane);
         int band = 0;
         for (int y0 = 0; y0 < m1rel; y0 += BH, band++) {
             const int y1 = (y0 + BH < m1rel) ? y0 + BH : m1rel;
@@ -351,10 +354,12 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
             // this wave's RPW rows of the next band (clamped and ignored where there is none)
             const int next_end = (y1 < m1rel) ? ((y1 + BH < m1rel) ? y1 + BH : m1rel) + 2 * halo : staged;
             u32x3 pw[RPW][KMAX];
+            if (stager) {
 #pragma unroll
-            for (int j = 0; j < RPW; j++) {
-                const int my_row = staged + wave + j * NW;
-                a_issue<KMAX>(p, img, lc, my_row < next_end ? my_row : staged - 1, pw[j]);
+                for (int j = 0; j < RPW; j++) {
+                    const int my_row = staged + wave + j * NW;
+                    a_issue<KMAX>(p, img, lc, my_row < next_end ? my_row : staged - 1, pw[j]);
+                }
             }
             __syncthreads();  // the band's rows are staged and converted (by the waves that loaded them)
             if (MULTI && threadIdx.x == 0) L.next[qsel ^ 1] = 0;
@@ -483,7 +488,6 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                             flush();
                             curmask = g;
                         }
-                        const bool two = (dx >> 16) & 1;  // some pixel of the chunk has a second interval
                         // pos = two 16-bit dword offsets into the ring (plain | mirrored << 16) of the lane's first probe:
                         // (slot of its first row) * rp + column - shift; the other probes are +2, +4 dwords and +2, +4 rows
                         // (no wrap: slots 0..3 are mirrored behind the ring)
@@ -496,17 +500,11 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
                                 for (int ix = 0; ix < NSX; ix++)
                                     cv[ix * NSX + iy] = b0[(XY2 ? 2 * iy : 0) * p.rp + (XY2 ? 2 * (mirrored ? 2 - ix : ix) : 0)];
                             }
-                            if (two) {  // rare: keep its compares out of the common path (no hoisting across the branch)
+                            // both intervals, always: a mask pixel whose hue class has a neighbour class usually has a second
+                            // interval (negative gaps pass, so it is wide); the OR is taken on the wave masks (s_or_b64)
 #pragma unroll
-                                for (int k = 0; k < NS; k++) {
-                                    uint32_t c = cv[k];
-                                    asm volatile("" : "+v"(c));
-                                    sc[k] += __popcll(__ballot(((c - iv.x) <= iv.y) | ((c - iv.z) <= iv.w)));
-                                }
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < NS; k++) sc[k] += __popcll(__ballot((cv[k] - iv.x) <= iv.y));
-                            }
+                            for (int k = 0; k < NS; k++)
+                                sc[k] += __popcll(__ballot((cv[k] - iv.x) <= iv.y) | __ballot((cv[k] - iv.z) <= iv.w));
                         };
                         if ((bpl >> i) & 1) probe9s(pos & 0xffffu, false, sacc);
                         if (MIRROR && ((bmi >> i) & 1)) probe9s(pos >> 16, true, sacc + NS);
@@ -536,7 +534,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
             }
             __syncthreads();  // the next band's phase A overwrites the oldest BH rows of the ring
             // ---- staging of the next band: commit the rows loaded at the top of this band, convert their non-black groups
-            {
+            if (stager) {
                 int qn = 0;
 #pragma unroll
                 for (int j = 0; j < RPW; j++) {
@@ -557,7 +555,7 @@ __global__ __launch_bounds__(NT, KMAX <= 3 ? 4 : 1) void scan_kernel(ScanParams 
         }
         __syncthreads();
         const int nm = MULTI ? p.n_masks : 1;
-        for (int g = threadIdx.x; g < nm; g += NT) {
+        for (int g = threadIdx.x; g < nm; g += NTH) {
             const int *c = L.cnt + g * NC;
             int best = 0, bm = 0;
 #pragma unroll
@@ -604,7 +602,7 @@ static int launch_one(cds_context *ctx, const ScanParams &p, hipStream_t stream)
     auto kern = p.nseg <= 2 ? scan_kernel<XY2, MIRROR, MULTI, 2> : p.nseg <= 3 ? scan_kernel<XY2, MIRROR, MULTI, 3>
                 : p.nseg <= 5 ? scan_kernel<XY2, MIRROR, MULTI, 5> : scan_kernel<XY2, MIRROR, MULTI, 8>;
     CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds_bytes, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MULTI ? NT_BATCH : NT), lds_bytes, stream, p);
     CDS_HIP(hipGetLastError());
     return CDS_OK;
 }

@@ -1,4 +1,4 @@
-for g in 32 48 64 96 128; do
+for g in 128 256; do
   echo "group $g"
-  CDS_SCAN_MASKS_PER_LAUNCH=$g MASKS=128 TARGETS=8192 DBGS="0" bash tools/ablate_multi.sh
+  CDS_SCAN_MASKS_PER_LAUNCH=$g MASKS=256 TARGETS=16384 DBGS="0" bash tools/ablate_multi.sh
 done
