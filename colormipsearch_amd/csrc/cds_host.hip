@@ -571,7 +571,9 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
                         const Px &p = bl[i];
                         xmin = std::min(xmin, p.x); xmax = std::max(xmax, p.x);
                         ymin = std::min(ymin, p.y); ymax = std::max(ymax, p.y);
-                        uint32_t cpl = (uint32_t)(p.x - ms->cx0), cmi = (uint32_t)(W - 1 - p.x - ms->cx0);
+                        // the mirrored column lies inside the window only when the window was made symmetric (mirror on);
+                        // without mirroring it is unused and must not spill into the neighbouring bit fields
+                        const uint32_t cpl = (uint32_t)(p.x - ms->cx0), cmi = mirror ? (uint32_t)(W - 1 - p.x - ms->cx0) : cpl;
                         if (group == 1) {
                             pos.push_back(cpl | (cmi << 11) | ((uint32_t)(p.y - m0) << 22));
                         } else {  // mask batches: dword offsets of the first probe inside the (non-wrapping) LDS ring

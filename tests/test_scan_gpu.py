@@ -255,6 +255,56 @@ def test_mask_touching_every_border(cds, oracle):
             assert np.array_equal(counts[0, t], q.score(targets[t])[2]), (xy, mirror, t)
 
 
+def test_random_geometry_and_parameter_sweep(cds, oracle):
+    """Seeded random sweep over image sizes, mask counts / shapes, thresholds, tolerances, shift and mirror settings:
+    all 18 per-transform counts of every (mask, target) pair against the oracle.  Exercises the single-mask kernel, the
+    batch kernel (different numbers of masks per launch) and every window / segment configuration small images reach."""
+    rng = np.random.default_rng(20261003)
+    lut = oracle.depth_lut()
+
+    def blobs(w, h, n, dense):
+        img = np.zeros((h, w, 3), dtype=np.uint8)
+        for _ in range(n):
+            bw, bh = int(rng.integers(1, max(2, w // 3))), int(rng.integers(1, max(2, h // 3)))
+            x0, y0 = int(rng.integers(0, w - bw + 1)), int(rng.integers(0, h - bh + 1))
+            if dense:
+                img[y0:y0 + bh, x0:x0 + bw] = rng.integers(0, 256, size=(bh, bw, 3))
+            else:
+                z = rng.integers(0, 256, size=(bh, bw))
+                br = rng.uniform(0.3, 1.0, size=(bh, bw, 1))
+                img[y0:y0 + bh, x0:x0 + bw] = (lut[z] * br).astype(np.uint8)
+        return img
+
+    for case in range(40):
+        w, h = int(rng.integers(24, 420)), int(rng.integers(8, 150))
+        n_masks = int(rng.choice([1, 1, 2, 3, 5, 9]))
+        masks = np.stack([blobs(w, h, int(rng.integers(1, 5)), False) for _ in range(n_masks)])
+        targets = [blobs(w, h, int(rng.integers(1, 8)), bool(rng.integers(0, 2))) for _ in range(4)]
+        targets += [masks[0], np.fliplr(masks[-1]), np.roll(masks[0], 2, axis=1), np.zeros_like(masks[0])]
+        targets = np.stack(targets)
+        mthr, dthr = int(rng.choice([0, 20, 60, 150])), int(rng.choice([0, 20, 90]))
+        ztol = float(rng.choice([0.0, 0.01, 0.02, 0.1, 0.5]))
+        xy, mirror = int(rng.choice([0, 2])), bool(rng.integers(0, 2))
+        rects = [(0, 0, w // 4, h // 5)] if rng.integers(0, 2) else []
+        if n_masks > 2 and rng.integers(0, 2):
+            os.environ["CDS_SCAN_MASKS_PER_LAUNCH"] = str(int(rng.integers(2, n_masks)))
+        try:
+            alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, mthr, mirror, None, 0, False, dthr, ztol, xy, rects)
+        finally:
+            os.environ.pop("CDS_SCAN_MASKS_PER_LAUNCH", None)
+        lib = cds.Library(w, h, len(targets))
+        lib.upload(0, targets)
+        counts = alg.searchLibraryCounts(lib)
+        scores, mir = alg.searchLibrary(lib)
+        for m in range(n_masks):
+            q = oracle.PixelMatchQuery(masks[m], mthr, dthr, ztol, xy, mirror, rects)
+            for t in range(len(targets)):
+                s, mi, c = q.score(targets[t])
+                ctx_info = (case, w, h, n_masks, m, t, mthr, dthr, ztol, xy, mirror)
+                assert np.array_equal(counts[m, t], c), ctx_info
+                assert scores[m, t] == s and bool(mir[m, t]) == mi, ctx_info
+
+
 def test_empty_and_classless_masks(cds, oracle):
     rects = cds.label_regions(W)
     black = np.zeros((H, W, 3), dtype=np.uint8)
