@@ -144,6 +144,46 @@ def test_small_and_odd_geometry(cds, oracle, w, h):
     assert np.array_equal(z, zgaps)
 
 
+def test_random_geometry_and_parameter_sweep(cds, oracle):
+    """Seeded random sweep for the shape scorer: image sizes (odd and even widths), several masks per set, thresholds,
+    mirroring, ROI masks, excluded rectangles, 8/16-bit-range gradients, sparse and dense targets."""
+    rng = np.random.default_rng(424242)
+    lut = oracle.depth_lut()
+
+    def strokes(w, h, n, lo=0.3):
+        img = np.zeros((h, w, 3), dtype=np.uint8)
+        for _ in range(n):
+            bw, bh = int(rng.integers(1, max(2, w // 3))), int(rng.integers(1, max(2, h // 3)))
+            x0, y0 = int(rng.integers(0, w - bw + 1)), int(rng.integers(0, h - bh + 1))
+            z = rng.integers(0, 256, size=(bh, bw))
+            br = rng.uniform(lo, 1.0, size=(bh, bw, 1))
+            img[y0:y0 + bh, x0:x0 + bw] = (lut[z] * br).astype(np.uint8)
+        return img
+
+    for case in range(10):
+        w, h = int(rng.integers(40, 300)), int(rng.integers(24, 140))
+        n_masks, n_t = int(rng.integers(1, 4)), 5
+        masks = np.stack([strokes(w, h, int(rng.integers(1, 4))) for _ in range(n_masks)])
+        targets = np.stack([strokes(w, h, int(rng.integers(1, 9)), lo=0.05) for _ in range(n_t - 2)] +
+                           [masks[0], np.fliplr(masks[-1])])
+        thr = int(rng.choice([0, 20, 50]))
+        mirror = bool(rng.integers(0, 2))
+        rects = [(0, 0, int(w // 5), int(h // 6))] if rng.integers(0, 2) else []
+        roi = (rng.random((h, w)) < 0.7).astype(np.uint8) if rng.integers(0, 3) == 0 else None
+        grads = rng.integers(0, int(rng.choice([5, 255, 700, 65535])), size=(n_t, h, w)).astype(np.uint16)
+        zgaps = np.stack([oracle.make_zgap(targets[i], thr, int(rng.choice([1, 3, 10])), rects) for i in range(n_t)])
+        lib = cds.Library(w, h, n_t)
+        lib.upload(0, targets)
+        lib.upload_variants(0, grads, zgaps)
+        alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, thr, mirror, roi, rects)
+        pm = np.repeat(np.arange(n_masks), n_t)
+        ps = np.tile(np.arange(n_t), n_masks)
+        gap, high, mir = alg.scoreLibraryPairs(lib, pm, ps)
+        for k, (m, t) in enumerate(zip(pm, ps)):
+            want = oracle.ShapeQuery(masks[m], thr, mirror, rects, roi).score(targets[t], grads[t], zgaps[t])
+            assert (int(gap[k]), int(high[k]), bool(mir[k])) == (want[0], want[1], want[3]), (case, w, h, m, t, thr, mirror, roi is not None)
+
+
 def test_normalized_scores_per_mask(cds, oracle):
     # GradientAreaGapUtils.calculateNormalizedScore applied per mask as CalculateGradientScoresCmd.java:616-645 does
     pix = np.array([636, 500, 0, 679])
