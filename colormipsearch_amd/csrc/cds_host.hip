@@ -359,7 +359,11 @@ int cds_library_upload(cds_library *lib, int64_t first, int64_t count, const uin
     if (count == 0) return CDS_OK;
     if (!rgb) return fail(CDS_ERR_INVALID_ARGUMENT, "rgb is NULL");
     CDS_HIP(hipSetDevice(lib->ctx->device));
-    // rows of consecutive images are consecutive rows of one tall pitched image
+    // rows of consecutive images are consecutive rows of one tall pitched image; the padding columns of a row must be
+    // black (the kernels treat them as off-image pixels), also in caller-owned memory (cds_library_wrap)
+    if (lib->pitch > 3 * lib->W)
+        CDS_HIP(hipMemset2DAsync(lib->d_rgb + (size_t)first * lib->img_stride + (size_t)3 * lib->W, lib->pitch, 0,
+                                 (size_t)(lib->pitch - 3 * lib->W), (size_t)lib->H * count, lib->ctx->stream));
     CDS_HIP(hipMemcpy2DAsync(lib->d_rgb + (size_t)first * lib->img_stride, lib->pitch, rgb, (size_t)3 * lib->W,
                              (size_t)3 * lib->W, (size_t)lib->H * count, hipMemcpyHostToDevice, lib->ctx->stream));
     CDS_HIP(hipStreamSynchronize(lib->ctx->stream));

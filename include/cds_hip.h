@@ -80,7 +80,8 @@ int cds_context_synchronize(cds_context *ctx);
 /* Device bytes for `capacity` targets of W x H (padded row pitch, see DESIGN.md "data layout"). */
 size_t cds_library_bytes(int32_t W, int32_t H, int64_t capacity);
 int cds_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t capacity, cds_library **out);
-/* Adopt caller-owned device memory (e.g. a torch tensor) of at least cds_library_bytes() bytes. */
+/* Adopt caller-owned device memory (e.g. a torch tensor) of at least cds_library_bytes() bytes; it need not be
+ * initialised: every upload / generate call writes whole padded rows of the slots it fills. */
 int cds_library_wrap(cds_context *ctx, int32_t W, int32_t H, int64_t capacity, void *device_ptr,
                      size_t device_bytes, cds_library **out);
 void cds_library_destroy(cds_library *lib);

@@ -305,6 +305,27 @@ def test_random_geometry_and_parameter_sweep(cds, oracle):
                 assert scores[m, t] == s and bool(mir[m, t]) == mi, ctx_info
 
 
+def test_wrapped_uninitialised_memory(cds, oracle):
+    """cds_library_wrap over memory full of garbage: uploads must leave black padding columns behind (shifted and mirrored
+    probes just beyond the right image border read them)."""
+    import torch
+    w, h, n = 70, 33, 3   # pitch 240 B = 80 pixels: 10 padding columns
+    rng = np.random.default_rng(3)
+    lut = oracle.depth_lut()
+    mask = np.zeros((h, w, 3), dtype=np.uint8)
+    mask[4:28, w - 12:w] = lut[rng.integers(0, 256, size=(24, 12))]
+    mask[10:20, 0:6] = lut[rng.integers(0, 256, size=(10, 6))]
+    targets = np.stack([mask, np.fliplr(mask), lut[rng.integers(0, 256, size=(h, w))].astype(np.uint8)])
+    buf = torch.full((cds.Library.bytes_required(w, h, n),), 0xA7, dtype=torch.uint8, device="cuda")
+    lib = cds.Library(w, h, n, device_buffer=buf)
+    lib.upload(0, targets)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.5, 2, [])
+    counts = alg.searchLibraryCounts(lib)
+    q = oracle.PixelMatchQuery(mask, 20, 20, 0.5, 2, True, [])
+    for t in range(n):
+        assert np.array_equal(counts[0, t], q.score(targets[t])[2]), t
+
+
 def test_empty_and_classless_masks(cds, oracle):
     rects = cds.label_regions(W)
     black = np.zeros((H, W, 3), dtype=np.uint8)
