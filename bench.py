@@ -67,10 +67,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CDS_BENCH_FORCE_DIST") == "1"   # (rehearsal of the N>1 code path on one GPU)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from colormipsearch_amd import cds
 
@@ -99,18 +101,18 @@ def main():
     alg_bytes_per_target = rows * 3 * W          # R x 3630 B
 
     scores = torch.empty(chunk, dtype=torch.int32, device=dev)
-    gathered = [torch.empty(chunk, dtype=torch.int32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty(chunk, dtype=torch.int32, device=dev) for _ in range(world)] if (use_dist and rank == 0) else None
 
     def step():
         alg.searchLibraryDevice(lib, 0, chunk, scores.data_ptr())
-        if world > 1:
+        if use_dist:
             dist.gather(scores, gathered, dst=0)
 
     for _ in range(args.warmup):
         step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -118,14 +120,14 @@ def main():
         ev[k][0].record(stream)
         alg.searchLibraryDevice(lib, 0, chunk, scores.data_ptr())
         ev[k][1].record(stream)
-        if world > 1:
+        if use_dist:
             dist.gather(scores, gathered, dst=0)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -227,7 +229,9 @@ def main():
             out["cpu_baseline"]["parity_failure"] = True
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        if rank == 0 and not torch.equal(gathered[0], scores):
+            raise SystemExit("gathered scores differ from the local ones")
         dist.destroy_process_group()
 
 
