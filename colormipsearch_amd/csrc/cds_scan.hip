@@ -67,7 +67,7 @@ constexpr int RR = 16;             // code ring rows = BH + 4: exactly what one 
 constexpr int RO = 16;             // occupancy ring rows
 constexpr int NT = 256;     // threads of the single-mask kernel = the waves that stage rows
 constexpr int NW = NT / 64;
-constexpr int NT_BATCH = 512;  // the batch kernel adds 4 waves that only probe (its LDS footprint allows 2-3 workgroups per CU)
+constexpr int NT_BATCH = 1024;  // the batch kernel adds 4 waves that only probe (its LDS footprint allows 2-3 workgroups per CU)
 constexpr int QCAP = 512;  // queue entries (one per non-black group); overflow falls back to in-place conversion
 constexpr int QW = QCAP / (NT / 64);  // ... per wave
 constexpr int MAXC = 4;    // chunks per wave and band whose mask data is fetched asynchronously at the top of the band
@@ -294,7 +294,7 @@ __device__ __forceinline__ uint32_t regions_occupied(const Lds &L, int occw, uin
 // each other's memory latency and barrier waits; the (tiny) occupancy ring is twice as deep so that phase A of the
 // next band can set bits while nobody reads the rows it replaces.
 template <bool XY2, bool MIRROR, bool MULTI, int KMAX>
-__global__ __launch_bounds__(MULTI ? NT_BATCH : NT, (!MULTI && KMAX <= 3) ? 4 : 1) void scan_kernel(ScanParams p) {  // one mask: 4 waves/SIMD, <= 128 VGPRs
+__global__ __launch_bounds__(MULTI ? NT_BATCH : NT, KMAX <= 3 ? (MULTI ? 8 : 4) : 1) void scan_kernel(ScanParams p) {  // one mask: 4 waves/SIMD, <= 128 VGPRs
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr int NS = XY2 ? 9 : 1;
     constexpr int NSX = XY2 ? 3 : 1;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(MULTI ? NT_BATCH : NT, (!MULTI && KMAX <= 3) ? 4 : 
             // this wave's RPW rows of the next band (clamped and ignored where there is none)
             const int next_end = (y1 < m1rel) ? ((y1 + BH < m1rel) ? y1 + BH : m1rel) + 2 * halo : staged;
             u32x3 pw[RPW][KMAX];
-            if (stager) {
+            if (!MULTI) {  // (the batch kernel stages after the probes instead: its staging is amortised over the masks)
 #pragma unroll
                 for (int j = 0; j < RPW; j++) {
                     const int my_row = staged + wave + j * NW;
@@ -534,7 +534,11 @@ __global__ __launch_bounds__(MULTI ? NT_BATCH : NT, (!MULTI && KMAX <= 3) ? 4 : 
             }
             __syncthreads();  // the next band's phase A overwrites the oldest BH rows of the ring
             // ---- staging of the next band: commit the rows loaded at the top of this band, convert their non-black groups
-            if (stager) {
+            if (MULTI) {
+                // batch kernel: no prefetch registers held across the probes (they would cost a third of the waves a SIMD can
+                // hold); the 4 staging waves load, commit and convert the next band's rows here
+                if (stager && next_end > staged) stage_a<KMAX, MULTI>(p, img, L, lc, staged, next_end - staged, wave, lane);
+            } else {
                 int qn = 0;
 #pragma unroll
                 for (int j = 0; j < RPW; j++) {

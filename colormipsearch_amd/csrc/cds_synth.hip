@@ -185,8 +185,8 @@ extern "C" int cds_library_generate_synthetic(cds_library *lib, uint64_t seed, i
     p.seed = seed; p.first_index = first_index; p.kind = kind;
     const int items = (p.wpad / 4) * p.H;
     p.blocks_per_image = (items + 255) / 256;
-    // the grid index is 32-bit: generate in slices
-    const int64_t max_imgs = (int64_t)0x7fffffff / p.blocks_per_image;
+    // HIP limits a launch to fewer than 2^32 work-items per grid dimension (blocks x 256 threads): generate in slices
+    const int64_t max_imgs = std::max<int64_t>(1, (int64_t)(0xffffffffu / 256u) / p.blocks_per_image);
     for (int64_t done = 0; done < count; done += max_imgs) {
         SynthParams q = p;
         const int64_t n = std::min<int64_t>(max_imgs, count - done);

@@ -88,6 +88,18 @@ def test_device_generator_equals_cpu_twin(cds, oracle):
     assert np.array_equal(got[5], oracle.synth_image(0xBADC0DE, 7, 2))
 
 
+
+def test_generator_beyond_one_launch(cds, oracle):
+    """A launch is limited to < 2^32 work-items: 26,000 images need more than one (the generator once stopped silently
+    after ~15,700 of 65,536 images)."""
+    n = 26000
+    lib = cds.Library(W, H, n)
+    lib.generate_synthetic(0xC0FFEE, 5, 0, n, kind=0)
+    for slot in (0, 24928, 24929, n - 1):
+        got = lib.download(slot, 1)[0]
+        assert np.array_equal(got, oracle.synth_image(0xC0FFEE, 5 + slot, 0)), slot
+
+
 @pytest.mark.parametrize("kind,n", [(0, 48), (1, 6)])
 def test_synthetic_library_parity(cds, oracle, kind, n):
     """BASELINE config 2 at a size the oracle finishes in seconds: 1 mask x n targets, xyShift 2, mirror."""
