@@ -10,21 +10,25 @@
 //   * one workgroup streams ONE target at a time: only the rows the mask can touch, and of those only the
 //     column window the mask (and its mirror image) can touch, as 12-byte (4 pixel) non-temporal loads, 768
 //     contiguous bytes per wave-instruction;
-//   * the mask's rows are cut into bands of 12; per band three phases separated by barriers:
-//     A  stage: raw 12-byte groups into a 16-row LDS ring as (a,b,c,0) (an all-black group is already its all-zero
-//        code), the segment ballots become occupancy words, non-black groups are queued.  The loads of band b+1 are
-//        issued at the top of band b by asm with manual s_waitcnt, so HBM requests stay in flight during B and P;
-//     B  convert only the queued groups, in place, to 32-bit "hue codes" = class<<29 | bits(med * v_rcp_f32(max))>>1
+//   * the mask's rows are cut into bands of 12; per band, two barriers:
+//     stage: raw 12-byte groups into a 16-row LDS ring as (a,b,c,0) (an all-black group is already its all-zero
+//        code), the segment ballots become occupancy words, and the staging wave converts the non-black groups it
+//        just wrote (its own small queue, no atomics) to 32-bit "hue codes" = class<<29 | bits(med * v_rcp_f32(max))>>1
 //        (0 = below threshold / no hue class).  The host builds its acceptance intervals from this device's own
 //        v_rcp_f32 table, so the device predicate is an integer range test that is bit-exact with the reference's
-//        double arithmetic by construction (cds_host.hip: build_ratio_table / intervals_for);
-//     P  probe: mask pixels are pre-sorted into spatially compact chunks of 64 per band; a wave takes one chunk and
-//        skips an orientation's 9 probes when the occupancy bits of the chunk's neighbourhood are all clear (one
-//        ballot for both orientations); otherwise every lane probes its 9 (18) transformed positions in LDS against
-//        its two code intervals (own hue class + at most one adjacent class) with per-lane counters;
-//   * no MFMA: byte compare / integer count; the kernel is instruction-issue- and HBM-bound.
-//   * CDS_SCAN_DEBUG bits (timing-only ablations, results are wrong with them): 1 skip probes, 2 skip phase B,
-//     4 never skip by occupancy, 8 no queue.
+//        double arithmetic by construction (cds_host.hip: build_ratio_table / intervals_for).  The loads of band b+1
+//        are issued at the top of band b by asm with manual s_waitcnt, so HBM requests stay in flight during the probes;
+//     probe: mask pixels are pre-sorted into spatially compact chunks of 64 per band; a wave tests the neighbourhoods of
+//        its chunks against the band's occupancy with one ballot and skips an orientation's 9 probes where all is
+//        black; otherwise every lane probes its 9 (18) transformed positions in LDS against its two code intervals
+//        (own hue class + at most one adjacent class);
+//   * mask batches (n_masks > 1) share the staging: chunk records band-major, blocks of chunks drawn from an LDS counter
+//     by 16 waves, records loaded only for occupied chunks, matches counted by s_bcnt1 into SGPR counters, a ring that
+//     never wraps (4 mirrored rows) with host-precomputed LDS offsets -- see the comment at the batch branch below;
+//   * no MFMA: byte compare / integer count; the kernel is instruction-issue-, synchronisation- and HBM-bound.
+//   * CDS_SCAN_DEBUG bits (timing-only ablations, results are wrong with them): 1 skip probes, 2 skip conversion,
+//     4 never skip by occupancy, 8 no queue, 16 skip the commit of prefetched rows, 64 every workgroup re-reads the
+//     first 8 images (rows come from L2 instead of HBM).
 #include "cds_internal.hpp"
 
 namespace cds {
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(MULTI ? NT_BATCH : NT, KMAX <= 3 ? (MULTI ? 8 : 4) 
     const LaneConst<KMAX> lc = make_lane_const<KMAX>(p, lane);
 
     for (int64_t t = blockIdx.x; t < p.count; t += gridDim.x) {
-        const uint8_t *img = p.lib + (size_t)t * p.img_stride;
+        const uint8_t *img = p.lib + (size_t)((p.debug & 64) ? (t & 7) : t) * p.img_stride;  // debug 64: timing with L2-resident rows
         const int ncnt = MULTI ? p.n_masks * NC : NC;
         for (int i = threadIdx.x; i < ncnt; i += NTH) L.cnt[i] = 0;
         if (threadIdx.x < 2) L.next[threadIdx.x] = 0;
