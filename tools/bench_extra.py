@@ -2,7 +2,7 @@
 """Secondary measurements for DESIGN.md (NOT the driver's bench line): BASELINE configs[2] (mask batches sharing
 one pass over the library) and configs[4] (GradientAreaGap on the top hits per mask), on one MI355X.
 
-    python tools/bench_extra.py --masks 64 --targets 16384          # config 3 in miniature
+    python tools/bench_extra.py --masks 128 --targets 16384         # config 3 in miniature
     python tools/bench_extra.py --gradscore --masks 32 --top 500    # config 5 in miniature
 """
 import argparse
@@ -20,7 +20,7 @@ W, H = 1210, 566
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--masks", type=int, default=64)
+    ap.add_argument("--masks", type=int, default=128)
     ap.add_argument("--targets", type=int, default=16384)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--gradscore", action="store_true")
