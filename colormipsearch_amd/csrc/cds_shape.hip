@@ -307,10 +307,14 @@ __device__ __forceinline__ int zs_of(int e, int thr) {
 }
 
 __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
-    // One workgroup scores one (mask, target) pair; one row per wave at a time, lanes over 4-pixel groups, no LDS and
-    // no barriers in the row loop.  The two orientation planes of a group decide what else is fetched: gradient +
-    // zslice (plain and reversed) when a gap bit is set, the target pixels when a high-expression bit is.
+    // One workgroup scores one (mask, target) pair; one row per wave at a time, lanes over 4-pixel groups, no barriers in
+    // the row loop.  The two orientation planes of a group decide what else is fetched: the target pixels when a
+    // high-expression bit is set (the wide ring around the mask: most groups), gradient + zslice (plain and reversed) when
+    // a gap bit is (the mask's own pixels: ~5 % of the groups).  The gap arithmetic is the expensive part and its groups
+    // are scattered, so a wave does not run it in place with a few lanes active: it appends the group to its own LDS
+    // queue and runs the gap code over 64 queued groups at a time, all lanes busy.
     __shared__ long long red[4][4];
+    __shared__ uint32_t gq[4][128];  // per wave: row << 9 | group of the queued groups
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool even_w = (p.W & 1) == 0;
     for (int64_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
@@ -329,45 +333,74 @@ __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
         const uint8_t *rf = p.rowflags + (size_t)m * p.H;
         unsigned gap0 = 0, gap1 = 0;  // per lane < 2^31 for H*W <= 2M pixels (gap <= 65535 per pixel)
         int high0 = 0, high1 = 0;
+        int qn = 0;  // wave-uniform: queued groups
+        // the gap arithmetic of the first n (<= 64) queued groups, one per lane
+        auto run_gaps = [&](int n) {
+            if (lane < n) {
+                const uint32_t e = gq[wave][lane];
+                const int y = (int)(e >> 9), x0 = 4 * (int)(e & 511);
+                const ushort4 qa = *reinterpret_cast<const ushort4 *>(pl0 + (size_t)y * p.wp + x0);
+                ushort4 qb = make_ushort4(0, 0, 0, 0);
+                if (p.mirror) qb = *reinterpret_cast<const ushort4 *>(pl1 + (size_t)y * p.wp + x0);
+                const int pa[4] = {qa.x, qa.y, qa.z, qa.w}, pb[4] = {qb.x, qb.y, qb.z, qb.w};
+                const uint16_t *zrow = reinterpret_cast<const uint16_t *>(zimg + (size_t)y * p.gpitch);
+                const ushort4 g = *reinterpret_cast<const ushort4 *>(gimg + (size_t)y * p.gpitch + (size_t)x0 * 2);
+                const ushort4 z = *reinterpret_cast<const ushort4 *>(zrow + x0);
+                const int gg[4] = {g.x, g.y, g.z, g.w}, zz[4] = {z.x, z.y, z.z, z.w};
+                int zm[4] = {0, 0, 0, 0};  // zslice at W-1-x for x = x0 .. x0+3
+                if (p.mirror) {
+                    const int xm = p.W - 4 - x0;  // element index of the reversed run (may be < 0 at the far right)
+                    if (even_w && xm >= 0) {
+                        const uint2 r = *reinterpret_cast<const uint2 *>(zrow + xm);  // xm even: 4-byte aligned
+                        zm[3] = r.x & 0xffff; zm[2] = r.x >> 16; zm[1] = r.y & 0xffff; zm[0] = r.y >> 16;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (p.W - 1 - x0 - j >= 0) zm[j] = zrow[p.W - 1 - x0 - j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (x0 + j >= p.W) break;
+                    gap0 += gap_of(pa[j], zs_of(zz[j], p.thr), gg[j]);
+                    if (p.mirror) gap1 += gap_of(pb[j], zs_of(zm[j], p.thr), gg[j]);
+                }
+            }
+        };
         for (int y = ya + wave; y < yb; y += 4) {  // wave-uniform
             const int flags = rf[y];
             if (!flags) continue;
             const int q0 = (flags & 2) ? aq0 : gq0, q1 = (flags & 2) ? aq1 : gq1;
-            const uint16_t *zrow = reinterpret_cast<const uint16_t *>(zimg + (size_t)y * p.gpitch);
             bool row_in_rects = false;  // wave-uniform: does any excluded rectangle intersect this row at all?
             for (int i = 0; i < p.nrects; i++) row_in_rects |= (y >= p.rects[i].y0 && y < p.rects[i].y1);
-            for (int gi = q0 + lane; gi < q1; gi += 64) {
+            for (int base = q0; base < q1; base += 64) {  // wave-uniform
+                const int gi = base + lane;
                 const int x0 = 4 * gi;
-                const ushort4 qa = *reinterpret_cast<const ushort4 *>(pl0 + (size_t)y * p.wp + x0);
-                ushort4 qb = make_ushort4(0, 0, 0, 0);
-                if (p.mirror) qb = *reinterpret_cast<const ushort4 *>(pl1 + (size_t)y * p.wp + x0);
+                ushort4 qa = make_ushort4(0, 0, 0, 0), qb = make_ushort4(0, 0, 0, 0);
+                if (gi < q1) {
+                    qa = *reinterpret_cast<const ushort4 *>(pl0 + (size_t)y * p.wp + x0);
+                    if (p.mirror) qb = *reinterpret_cast<const ushort4 *>(pl1 + (size_t)y * p.wp + x0);
+                }
                 const int all = qa.x | qa.y | qa.z | qa.w | qb.x | qb.y | qb.z | qb.w;
-                if (!all) continue;
-                const int pa[4] = {qa.x, qa.y, qa.z, qa.w}, pb[4] = {qb.x, qb.y, qb.z, qb.w};
-                if (all & (kPlaneS | kPlaneQM)) {
-                    const ushort4 g = *reinterpret_cast<const ushort4 *>(gimg + (size_t)y * p.gpitch + (size_t)x0 * 2);
-                    const ushort4 z = *reinterpret_cast<const ushort4 *>(zrow + x0);
-                    const int gg[4] = {g.x, g.y, g.z, g.w}, zz[4] = {z.x, z.y, z.z, z.w};
-                    int zm[4] = {0, 0, 0, 0};  // zslice at W-1-x for x = x0 .. x0+3
-                    if (p.mirror) {
-                        const int xm = p.W - 4 - x0;  // element index of the reversed run (may be < 0 at the far right)
-                        if (even_w && xm >= 0) {
-                            const uint2 r = *reinterpret_cast<const uint2 *>(zrow + xm);  // xm even: 4-byte aligned
-                            zm[3] = r.x & 0xffff; zm[2] = r.x >> 16; zm[1] = r.y & 0xffff; zm[0] = r.y >> 16;
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; j++)
-                                if (p.W - 1 - x0 - j >= 0) zm[j] = zrow[p.W - 1 - x0 - j];
-                        }
+                const bool has_gap = (all & (kPlaneS | kPlaneQM)) != 0;
+                const unsigned long long bal = __ballot(has_gap);
+                if (bal) {  // wave-uniform
+                    if (has_gap) {
+                        const int at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+                        gq[wave][at] = ((uint32_t)y << 9) | (uint32_t)gi;
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (x0 + j >= p.W) break;
-                        gap0 += gap_of(pa[j], zs_of(zz[j], p.thr), gg[j]);
-                        if (p.mirror) gap1 += gap_of(pb[j], zs_of(zm[j], p.thr), gg[j]);
+                    qn += __popcll(bal);
+                    if (qn >= 64) {
+                        run_gaps(64);
+                        const int rest = qn - 64;
+                        uint32_t mv = 0;
+                        if (lane < rest) mv = gq[wave][64 + lane];
+                        if (lane < rest) gq[wave][lane] = mv;
+                        qn = rest;
                     }
                 }
                 if (all & kPlaneQH) {
+                    const int pa[4] = {qa.x, qa.y, qa.z, qa.w}, pb[4] = {qb.x, qb.y, qb.z, qb.w};
                     const uint32_t *src = reinterpret_cast<const uint32_t *>(timg + (size_t)y * p.pitch + (size_t)x0 * 3);
                     const uint32_t a = src[0], b = src[1], c = src[2];
                     const int mx[4] = {max(max((int)(a & 255), (int)((a >> 8) & 255)), (int)((a >> 16) & 255)),
@@ -385,6 +418,7 @@ __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
                 }
             }
         }
+        run_gaps(qn);  // qn < 64
         long long v[4] = {(long long)gap0, (long long)high0, (long long)gap1, (long long)high1};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
