@@ -103,20 +103,19 @@ __device__ __forceinline__ uint4 convert4(uint32_t a, uint32_t b, uint32_t c, fl
 }
 
 struct Lds {
-    uint32_t *ring;   // [RR][rp]   codes (or raw groups between phase A and phase B); row pitch rp = wc + 4, see ScanParams
+    uint32_t *ring;   // [RR][rp]   codes (raw groups between a row's commit and its conversion); row pitch rp = wc + 4, see ScanParams
     uint32_t *occ;    // [RR][occw] one bit per 4-pixel group (32 groups per word): group non-black
     uint16_t *queue;  // [NW][QW]   per wave: ring index / 4 of the non-black groups it staged and still has to convert
     int *next;        // [2]        mask batches: next block of chunks to hand out, double-buffered by band parity
     int *cnt;         // counters
 };
 
-// Phase A for rows [ra, ra+n) (rows relative to m0-halo): wave w stages rows ra+w, ra+w+NW, ...  A row is
-// K = ceil(gpr/64) segments of 64 groups (12 bytes each): lane l of segment k loads group 64k+l, so every load
-// instruction reads 768 contiguous bytes from a wave-uniform row pointer; all K loads of a row are in flight
-// together (the lane offsets are clamped, not branched, for the lanes beyond the window).  The raw group goes to
-// the ring as (a,b,c,0) -- a black group is already its all-zero code --, the segment's ballot IS its two
-// occupancy words, and every non-black group is queued for phase B.
-// Per-lane constants of phase A, computed once per kernel: for segment k the byte offset of this lane's group inside
+// Staging of target rows (rows relative to m0-halo).  A row is K = ceil(gpr/64) segments of 64 groups (12 bytes each):
+// lane l of segment k loads group 64k+l, so every load instruction reads 768 contiguous bytes from a wave-uniform row
+// pointer; all K loads of a row are in flight together (the lane offsets are clamped, not branched, for the lanes beyond
+// the window).  The raw group goes to the ring as (a,b,c,0) -- a black group is already its all-zero code --, the
+// segment's ballot IS its two occupancy words, and every non-black group is queued for the conversion that follows.
+// Per-lane constants of the staging, computed once per kernel: for segment k the byte offset of this lane's group inside
 // an image row, the dword offset of its slot inside a ring row, and whether the lane's data is real.
 // Lanes beyond the window (or beyond the image columns) re-read the window's first in-image group: no extra traffic;
 // lanes beyond the window also re-write that group's slot with the same value (a benign duplicate), lanes inside the
@@ -292,11 +291,9 @@ __device__ __forceinline__ uint32_t regions_occupied(const Lds &L, int occw, uin
 // MULTI: several masks share the staged rows (counts by wave ballot into LDS) else one mask with
 // per-lane counters kept in registers for the whole target.
 //
-// Per band of BH mask rows the workgroup runs three phases separated by barriers -- A: stage the band's new target
-// rows (raw) and queue the non-black groups; B: convert the queued groups; P: probe.  The code ring holds exactly
-// the BH + 4 rows one band needs (18.9 KB for the benchmark window), so that 7-8 workgroups share a CU and cover
-// each other's memory latency and barrier waits; the (tiny) occupancy ring is twice as deep so that phase A of the
-// next band can set bits while nobody reads the rows it replaces.
+// Per band of BH mask rows: the band's new target rows are staged (the staging wave converts what it wrote), barrier,
+// probe, barrier.  The code ring holds exactly the BH + 4 rows one band needs (38 KB for the benchmark window): four
+// workgroups share a CU and cover each other's memory latency and barrier waits.
 template <bool XY2, bool MIRROR, bool MULTI, int KMAX>
 __global__ __launch_bounds__(MULTI ? NT_BATCH : NT, KMAX <= 3 ? (MULTI ? 8 : 4) : 1) void scan_kernel(ScanParams p) {  // one mask: 4 waves/SIMD, <= 128 VGPRs
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -332,7 +329,7 @@ __global__ __launch_bounds__(MULTI ? NT_BATCH : NT, KMAX <= 3 ? (MULTI ? 8 : 4) 
         // band b = mask rows [b*BH, (b+1)*BH) needs target rows [b*BH, (b+1)*BH + 2*halo) (relative to m0-halo).
         // Band 0 is staged directly.  Every later band adds BH = NW new rows, one per wave: at the top of band b the
         // wave issues (asynchronously) the mask data of band b and then the loads of ITS row of band b+1, which stay
-        // in flight during phases B and P of band b; after the band's last barrier the row is committed to the ring.
+        // in flight during the probes of band b; after the band's last barrier the row is committed to the ring.
         int staged = ((BH < m1rel) ? BH : m1rel) + 2 * halo;
         const bool stager = !MULTI || wave < NW;  // wave-uniform: the batch kernel's extra waves only probe
         if (stager) stage_a<KMAX, MULTI>(p, img, L, lc, 0, staged, wave, lane);
@@ -536,7 +533,7 @@ __global__ __launch_bounds__(MULTI ? NT_BATCH : NT, KMAX <= 3 ? (MULTI ? 8 : 4) 
                 }
                 flush();
             }
-            __syncthreads();  // the next band's phase A overwrites the oldest BH rows of the ring
+            __syncthreads();  // all probes of this band are done: the staging of the next band overwrites the oldest BH ring rows
             // ---- staging of the next band: commit the rows loaded at the top of this band, convert their non-black groups
             if (MULTI) {
                 // batch kernel: no prefetch registers held across the probes (they would cost a third of the waves a SIMD can
