@@ -338,6 +338,28 @@ def test_wrapped_uninitialised_memory(cds, oracle):
         assert np.array_equal(counts[0, t], q.score(targets[t])[2]), t
 
 
+def test_dense_full_frame_masks(cds, oracle):
+    """Every pixel of the frame is a mask pixel (684 K of them: ~230 chunks per band, far more than the prefetched ones),
+    one mask and a batch of two, sparse and dense targets."""
+    rects = cds.label_regions(W)
+    rng = np.random.default_rng(99)
+    lut = oracle.depth_lut()
+    masks = np.stack([lut[rng.integers(0, 256, size=(H, W))].astype(np.uint8) for _ in range(2)])
+    targets = np.stack([oracle.synth_image(0xC0FFEE, 11, 0), oracle.synth_image(0xC0FFEE, 12, 1), masks[1]])
+    lib = cds.Library(W, H, len(targets))
+    lib.upload(0, targets)
+    want = []
+    for m in range(2):
+        q = oracle.PixelMatchQuery(masks[m], 20, 20, 0.01, 2, True, rects)
+        want.append(np.stack([q.score(t)[2] for t in targets]))
+    one = cds.PixelMatchColorDepthSearchAlgorithm(masks[0], 20, True, None, 0, False, 20, 0.01, 2, rects)
+    assert np.array_equal(one.searchLibraryCounts(lib)[0], want[0])
+    both = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    c = both.searchLibraryCounts(lib)
+    assert np.array_equal(c[0], want[0]) and np.array_equal(c[1], want[1])
+    assert c[1, 2, 4] > 0.9 * both.getQuerySize(1)   # the mask against itself, unshifted
+
+
 def test_empty_and_classless_masks(cds, oracle):
     rects = cds.label_regions(W)
     black = np.zeros((H, W, 3), dtype=np.uint8)
