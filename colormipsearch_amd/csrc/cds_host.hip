@@ -543,6 +543,17 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
     // mask by mask with the single-mask kernel (same results)
     if (group > 1 && scan_lds_bytes(ms->wc, group, true, shift == 2, mirror) > ctx->lds_per_block) group = 1;
     ms->group = group;
+    // Record layout: the batch kernel's (band-major chunks, LDS offsets) for groups of masks -- and for a single mask
+    // with so many pixels that its probes outweigh the staging (the batch kernel deals any number of chunks per band to
+    // 16 waves; the single-mask kernel prefetches 4 chunks per wave and band and crawls through the rest).
+    bool batch = group > 1;
+    if (!batch) {
+        const char *fb = getenv("CDS_SCAN_SINGLE_AS_BATCH");  // "1" always, "0" never, unset: by size
+        const size_t px_per_band = total / (size_t)std::max(1, (m1 - m0 + kScanBandRows - 1) / kScanBandRows);
+        const bool big = px_per_band > (size_t)kBatchForSinglePxPerBand;
+        if ((fb ? atoi(fb) != 0 : big) && scan_lds_bytes(ms->wc, 1, true, shift == 2, mirror) <= ctx->lds_per_block) batch = true;
+    }
+    ms->batch = batch;
     const int ngroups = (n_masks + group - 1) / group;
     std::vector<uint32_t> bandptr((size_t)ngroups * (nbands + 1));
     std::vector<uint4> chunks;
@@ -578,7 +589,7 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
                         // the mirrored column lies inside the window only when the window was made symmetric (mirror on);
                         // without mirroring it is unused and must not spill into the neighbouring bit fields
                         const uint32_t cpl = (uint32_t)(p.x - ms->cx0), cmi = mirror ? (uint32_t)(W - 1 - p.x - ms->cx0) : cpl;
-                        if (group == 1) {
+                        if (!batch) {
                             pos.push_back(cpl | (cmi << 11) | ((uint32_t)(p.y - m0) << 22));
                         } else {  // mask batches: dword offsets of the first probe inside the (non-wrapping) LDS ring
                             const uint32_t row0 = (uint32_t)((p.y - m0) & 15) * (uint32_t)ring_pitch(ms->wc);
@@ -674,7 +685,7 @@ static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t fi
             p.pitch = lib->pitch; p.W = lib->W; p.H = lib->H; p.wpad = lib->pitch / 3;
             p.count = count;
             p.n_masks = std::min(chunk, ms->n_masks - g0);
-            p.batch = chunk > 1;
+            p.batch = ms->batch;
             p.nrows = ms->m1 - ms->m0;
             p.m0 = ms->m0;
             p.halo = ms->params.xy_shift;

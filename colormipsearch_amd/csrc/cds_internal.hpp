@@ -23,6 +23,9 @@ int hip_fail(hipError_t e, const char *what);
 
 // ---- scan kernel geometry shared by host preparation and device code (cds_scan.hip) ----
 constexpr int kScanBandRows = 12;  // mask rows per band
+// a single mask with more pixels per band than this would use the batch kernel; measured (tools/big_mask.py): the
+// single-mask kernel stays ahead up to at least 65 K mask pixels (3.2 vs 6.1 ms per 16 K targets), so: never by default
+constexpr int kBatchForSinglePxPerBand = 1 << 30;
 
 // ---- geometry limits (bit-packing of the mask pixel records, see cds_scan.hip) ----
 constexpr int kMaxW = 2000;
@@ -124,6 +127,7 @@ struct cds_maskset {
     cds_pixmatch_params params{};
     int W = 0, H = 0, n_masks = 0;
     int group = 1;               // masks per launch; the chunk arrays are laid out per group (cds_maskset_create)
+    bool batch = false;          // records are in the batch kernel's layout
     std::vector<int32_t> sizes;  // query size P per mask (includes class-less pixels)
     int m0 = 0, m1 = 0, cx0 = 0, wc = 0;
     uint32_t *d_bandptr = nullptr;

@@ -267,10 +267,13 @@ def test_mask_touching_every_border(cds, oracle):
             assert np.array_equal(counts[0, t], q.score(targets[t])[2]), (xy, mirror, t)
 
 
-def test_random_geometry_and_parameter_sweep(cds, oracle):
+@pytest.mark.parametrize("single_as_batch", [False, True])
+def test_random_geometry_and_parameter_sweep(cds, oracle, single_as_batch, monkeypatch):
     """Seeded random sweep over image sizes, mask counts / shapes, thresholds, tolerances, shift and mirror settings:
     all 18 per-transform counts of every (mask, target) pair against the oracle.  Exercises the single-mask kernel, the
     batch kernel (different numbers of masks per launch) and every window / segment configuration small images reach."""
+    if single_as_batch:   # single masks through the batch kernel (it is otherwise only reached with >= 2 masks)
+        monkeypatch.setenv("CDS_SCAN_SINGLE_AS_BATCH", "1")
     rng = np.random.default_rng(20261003)
     lut = oracle.depth_lut()
 
