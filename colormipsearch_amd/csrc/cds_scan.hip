@@ -263,30 +263,6 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
-// Occupancy test of a chunk's neighbourhoods, both orientations in one ballot: lanes 0..31 look at the plain
-// region, lanes 32..63 at the mirrored one.  A region = groups [g0, g1] x ring rows [r0, r0+nr) with nr <= 16; its
-// descriptor is g0 | g1 << 9 | testable << 31 (the host marks a region testable when it spans <= 2 occupancy words
-// per row).  Lane l of a half tests word (row l>>1, word (g0>>5) + (l&1)).  Returns bit 0: plain region has an
-// occupied group (or is not testable), bit 1: same for the mirrored region.
-__device__ __forceinline__ uint32_t regions_occupied(const Lds &L, int occw, uint32_t dplain, uint32_t dmirror, int r0, int nr, int lane) {
-    const uint32_t desc = lane < 32 ? dplain : dmirror;
-    const int l = lane & 31;
-    const int g0 = desc & 511, g1 = (desc >> 9) & 511;
-    const int wd = (g0 >> 5) + (l & 1);
-    const int q = l >> 1;
-    bool hit = !(desc >> 31);  // untestable: treat as occupied
-    if ((desc >> 31) && q < nr && wd <= (g1 >> 5)) {
-        const uint32_t w = L.occ[((r0 + q) & (RO - 1)) * occw + wd];
-        const int lo = g0 - 32 * wd, hi = g1 - 32 * wd;
-        uint32_t m = ~0u;
-        if (lo > 0) m &= ~0u << lo;
-        if (hi < 31) m &= ~(~0u << (hi + 1));
-        hit = (w & m) != 0;
-    }
-    const unsigned long long bal = __ballot(hit);
-    return ((uint32_t)bal != 0 ? 1u : 0u) | ((uint32_t)(bal >> 32) != 0 ? 2u : 0u);
-}
-
 // XY2: xyShift == 2 (9 shifts) else 0 (1 shift).  MIRROR: also the mirrored orientation.
 // MULTI: several masks share the staged rows (counts by wave ballot into LDS) else one mask with
 // per-lane counters kept in registers for the whole target.
@@ -402,32 +378,42 @@ __global__ __launch_bounds__(MULTI ? NT_BATCH : NT, KMAX <= 3 ? (MULTI ? 8 : 4) 
                         for (int r = 0; r < RO; r++) bo |= L.occ[r * OCCW + lane];
                     }
                     const int kk = lane & 31;
-                    uint32_t dz = pch[0].z, dw = pch[0].w;
+                    // rounds of MAXC chunks per wave: the first round's records were prefetched at the top of the band; a mask
+                    // with more chunks than that requests the next MAXC together and waits for them (the band's rows have long
+                    // landed by then), instead of crawling through them one load latency at a time
+                    for (uint32_t cbase = cbeg0 + wave; cbase < cend0; cbase += MAXC * NW) {  // wave-uniform
+                        if (cbase != cbeg0 + wave) {
 #pragma unroll
-                    for (int k = 1; k < MAXC; k++) {
-                        dz = kk == k ? pch[k].z : dz;
-                        dw = kk == k ? pch[k].w : dw;
-                    }
-                    const uint32_t desc = (lane < 32 || !MIRROR) ? dz : dw;
-                    const int g0 = desc & 511, g1 = (desc >> 9) & 511;
-                    const uint32_t wlo = __shfl(bo, g0 >> 5, 64), whi = __shfl(bo, (g0 >> 5) + 1, 64);
-                    const unsigned long long bits = (((unsigned long long)whi << 32) | wlo) >> (g0 & 31);
-                    const int width = g1 - g0 + 1;
-                    const unsigned long long wm = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
-                    const bool hit = kk < MAXC && (MIRROR || lane < 32) && (!(desc >> 31) || (bits & wm) != 0 || (p.debug & 4));
-                    const unsigned long long bal = __ballot(hit);
-                    uint32_t ci = cbeg0 + wave;
+                            for (int k = 0; k < MAXC; k++) {
+                                uint32_t ci = cbase + k * NW;
+                                ci = ci < cend0 ? ci : cbase;
+                                pch[k] = async_ld16(p.chunks + ci);
+                                ppos[k] = async_ld4(p.px_pos + (size_t)ci * 64 + lane);
+                                piv[k] = async_ld16(p.px_iv + (size_t)ci * 64 + lane);
+                            }
 #pragma unroll
-                    for (int k = 0; k < MAXC; k++) {
-                        if (ci < cend0)
-                            probe_chunk((uint32_t)((bal >> k) & 1) | (uint32_t)(((bal >> (32 + k)) & 1) << 1), ppos[k],
-                                        make_uint4(piv[k].x, piv[k].y, piv[k].z, piv[k].w), acc);
-                        ci += NW;
-                    }
-                    for (; ci < cend0; ci += NW) {  // (compiler-issued loads: also wait for the rows in flight; rare)
-                        const uint4 ch = p.chunks[ci];
-                        const uint32_t occ2 = (p.debug & 4) ? 3u : regions_occupied(L, OCCW, ch.z, MIRROR ? ch.w : (1u << 31), ch.y & 1023, (ch.y >> 10) & 31, lane);
-                        probe_chunk(occ2, p.px_pos[ci * 64 + lane], p.px_iv[ci * 64 + lane], acc);
+                            for (int k = 0; k < MAXC; k++) wait_mask<0>(pch[k], ppos[k], piv[k]);
+                        }
+                        uint32_t dz = pch[0].z, dw = pch[0].w;
+#pragma unroll
+                        for (int k = 1; k < MAXC; k++) {
+                            dz = kk == k ? pch[k].z : dz;
+                            dw = kk == k ? pch[k].w : dw;
+                        }
+                        const uint32_t desc = (lane < 32 || !MIRROR) ? dz : dw;
+                        const int g0 = desc & 511, g1 = (desc >> 9) & 511;
+                        const uint32_t wlo = __shfl(bo, g0 >> 5, 64), whi = __shfl(bo, (g0 >> 5) + 1, 64);
+                        const unsigned long long bits = (((unsigned long long)whi << 32) | wlo) >> (g0 & 31);
+                        const int width = g1 - g0 + 1;
+                        const unsigned long long wm = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
+                        const bool hit = kk < MAXC && (MIRROR || lane < 32) && (!(desc >> 31) || (bits & wm) != 0 || (p.debug & 4));
+                        const unsigned long long bal = __ballot(hit);
+#pragma unroll
+                        for (int k = 0; k < MAXC; k++) {
+                            if (cbase + k * NW < cend0)
+                                probe_chunk((uint32_t)((bal >> k) & 1) | (uint32_t)(((bal >> (32 + k)) & 1) << 1), ppos[k],
+                                            make_uint4(piv[k].x, piv[k].y, piv[k].z, piv[k].w), acc);
+                        }
                     }
                 }
             } else if (!(p.debug & 1)) {
