@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcds_hip.so")
+LIB_PATH = os.environ.get("CDS_HIP_LIBRARY") or os.path.join(_HERE, "libcds_hip.so")   # (override: A/B runs of two builds)
 
 CDS_OK = 0
 CDS_ERR_INVALID_ARGUMENT = -1
