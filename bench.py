@@ -186,6 +186,8 @@ def main():
                 "kernel_ms_per_launch": kern_ms,
                 # the kernel fetches only the column window of each row, so real traffic < algorithmic bytes
                 "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+                "note": "achieved = algorithmic bytes (mask rows x 3630 B per target, SURVEY 8d) / kernel time; the kernel "
+                        "fetches only the mask's column window of those rows, so the PMC traffic is lower and frac may exceed 1",
             },
         }
 
