@@ -614,8 +614,16 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
         }
         bandptr[(size_t)q * (nbands + 1) + nbands] = (uint32_t)chunks.size();
     }
+    // slack behind the arrays: the single-mask kernel prefetches the records of kScanPrefetchChunks chunks at a fixed stride
+    // without clamping (a wave with fewer chunks in the band reads -- and ignores -- what follows)
+    for (int i = 0; i < kScanPrefetchSlack; i++) {
+        chunks.push_back(make_uint4(0, 0, 0, 0));
+        for (int l = 0; l < 64; l++) {
+            pos.push_back(0);
+            ivs.push_back(make_uint4(kEmptyIv.lo1, kEmptyIv.len1, kEmptyIv.lo2, kEmptyIv.len2));
+        }
+    }
     total = pos.size();
-    if (chunks.empty()) chunks.push_back(make_uint4(0, 0, 0, 0));
     hipSetDevice(ctx->device);
     hipError_t e = hipMalloc(&ms->d_bandptr, bandptr.size() * 4);
     if (e == hipSuccess) e = hipMalloc(&ms->d_chunks, chunks.size() * sizeof(uint4));

@@ -23,6 +23,7 @@ int hip_fail(hipError_t e, const char *what);
 
 // ---- scan kernel geometry shared by host preparation and device code (cds_scan.hip) ----
 constexpr int kScanBandRows = 12;  // mask rows per band
+constexpr int kScanPrefetchSlack = 16;  // chunks of slack behind the record arrays (4 waves x 4 prefetched chunks)
 // a single mask with more pixels per band than this would use the batch kernel; measured (tools/big_mask.py): the
 // single-mask kernel stays ahead up to at least 65 K mask pixels (3.2 vs 6.1 ms per 16 K targets), so: never by default
 constexpr int kBatchForSinglePxPerBand = 1 << 30;

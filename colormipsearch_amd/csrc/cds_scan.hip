@@ -60,6 +60,20 @@ template <int N>
 __device__ __forceinline__ void wait_mask(u32x4 &ch, uint32_t &pos, u32x4 &iv) {  // at most N loads still outstanding
     asm volatile("s_waitcnt vmcnt(%3)" : "+v"(ch), "+v"(pos), "+v"(iv) : "n"(N) : "memory");
 }
+// ... with a wave-uniform (SGPR) base, a per-lane 32-bit offset and an immediate offset (-4096..4095): four chunks at a fixed
+// stride cost one base computation instead of four 64-bit per-lane addresses
+template <int OFF>
+__device__ __forceinline__ u32x4 async_ld16_s(uint32_t voff, const void *sbase) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ uint32_t async_ld4_s(uint32_t voff, const void *sbase) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+    return v;
+}
 __device__ __forceinline__ uint32_t async_ld4(const void *ptr) {
     uint32_t v;
     asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
@@ -319,14 +333,26 @@ __global__ __launch_bounds__(MULTI ? NT_BATCH : NT, KMAX <= 3 ? (MULTI ? 8 : 4) 
             u32x4 pch[MAXC], piv[MAXC];
             uint32_t ppos[MAXC];
             if (!MULTI) {
-#pragma unroll
-                for (int k = 0; k < MAXC; k++) {
-                    uint32_t ci = cbeg0 + wave + k * NW;
-                    ci = ci < cend0 ? ci : cbeg0;
-                    pch[k] = async_ld16(p.chunks + ci);
-                    ppos[k] = async_ld4(p.px_pos + (size_t)ci * 64 + lane);
-                    piv[k] = async_ld16(p.px_iv + (size_t)ci * 64 + lane);
-                }
+                // chunks cbeg0 + wave + k*NW, k < MAXC, without clamping (the arrays have slack): one scalar base per array
+                // (two for the 4 KB-strided interval records) and immediate offsets
+                static_assert(MAXC == 4 && NW == 4, "immediate offsets below");
+                const uint32_t c0 = cbeg0 + wave;
+                const uint4 *dbase = p.chunks + c0;
+                const uint32_t *pbase = p.px_pos + (size_t)c0 * 64;
+                const uint4 *ibase1 = p.px_iv + (size_t)(c0 + NW) * 64, *ibase3 = p.px_iv + (size_t)(c0 + 3 * NW) * 64;
+                const uint32_t zero = 0, l4 = (uint32_t)lane * 4u, l16 = (uint32_t)lane * 16u;
+                pch[0] = async_ld16_s<0>(zero, dbase);
+                ppos[0] = async_ld4_s<0>(l4, pbase);
+                piv[0] = async_ld16_s<-4096>(l16, ibase1);
+                pch[1] = async_ld16_s<64>(zero, dbase);
+                ppos[1] = async_ld4_s<1024>(l4, pbase);
+                piv[1] = async_ld16_s<0>(l16, ibase1);
+                pch[2] = async_ld16_s<128>(zero, dbase);
+                ppos[2] = async_ld4_s<2048>(l4, pbase);
+                piv[2] = async_ld16_s<-4096>(l16, ibase3);
+                pch[3] = async_ld16_s<192>(zero, dbase);
+                ppos[3] = async_ld4_s<3072>(l4, pbase);
+                piv[3] = async_ld16_s<0>(l16, ibase3);
             }
             // this wave's RPW rows of the next band (clamped and ignored where there is none)
             const int next_end = (y1 < m1rel) ? ((y1 + BH < m1rel) ? y1 + BH : m1rel) + 2 * halo : staged;
