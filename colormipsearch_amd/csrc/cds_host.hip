@@ -630,6 +630,7 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
     if (e == hipSuccess) e = hipMalloc(&ms->d_px_pos, total * 4);
     if (e == hipSuccess) e = hipMalloc(&ms->d_px_iv, total * sizeof(uint4));
     if (e == hipSuccess) e = hipMemcpy(ms->d_bandptr, bandptr.data(), bandptr.size() * 4, hipMemcpyHostToDevice);
+    ms->h_bandptr = bandptr;
     if (e == hipSuccess) e = hipMemcpy(ms->d_chunks, chunks.data(), chunks.size() * sizeof(uint4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ms->d_px_pos, pos.data(), total * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ms->d_px_iv, ivs.data(), total * sizeof(uint4), hipMemcpyHostToDevice);
@@ -712,9 +713,35 @@ static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t fi
             p.out_stride = count;
             p.out_offset = 0;
             if (const char *e = getenv("CDS_SCAN_DEBUG")) p.debug = atoi(e);
+            // Band slices (mask batches): every probe of a (mask, band) re-reads that band's pixel records; a group's records
+            // (~20 B per mask pixel: 38 MB for 128 benchmark masks) exceed an XCD's 4 MB L2, so one launch over all bands
+            // streams them from the Infinity Cache for every target (239 GB per 16,384 targets).  Launching slice by slice
+            // (all workgroups on the same few bands at the same time) keeps more of a slice's records in L2 (121 GB with
+            // 3-band slices); the per-transform counts travel from slice to slice in a scratch buffer (or the caller's
+            // counts array).  Measured: +6 % with 3..5 bands per slice; single-band slices lose it again to staging.
+            const std::vector<uint32_t> &bp = ms->h_bandptr;
+            const size_t gb = (size_t)(g0 / chunk) * (ms->nbands + 1);
+            const size_t group_bytes = (size_t)(bp[gb + ms->nbands] - bp[gb]) * 64 * 20;
+            int slice = ms->nbands;
+            if (ms->batch && ms->nbands > 1) {
+                const size_t budget = (size_t)10 << 20;  // ~10 MB of records per slice (4 bands of 128 benchmark masks)
+                const size_t per_band = std::max<size_t>(1, group_bytes / ms->nbands);
+                if (group_bytes > budget) slice = (int)std::max<size_t>(1, budget / per_band);
+                if (const char *e = getenv("CDS_SCAN_BAND_SLICE")) slice = atoi(e) > 0 ? std::min(atoi(e), ms->nbands) : ms->nbands;
+            }
+            int32_t *scratch = nullptr;
+            if (slice < ms->nbands && !p.counts) {
+                CDS_HIP(hipMallocAsync((void **)&scratch, (size_t)p.n_masks * count * CDS_N_TRANSFORMS * sizeof(int32_t), st));
+                p.counts = scratch;
+            }
             if (timed_sync) CDS_HIP(hipEventRecord(ev0, st));
-            rc = launch_scan(ctx, p, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
-            if (rc) return rc;
+            for (int b0 = 0; b0 < ms->nbands; b0 += slice) {
+                p.band_begin = b0;
+                p.band_end = std::min(ms->nbands, b0 + slice);
+                rc = launch_scan(ctx, p, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
+                if (rc) return rc;
+            }
+            if (scratch) CDS_HIP(hipFreeAsync(scratch, st));
             if (timed_sync) {
                 CDS_HIP(hipEventRecord(ev1, st));
                 CDS_HIP(hipEventSynchronize(ev1));

@@ -102,6 +102,8 @@ struct ScanParams {
     int nseg;             // ceil(gpr / 64): 64-group segments per staged row
     int occw;             // occupancy words (u32, one bit per group) per ring row = 2 * nseg
     int nbands;           // ceil(nrows / kScanBandRows)
+    int band_begin, band_end;  // bands of this launch (a band slice; [0, nbands) = everything); slices after the first add to
+                               // the counts in `counts`, the last one writes `out`
     float data_thr;
     const uint32_t *bandptr;  // [nbands+1] of this launch's mask group -> chunk index (chunks are stored band, mask, chunk)
     const uint4 *chunks;      // x: pixels | mask-in-group << 8 | has-second-interval << 16, y: r0 | nr<<10,
@@ -132,6 +134,7 @@ struct cds_maskset {
     std::vector<int32_t> sizes;  // query size P per mask (includes class-less pixels)
     int m0 = 0, m1 = 0, cx0 = 0, wc = 0;
     uint32_t *d_bandptr = nullptr;
+    std::vector<uint32_t> h_bandptr;  // host copy (slice planning)
     uint4 *d_chunks = nullptr;
     int nbands = 0;
     uint32_t *d_px_pos = nullptr;

@@ -320,12 +320,16 @@ __global__ __launch_bounds__(MULTI ? NT_BATCH : NT, KMAX <= 3 ? (MULTI ? 8 : 4) 
         // Band 0 is staged directly.  Every later band adds BH = NW new rows, one per wave: at the top of band b the
         // wave issues (asynchronously) the mask data of band b and then the loads of ITS row of band b+1, which stay
         // in flight during the probes of band b; after the band's last barrier the row is committed to the ring.
-        int staged = ((BH < m1rel) ? BH : m1rel) + 2 * halo;
+        // A launch may cover only the bands [band_begin, band_end) of the masks (band slices of a mask batch: the records of
+        // one slice stay L2-resident while every workgroup of the launch works on it; the per-transform counts are carried
+        // from slice to slice in p.counts).
+        int band = p.band_begin;
+        const int yb0 = band * BH;
+        int staged = ((yb0 + BH < m1rel) ? yb0 + BH : m1rel) + 2 * halo;
         const bool stager = !MULTI || wave < NW;  // wave-uniform: the batch kernel's extra waves only probe
-        if (stager) stage_a<KMAX, MULTI>(p, img, L, lc, 0, staged, wave, lane);
-        int band = 0;
-        for (int y0 = 0; y0 < m1rel; y0 += BH, band++) {
-            const int y1 = (y0 + BH < m1rel) ? y0 + BH : m1rel;
+        if (stager) stage_a<KMAX, MULTI>(p, img, L, lc, yb0, staged - yb0, wave, lane);
+        for (int y0 = yb0; y0 < m1rel && band < p.band_end; y0 += BH, band++) {
+            const int y1 = (y0 + BH < m1rel && band + 1 < p.band_end) ? y0 + BH : m1rel;
             const int qsel = band & 1;
             // mask data of this wave's first MAXC chunks of the band (chunks are padded to 64 pixels: pixel index =
             // chunk * 64 + lane); a wave without a chunk re-reads the band's first chunk and ignores it
@@ -572,21 +576,36 @@ __global__ __launch_bounds__(MULTI ? NT_BATCH : NT, KMAX <= 3 ? (MULTI ? 8 : 4) 
         }
         __syncthreads();
         const int nm = MULTI ? p.n_masks : 1;
+        const bool first_slice = p.band_begin == 0, last_slice = p.band_end >= p.nbands;
         for (int g = threadIdx.x; g < nm; g += NTH) {
-            const int *c = L.cnt + g * NC;
-            int best = 0, bm = 0;
+            int c[NC];
 #pragma unroll
-            for (int k = 0; k < NS; k++) best = c[k] > best ? c[k] : best;
-            if (MIRROR) {
+            for (int k = 0; k < NC; k++) c[k] = L.cnt[g * NC + k];
+            int32_t *co = p.counts ? p.counts + ((size_t)g * p.out_stride + p.out_offset + t) * CDS_N_TRANSFORMS : nullptr;
+            if (!first_slice) {  // add the counts of the earlier band slices (p.counts is mandatory when slicing)
 #pragma unroll
-                for (int k = 0; k < NS; k++) bm = c[NS + k] > bm ? c[NS + k] : bm;
+                for (int k = 0; k < NS; k++) {
+                    c[k] += co[k];
+                    if (MIRROR) c[NS + k] += co[9 + k];
+                }
             }
-            int32_t packed = best;
-            if (MIRROR && bm > best) packed = (int32_t)((uint32_t)bm | 0x80000000u);
-            p.out[(size_t)g * p.out_stride + p.out_offset + t] = packed;
-            if (p.counts) {
-                int32_t *co = p.counts + ((size_t)g * p.out_stride + p.out_offset + t) * CDS_N_TRANSFORMS;
-                for (int k = 0; k < CDS_N_TRANSFORMS; k++) co[k] = 0;
+            if (last_slice) {
+                int best = 0, bm = 0;
+#pragma unroll
+                for (int k = 0; k < NS; k++) best = c[k] > best ? c[k] : best;
+                if (MIRROR) {
+#pragma unroll
+                    for (int k = 0; k < NS; k++) bm = c[NS + k] > bm ? c[NS + k] : bm;
+                }
+                int32_t packed = best;
+                if (MIRROR && bm > best) packed = (int32_t)((uint32_t)bm | 0x80000000u);
+                p.out[(size_t)g * p.out_stride + p.out_offset + t] = packed;
+            }
+            if (co) {
+                if (first_slice) {
+                    for (int k = 0; k < CDS_N_TRANSFORMS; k++) co[k] = 0;
+                }
+#pragma unroll
                 for (int k = 0; k < NS; k++) {
                     co[k] = c[k];
                     if (MIRROR) co[9 + k] = c[NS + k];
