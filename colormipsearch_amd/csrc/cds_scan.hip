@@ -362,10 +362,24 @@ __global__ __launch_bounds__(MULTI ? NT_BATCH : NT, KMAX <= 3 ? (MULTI ? 8 : 4) 
             const int next_end = (y1 < m1rel) ? ((y1 + BH < m1rel) ? y1 + BH : m1rel) + 2 * halo : staged;
             u32x3 pw[RPW][KMAX];
             if (!MULTI) {  // (the batch kernel stages after the probes instead: its staging is amortised over the masks)
+                const int r0 = staged + wave, row0 = r0 + p.m0 - p.halo;  // this wave's first new row: ring row / image row
+                if (r0 + (RPW - 1) * NW < next_end && row0 >= 0 && row0 + (RPW - 1) * NW < p.H) {
+                    // the usual case (all rows exist and lie inside the image): one row pointer, constant strides
+                    const uint8_t *rowp = img + (uint32_t)(row0 * p.pitch);
+                    const uint32_t step = (uint32_t)(NW * p.pitch);
 #pragma unroll
-                for (int j = 0; j < RPW; j++) {
-                    const int my_row = staged + wave + j * NW;
-                    a_issue<KMAX>(p, img, lc, my_row < next_end ? my_row : staged - 1, pw[j]);
+                    for (int j = 0; j < RPW; j++) {
+#pragma unroll
+                        for (int k = 0; k < KMAX; k++)
+                            asm volatile("global_load_dwordx3 %0, %1, %2 nt" : "=v"(pw[j][k]) : "v"(lc.ldoff[k]), "s"(rowp) : "memory");
+                        rowp += step;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < RPW; j++) {
+                        const int my_row = r0 + j * NW;
+                        a_issue<KMAX>(p, img, lc, my_row < next_end ? my_row : staged - 1, pw[j]);
+                    }
                 }
             }
             __syncthreads();  // the band's rows are staged and converted (by the waves that loaded them)
