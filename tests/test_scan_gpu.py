@@ -363,6 +363,27 @@ def test_dense_full_frame_masks(cds, oracle):
     assert c[1, 2, 4] > 0.9 * both.getQuerySize(1)   # the mask against itself, unshifted
 
 
+@pytest.mark.parametrize("slice_bands", [1, 2, 7])
+def test_band_slices_of_a_mask_batch(cds, oracle, slice_bands, monkeypatch):
+    """A mask batch scanned in band slices (several launches per group; the per-transform counts travel between them,
+    through the caller's counts array or an internal scratch buffer) gives the results of the single launch."""
+    rects = cds.label_regions(W)
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(5)])
+    targets = np.stack([oracle.synth_image(0xC0FFEE, 300 + i, 0) for i in range(5)] + [masks[2], np.fliplr(masks[4])])
+    lib = cds.Library(W, H, len(targets))
+    lib.upload(0, targets)
+    monkeypatch.setenv("CDS_SCAN_BAND_SLICE", str(slice_bands))
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    counts = alg.searchLibraryCounts(lib)          # slices accumulate in the caller's counts
+    scores, mir = alg.searchLibrary(lib)           # slices accumulate in the scratch buffer
+    for m in range(len(masks)):
+        q = oracle.PixelMatchQuery(masks[m], 20, 20, 0.01, 2, True, rects)
+        for t in range(len(targets)):
+            s, mi, c = q.score(targets[t])
+            assert np.array_equal(counts[m, t], c), (m, t)
+            assert scores[m, t] == s and bool(mir[m, t]) == mi, (m, t)
+
+
 def test_empty_and_classless_masks(cds, oracle):
     rects = cds.label_regions(W)
     black = np.zeros((H, W, 3), dtype=np.uint8)
