@@ -344,12 +344,53 @@ void cds_library_destroy(cds_library *lib) {
     if (lib->d_grad) hipFree(lib->d_grad);
     if (lib->d_zgap) hipFree(lib->d_zgap);
     if (lib->d_zslice) hipFree(lib->d_zslice);
+    if (lib->d_stage) hipFree(lib->d_stage);
     delete lib;
 }
 
 static int check_range(const cds_library *lib, int64_t first, int64_t count) {
     if (!lib) return fail(CDS_ERR_INVALID_ARGUMENT, "library is NULL");
     if (first < 0 || count < 0 || first + count > lib->capacity) return fail(CDS_ERR_INVALID_ARGUMENT, "slot range outside the library");
+    return CDS_OK;
+}
+
+// Host <-> pitched device rows through a contiguous staging buffer kept with the library: ONE transfer per piece (<= 64 MB)
+// plus a device-side 2-D copy.  (A host-side 2-D copy of pageable memory degenerates into one small transfer per image
+// row: 4 ms for a single 1210x566 image instead of 0.2 ms.)
+static int stage_reserve(cds_library *lib, size_t bytes) {
+    if (lib->stage_bytes >= bytes) return CDS_OK;
+    if (lib->d_stage) hipFree(lib->d_stage);
+    lib->d_stage = nullptr; lib->stage_bytes = 0;
+    CDS_HIP(hipMalloc(&lib->d_stage, bytes));
+    lib->stage_bytes = bytes;
+    return CDS_OK;
+}
+
+static int rows_h2d(cds_library *lib, uint8_t *dst, size_t dpitch, const uint8_t *src, size_t row_bytes, size_t rows) {
+    const size_t piece_rows = std::max<size_t>(1, ((size_t)64 << 20) / row_bytes);
+    std::lock_guard<std::mutex> lk(lib->stage_mu);
+    int rc = stage_reserve(lib, std::min(piece_rows, rows) * row_bytes);
+    if (rc) return rc;
+    for (size_t done = 0; done < rows; done += piece_rows) {
+        const size_t n = std::min(piece_rows, rows - done);
+        CDS_HIP(hipMemcpyAsync(lib->d_stage, src + done * row_bytes, n * row_bytes, hipMemcpyHostToDevice, lib->ctx->stream));
+        CDS_HIP(hipMemcpy2DAsync(dst + done * dpitch, dpitch, lib->d_stage, row_bytes, row_bytes, n, hipMemcpyDeviceToDevice, lib->ctx->stream));
+        CDS_HIP(hipStreamSynchronize(lib->ctx->stream));  // the staging buffer is reused by the next piece
+    }
+    return CDS_OK;
+}
+
+static int rows_d2h(cds_library *lib, uint8_t *dst, const uint8_t *src, size_t spitch, size_t row_bytes, size_t rows) {
+    const size_t piece_rows = std::max<size_t>(1, ((size_t)64 << 20) / row_bytes);
+    std::lock_guard<std::mutex> lk(lib->stage_mu);
+    int rc = stage_reserve(lib, std::min(piece_rows, rows) * row_bytes);
+    if (rc) return rc;
+    for (size_t done = 0; done < rows; done += piece_rows) {
+        const size_t n = std::min(piece_rows, rows - done);
+        CDS_HIP(hipMemcpy2DAsync(lib->d_stage, row_bytes, src + done * spitch, spitch, row_bytes, n, hipMemcpyDeviceToDevice, lib->ctx->stream));
+        CDS_HIP(hipMemcpyAsync(dst + done * row_bytes, lib->d_stage, n * row_bytes, hipMemcpyDeviceToHost, lib->ctx->stream));
+        CDS_HIP(hipStreamSynchronize(lib->ctx->stream));
+    }
     return CDS_OK;
 }
 
@@ -364,10 +405,7 @@ int cds_library_upload(cds_library *lib, int64_t first, int64_t count, const uin
     if (lib->pitch > 3 * lib->W)
         CDS_HIP(hipMemset2DAsync(lib->d_rgb + (size_t)first * lib->img_stride + (size_t)3 * lib->W, lib->pitch, 0,
                                  (size_t)(lib->pitch - 3 * lib->W), (size_t)lib->H * count, lib->ctx->stream));
-    CDS_HIP(hipMemcpy2DAsync(lib->d_rgb + (size_t)first * lib->img_stride, lib->pitch, rgb, (size_t)3 * lib->W,
-                             (size_t)3 * lib->W, (size_t)lib->H * count, hipMemcpyHostToDevice, lib->ctx->stream));
-    CDS_HIP(hipStreamSynchronize(lib->ctx->stream));
-    return CDS_OK;
+    return rows_h2d(lib, lib->d_rgb + (size_t)first * lib->img_stride, lib->pitch, rgb, (size_t)3 * lib->W, (size_t)lib->H * count);
 }
 
 int cds_library_download(cds_library *lib, int64_t first, int64_t count, uint8_t *rgb) {
@@ -376,10 +414,7 @@ int cds_library_download(cds_library *lib, int64_t first, int64_t count, uint8_t
     if (count == 0) return CDS_OK;
     if (!rgb) return fail(CDS_ERR_INVALID_ARGUMENT, "rgb is NULL");
     CDS_HIP(hipSetDevice(lib->ctx->device));
-    CDS_HIP(hipMemcpy2DAsync(rgb, (size_t)3 * lib->W, lib->d_rgb + (size_t)first * lib->img_stride, lib->pitch,
-                             (size_t)3 * lib->W, (size_t)lib->H * count, hipMemcpyDeviceToHost, lib->ctx->stream));
-    CDS_HIP(hipStreamSynchronize(lib->ctx->stream));
-    return CDS_OK;
+    return rows_d2h(lib, rgb, lib->d_rgb + (size_t)first * lib->img_stride, lib->pitch, (size_t)3 * lib->W, (size_t)lib->H * count);
 }
 
 int cds_library_ensure_variants(cds_library *lib) {
@@ -411,14 +446,15 @@ int cds_library_upload_variants(cds_library *lib, int64_t first, int64_t count, 
     rc = cds_library_ensure_variants(lib);
     if (rc) return rc;
     if (grad) {
-        CDS_HIP(hipMemcpy2DAsync((uint8_t *)lib->d_grad + (size_t)first * lib->grad_stride, lib->gpitch, grad,
-                                 (size_t)2 * lib->W, (size_t)2 * lib->W, (size_t)lib->H * count, hipMemcpyHostToDevice,
-                                 lib->ctx->stream));
+        rc = rows_h2d(lib, (uint8_t *)lib->d_grad + (size_t)first * lib->grad_stride, lib->gpitch, (const uint8_t *)grad,
+                      (size_t)2 * lib->W, (size_t)lib->H * count);
+        if (rc) return rc;
         for (int64_t i = 0; i < count; i++) lib->has_grad[(size_t)(first + i)] = 1;
     }
     if (zgap_rgb) {
-        CDS_HIP(hipMemcpy2DAsync(lib->d_zgap + (size_t)first * lib->img_stride, lib->pitch, zgap_rgb, (size_t)3 * lib->W,
-                                 (size_t)3 * lib->W, (size_t)lib->H * count, hipMemcpyHostToDevice, lib->ctx->stream));
+        rc = rows_h2d(lib, lib->d_zgap + (size_t)first * lib->img_stride, lib->pitch, zgap_rgb, (size_t)3 * lib->W,
+                      (size_t)lib->H * count);
+        if (rc) return rc;
         for (int64_t i = 0; i < count; i++) lib->has_zgap[(size_t)(first + i)] = 1;
         rc = refresh_zslice(lib, first, count);
         if (rc) return rc;
@@ -433,13 +469,16 @@ int cds_library_download_variants(cds_library *lib, int64_t first, int64_t count
     if (count == 0) return CDS_OK;
     if (!lib->d_grad || !lib->d_zgap) return fail(CDS_ERR_INVALID_ARGUMENT, "library holds no variants");
     CDS_HIP(hipSetDevice(lib->ctx->device));
-    if (grad)
-        CDS_HIP(hipMemcpy2DAsync(grad, (size_t)2 * lib->W, (uint8_t *)lib->d_grad + (size_t)first * lib->grad_stride,
-                                 lib->gpitch, (size_t)2 * lib->W, (size_t)lib->H * count, hipMemcpyDeviceToHost,
-                                 lib->ctx->stream));
-    if (zgap_rgb)
-        CDS_HIP(hipMemcpy2DAsync(zgap_rgb, (size_t)3 * lib->W, lib->d_zgap + (size_t)first * lib->img_stride, lib->pitch,
-                                 (size_t)3 * lib->W, (size_t)lib->H * count, hipMemcpyDeviceToHost, lib->ctx->stream));
+    if (grad) {
+        rc = rows_d2h(lib, (uint8_t *)grad, (const uint8_t *)lib->d_grad + (size_t)first * lib->grad_stride, lib->gpitch,
+                      (size_t)2 * lib->W, (size_t)lib->H * count);
+        if (rc) return rc;
+    }
+    if (zgap_rgb) {
+        rc = rows_d2h(lib, zgap_rgb, lib->d_zgap + (size_t)first * lib->img_stride, lib->pitch, (size_t)3 * lib->W,
+                      (size_t)lib->H * count);
+        if (rc) return rc;
+    }
     CDS_HIP(hipStreamSynchronize(lib->ctx->stream));
     return CDS_OK;
 }
@@ -649,6 +688,8 @@ void cds_maskset_destroy(cds_maskset *ms) {
     if (ms->d_chunks) hipFree(ms->d_chunks);
     if (ms->d_px_pos) hipFree(ms->d_px_pos);
     if (ms->d_px_iv) hipFree(ms->d_px_iv);
+    if (ms->pair_scores) hipFree(ms->pair_scores);
+    if (ms->pair_lib) cds_library_destroy(ms->pair_lib);
     delete ms;
 }
 
@@ -830,19 +871,26 @@ int cds_score_pair(const cds_maskset *ms, int32_t mask_index, const uint8_t *tar
                  ms->W, ms->H, W, H);
         return fail(CDS_ERR_INVALID_ARGUMENT, buf);
     }
-    cds_library *lib = nullptr;
-    int rc = cds_library_create(ms->ctx, W, H, 1, &lib);
-    if (rc) return rc;
-    rc = cds_library_upload(lib, 0, 1, target_rgb);
-    std::vector<int32_t> s((size_t)ms->n_masks);
-    std::vector<uint8_t> m((size_t)ms->n_masks);
-    if (rc == CDS_OK) rc = cds_search(ms, lib, 0, 1, s.data(), m.data());
-    cds_library_destroy(lib);
-    if (rc == CDS_OK) {
-        *score = s[(size_t)mask_index];
-        *mirrored = m[(size_t)mask_index];
+    // the per-pair call of the reference's interface: one resident slot and one device score array are kept with the mask
+    // set (created on first use), so a call costs an upload, a one-workgroup launch and a 4-byte-per-mask read-back
+    std::lock_guard<std::mutex> lk(ms->pair_mu);
+    int rc = CDS_OK;
+    if (!ms->pair_lib) {
+        rc = cds_library_create(ms->ctx, W, H, 1, &ms->pair_lib);
+        if (rc) return rc;
+        hipError_t e = hipMalloc(&ms->pair_scores, (size_t)ms->n_masks * sizeof(int32_t));
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc(pair scores)");
     }
-    return rc;
+    rc = cds_library_upload(ms->pair_lib, 0, 1, target_rgb);
+    if (rc) return rc;
+    rc = search_impl(ms, ms->pair_lib, 0, 1, ms->pair_scores, nullptr, false);
+    if (rc) return rc;
+    std::vector<int32_t> packed((size_t)ms->n_masks);
+    CDS_HIP(hipMemcpyAsync(packed.data(), ms->pair_scores, packed.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ms->ctx->stream));
+    CDS_HIP(hipStreamSynchronize(ms->ctx->stream));
+    *score = packed[(size_t)mask_index] & 0x7fffffff;
+    *mirrored = (uint8_t)((uint32_t)packed[(size_t)mask_index] >> 31);
+    return CDS_OK;
 }
 
 float cds_pixel_match_normalized(int32_t score, int32_t query_size) {

@@ -80,6 +80,9 @@ struct cds_library {
     uint8_t *d_zgap = nullptr;   // lazily allocated, same layout as d_rgb
     uint16_t *d_zslice = nullptr;  // derived from d_zgap, gradient layout: (slice number - 1) | max channel << 8
     std::vector<uint8_t> has_grad, has_zgap;  // per slot
+    uint8_t *d_stage = nullptr;  // contiguous staging buffer of the host <-> pitched-rows transfers
+    size_t stage_bytes = 0;
+    std::mutex stage_mu;
     std::mutex mu;
 };
 
@@ -140,6 +143,10 @@ struct cds_maskset {
     uint32_t *d_px_pos = nullptr;
     uint4 *d_px_iv = nullptr;
     size_t n_px = 0;
+    // cds_score_pair: one resident slot + device scores, created on first use
+    mutable std::mutex pair_mu;
+    mutable cds_library *pair_lib = nullptr;
+    mutable int32_t *pair_scores = nullptr;
     // timing of the last search
     mutable std::mutex mu;
     mutable double last_ms = 0;

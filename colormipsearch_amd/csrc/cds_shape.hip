@@ -471,6 +471,8 @@ struct cds_shapeset {
     mutable std::mutex mu;
     mutable double last_ms = 0;
     mutable int last_launches = 0;
+    mutable std::mutex pair_mu;           // cds_shape_score_pair: one resident slot, created on first use
+    mutable cds_library *pair_lib = nullptr;
 };
 
 extern "C" {
@@ -618,6 +620,7 @@ void cds_shapeset_destroy(cds_shapeset *ss) {
     if (ss->d_planes) hipFree(ss->d_planes);
     if (ss->d_boxes) hipFree(ss->d_boxes);
     if (ss->d_rowflags) hipFree(ss->d_rowflags);
+    if (ss->pair_lib) cds_library_destroy(ss->pair_lib);
     delete ss;
 }
 
@@ -729,14 +732,17 @@ int cds_shape_score_pair(const cds_shapeset *ss, int32_t mask_index, const uint8
         return CDS_OK;
     }
     if (W != ss->W || H != ss->H) return fail(CDS_ERR_INVALID_ARGUMENT, "target image size must match the query image size");
-    cds_library *lib = nullptr;
-    int rc = cds_library_create(ss->ctx, W, H, 1, &lib);
-    if (rc) return rc;
-    rc = cds_library_upload(lib, 0, 1, target_rgb);
-    if (rc == CDS_OK) rc = cds_library_upload_variants(lib, 0, 1, grad, zgap_rgb);
+    // one resident slot (with its variant planes) is kept with the mask set for the per-pair call of the reference's interface
+    std::lock_guard<std::mutex> lk(ss->pair_mu);
+    int rc = CDS_OK;
+    if (!ss->pair_lib) {
+        rc = cds_library_create(ss->ctx, W, H, 1, &ss->pair_lib);
+        if (rc) return rc;
+    }
+    rc = cds_library_upload(ss->pair_lib, 0, 1, target_rgb);
+    if (rc == CDS_OK) rc = cds_library_upload_variants(ss->pair_lib, 0, 1, grad, zgap_rgb);
     int64_t slot = 0;
-    if (rc == CDS_OK) rc = cds_gradscore(ss, lib, 1, &mask_index, &slot, gradient_area_gap, high_expression_area, mirrored);
-    cds_library_destroy(lib);
+    if (rc == CDS_OK) rc = cds_gradscore(ss, ss->pair_lib, 1, &mask_index, &slot, gradient_area_gap, high_expression_area, mirrored);
     return rc;
 }
 
