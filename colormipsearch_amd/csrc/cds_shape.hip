@@ -168,7 +168,8 @@ static int max_filter_host(cds_context *ctx, const uint8_t *src, int W, int H, d
     CDS_HIP(hipSetDevice(ctx->device));
     std::vector<int> hw;
     const int k = line_radii(radius, hw);
-    const int pitch = rgb_pitch(W);
+    const int pitch = 3 * W;  // contiguous rows: the kernels below access bytes, and one plain transfer each way replaces
+                              // a host-side pitched copy (one small transfer per row: ~4 ms per image)
     const size_t bytes = (size_t)pitch * H;
     uint8_t *d_a = nullptr, *d_b = nullptr;
     int *d_hw = nullptr;
@@ -179,9 +180,8 @@ static int max_filter_host(cds_context *ctx, const uint8_t *src, int W, int H, d
     MF_HIP(hipMalloc(&d_a, bytes));
     MF_HIP(hipMalloc(&d_b, bytes));
     MF_HIP(hipMalloc(&d_hw, hw.size() * sizeof(int)));
-    MF_HIP(hipMemsetAsync(d_a, 0, bytes, st));
     MF_HIP(hipMemsetAsync(d_b, 0, bytes, st));
-    MF_HIP(hipMemcpy2DAsync(d_a, pitch, src, (size_t)3 * W, (size_t)3 * W, H, hipMemcpyHostToDevice, st));
+    MF_HIP(hipMemcpyAsync(d_a, src, bytes, hipMemcpyHostToDevice, st));
     MF_HIP(hipMemcpyAsync(d_hw, hw.data(), hw.size() * sizeof(int), hipMemcpyHostToDevice, st));
     MaxFilterParams p{};
     p.pitch = pitch; p.W = W; p.H = H; p.k = k; p.thr = thr; p.nrects = nrects; p.hw = d_hw;
@@ -206,7 +206,7 @@ static int max_filter_host(cds_context *ctx, const uint8_t *src, int W, int H, d
         hipLaunchKernelGGL(max_filter_kernel, dim3((p.bx1 - p.bx0 + 255) / 256, p.by1 - p.by0), dim3(256), 0, st, p);
         MF_HIP(hipGetLastError());
     }
-    MF_HIP(hipMemcpy2DAsync(dst, (size_t)3 * W, d_b, pitch, (size_t)3 * W, H, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipMemcpyAsync(dst, d_b, bytes, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
 #undef MF_HIP
     cleanup();
