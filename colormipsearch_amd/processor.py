@@ -72,6 +72,82 @@ def selectTopRankedElements(items: Sequence, groupingCriteria, scoreExtractor, t
     return ranked
 
 
+@dataclass
+class MatchTable:
+    """Columnar form of a list of CDMatch records (numpy arrays of equal length): what the pipeline uses at scale -- a
+    1024-mask x 1M-target search yields millions of matches, far too many for one Python object each."""
+    maskIndex: np.ndarray
+    targetIndex: np.ndarray
+    matchingPixels: np.ndarray
+    matchingPixelsRatio: np.ndarray            # float32, as PixelMatchScore.getNormalizedScore
+    mirrored: np.ndarray
+    gradientAreaGap: Optional[np.ndarray] = None     # int64, -1 = not computed
+    highExpressionArea: Optional[np.ndarray] = None
+    normalizedScore: Optional[np.ndarray] = None     # float32
+
+    def __len__(self):
+        return len(self.maskIndex)
+
+    def take(self, idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        opt = lambda a: None if a is None else a[idx]
+        return MatchTable(self.maskIndex[idx], self.targetIndex[idx], self.matchingPixels[idx], self.matchingPixelsRatio[idx],
+                          self.mirrored[idx], opt(self.gradientAreaGap), opt(self.highExpressionArea), opt(self.normalizedScore))
+
+    def gradScores(self):
+        """CDMatchEntity.getGradScore per row (API/model/CDMatchEntity.java:75-84): -1 where a score is missing."""
+        g, h = self.gradientAreaGap, self.highExpressionArea
+        ok = (g >= 0) & (h >= 0)
+        return np.where(ok, g + h // 3, -1).astype(np.int64)
+
+    def to_matches(self) -> List["CDMatch"]:
+        out = []
+        for i in range(len(self)):
+            mt = CDMatch(int(self.maskIndex[i]), int(self.targetIndex[i]), int(self.matchingPixels[i]),
+                         float(self.matchingPixelsRatio[i]), bool(self.mirrored[i]))
+            if self.gradientAreaGap is not None and self.gradientAreaGap[i] != -1:
+                mt.gradientAreaGap = int(self.gradientAreaGap[i])
+            if self.highExpressionArea is not None and self.highExpressionArea[i] != -1:
+                mt.highExpressionArea = int(self.highExpressionArea[i])
+            if self.normalizedScore is not None:
+                mt.normalizedScore = float(self.normalizedScore[i])
+            out.append(mt)
+        return out
+
+
+def _group_codes(names):
+    """Integer code per item for a grouping attribute; blank / missing -> "UNKNOWN" (ItemsHandling.java:84-88)."""
+    keys = np.array(["UNKNOWN" if (n is None or str(n).strip() == "") else str(n) for n in names], dtype=object)
+    _, codes = np.unique(keys, return_inverse=True)
+    return codes.astype(np.int64)
+
+
+def _top_ranked(idx, group, score, top_results, limit_sub_results):
+    """Vectorised selectTopRankedElements over the items `idx` (their order = the input order): returns the kept items, groups
+    ranked by their best score (descending, ties in first-occurrence order), items inside a group by descending score (ties
+    in input order) -- exactly the order the list version produces."""
+    if len(idx) == 0:
+        return idx
+    g, sc = group[idx], score[idx].astype(np.float64)
+    first = np.full(g.max() + 1, len(idx), dtype=np.int64)
+    np.minimum.at(first, g, np.arange(len(idx)))                      # first occurrence of each group (dict insertion order)
+    order = np.lexsort((np.arange(len(idx)), -sc, first[g]))         # by group (insertion order), then score desc, stable
+    g_sorted = g[order]
+    starts = np.flatnonzero(np.r_[True, g_sorted[1:] != g_sorted[:-1]])
+    rank_in_group = np.arange(len(idx)) - np.repeat(starts, np.diff(np.r_[starts, len(idx)]))
+    keep = np.ones(len(idx), dtype=bool) if limit_sub_results <= 0 else rank_in_group < limit_sub_results
+    best = sc[order][starts]                                          # best score of each group (groups in insertion order)
+    grank = np.argsort(-best, kind="stable")                          # ranked groups
+    if 0 < top_results < len(grank):
+        grank = grank[:top_results]
+    pos_of_group = np.full(len(starts), -1, dtype=np.int64)
+    pos_of_group[grank] = np.arange(len(grank))
+    gi = np.repeat(np.arange(len(starts)), np.diff(np.r_[starts, len(idx)]))
+    sel = keep & (pos_of_group[gi] >= 0)
+    final = np.lexsort((np.arange(len(idx))[sel], pos_of_group[gi][sel]))
+    return idx[order][sel][final]
+
+
 class GpuColorMIPSearchProcessor:
     """masks: uint8[n_masks,H,W,3]; the targets live in a `cds.Library` (+ `targets` metadata, one NeuronInfo per slot)."""
 
@@ -98,6 +174,60 @@ class GpuColorMIPSearchProcessor:
             for t in np.flatnonzero(keep):
                 out.append(CDMatch(m, int(t), int(scores[m, t]), float(ratio[t]), bool(mirrored[m, t])))
         return out
+
+    def findAllColorDepthMatchesTable(self, masks) -> MatchTable:
+        """findAllColorDepthMatches in columnar form (same rows, same order)."""
+        alg = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold(masks)
+        scores, mirrored = alg.searchLibrary(self.library, self.first, self.count)
+        sizes = np.asarray(alg.getQuerySizes())
+        mi, ti, sc, ra, mr = [], [], [], [], []
+        for m in range(alg.n_masks):
+            if sizes[m] == 0:
+                continue
+            t = np.flatnonzero(self.colorMIPSearch.isMatchArray(scores[m], int(sizes[m])))
+            mi.append(np.full(len(t), m, dtype=np.int32)); ti.append(t.astype(np.int64)); sc.append(scores[m, t].astype(np.int32))
+            ra.append((scores[m, t].astype(np.float64) / float(sizes[m])).astype(np.float32)); mr.append(mirrored[m, t].astype(bool))
+        cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dtype=dt)
+        return MatchTable(cat(mi, np.int32), cat(ti, np.int64), cat(sc, np.int32), cat(ra, np.float32), cat(mr, bool))
+
+    def selectBestMatchesTable(self, table: MatchTable, topLineMatches, topSamplesPerLine, topMatchesPerSample) -> MatchTable:
+        """selectBestMatches in columnar form: per mask top lines -> top samples per line -> top matches per sample."""
+        lines = _group_codes([t.publishedName for t in self.targets])[table.targetIndex]
+        samples = _group_codes([t.neuronId for t in self.targets])[table.targetIndex]
+        score = table.matchingPixels
+        out = []
+        for m in np.unique(table.maskIndex):                     # ascending mask order, as the list version
+            idx = np.flatnonzero(table.maskIndex == m)
+            kept_lines = _top_ranked(idx, lines, score, topLineMatches, -1)
+            # per kept line (in rank order) the sample ranking
+            lcodes = lines[kept_lines]
+            bounds = np.flatnonzero(np.r_[True, lcodes[1:] != lcodes[:-1]])
+            for a, b in zip(bounds, np.r_[bounds[1:], len(kept_lines)]):
+                out.append(_top_ranked(kept_lines[a:b], samples, score, topSamplesPerLine, topMatchesPerSample))
+        return table.take(np.concatenate(out) if out else np.zeros(0, dtype=np.int64))
+
+    def calculateGradientScoresTable(self, masks, table: MatchTable, queryThreshold, mirrorMask=True, roiMask=None,
+                                     excludedRegions=cds.label_regions) -> MatchTable:
+        """Shape scores for the table's pairs (one launch) and the per-mask normalisation, in columnar form."""
+        n = len(table)
+        table.gradientAreaGap = np.full(n, -1, dtype=np.int64)
+        table.highExpressionArea = np.full(n, -1, dtype=np.int64)
+        table.normalizedScore = np.zeros(n, dtype=np.float32)
+        if n == 0:
+            return table
+        alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, queryThreshold, mirrorMask, roiMask, excludedRegions,
+                                                        context=self.library.ctx)
+        gap, high, _ = alg.scoreLibraryPairs(self.library, table.maskIndex.astype(np.int32), (self.first + table.targetIndex).astype(np.int64))
+        table.gradientAreaGap[:] = gap
+        table.highExpressionArea[:] = high
+        grad = table.gradScores()
+        for m in np.unique(table.maskIndex):                     # CalculateGradientScoresCmd.normalizeScores (:616-645)
+            rows = np.flatnonzero(table.maskIndex == m)
+            max_pix = max(-1, int(table.matchingPixels[rows].max()))
+            max_grad = max(-1, int(grad[rows].max()))
+            table.normalizedScore[rows] = [np.float32(cds.calculateNormalizedScore(int(p), int(g), max_pix, max_grad))
+                                           for p, g in zip(table.matchingPixels[rows], grad[rows])]
+        return table
 
     # ---- gradientScores ---------------------------------------------------------------------------
     def selectBestMatches(self, matches: List[CDMatch], topLineMatches, topSamplesPerLine, topMatchesPerSample) -> List[CDMatch]:

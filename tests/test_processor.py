@@ -58,6 +58,19 @@ def test_normalizeScores_matches_reference_formula(oracle):
     assert ms[2].normalizedScore == 10.0 and ms[3].normalizedScore == 5.0   # no shape score: the pixel score itself
 
 
+def test_vectorised_ranking_equals_list_version():
+    """_top_ranked (numpy) reproduces selectTopRankedElements: group order, in-group order, both cuts, ties."""
+    rng = np.random.default_rng(1)
+    for trial in range(400):
+        n = int(rng.integers(1, 70))
+        groups, scores = rng.integers(0, 6, size=n), rng.integers(0, 8, size=n)
+        top, lim = int(rng.integers(-1, 5)), int(rng.integers(-1, 4))
+        ref = P.selectTopRankedElements(list(range(n)), lambda i: f"g{groups[i]}", lambda i: scores[i], top, lim)
+        want = [i for _, _, items in ref for i in items]
+        got = P._top_ranked(np.arange(n), groups.astype(np.int64), scores, top, lim).tolist()
+        assert got == want, (trial, n, top, lim)
+
+
 @pytest.mark.gpu
 def test_pipeline_equals_oracle_pipeline(oracle):
     from colormipsearch_amd import cds
@@ -105,3 +118,12 @@ def test_pipeline_equals_oracle_pipeline(oracle):
         mp, mg = max(mt.matchingPixels for mt in items), max(mt.getGradScore() for mt in items)
         for mt in items:
             assert mt.normalizedScore == float(np.float32(oracle.normalized_score(mt.matchingPixels, mt.getGradScore(), mp, mg)))
+    # the columnar pipeline gives the same rows in the same order
+    key = lambda mt: (mt.maskIndex, mt.targetIndex, mt.matchingPixels, mt.matchingPixelsRatio, mt.mirrored,
+                      mt.gradientAreaGap, mt.highExpressionArea, mt.normalizedScore)
+    table = proc.findAllColorDepthMatchesTable(masks)
+    assert [key(a)[:5] for a in table.to_matches()] == [key(b)[:5] for b in matches]
+    best_t = proc.selectBestMatchesTable(table, 3, 2, 1)
+    assert [key(a)[:5] for a in best_t.to_matches()] == [key(b)[:5] for b in best]
+    scored_t = proc.calculateGradientScoresTable(masks, best_t, 20, True, None, cds.label_regions)
+    assert [key(a) for a in scored_t.to_matches()] == [key(b) for b in scored]
