@@ -3,6 +3,8 @@
 //
 // Reference citations: API/ = colormipsearch-api/src/main/java/org/janelia/colormipsearch/.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -507,36 +509,54 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
     std::vector<std::vector<Px>> per_mask((size_t)n_masks);
     std::vector<int32_t> sizes((size_t)n_masks, 0);
     int m0 = H, m1 = 0, xlo = W, xhi = 0;  // over all device pixels of all masks
-    std::unordered_map<uint64_t, Intervals> cache;
-    for (int m = 0; m < n_masks; m++) {
-        const uint8_t *img = masks_rgb + (size_t)m * img_bytes;
-        std::vector<Px> &list = per_mask[(size_t)m];
-        for (int y = 0; y < H; y++)
-            for (int x = 0; x < W; x++) {
-                if (in_rects(excluded, n_excluded, x, y)) continue;
-                const uint8_t *p = img + 3 * ((size_t)y * W + x);
-                int r = p[0], g = p[1], b = p[2];
-                if (!(r > params->mask_threshold || g > params->mask_threshold || b > params->mask_threshold)) continue;
-                sizes[(size_t)m]++;  // getQuerySize counts every position, class or not
-                double a;
-                int c1 = hue_class(r, g, b, &a);
-                if (c1 == C_NONE) continue;  // pxGap is 10000 against everything
-                uint64_t key;
-                memcpy(&key, &a, 8);
-                key ^= (uint64_t)c1 << 61;   // a < 1 so the top bits of its encoding are free
-                auto it = cache.find(key);
-                Intervals iv;
-                if (it == cache.end()) {
-                    iv = intervals_for(ctx->ratios, c1, a, params->z_tolerance);
-                    cache.emplace(key, iv);
-                } else {
-                    iv = it->second;
-                }
-                if (iv.len1 == 0 && iv.lo1 == 1 && iv.len2 == 0 && iv.lo2 == 1) continue;  // can never match
-                list.push_back({x, y, iv});
-                m0 = std::min(m0, y); m1 = std::max(m1, y + 1);
-                xlo = std::min(xlo, x); xhi = std::max(xhi, x + 1);
+    // the masks are independent: host threads take them in turn (each with its own interval cache)
+    {
+        const unsigned hc = std::thread::hardware_concurrency();
+        const int n_threads = std::max(1, std::min<int>(n_masks, (int)std::min<unsigned>(hc ? hc : 1u, 16u)));
+        std::atomic<int> next{0};
+        std::mutex merge;
+        auto worker = [&]() {
+            std::unordered_map<uint64_t, Intervals> cache;
+            int lm0 = H, lm1 = 0, lxlo = W, lxhi = 0;
+            for (int m = next.fetch_add(1); m < n_masks; m = next.fetch_add(1)) {
+                const uint8_t *img = masks_rgb + (size_t)m * img_bytes;
+                std::vector<Px> &list = per_mask[(size_t)m];
+                int32_t size = 0;
+                for (int y = 0; y < H; y++)
+                    for (int x = 0; x < W; x++) {
+                        if (in_rects(excluded, n_excluded, x, y)) continue;
+                        const uint8_t *p = img + 3 * ((size_t)y * W + x);
+                        int r = p[0], g = p[1], b = p[2];
+                        if (!(r > params->mask_threshold || g > params->mask_threshold || b > params->mask_threshold)) continue;
+                        size++;  // getQuerySize counts every position, class or not
+                        double a;
+                        int c1 = hue_class(r, g, b, &a);
+                        if (c1 == C_NONE) continue;  // pxGap is 10000 against everything
+                        uint64_t key;
+                        memcpy(&key, &a, 8);
+                        key ^= (uint64_t)c1 << 61;   // a < 1 so the top bits of its encoding are free
+                        auto it = cache.find(key);
+                        Intervals iv;
+                        if (it == cache.end()) {
+                            iv = intervals_for(ctx->ratios, c1, a, params->z_tolerance);
+                            cache.emplace(key, iv);
+                        } else {
+                            iv = it->second;
+                        }
+                        if (iv.len1 == 0 && iv.lo1 == 1 && iv.len2 == 0 && iv.lo2 == 1) continue;  // can never match
+                        list.push_back({x, y, iv});
+                        lm0 = std::min(lm0, y); lm1 = std::max(lm1, y + 1);
+                        lxlo = std::min(lxlo, x); lxhi = std::max(lxhi, x + 1);
+                    }
+                sizes[(size_t)m] = size;
             }
+            std::lock_guard<std::mutex> lk(merge);
+            m0 = std::min(m0, lm0); m1 = std::max(m1, lm1); xlo = std::min(xlo, lxlo); xhi = std::max(xhi, lxhi);
+        };
+        std::vector<std::thread> pool;
+        for (int i = 1; i < n_threads; i++) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
     }
     cds_maskset *ms = new cds_maskset();
     ms->ctx = ctx; ms->params = *params; ms->W = W; ms->H = H; ms->n_masks = n_masks; ms->sizes = sizes;
