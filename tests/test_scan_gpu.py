@@ -274,7 +274,7 @@ def test_random_geometry_and_parameter_sweep(cds, oracle, single_as_batch, monke
     batch kernel (different numbers of masks per launch) and every window / segment configuration small images reach."""
     if single_as_batch:   # single masks through the batch kernel (it is otherwise only reached with >= 2 masks)
         monkeypatch.setenv("CDS_SCAN_SINGLE_AS_BATCH", "1")
-    rng = np.random.default_rng(20261003)
+    rng = np.random.default_rng(int(os.environ.get("CDS_TEST_SWEEP_SEED", "20261003")))
     lut = oracle.depth_lut()
 
     def blobs(w, h, n, dense):
@@ -290,7 +290,7 @@ def test_random_geometry_and_parameter_sweep(cds, oracle, single_as_batch, monke
                 img[y0:y0 + bh, x0:x0 + bw] = (lut[z] * br).astype(np.uint8)
         return img
 
-    for case in range(40):
+    for case in range(int(os.environ.get("CDS_TEST_SWEEP_CASES", "40"))):   # (a one-off soak run uses more)
         w, h = int(rng.integers(24, 420)), int(rng.integers(8, 150))
         n_masks = int(rng.choice([1, 1, 2, 3, 5, 9]))
         masks = np.stack([blobs(w, h, int(rng.integers(1, 5)), False) for _ in range(n_masks)])

@@ -1,4 +1,6 @@
 """GPU parity tests of kernel 2 (GradientAreaGap scorer) and of the mask preparation / max filter it needs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -147,7 +149,7 @@ def test_small_and_odd_geometry(cds, oracle, w, h):
 def test_random_geometry_and_parameter_sweep(cds, oracle):
     """Seeded random sweep for the shape scorer: image sizes (odd and even widths), several masks per set, thresholds,
     mirroring, ROI masks, excluded rectangles, 8/16-bit-range gradients, sparse and dense targets."""
-    rng = np.random.default_rng(424242)
+    rng = np.random.default_rng(int(os.environ.get("CDS_TEST_SWEEP_SEED", "424242")))
     lut = oracle.depth_lut()
 
     def strokes(w, h, n, lo=0.3):
@@ -160,7 +162,7 @@ def test_random_geometry_and_parameter_sweep(cds, oracle):
             img[y0:y0 + bh, x0:x0 + bw] = (lut[z] * br).astype(np.uint8)
         return img
 
-    for case in range(10):
+    for case in range(int(os.environ.get("CDS_TEST_SWEEP_CASES", "10"))):
         w, h = int(rng.integers(40, 300)), int(rng.integers(24, 140))
         n_masks, n_t = int(rng.integers(1, 4)), 5
         masks = np.stack([strokes(w, h, int(rng.integers(1, 4))) for _ in range(n_masks)])

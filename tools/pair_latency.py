@@ -32,3 +32,20 @@ try:
 except Exception as e:  # the mirror's variant-supplier keys may differ
     out["shape_pair_error"] = str(e)[:100]
 print(json.dumps(out))
+
+# small batched calls (the reference's per-mask granularity): 500 pairs / 1 mask x 4096 targets per call
+lib2 = cds.Library(W, H, 4096)
+lib2.generate_synthetic(0xC0FFEE, 0, 0, 4096, kind=0, with_variants=True)
+pm = np.zeros(500, dtype=np.int32); ps = np.arange(500, dtype=np.int64) * 8
+sh.scoreLibraryPairs(lib2, pm, ps)
+t0 = time.perf_counter()
+for _ in range(50):
+    sh.scoreLibraryPairs(lib2, pm, ps)
+out2 = {"gradscore_500_pairs_call_ms": round((time.perf_counter() - t0) / 50 * 1e3, 3), "gradscore_kernel_ms": round(sh.lastKernelMs()[0], 3)}
+alg.searchLibrary(lib2)
+t0 = time.perf_counter()
+for _ in range(50):
+    alg.searchLibrary(lib2)
+out2["search_4096_targets_call_ms"] = round((time.perf_counter() - t0) / 50 * 1e3, 3)
+out2["search_kernel_ms"] = round(alg.lastKernelMs()[0], 3)
+print(json.dumps(out2))
