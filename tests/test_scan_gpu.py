@@ -384,6 +384,40 @@ def test_band_slices_of_a_mask_batch(cds, oracle, slice_bands, monkeypatch):
             assert scores[m, t] == s and bool(mir[m, t]) == mi, (m, t)
 
 
+def test_full_geometry_parameter_sweep(cds, oracle):
+    """Seeded random thresholds / tolerances / shift / mirror / mask shapes at the production geometry (1210 x 566): the
+    window, segment count and band structure vary with the mask, the code intervals with the tolerance."""
+    rng = np.random.default_rng(int(os.environ.get("CDS_TEST_SWEEP_SEED", "77")))
+    rects = cds.label_regions(W)
+    base = [oracle.synth_image(0xBADC0DE, i, 2) for i in range(3)]
+    tg = [oracle.synth_image(0xC0FFEE, 700 + i, 0) for i in range(4)] + [oracle.synth_image(0xC0FFEE, 3, 1)]
+    for case in range(int(os.environ.get("CDS_TEST_SWEEP_CASES", "40")) // 7 + 1):
+        n_masks = int(rng.choice([1, 2, 3]))
+        masks = []
+        for i in range(n_masks):
+            m = base[int(rng.integers(0, 3))].copy()
+            if rng.integers(0, 2):      # keep a random sub-rectangle only: narrower windows, fewer bands
+                x0, x1 = sorted(rng.integers(300, 900, size=2)); y0, y1 = sorted(rng.integers(160, 340, size=2))
+                keep = np.zeros((H, W), dtype=bool); keep[y0:y1 + 8, x0:x1 + 16] = True
+                m[~keep] = 0
+            if rng.integers(0, 3) == 0:
+                m = np.roll(m, int(rng.integers(-300, 300)), axis=1)   # away from the centre (asymmetric windows)
+            masks.append(m)
+        masks = np.stack(masks)
+        targets = np.stack(tg + [masks[0], np.fliplr(masks[-1])])
+        mthr, dthr = int(rng.choice([20, 20, 50, 100])), int(rng.choice([20, 20, 60]))
+        ztol = float(rng.choice([0.01, 0.01, 0.02, 0.05, 0.3]))
+        xy, mirror = int(rng.choice([0, 2, 2])), bool(rng.integers(0, 4) > 0)
+        lib = cds.Library(W, H, len(targets))
+        lib.upload(0, targets)
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, mthr, mirror, None, 0, False, dthr, ztol, xy, rects)
+        counts = alg.searchLibraryCounts(lib)
+        for m in range(n_masks):
+            q = oracle.PixelMatchQuery(masks[m], mthr, dthr, ztol, xy, mirror, rects)
+            for t in range(len(targets)):
+                assert np.array_equal(counts[m, t], q.score(targets[t])[2]), (case, m, t, mthr, dthr, ztol, xy, mirror)
+
+
 def test_empty_and_classless_masks(cds, oracle):
     rects = cds.label_regions(W)
     black = np.zeros((H, W, 3), dtype=np.uint8)
