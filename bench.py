@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--kind", type=int, default=0, help="0 sparse-lut targets (default), 1 dense-uniform")
     ap.add_argument("--cpu-sample", type=int, default=0, help="targets in the cpu_baseline sample (0 = 8000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the secondary (batched-mask) measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -229,6 +230,27 @@ def main():
         }
         if not ok:
             out["cpu_baseline"]["parity_failure"] = True
+    # ---- secondary measurement (not `value`): BASELINE configs[2] in miniature -- 128 masks share one pass over the first
+    # 16,384 resident targets (the production shape: many masks against one library)
+    if rank == 0 and world == 1 and not args.no_aux and chunk >= 16384:
+        n_m, n_t = 128, 16384
+        mlib2 = cds.Library(W, H, n_m, context=ctx)
+        mlib2.generate_synthetic(MASK_SEED, 0, 0, n_m, kind=2)
+        batch = cds.PixelMatchColorDepthSearchAlgorithm(mlib2.download(0, n_m), MASK_THR, MIRROR, None, 0, False, DATA_THR, ZTOL,
+                                                        XY_SHIFT, rects, context=ctx)
+        bscores = torch.empty(n_m * n_t, dtype=torch.int32, device=dev)
+        batch.searchLibraryDevice(lib, 0, n_t, bscores.data_ptr())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(2):
+            batch.searchLibraryDevice(lib, 0, n_t, bscores.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        bms = e0.elapsed_time(e1) / 2
+        same = bool(torch.equal(bscores[:n_t], scores[:n_t]))   # mask 0 of the batch is the benchmark mask
+        out["aux"] = {"workload": f"{n_m} masks x {n_t} resident targets in one batched pass (BASELINE configs[2] shape)",
+                      "comparisons_per_s": n_m * n_t / (bms * 1e-3), "ms_per_pass": bms,
+                      "mask0_scores_equal_single_mask_scan": same}
     if rank == 0:
         print(json.dumps(out))
     if use_dist:
