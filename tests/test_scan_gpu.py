@@ -363,8 +363,8 @@ def test_dense_full_frame_masks(cds, oracle):
     assert c[1, 2, 4] > 0.9 * both.getQuerySize(1)   # the mask against itself, unshifted
 
 
-@pytest.mark.parametrize("slice_bands", [1, 2, 7])
-def test_band_slices_of_a_mask_batch(cds, oracle, slice_bands, monkeypatch):
+@pytest.mark.parametrize("slice_bands,per_launch", [(1, None), (2, 3), (7, None), (3, 2)])
+def test_band_slices_of_a_mask_batch(cds, oracle, slice_bands, per_launch, monkeypatch):
     """A mask batch scanned in band slices (several launches per group; the per-transform counts travel between them,
     through the caller's counts array or an internal scratch buffer) gives the results of the single launch."""
     rects = cds.label_regions(W)
@@ -373,6 +373,8 @@ def test_band_slices_of_a_mask_batch(cds, oracle, slice_bands, monkeypatch):
     lib = cds.Library(W, H, len(targets))
     lib.upload(0, targets)
     monkeypatch.setenv("CDS_SCAN_BAND_SLICE", str(slice_bands))
+    if per_launch:   # several groups of masks (launch sets), each in band slices
+        monkeypatch.setenv("CDS_SCAN_MASKS_PER_LAUNCH", str(per_launch))
     alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects)
     counts = alg.searchLibraryCounts(lib)          # slices accumulate in the caller's counts
     scores, mir = alg.searchLibrary(lib)           # slices accumulate in the scratch buffer
