@@ -403,17 +403,19 @@ __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
                     const int pa[4] = {qa.x, qa.y, qa.z, qa.w}, pb[4] = {qb.x, qb.y, qb.z, qb.w};
                     const uint32_t *src = reinterpret_cast<const uint32_t *>(timg + (size_t)y * p.pitch + (size_t)x0 * 3);
                     const uint32_t a = src[0], b = src[1], c = src[2];
-                    const int mx[4] = {max(max((int)(a & 255), (int)((a >> 8) & 255)), (int)((a >> 16) & 255)),
-                                       max(max((int)(a >> 24), (int)(b & 255)), (int)((b >> 8) & 255)),
-                                       max(max((int)((b >> 16) & 255), (int)(b >> 24)), (int)(c & 255)),
-                                       max(max((int)((c >> 8) & 255), (int)((c >> 16) & 255)), (int)(c >> 24))};
+                    if ((a | b | c) != 0) {  // a black target group has no signal (targets are sparse: whole waves skip this)
+                        const int mx[4] = {max(max((int)(a & 255), (int)((a >> 8) & 255)), (int)((a >> 16) & 255)),
+                                           max(max((int)(a >> 24), (int)(b & 255)), (int)((b >> 8) & 255)),
+                                           max(max((int)((b >> 16) & 255), (int)(b >> 24)), (int)(c & 255)),
+                                           max(max((int)((c >> 8) & 255), (int)((c >> 16) & 255)), (int)(c >> 24))};
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int x = x0 + j;
-                        if (x >= p.W) break;
-                        const bool sig = mx[j] > p.thr && !(row_in_rects && dev_in_rects(p.rects, p.nrects, x, y));
-                        high0 += (sig && (pa[j] & kPlaneQH)) ? 1 : 0;
-                        high1 += (sig && (pb[j] & kPlaneQH)) ? 1 : 0;
+                        for (int j = 0; j < 4; j++) {
+                            const int x = x0 + j;
+                            if (x >= p.W) break;
+                            const bool sig = mx[j] > p.thr && !(row_in_rects && dev_in_rects(p.rects, p.nrects, x, y));
+                            high0 += (sig && (pa[j] & kPlaneQH)) ? 1 : 0;
+                            high1 += (sig && (pb[j] & kPlaneQH)) ? 1 : 0;
+                        }
                     }
                 }
             }
