@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
     // are scattered, so a wave does not run it in place with a few lanes active: it appends the group to its own LDS
     // queue and runs the gap code over 64 queued groups at a time, all lanes busy.
     __shared__ long long red[4][4];
-    __shared__ uint32_t gq[4][128];  // per wave: row << 9 | group of the queued groups
+    __shared__ uint32_t gq[4][128];  // per wave: row << 9 | group of the queued gap groups
+    __shared__ uint32_t hq[4][128];  // ... and of the queued high-expression groups (QH bit set, target group not black)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool even_w = (p.W & 1) == 0;
     for (int64_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
         const uint8_t *rf = p.rowflags + (size_t)m * p.H;
         unsigned gap0 = 0, gap1 = 0;  // per lane < 2^31 for H*W <= 2M pixels (gap <= 65535 per pixel)
         int high0 = 0, high1 = 0;
-        int qn = 0;  // wave-uniform: queued groups
+        int qn = 0, hn = 0;  // wave-uniform: queued gap / high-expression groups
         // the gap arithmetic of the first n (<= 64) queued groups, one per lane
         auto run_gaps = [&](int n) {
             if (lane < n) {
@@ -367,12 +368,35 @@ __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
                 }
             }
         };
+        // the high-expression count of the first n (<= 64) queued groups, one per lane
+        auto run_high = [&](int n) {
+            if (lane < n) {
+                const uint32_t e = hq[wave][lane];
+                const int y = (int)(e >> 9), x0 = 4 * (int)(e & 511);
+                const ushort4 qa = *reinterpret_cast<const ushort4 *>(pl0 + (size_t)y * p.wp + x0);
+                ushort4 qb = make_ushort4(0, 0, 0, 0);
+                if (p.mirror) qb = *reinterpret_cast<const ushort4 *>(pl1 + (size_t)y * p.wp + x0);
+                const int pa[4] = {qa.x, qa.y, qa.z, qa.w}, pb[4] = {qb.x, qb.y, qb.z, qb.w};
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(timg + (size_t)y * p.pitch + (size_t)x0 * 3);
+                const uint32_t a = src[0], b = src[1], c = src[2];
+                const int mx[4] = {max(max((int)(a & 255), (int)((a >> 8) & 255)), (int)((a >> 16) & 255)),
+                                   max(max((int)(a >> 24), (int)(b & 255)), (int)((b >> 8) & 255)),
+                                   max(max((int)((b >> 16) & 255), (int)(b >> 24)), (int)(c & 255)),
+                                   max(max((int)((c >> 8) & 255), (int)((c >> 16) & 255)), (int)(c >> 24))};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int x = x0 + j;
+                    if (x >= p.W) break;
+                    const bool sig = mx[j] > p.thr && !dev_in_rects(p.rects, p.nrects, x, y);
+                    high0 += (sig && (pa[j] & kPlaneQH)) ? 1 : 0;
+                    high1 += (sig && (pb[j] & kPlaneQH)) ? 1 : 0;
+                }
+            }
+        };
         for (int y = ya + wave; y < yb; y += 4) {  // wave-uniform
             const int flags = rf[y];
             if (!flags) continue;
             const int q0 = (flags & 2) ? aq0 : gq0, q1 = (flags & 2) ? aq1 : gq1;
-            bool row_in_rects = false;  // wave-uniform: does any excluded rectangle intersect this row at all?
-            for (int i = 0; i < p.nrects; i++) row_in_rects |= (y >= p.rects[i].y0 && y < p.rects[i].y1);
             for (int base = q0; base < q1; base += 64) {  // wave-uniform
                 const int gi = base + lane;
                 const int x0 = 4 * gi;
@@ -399,27 +423,32 @@ __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
                         qn = rest;
                     }
                 }
+                // high-expression groups: the target group is fetched here (12 bytes), the arithmetic only for the few that are
+                // not black -- queued like the gap groups
+                bool has_high = false;
                 if (all & kPlaneQH) {
-                    const int pa[4] = {qa.x, qa.y, qa.z, qa.w}, pb[4] = {qb.x, qb.y, qb.z, qb.w};
                     const uint32_t *src = reinterpret_cast<const uint32_t *>(timg + (size_t)y * p.pitch + (size_t)x0 * 3);
-                    const uint32_t a = src[0], b = src[1], c = src[2];
-                    if ((a | b | c) != 0) {  // a black target group has no signal (targets are sparse: whole waves skip this)
-                        const int mx[4] = {max(max((int)(a & 255), (int)((a >> 8) & 255)), (int)((a >> 16) & 255)),
-                                           max(max((int)(a >> 24), (int)(b & 255)), (int)((b >> 8) & 255)),
-                                           max(max((int)((b >> 16) & 255), (int)(b >> 24)), (int)(c & 255)),
-                                           max(max((int)((c >> 8) & 255), (int)((c >> 16) & 255)), (int)(c >> 24))};
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int x = x0 + j;
-                            if (x >= p.W) break;
-                            const bool sig = mx[j] > p.thr && !(row_in_rects && dev_in_rects(p.rects, p.nrects, x, y));
-                            high0 += (sig && (pa[j] & kPlaneQH)) ? 1 : 0;
-                            high1 += (sig && (pb[j] & kPlaneQH)) ? 1 : 0;
-                        }
+                    has_high = (src[0] | src[1] | src[2]) != 0;
+                }
+                const unsigned long long balh = __ballot(has_high);
+                if (balh) {  // wave-uniform
+                    if (has_high) {
+                        const int at = hn + __builtin_amdgcn_mbcnt_hi((uint32_t)(balh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)balh, 0));
+                        hq[wave][at] = ((uint32_t)y << 9) | (uint32_t)gi;
+                    }
+                    hn += __popcll(balh);
+                    if (hn >= 64) {
+                        run_high(64);
+                        const int rest = hn - 64;
+                        uint32_t mv = 0;
+                        if (lane < rest) mv = hq[wave][64 + lane];
+                        if (lane < rest) hq[wave][lane] = mv;
+                        hn = rest;
                     }
                 }
             }
         }
+        run_high(hn);  // hn < 64
         run_gaps(qn);  // qn < 64
         long long v[4] = {(long long)gap0, (long long)high0, (long long)gap1, (long long)high1};
 #pragma unroll
