@@ -12,6 +12,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # keep libcds_hip.so in step with its sources (a no-op when it is up to date; hipcc cross-compiles without a GPU)
+    import shutil
+    import subprocess
+    if shutil.which("make") and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        r = subprocess.run(["make", "-s", "-j4", "-C", os.path.join(ROOT, "colormipsearch_amd", "csrc")], capture_output=True, text=True)
+        if r.returncode != 0:
+            print("WARNING: building libcds_hip.so failed:\n" + r.stdout[-2000:] + r.stderr[-2000:], file=sys.stderr)
 
 
 @pytest.fixture(scope="session")
