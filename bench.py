@@ -75,6 +75,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
+    if not os.path.exists(os.path.join(ROOT, "colormipsearch_amd", "libcds_hip.so")) and rank == 0:
+        import __graft_entry__
+        __graft_entry__.build()   # (normally built beforehand; hipcc is in the image)
+    if world > 1:
+        dist.barrier()
     from colormipsearch_amd import cds
 
     ctx = cds.Context(local_rank)
