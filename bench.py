@@ -256,12 +256,22 @@ def main():
         out["aux"] = {"workload": f"{n_m} masks x {n_t} resident targets in one batched pass (BASELINE configs[2] shape)",
                       "comparisons_per_s": n_m * n_t / (bms * 1e-3), "ms_per_pass": bms,
                       "mask0_scores_equal_single_mask_scan": same}
+    failed = []
     if rank == 0:
+        if out.get("cpu_baseline", {}).get("parity_failure"):
+            failed.append("GPU scores differ from the CPU oracle's on the sampled targets")
+        if out.get("aux", {}).get("mask0_scores_equal_single_mask_scan") is False:
+            failed.append("batched-mask scan disagrees with the single-mask scan")
+        if failed:
+            out["value"] = None     # a wrong result is not a measurement
+            out["parity_failure"] = failed
         print(json.dumps(out))
     if use_dist:
         if rank == 0 and not torch.equal(gathered[0], scores):
             raise SystemExit("gathered scores differ from the local ones")
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit("bench.py: parity failure: " + "; ".join(failed))
 
 
 if __name__ == "__main__":

@@ -744,9 +744,26 @@ static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t fi
     if (ms->n_px > 0) {
         const int chunk = ms->group;  // masks per launch (fixed when the mask set was laid out)
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        int32_t *scratch = nullptr;
+        // every error path below leaves through this: the events and the stream-ordered scratch buffer are released
+        auto cleanup = [&]() {
+            if (ev0) hipEventDestroy(ev0);
+            if (ev1) hipEventDestroy(ev1);
+            if (scratch) hipFreeAsync(scratch, st);
+            ev0 = ev1 = nullptr;
+            scratch = nullptr;
+        };
+#define SI_HIP(call)                                   \
+    do {                                               \
+        hipError_t _e = (call);                        \
+        if (_e != hipSuccess) {                        \
+            cleanup();                                 \
+            return cds::hip_fail(_e, #call);           \
+        }                                              \
+    } while (0)
         if (timed_sync) {
-            CDS_HIP(hipEventCreate(&ev0));
-            CDS_HIP(hipEventCreate(&ev1));
+            SI_HIP(hipEventCreate(&ev0));
+            SI_HIP(hipEventCreate(&ev1));
         }
         for (int g0 = 0; g0 < ms->n_masks; g0 += chunk) {
             ScanParams p{};
@@ -790,32 +807,36 @@ static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t fi
                 if (group_bytes > budget) slice = (int)std::max<size_t>(1, budget / per_band);
                 if (const char *e = getenv("CDS_SCAN_BAND_SLICE")) slice = atoi(e) > 0 ? std::min(atoi(e), ms->nbands) : ms->nbands;
             }
-            int32_t *scratch = nullptr;
             if (slice < ms->nbands && !p.counts) {
-                CDS_HIP(hipMallocAsync((void **)&scratch, (size_t)p.n_masks * count * CDS_N_TRANSFORMS * sizeof(int32_t), st));
+                SI_HIP(hipMallocAsync((void **)&scratch, (size_t)p.n_masks * count * CDS_N_TRANSFORMS * sizeof(int32_t), st));
                 p.counts = scratch;
             }
-            if (timed_sync) CDS_HIP(hipEventRecord(ev0, st));
+            if (timed_sync) SI_HIP(hipEventRecord(ev0, st));
             for (int b0 = 0; b0 < ms->nbands; b0 += slice) {
                 p.band_begin = b0;
                 p.band_end = std::min(ms->nbands, b0 + slice);
                 rc = launch_scan(ctx, p, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
-                if (rc) return rc;
+                if (rc) {
+                    cleanup();
+                    return rc;
+                }
             }
-            if (scratch) CDS_HIP(hipFreeAsync(scratch, st));
+            if (scratch) {
+                int32_t *s = scratch;
+                scratch = nullptr;
+                SI_HIP(hipFreeAsync(s, st));
+            }
             if (timed_sync) {
-                CDS_HIP(hipEventRecord(ev1, st));
-                CDS_HIP(hipEventSynchronize(ev1));
+                SI_HIP(hipEventRecord(ev1, st));
+                SI_HIP(hipEventSynchronize(ev1));
                 float t = 0;
-                CDS_HIP(hipEventElapsedTime(&t, ev0, ev1));
+                SI_HIP(hipEventElapsedTime(&t, ev0, ev1));
                 ms_sum += t;
             }
             launches++;
         }
-        if (timed_sync) {
-            hipEventDestroy(ev0);
-            hipEventDestroy(ev1);
-        }
+        cleanup();
+#undef SI_HIP
     }
     if (timed_sync) {
         std::lock_guard<std::mutex> lk(ms->mu);
@@ -895,11 +916,16 @@ int cds_score_pair(const cds_maskset *ms, int32_t mask_index, const uint8_t *tar
     // set (created on first use), so a call costs an upload, a one-workgroup launch and a 4-byte-per-mask read-back
     std::lock_guard<std::mutex> lk(ms->pair_mu);
     int rc = CDS_OK;
-    if (!ms->pair_lib) {
-        rc = cds_library_create(ms->ctx, W, H, 1, &ms->pair_lib);
-        if (rc) return rc;
+    if (!ms->pair_lib || !ms->pair_scores) {  // (both or neither: a half-made pair of an earlier failed call is remade)
+        if (!ms->pair_lib) {
+            rc = cds_library_create(ms->ctx, W, H, 1, &ms->pair_lib);
+            if (rc) return rc;
+        }
         hipError_t e = hipMalloc(&ms->pair_scores, (size_t)ms->n_masks * sizeof(int32_t));
-        if (e != hipSuccess) return hip_fail(e, "hipMalloc(pair scores)");
+        if (e != hipSuccess) {
+            ms->pair_scores = nullptr;
+            return hip_fail(e, "hipMalloc(pair scores)");
+        }
     }
     rc = cds_library_upload(ms->pair_lib, 0, 1, target_rgb);
     if (rc) return rc;

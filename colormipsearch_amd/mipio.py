@@ -12,6 +12,7 @@
 import io
 import json
 import os
+import re
 import zipfile
 
 import numpy as np
@@ -114,7 +115,9 @@ def write_matches_per_mask(out_dir, matches, mask_infos, target_infos):
     paths = []
     for mi, items in by_mask.items():
         items = sorted(items, key=lambda v: -v.matchingPixels)
-        path = os.path.join(out_dir, f"{mask_infos[mi].get('mipId', mi)}.json")
+        # the id comes from input metadata: keep it a plain file name inside out_dir
+        name = re.sub(r"[^A-Za-z0-9._-]", "_", os.path.basename(str(mask_infos[mi].get("mipId", mi)))).lstrip(".") or str(mi)
+        path = os.path.join(out_dir, f"{name}.json")
         with open(path, "w") as f:
             json.dump(match_records(items, mask_infos, target_infos), f, indent=1)
         paths.append(path)

@@ -1,7 +1,8 @@
 #!/bin/bash
 # memory-path PMC counters of the single-mask scan kernel (per target)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}
 OUT=$R/gpurun_out/pmc_mem
 rm -rf $OUT; mkdir -p $OUT
 ARGS="$R/bench.py --chunk 16384 --steps 3 --warmup 1 --no-cpu-baseline"

@@ -1,7 +1,8 @@
 #!/bin/bash
 # PMC counters of the batched-mask scan (per mask x target pair)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}
 M=${MASKS:-32}; T=${TARGETS:-16384}
 OUT=$R/gpurun_out/pmc_multi
 rm -rf $OUT; mkdir -p $OUT

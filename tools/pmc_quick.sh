@@ -1,7 +1,8 @@
 #!/bin/bash
 # quick PMC comparison of scan-kernel variants selected by CDS_SCAN_DEBUG values in $DBGS
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}
 for dbg in ${DBGS:-0 3}; do
   OUT=$R/gpurun_out/pmcq_$dbg
   rm -rf $OUT; mkdir -p $OUT
