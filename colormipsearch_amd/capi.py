@@ -81,6 +81,17 @@ SIGNATURES = {
     "cds_pixel_match_normalized": (ctypes.c_float, [_i32, _i32]),
     "cds_is_match": (_i, [_i32, _i32, ctypes.c_double]),
     "cds_maskset_last_kernel_ms": (_i, [_vp, ctypes.POINTER(ctypes.c_double), _i32p]),
+    "cds_sparse_library_create": (_i, [_vp, _i32, _i32, _i64, _i64, ctypes.POINTER(_vp)]),
+    "cds_sparse_library_destroy": (None, [_vp]),
+    "cds_sparse_library_append": (_i, [_vp, _vp, _i64, _i64]),
+    "cds_sparse_library_append_host": (_i, [_vp, _i64, _u8p]),
+    "cds_sparse_library_size": (_i64, [_vp]),
+    "cds_sparse_library_pixels": (_i64, [_vp]),
+    "cds_sparse_library_clear": (_i, [_vp]),
+    "cds_sparse_library_image_records": (_i, [_vp, _i64, _u32p, _i64, _i64p, _u32p]),
+    "cds_search_sparse": (_i, [_vp, _vp, _i64, _i64, _i32p, _u8p]),
+    "cds_search_sparse_device": (_i, [_vp, _vp, _i64, _i64, _vp]),
+    "cds_search_sparse_counts": (_i, [_vp, _vp, _i64, _i64, _i32p]),
     "cds_shapeset_create": (_i, [_vp, _i32, _u8p, _i32, _i32, _i32, _i32, _u8p, _rp, _i32, ctypes.POINTER(_vp)]),
     "cds_shapeset_destroy": (None, [_vp]),
     "cds_shapeset_mask_stats": (_i, [_vp, _i64p, _i64p]),

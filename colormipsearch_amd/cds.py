@@ -196,6 +196,65 @@ class Library:
                                                             int(first_slot), int(count), int(kind), int(bool(with_variants))))
 
 
+class SparseLibrary:
+    """A resident shard of target MIPs kept as signal-pixel lists (cds_sparse_library): ~4 % of the dense bytes,
+    for searches that need the pixel-match score only (`searchSparseLibrary*`)."""
+
+    def __init__(self, width, height, capacity_images, capacity_pixels, context=None):
+        self.ctx = context or default_context()
+        self._lib = capi.load()
+        self.width, self.height = int(width), int(height)
+        self.capacity_images, self.capacity_pixels = int(capacity_images), int(capacity_pixels)
+        h = ctypes.c_void_p()
+        capi.check(self._lib.cds_sparse_library_create(self.ctx._h, self.width, self.height, self.capacity_images,
+                                                       self.capacity_pixels, ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cds_sparse_library_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._lib.cds_sparse_library_size(self._h))
+
+    @property
+    def pixels(self):
+        return int(self._lib.cds_sparse_library_pixels(self._h))
+
+    def clear(self):
+        capi.check(self._lib.cds_sparse_library_clear(self._h))
+
+    def append_from(self, library, first=0, count=None):
+        """Append dense resident slots [first, first+count) of `library` (device to device)."""
+        count = library.capacity - first if count is None else int(count)
+        capi.check(self._lib.cds_sparse_library_append(self._h, library._h, int(first), count))
+
+    def append(self, images):
+        """Append host images uint8[n,H,W,3]."""
+        imgs = capi.rgb_images(images)
+        if imgs.shape[1:3] != (self.height, self.width):
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "image size does not match the library")
+        capi.check(self._lib.cds_sparse_library_append_host(self._h, imgs.shape[0], capi.as_u8p(imgs)))
+
+    def image_records(self, index):
+        """(records uint32[n], row_offsets uint32[H+1]) of one image -- diagnostic."""
+        n = ctypes.c_int64()
+        capi.check(self._lib.cds_sparse_library_image_records(self._h, int(index), None, 0, ctypes.byref(n), None))
+        rec = np.zeros(n.value, dtype=np.uint32)
+        rows = np.zeros(self.height + 1, dtype=np.uint32)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        capi.check(self._lib.cds_sparse_library_image_records(self._h, int(index), rec.ctypes.data_as(u32p), n.value,
+                                                              ctypes.byref(n), rows.ctypes.data_as(u32p)))
+        return rec, rows
+
+
 # --------------------------------------------------------------------------------------------------
 # scores
 # --------------------------------------------------------------------------------------------------
@@ -440,6 +499,24 @@ class PixelMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
     def searchLibraryDevice(self, library, first, count, d_scores_ptr):
         """Asynchronous; d_scores_ptr = device pointer to int32[n_masks*count] (score | mirrored<<31)."""
         capi.check(self._lib.cds_search_device(self._h, library._h, int(first), int(count), ctypes.c_void_p(int(d_scores_ptr))))
+
+    def searchSparseLibrary(self, sparse_library, first=0, count=None):
+        """searchLibrary over a SparseLibrary: identical results."""
+        count = len(sparse_library) - first if count is None else int(count)
+        scores = np.zeros((self.n_masks, count), dtype=np.int32)
+        mir = np.zeros((self.n_masks, count), dtype=np.uint8)
+        capi.check(self._lib.cds_search_sparse(self._h, sparse_library._h, int(first), count, capi.as_i32p(scores), capi.as_u8p(mir)))
+        return scores, mir.astype(bool)
+
+    def searchSparseLibraryCounts(self, sparse_library, first=0, count=None):
+        count = len(sparse_library) - first if count is None else int(count)
+        counts = np.zeros((self.n_masks, count, capi.CDS_N_TRANSFORMS), dtype=np.int32)
+        capi.check(self._lib.cds_search_sparse_counts(self._h, sparse_library._h, int(first), count, capi.as_i32p(counts)))
+        return counts
+
+    def searchSparseLibraryDevice(self, sparse_library, first, count, d_scores_ptr):
+        capi.check(self._lib.cds_search_sparse_device(self._h, sparse_library._h, int(first), int(count),
+                                                      ctypes.c_void_p(int(d_scores_ptr))))
 
     def lastKernelMs(self):
         ms, n = ctypes.c_double(), ctypes.c_int32()

@@ -563,6 +563,18 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
     size_t total = 0;
     for (auto &l : per_mask) total += l.size();
     ms->n_px = total;
+    {   // the same device pixels laid out for the sparse scan (cds_sparse.hip)
+        std::vector<std::vector<MaskPx>> spx((size_t)n_masks);
+        for (int m = 0; m < n_masks; m++) {
+            spx[(size_t)m].reserve(per_mask[(size_t)m].size());
+            for (const Px &q : per_mask[(size_t)m]) spx[(size_t)m].push_back({q.x, q.y, q.iv.lo1, q.iv.len1, q.iv.lo2, q.iv.len2});
+        }
+        int rc = build_sparse_plans(ms, spx);
+        if (rc) {
+            delete ms;
+            return rc;
+        }
+    }
     if (total == 0) {  // nothing can ever match: the search returns zeros without a launch
         ms->m0 = ms->m1 = 0;
         *out = ms;
@@ -708,6 +720,7 @@ void cds_maskset_destroy(cds_maskset *ms) {
     if (ms->d_chunks) hipFree(ms->d_chunks);
     if (ms->d_px_pos) hipFree(ms->d_px_pos);
     if (ms->d_px_iv) hipFree(ms->d_px_iv);
+    free_sparse_plans(ms);
     if (ms->pair_scores) hipFree(ms->pair_scores);
     if (ms->pair_lib) cds_library_destroy(ms->pair_lib);
     delete ms;

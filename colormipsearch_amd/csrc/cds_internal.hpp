@@ -125,8 +125,77 @@ int launch_scan(cds_context *ctx, const ScanParams &p, bool xy2, bool mirror, hi
 size_t scan_lds_bytes(int wc, int n_masks, bool batch, bool xy2, bool mirror);  // dynamic LDS of one workgroup
 int refresh_zslice(cds_library *lib, int64_t first, int64_t count);  // cds_shape.hip: zgap RGB -> zslice plane
 int init_rcp_table(cds_context *ctx);
+struct MaskPx {
+    int x, y;
+    uint32_t lo1, len1, lo2, len2;
+};
+// cds_sparse.hip: build the sparse-scan plans of a mask set from its device pixels (called by cds_maskset_create)
+int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &per_mask);
+void free_sparse_plans(cds_maskset *ms);
 
 }  // namespace cds
+
+namespace cds {
+
+// ---- sparse library (cds_sparse.hip) ------------------------------------------------------------------------------
+// Record of one signal pixel (a pixel with a strict maximum channel -- every other pixel has no hue class and can never
+// match, AbstractColorDepthSearchAlgorithm.java:195-225): the hue class and the two channel values its ratio is made of.
+//   bit 31 first record of its image row | bits 30..20 x | bits 18..16 hue class 1..6 | bits 15..8 second channel | bits 7..0 max
+// A row without signal pixels holds one filler record (bit 31 only), so "row = rows started so far" holds everywhere.
+constexpr uint32_t kRecRowFlag = 0x80000000u;
+constexpr int kRecXShift = 20;
+constexpr int kRecClsShift = 16;
+
+// One mask prepared for the sparse scan: the mask's bounding box cut into slabs of `slab_rows` mask rows; per slab one
+// ready-to-copy LDS image [plane u16 (slab_rows + 8) x pitch | near bitmap u32 (slab_rows + 4) x nwpr]:
+//   plane[(my - slab_y0) + 4][(mx - xlo) + 4] = 1-based index of the mask pixel's interval record (0 = no mask pixel);
+//   near bit (ty - (slab_y0 - 2), tx - (xlo - 2)) = some transform maps target pixel (tx, ty) onto a mask pixel of the slab.
+struct SparseMaskPlan {
+    int xlo = 0, cols = 0, ylo = 0, nrows = 0;  // bounding box of the mask's device pixels
+    int pitch = 0;        // plane row pitch in u16 elements (multiple of 8, >= cols + 8)
+    int nwpr = 0;         // near-bitmap words per row
+    int slab_rows = 0, n_slabs = 0;
+    int near_off = 0;     // byte offset of the near bitmap inside a slab image
+    int slab_bytes = 0;   // multiple of 16
+    int n_iv = 0;         // interval records (index 0 = the empty record) -- iv table has n_iv entries
+    bool iv_in_lds = true;
+    size_t slabs_off = 0; // byte offset of this mask's slab images in cds_maskset::d_sp_slabs
+    size_t iv_off = 0;    // element offset of its interval table in cds_maskset::d_sp_iv
+    size_t lds_bytes = 0; // dynamic LDS of one workgroup
+};
+
+struct SparseScanParams {
+    const uint32_t *px;       // record arena
+    const uint64_t *img_off;  // [n+1] first record of every image
+    const uint32_t *rowptr;   // [n][H+1] record offsets of the rows inside their image
+    int64_t first, count;
+    int W, H;
+    const uint8_t *slabs;
+    const uint4 *iv;
+    int n_iv, iv_in_lds;
+    int xlo, cols, ylo, nrows, pitch, nwpr, slab_rows, n_slabs, near_off, slab_bytes;
+    int thr;
+    int group;                // targets a wave takes per grab
+    uint32_t *work;           // [n_slabs] next target of every slab (zero before the launch)
+    int32_t *out;             // [count] score | mirrored << 31 (written directly when there is one slab and no partial)
+    int32_t *partial;         // [n_slabs][count][18] per-transform counts of every slab, or NULL
+};
+
+}  // namespace cds
+
+struct cds_sparse_library {
+    cds_context *ctx = nullptr;
+    int W = 0, H = 0;
+    int64_t cap_images = 0, cap_px = 0;
+    int64_t n_images = 0, n_px = 0;
+    uint32_t *d_px = nullptr;
+    uint64_t *d_img_off = nullptr;  // [cap_images + 1]
+    uint32_t *d_rowptr = nullptr;   // [cap_images][H + 1]
+    uint32_t *d_tmp = nullptr;      // append scratch: per-image totals of one batch
+    int64_t tmp_images = 0;
+    cds_library *stage = nullptr;   // dense staging slots of cds_sparse_library_append_host
+    std::mutex mu;
+};
 
 struct cds_maskset {
     cds_context *ctx = nullptr;
@@ -143,6 +212,12 @@ struct cds_maskset {
     uint32_t *d_px_pos = nullptr;
     uint4 *d_px_iv = nullptr;
     size_t n_px = 0;
+    // sparse scan (cds_sparse.hip): per mask a plan, slab images and interval tables
+    std::vector<cds::SparseMaskPlan> sp_plans;
+    uint8_t *d_sp_slabs = nullptr;
+    uint4 *d_sp_iv = nullptr;
+    uint32_t *d_sp_work = nullptr;   // work counters of one launch
+    mutable std::mutex sp_mu;        // one sparse search at a time per mask set (the work counters are shared)
     // cds_score_pair: one resident slot + device scores, created on first use
     mutable std::mutex pair_mu;
     mutable cds_library *pair_lib = nullptr;

@@ -1,0 +1,862 @@
+// cds_sparse.hip -- kernel 1 over a SPARSE resident library: the signal pixels of every target instead of its frame.
+//
+// What it computes: exactly what cds_scan.hip computes (reference: API/cds/PixelMatchColorDepthSearchAlgorithm.java:166-263,
+// predicate API/cds/AbstractColorDepthSearchAlgorithm.java:157-390) -- per (mask, target) and transform (9 xy-shifts x
+// {plain, mirrored}) the number of mask pixels whose transformed target pixel passes the data threshold and lies within
+// zTolerance in hue-ratio space; max over shifts; mirrored only if strictly greater.
+//
+// Why another layout.  A color-depth MIP is a few percent signal on black (the reference's LM fixtures: 0.3-9 %); a pixel
+// without a strict maximum channel (black, grey, two equal maxima) has no hue class and can never match anything.  The
+// dense scan streams 300 KB of mostly zeros per target to find the ~6 K pixels that matter; 1 M targets are 2 TB and do not
+// fit one GPU.  Here the library keeps, per image, its signal pixels only, as 4-byte records in row-major order
+// (x | hue class | second channel | max channel -- independent of every search parameter) plus one row-pointer array:
+// ~80 KB per synthetic target instead of 2.06 MB, so a 1 M-target library (80 GB) is RESIDENT in one MI355X's 288 GB.
+//
+// The scan turns around accordingly (target-centric instead of the reference's mask-centric gather):
+//   * the MASK lives in LDS: a u16 plane over its bounding box (index of the pixel's acceptance-interval record, 0 = no
+//     mask pixel), the table of distinct interval records, and a "near" bitmap = the plane dilated by the 9 xy-shifts.
+//     A mask taller than the LDS budget is cut into slabs of rows; per-transform counts of the slabs are summed at the end.
+//   * a WAVE streams one target's records (coalesced dword loads, the rows a slab can reach are one contiguous run thanks
+//     to the row pointers), 64 pixels per step: row from the row-start flags (ballot + mbcnt), threshold on the max
+//     channel, one bitmap probe per orientation "can any shift of this pixel land on a mask pixel?" -- the survivors
+//     (~13 %) go to a per-wave LDS queue;
+//   * queued pixels are evaluated 64 at a time with every lane busy: hue code = class << 29 | bits(second * v_rcp_f32(max)) >> 1
+//     (the same code the dense kernel computes, so the host's interval tables apply unchanged and the integer range test
+//     is bit-exact with the reference's double arithmetic, cds_host.hip), 9 plane lookups with immediate offsets, 9
+//     interval fetches, 2 compares each, matches counted by s_bcnt1 of the ballot into wave-uniform (SGPR) counters;
+//   * no barriers, no staging, no atomics on the data path: waves are independent, targets are drawn in small groups
+//     from a global counter (persistent grid, every workgroup visits every slab), ~25 KB of HBM traffic per target.
+//   * no MFMA: integer compare / count.
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+
+#include "cds_internal.hpp"
+
+namespace cds {
+
+constexpr int SP_QCAP = 128;                          // queue entries per wave and orientation (appends <= 64, drained at >= 64)
+constexpr int SP_QBYTES = 2 * (SP_QCAP * 4 + SP_QCAP * 2);  // two queues of (u32 record, u16 plane offset)
+constexpr int SP_MAX_IV_LDS = 2048;                   // interval records kept in LDS (32 KB); larger tables are read from L2
+constexpr int SP_MAX_SLABS = 256;
+constexpr int SP_PAD = 4;                             // zero rows / columns around a slab's plane (two shifts of 2)
+
+// =================================================================================================
+//                         dense resident slots  ->  sparse records
+// =================================================================================================
+struct BuildParams {
+    const uint8_t *rgb;  // first source slot
+    size_t img_stride;
+    int pitch, W, H;
+    int64_t count;       // images of this batch
+    int64_t dst_first;   // index of the batch's first image in the sparse library
+    uint32_t *px;
+    uint64_t *img_off;
+    uint32_t *rowptr;
+    uint32_t *tmp;       // [count] records per image
+    uint64_t *total;     // [1] records of the whole batch (read back by the host)
+};
+
+// hue class (AbstractColorDepthSearchAlgorithm.java:195-225; the nibble table of cds_scan.hip) and the two channels its
+// ratio is made of; 0 for a pixel without a strict maximum channel
+__device__ __forceinline__ uint32_t px_record(uint32_t r, uint32_t g, uint32_t b) {
+    const uint32_t mx = max(r, max(g, b)), mn = min(r, min(g, b)), md = r + g + b - mx - mn;
+    const uint32_t idx = (r > g ? 4u : 0u) | (g > b ? 8u : 0u) | (b > r ? 16u : 0u);
+    const uint32_t cls = (0x03125460u >> idx) & 7u;
+    return mx > md ? (cls << kRecClsShift) | (md << 8) | mx : 0u;
+}
+
+// One wave per image row.  FILL = false: records of the row (at least 1: the filler) -> rowptr[img][row + 1];
+// FILL = true: write them (x ascending) at img_off[img] + rowptr[img][row].
+template <bool FILL>
+__global__ __launch_bounds__(256) void sparse_rows_kernel(BuildParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= p.count * p.H) return;  // wave-uniform
+    const int64_t img = wid / p.H;
+    const int row = (int)(wid - img * p.H);
+    const uint8_t *rowp = p.rgb + (size_t)img * p.img_stride + (size_t)row * p.pitch;
+    uint32_t *rp = p.rowptr + (size_t)(p.dst_first + img) * (p.H + 1);
+    uint32_t *dst = nullptr;
+    if (FILL) dst = p.px + p.img_off[p.dst_first + img] + rp[row];
+    const int gpr = p.pitch / 12;  // 4-pixel groups per row (the padding columns are black)
+    int n = 0;
+    for (int g0 = 0; g0 < gpr; g0 += 64) {
+        const int g = g0 + lane;
+        uint32_t a = 0, b = 0, c = 0;
+        if (g < gpr) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(rowp + (size_t)g * 12);
+            a = q[0], b = q[1], c = q[2];
+        }
+        uint32_t rec[4];
+        rec[0] = px_record(a & 255, (a >> 8) & 255, (a >> 16) & 255);
+        rec[1] = px_record(a >> 24, b & 255, (b >> 8) & 255);
+        rec[2] = px_record((b >> 16) & 255, b >> 24, c & 255);
+        rec[3] = px_record((c >> 8) & 255, (c >> 16) & 255, c >> 24);
+        int below = 0, all = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long bal = __ballot(rec[j] != 0);
+            below += __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+            all += __popcll(bal);
+        }
+        if (FILL) {
+            int pos = n + below;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (rec[j]) {
+                    dst[pos] = rec[j] | ((uint32_t)(4 * g + j) << kRecXShift) | (pos == 0 ? kRecRowFlag : 0u);
+                    pos++;
+                }
+        }
+        n += all;
+    }
+    if (!FILL) {
+        if (lane == 0) rp[row + 1] = (uint32_t)(n > 0 ? n : 1);
+    } else if (n == 0 && lane == 0) {
+        dst[0] = kRecRowFlag;  // row filler
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+// One workgroup (256 threads) per image: rowptr[img][1..H] (record counts) -> exclusive offsets in place, total -> tmp[img].
+__global__ __launch_bounds__(256) void sparse_rowscan_kernel(BuildParams p) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *rp = p.rowptr + (size_t)(p.dst_first + blockIdx.x) * (p.H + 1);
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    // the counts sit one slot to the right of the offsets they turn into: read a tile, barrier, write it
+    for (int base = 0; base < p.H; base += 256) {
+        const int i = base + (int)threadIdx.x;
+        const uint32_t v = i < p.H ? rp[i + 1] : 0u;
+        const uint32_t inc = wave_incl_scan(v, lane);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (int w = 0; w < wave; w++) off += wsum[w];
+        const uint32_t excl = off + inc - v;
+        __syncthreads();  // every count of the tile has been read, carry_s and wsum have been consumed
+        if (i < p.H) rp[i] = excl;
+        if (threadIdx.x == 255) carry_s = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        rp[p.H] = carry_s;
+        p.tmp[blockIdx.x] = carry_s;
+    }
+}
+
+// One workgroup (1024 threads): img_off[dst_first + i + 1] = img_off[dst_first] + sum of tmp[0..i]; batch total -> *total.
+__global__ __launch_bounds__(1024) void sparse_imgscan_kernel(BuildParams p) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = p.img_off[p.dst_first];
+    __syncthreads();
+    const unsigned long long start = carry_s;
+    for (int64_t base = 0; base < p.count; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        unsigned long long v = i < p.count ? p.tmp[i] : 0ull;
+        const unsigned long long own = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long u = __shfl_up(v, o, 64);
+            if (lane >= o) v += u;
+        }
+        if (lane == 63) wsum[wave] = v;
+        __syncthreads();
+        unsigned long long off = carry_s;
+        for (int w = 0; w < wave; w++) off += wsum[w];
+        __syncthreads();
+        (void)own;
+        if (i < p.count) p.img_off[p.dst_first + i + 1] = off + v;
+        if (threadIdx.x == 1023) carry_s = off + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *p.total = carry_s - start;
+}
+
+// =================================================================================================
+//                                       the sparse scan
+// =================================================================================================
+template <bool XY2, bool MIRROR, bool IVLDS>
+__global__ __launch_bounds__(1024, 8) void sparse_scan_kernel(SparseScanParams p) {
+    extern __shared__ uint4 lds4[];
+    constexpr int NS = XY2 ? 9 : 1, NSX = XY2 ? 3 : 1, NO = MIRROR ? 2 : 1, NC = NS * NO;
+    constexpr int HALO = XY2 ? 2 : 0;
+    uint8_t *lds = reinterpret_cast<uint8_t *>(lds4);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint4 *ivt = lds4;
+    uint8_t *slab = lds + (IVLDS ? (size_t)p.n_iv * 16 : 0);
+    const uint16_t *plane = reinterpret_cast<const uint16_t *>(slab);
+    const uint32_t *nearb = reinterpret_cast<const uint32_t *>(slab + p.near_off);
+    uint8_t *qb = slab + p.slab_bytes + (size_t)wave * SP_QBYTES;
+    uint32_t *qrec0 = reinterpret_cast<uint32_t *>(qb), *qrec1 = qrec0 + SP_QCAP;
+    uint16_t *qoff0 = reinterpret_cast<uint16_t *>(qrec1 + SP_QCAP), *qoff1 = qoff0 + SP_QCAP;
+    if (IVLDS)
+        for (int i = threadIdx.x; i < p.n_iv; i += blockDim.x) ivt[i] = p.iv[i];
+    const int safe_off = SP_PAD * p.pitch + SP_PAD;  // an in-range plane offset for idle lanes
+
+    for (int si = 0; si < p.n_slabs; si++) {
+        const int s = (int)((blockIdx.x + (unsigned)si) % (unsigned)p.n_slabs);  // every workgroup visits every slab
+        __syncthreads();  // the previous slab's waves are done with the LDS image
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.slabs + (size_t)s * p.slab_bytes);
+            uint4 *dst = reinterpret_cast<uint4 *>(slab);
+            for (int i = threadIdx.x; i < p.slab_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        }
+        __syncthreads();
+        const int ys0 = p.ylo + s * p.slab_rows;  // first mask row of the slab
+        const int rows_s = min(p.slab_rows, p.nrows - s * p.slab_rows);
+        const int ra = max(ys0 - HALO, 0), rb = min(ys0 + rows_s + HALO, p.H);  // target rows [ra, rb)
+        const int ry0 = ys0 - 2, cx0 = p.xlo - 2, cm0 = p.W - 1 - cx0;
+        const unsigned wnear = (unsigned)(p.cols + 4);
+
+        for (;;) {
+            uint32_t tb = 0;
+            if (lane == 0) tb = atomicAdd(&p.work[s], (uint32_t)p.group);
+            tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
+            if ((int64_t)tb >= p.count) break;
+            const int64_t te = min((int64_t)tb + p.group, p.count);
+            for (int64_t t = tb; t < te; t++) {
+                const int64_t ti = p.first + t;
+                const uint32_t *P = p.px + p.img_off[ti];
+                const uint32_t *rp = p.rowptr + (size_t)ti * (p.H + 1);
+                const uint32_t a = rp[ra], b = rp[rb];
+                int c[NC];
+#pragma unroll
+                for (int k = 0; k < NC; k++) c[k] = 0;
+                int qh0 = 0, qt0 = 0, qh1 = 0, qt1 = 0;  // queue heads / tails (monotonic, wave-uniform)
+
+                // evaluate up to 64 queued pixels of one orientation: every lane busy
+                auto round = [&](const uint32_t *qrec, const uint16_t *qoff, int &qh, const int qt, int *cc) {
+                    const int n = min(qt - qh, 64);
+                    __builtin_amdgcn_wave_barrier();
+                    const int e = (qh + lane) & (SP_QCAP - 1);
+                    const bool valid = lane < n;
+                    const uint32_t r = qrec[e];
+                    const int off = valid ? (int)qoff[e] : safe_off;
+                    const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
+                    uint32_t code = (((r >> kRecClsShift) & 7u) << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
+                    code = valid ? code : 0u;  // 0 lies in no interval
+                    const uint16_t *c0 = plane + off;
+#pragma unroll
+                    for (int iy = 0; iy < NSX; iy++) {
+                        const uint16_t *rowp = XY2 ? c0 + (1 - iy) * 2 * p.pitch : c0;  // mask row = target row - dy
+                        uint32_t idx[NSX];
+#pragma unroll
+                        for (int ix = 0; ix < NSX; ix++) idx[ix] = rowp[XY2 ? (1 - ix) * 2 : 0];  // mask column = target column - dx
+#pragma unroll
+                        for (int ix = 0; ix < NSX; ix++) {
+                            const uint4 iv = IVLDS ? ivt[idx[ix]] : p.iv[idx[ix]];
+                            const bool m = ((code - iv.x) <= iv.y) | ((code - iv.z) <= iv.w);
+                            cc[ix * NSX + iy] += __popcll(__ballot(m));
+                        }
+                    }
+                    qh += n;
+                };
+                auto append = [&](uint32_t *qrec, uint16_t *qoff, int &qt, const bool hit, const uint32_t r, const int off) {
+                    const unsigned long long hb = __ballot(hit);
+                    if (hb) {  // wave-uniform
+                        const int slot = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0))) & (SP_QCAP - 1);
+                        if (hit) {
+                            qrec[slot] = r;
+                            qoff[slot] = (uint16_t)off;
+                        }
+                        qt += __popcll(hb);
+                    }
+                };
+
+                int yrun = ra - 1;  // rows started before the current block, minus one
+                uint32_t rec = (a + (uint32_t)lane < b) ? P[a + lane] : 0u;
+                for (uint32_t i = a; i < b; i += 64) {  // wave-uniform
+                    const uint32_t inext = i + 64 + (uint32_t)lane;
+                    const uint32_t nxt = inext < b ? P[inext] : 0u;  // in flight during this block
+                    const uint32_t fl = rec >> 31;
+                    const unsigned long long fb = __ballot(fl != 0);
+                    const int y = yrun + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0)) + (int)fl;
+                    yrun += __popcll(fb);
+                    const int d = (int)(rec & 255u), x = (int)((rec >> kRecXShift) & 2047u);
+                    const bool pass = d > p.thr;
+                    const int ry = y - ry0;  // row of the near bitmap; the plane row is ry + 2
+                    {
+                        const int cx = x - cx0;
+                        const bool inw = (unsigned)cx < wnear;
+                        const int cc = inw ? cx : 0;
+                        const uint32_t w = nearb[ry * p.nwpr + (cc >> 5)];
+                        const bool hit = pass && inw && ((w >> (cc & 31)) & 1u);
+                        append(qrec0, qoff0, qt0, hit, rec, (ry + 2) * p.pitch + cx + 2);
+                        if (qt0 - qh0 >= 64) round(qrec0, qoff0, qh0, qt0, c);
+                    }
+                    if (MIRROR) {
+                        const int cx = cm0 - x;  // the mask column a mirrored probe of this pixel lands on, bitmap-relative
+                        const bool inw = (unsigned)cx < wnear;
+                        const int cc = inw ? cx : 0;
+                        const uint32_t w = nearb[ry * p.nwpr + (cc >> 5)];
+                        const bool hit = pass && inw && ((w >> (cc & 31)) & 1u);
+                        append(qrec1, qoff1, qt1, hit, rec, (ry + 2) * p.pitch + cx + 2);
+                        if (qt1 - qh1 >= 64) round(qrec1, qoff1, qh1, qt1, c + NS);
+                    }
+                    rec = nxt;
+                }
+                while (qt0 > qh0) round(qrec0, qoff0, qh0, qt0, c);
+                if (MIRROR)
+                    while (qt1 > qh1) round(qrec1, qoff1, qh1, qt1, c + NS);
+
+                if (p.partial) {  // per-transform counts of this slab: lane k holds transform k (the 18-entry layout of the ABI)
+                    int v = 0;
+#pragma unroll
+                    for (int k = 0; k < NS; k++) {
+                        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[k])), "n"(k));
+                        if (MIRROR) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[NS + k])), "n"(9 + k));
+                    }
+                    if (lane < CDS_N_TRANSFORMS) p.partial[((size_t)s * p.count + t) * CDS_N_TRANSFORMS + lane] = v;
+                } else {
+                    int best = 0, bm = 0;
+#pragma unroll
+                    for (int k = 0; k < NS; k++) best = max(best, c[k]);
+                    if (MIRROR) {
+#pragma unroll
+                        for (int k = 0; k < NS; k++) bm = max(bm, c[NS + k]);
+                    }
+                    int32_t packed = best;
+                    if (MIRROR && bm > best) packed = (int32_t)((uint32_t)bm | 0x80000000u);
+                    if (lane == 0) p.out[t] = packed;
+                }
+            }
+        }
+    }
+}
+
+// sum of the slabs' per-transform counts -> score | mirrored << 31 (and, optionally, the 18 counts)
+__global__ __launch_bounds__(256) void sparse_finalize_kernel(const int32_t *partial, int n_slabs, int64_t count, int32_t *out,
+                                                              int32_t *counts) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    int best = 0, bm = 0;
+    for (int k = 0; k < CDS_N_TRANSFORMS; k++) {
+        int v = 0;
+        for (int s = 0; s < n_slabs; s++) v += partial[((size_t)s * count + t) * CDS_N_TRANSFORMS + k];
+        if (counts) counts[(size_t)t * CDS_N_TRANSFORMS + k] = v;
+        if (k < 9) best = v > best ? v : best;
+        else bm = v > bm ? v : bm;
+    }
+    out[t] = bm > best ? (int32_t)((uint32_t)bm | 0x80000000u) : best;
+}
+
+// =================================================================================================
+//                                   host: mask plans
+// =================================================================================================
+static size_t slab_image_bytes(int R, int pitch, int nwpr, int *near_off) {
+    const size_t plane = (size_t)round_up((R + 2 * SP_PAD) * pitch * 2, 16);
+    if (near_off) *near_off = (int)plane;
+    return plane + (size_t)round_up((R + 4) * nwpr * 4, 16);
+}
+
+void free_sparse_plans(cds_maskset *ms) {
+    if (ms->d_sp_slabs) hipFree(ms->d_sp_slabs);
+    if (ms->d_sp_iv) hipFree(ms->d_sp_iv);
+    if (ms->d_sp_work) hipFree(ms->d_sp_work);
+    ms->d_sp_slabs = nullptr;
+    ms->d_sp_iv = nullptr;
+    ms->d_sp_work = nullptr;
+    ms->sp_plans.clear();
+}
+
+static int sparse_threads() {
+    int t = 1024;
+    if (const char *e = getenv("CDS_SPARSE_THREADS")) t = atoi(e);
+    t = std::max(64, std::min(1024, t)) / 64 * 64;
+    return t;
+}
+
+int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &per_mask) {
+    cds_context *ctx = ms->ctx;
+    const bool xy2 = ms->params.xy_shift == 2;
+    const int threads = sparse_threads();
+    size_t budget = (size_t)80 << 10;  // two workgroups of 1024 threads per CU
+    if (const char *e = getenv("CDS_SPARSE_LDS_KB")) budget = (size_t)std::max(8, atoi(e)) << 10;
+    budget = std::min(budget, ctx->lds_per_block);
+    const size_t n_masks = per_mask.size();
+    ms->sp_plans.assign(n_masks, SparseMaskPlan());
+    std::vector<std::vector<uint8_t>> slab_of(n_masks);
+    std::vector<std::vector<uint4>> iv_of(n_masks);
+    struct Key {
+        uint32_t a, b, c, d;
+        bool operator==(const Key &o) const { return a == o.a && b == o.b && c == o.c && d == o.d; }
+    };
+    struct KeyHash {
+        size_t operator()(const Key &k) const {
+            uint64_t h = (uint64_t)k.a * 0x9E3779B97F4A7C15ull ^ ((uint64_t)k.b << 32 | k.c) * 0xC2B2AE3D27D4EB4Full ^ k.d;
+            return (size_t)(h ^ (h >> 29));
+        }
+    };
+    auto plan_one = [&](size_t m) {
+        const std::vector<MaskPx> &L = per_mask[m];
+        SparseMaskPlan &pl = ms->sp_plans[m];
+        if (L.empty()) return;  // n_slabs == 0: nothing can match
+        int xlo = ms->W, xhi = -1, ylo = ms->H, yhi = -1;
+        for (const MaskPx &q : L) {
+            xlo = std::min(xlo, q.x), xhi = std::max(xhi, q.x);
+            ylo = std::min(ylo, q.y), yhi = std::max(yhi, q.y);
+        }
+        pl.xlo = xlo, pl.cols = xhi - xlo + 1, pl.ylo = ylo, pl.nrows = yhi - ylo + 1;
+        pl.pitch = round_up(pl.cols + 2 * SP_PAD, 8);
+        pl.nwpr = (pl.cols + 4 + 31) / 32;
+        // distinct interval records of this mask; index 0 = the empty record
+        std::unordered_map<Key, uint32_t, KeyHash> dict;
+        std::vector<uint4> &tab = iv_of[m];
+        tab.push_back(make_uint4(1u, 0u, 1u, 0u));
+        std::vector<uint16_t> pidx(L.size());
+        for (size_t i = 0; i < L.size(); i++) {
+            const Key k{L[i].lo1, L[i].len1, L[i].lo2, L[i].len2};
+            auto it = dict.find(k);
+            if (it == dict.end()) {
+                if (tab.size() >= 65535) {
+                    pl.n_slabs = -1;  // (a mask with more than 65,534 distinct interval records: use the dense scan)
+                    tab.clear();
+                    return;
+                }
+                it = dict.emplace(k, (uint32_t)tab.size()).first;
+                tab.push_back(make_uint4(k.a, k.b, k.c, k.d));
+            }
+            pidx[i] = (uint16_t)it->second;
+        }
+        pl.n_iv = (int)tab.size();
+        pl.iv_in_lds = pl.n_iv <= SP_MAX_IV_LDS;
+        const size_t fixed = (pl.iv_in_lds ? (size_t)pl.n_iv * 16 : 0) + (size_t)(threads / 64) * SP_QBYTES;
+        auto fits = [&](int R, size_t bud) {
+            return fixed + slab_image_bytes(R, pl.pitch, pl.nwpr, nullptr) <= bud && (R + 2 * SP_PAD) * pl.pitch <= 65535;
+        };
+        size_t bud = budget;
+        if (!fits(1, bud)) bud = ctx->lds_per_block;
+        if (!fits(1, bud)) {
+            pl.n_slabs = -1;
+            tab.clear();
+            return;
+        }
+        int R = 1;
+        while (R < pl.nrows && fits(R + 1, bud)) R++;
+        pl.n_slabs = (pl.nrows + R - 1) / R;
+        if (pl.n_slabs > SP_MAX_SLABS) {
+            pl.n_slabs = -1;
+            tab.clear();
+            return;
+        }
+        R = (pl.nrows + pl.n_slabs - 1) / pl.n_slabs;
+        pl.slab_rows = R;
+        pl.slab_bytes = (int)slab_image_bytes(R, pl.pitch, pl.nwpr, &pl.near_off);
+        pl.lds_bytes = fixed + (size_t)pl.slab_bytes;
+        std::vector<uint8_t> &slabs = slab_of[m];
+        slabs.assign((size_t)pl.n_slabs * pl.slab_bytes, 0);
+        const int prow_n = R + 2 * SP_PAD;
+        for (int s = 0; s < pl.n_slabs; s++) {
+            uint8_t *img = slabs.data() + (size_t)s * pl.slab_bytes;
+            uint16_t *plane = reinterpret_cast<uint16_t *>(img);
+            uint32_t *nearb = reinterpret_cast<uint32_t *>(img + pl.near_off);
+            const int ys0 = ylo + s * R;
+            for (size_t i = 0; i < L.size(); i++) {
+                const int rr = L[i].y - ys0;
+                if (rr < 0 || rr >= R) continue;
+                plane[(size_t)(rr + SP_PAD) * pl.pitch + (L[i].x - xlo) + SP_PAD] = pidx[i];
+                // the target pixels that reach this mask pixel under some shift: (x + dx, y + dy)
+                for (int dy = xy2 ? -2 : 0; dy <= (xy2 ? 2 : 0); dy += 2)
+                    for (int dx = xy2 ? -2 : 0; dx <= (xy2 ? 2 : 0); dx += 2) {
+                        const int ry = rr + 2 + dy, cx = (L[i].x - xlo) + 2 + dx;  // bitmap origin = (xlo - 2, ys0 - 2)
+                        nearb[(size_t)ry * pl.nwpr + (cx >> 5)] |= 1u << (cx & 31);
+                    }
+            }
+            (void)prow_n;
+        }
+    };
+    {
+        const unsigned hc = std::thread::hardware_concurrency();
+        const int n_threads = std::max(1, std::min<int>((int)n_masks, (int)std::min<unsigned>(hc ? hc : 1u, 16u)));
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t m = next.fetch_add(1); m < n_masks; m = next.fetch_add(1)) plan_one(m);
+        };
+        std::vector<std::thread> pool;
+        for (int i = 1; i < n_threads; i++) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+    }
+    size_t slab_total = 0, iv_total = 0;
+    for (size_t m = 0; m < n_masks; m++) {
+        ms->sp_plans[m].slabs_off = slab_total;
+        ms->sp_plans[m].iv_off = iv_total;
+        slab_total += slab_of[m].size();
+        iv_total += iv_of[m].size();
+    }
+    hipSetDevice(ctx->device);
+    hipError_t e = hipSuccess;
+    if (slab_total > 0) {
+        e = hipMalloc(&ms->d_sp_slabs, slab_total);
+        if (e == hipSuccess) e = hipMalloc(&ms->d_sp_iv, iv_total * sizeof(uint4));
+        if (e == hipSuccess) e = hipMalloc(&ms->d_sp_work, SP_MAX_SLABS * sizeof(uint32_t));
+        for (size_t m = 0; m < n_masks && e == hipSuccess; m++) {
+            if (slab_of[m].empty()) continue;
+            e = hipMemcpy(ms->d_sp_slabs + ms->sp_plans[m].slabs_off, slab_of[m].data(), slab_of[m].size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess)
+                e = hipMemcpy(ms->d_sp_iv + ms->sp_plans[m].iv_off, iv_of[m].data(), iv_of[m].size() * sizeof(uint4), hipMemcpyHostToDevice);
+        }
+    }
+    if (e != hipSuccess) {
+        free_sparse_plans(ms);
+        return hip_fail(e, "sparse mask plans");
+    }
+    return CDS_OK;
+}
+
+template <bool XY2, bool MIRROR>
+static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t lds_bytes, int threads, hipStream_t st) {
+    auto kern = p.iv_in_lds ? sparse_scan_kernel<XY2, MIRROR, true> : sparse_scan_kernel<XY2, MIRROR, false>;
+    CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    // persistent grid: as many workgroups as fit (LDS and the 2048 threads of a CU), every one visits every slab
+    int per_cu = (int)std::min<size_t>((size_t)(2048 / threads), ctx->lds_per_block / std::max<size_t>(lds_bytes, 1));
+    per_cu = std::max(1, per_cu);
+    if (const char *e = getenv("CDS_SPARSE_WGS_PER_CU")) per_cu = std::max(1, atoi(e));
+    const int64_t waves = threads / 64;
+    const int64_t need = (p.count * p.n_slabs + (int64_t)p.group * waves - 1) / ((int64_t)p.group * waves);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cus * per_cu, need));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, st, p);
+    CDS_HIP(hipGetLastError());
+    return CDS_OK;
+}
+
+static int launch_sparse(cds_context *ctx, const SparseScanParams &p, size_t lds_bytes, int threads, bool xy2, bool mirror,
+                         hipStream_t st) {
+    if (xy2) return mirror ? launch_sparse_one<true, true>(ctx, p, lds_bytes, threads, st) : launch_sparse_one<true, false>(ctx, p, lds_bytes, threads, st);
+    return mirror ? launch_sparse_one<false, true>(ctx, p, lds_bytes, threads, st) : launch_sparse_one<false, false>(ctx, p, lds_bytes, threads, st);
+}
+
+static int sparse_check_range(const cds_sparse_library *sl, int64_t first, int64_t count) {
+    if (!sl) return fail(CDS_ERR_INVALID_ARGUMENT, "sparse library is NULL");
+    if (first < 0 || count < 0 || first + count > sl->n_images) return fail(CDS_ERR_INVALID_ARGUMENT, "image range outside the sparse library");
+    return CDS_OK;
+}
+
+// d_scores[m * count + t]; d_counts optional [m][t][18]
+static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, int32_t *d_scores,
+                              int32_t *d_counts, bool timed) {
+    if (!ms || !sl) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    int rc = sparse_check_range(sl, first, count);
+    if (rc) return rc;
+    if (sl->W != ms->W || sl->H != ms->H) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "Invalid image size - target's image size (%d, %d) must match query's image size: (%d, %d)",
+                 ms->W, ms->H, sl->W, sl->H);  // PixelMatchColorDepthSearchAlgorithm.java:171-175
+        return fail(CDS_ERR_INVALID_ARGUMENT, buf);
+    }
+    if (sl->ctx != ms->ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "mask set and library belong to different contexts");
+    if (count == 0) return CDS_OK;
+    if (count >= ((int64_t)1 << 31)) return fail(CDS_ERR_UNSUPPORTED, "more than 2^31 targets in one call");
+    for (const SparseMaskPlan &pl : ms->sp_plans)
+        if (pl.n_slabs < 0) return fail(CDS_ERR_UNSUPPORTED, "a mask of this set cannot be laid out for the sparse scan (use the dense library)");
+    cds_context *ctx = ms->ctx;
+    CDS_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::lock_guard<std::mutex> lk(ms->sp_mu);
+    const int threads = sparse_threads();
+    int group = count >= 65536 ? 4 : (count >= 4096 ? 2 : 1);
+    if (const char *e = getenv("CDS_SPARSE_GROUP")) group = std::max(1, atoi(e));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int32_t *partial = nullptr;
+    auto cleanup = [&]() {
+        if (ev0) hipEventDestroy(ev0);
+        if (ev1) hipEventDestroy(ev1);
+        if (partial) hipFreeAsync(partial, st);
+        ev0 = ev1 = nullptr;
+        partial = nullptr;
+    };
+#define SP_HIP(call)                         \
+    do {                                     \
+        hipError_t _e = (call);              \
+        if (_e != hipSuccess) {              \
+            cleanup();                       \
+            return cds::hip_fail(_e, #call); \
+        }                                    \
+    } while (0)
+    int max_slabs = 0;
+    for (const SparseMaskPlan &pl : ms->sp_plans) max_slabs = std::max(max_slabs, pl.n_slabs);
+    const bool want_partial = d_counts != nullptr || max_slabs > 1;
+    if (want_partial) SP_HIP(hipMallocAsync((void **)&partial, (size_t)std::max(1, max_slabs) * count * CDS_N_TRANSFORMS * sizeof(int32_t), st));
+    if (timed) {
+        SP_HIP(hipEventCreate(&ev0));
+        SP_HIP(hipEventCreate(&ev1));
+        SP_HIP(hipEventRecord(ev0, st));
+    }
+    int launches = 0;
+    for (int m = 0; m < ms->n_masks; m++) {
+        const SparseMaskPlan &pl = ms->sp_plans[(size_t)m];
+        int32_t *out = d_scores + (size_t)m * count;
+        int32_t *cnt = d_counts ? d_counts + (size_t)m * count * CDS_N_TRANSFORMS : nullptr;
+        if (pl.n_slabs == 0) {  // no mask pixel can ever match
+            SP_HIP(hipMemsetAsync(out, 0, (size_t)count * sizeof(int32_t), st));
+            if (cnt) SP_HIP(hipMemsetAsync(cnt, 0, (size_t)count * CDS_N_TRANSFORMS * sizeof(int32_t), st));
+            continue;
+        }
+        SparseScanParams p{};
+        p.px = sl->d_px; p.img_off = sl->d_img_off; p.rowptr = sl->d_rowptr;
+        p.first = first; p.count = count; p.W = sl->W; p.H = sl->H;
+        p.slabs = ms->d_sp_slabs + pl.slabs_off;
+        p.iv = ms->d_sp_iv + pl.iv_off;
+        p.n_iv = pl.n_iv; p.iv_in_lds = pl.iv_in_lds ? 1 : 0;
+        p.xlo = pl.xlo; p.cols = pl.cols; p.ylo = pl.ylo; p.nrows = pl.nrows; p.pitch = pl.pitch; p.nwpr = pl.nwpr;
+        p.slab_rows = pl.slab_rows; p.n_slabs = pl.n_slabs; p.near_off = pl.near_off; p.slab_bytes = pl.slab_bytes;
+        p.thr = std::max(0, ms->params.data_threshold);  // a pixel whose maximum is 0 is black and has no hue class anyway
+        p.group = group;
+        p.work = ms->d_sp_work;
+        p.out = out;
+        const bool use_partial = cnt != nullptr || pl.n_slabs > 1;
+        p.partial = use_partial ? partial : nullptr;
+        SP_HIP(hipMemsetAsync(ms->d_sp_work, 0, (size_t)pl.n_slabs * sizeof(uint32_t), st));
+        rc = launch_sparse(ctx, p, pl.lds_bytes, threads, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
+        if (use_partial) {
+            hipLaunchKernelGGL(sparse_finalize_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, partial, pl.n_slabs, count, out, cnt);
+            SP_HIP(hipGetLastError());
+        }
+        launches++;
+    }
+    if (timed) {
+        SP_HIP(hipEventRecord(ev1, st));
+        SP_HIP(hipEventSynchronize(ev1));
+        float t = 0;
+        SP_HIP(hipEventElapsedTime(&t, ev0, ev1));
+        std::lock_guard<std::mutex> lk2(ms->mu);
+        ms->last_ms = launches ? t / launches : 0;
+        ms->last_launches = launches;
+    }
+    cleanup();
+#undef SP_HIP
+    return CDS_OK;
+}
+
+}  // namespace cds
+
+using namespace cds;
+
+// =================================================================================================
+//                                            C ABI
+// =================================================================================================
+extern "C" {
+
+int cds_sparse_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t capacity_images, int64_t capacity_pixels,
+                              cds_sparse_library **out) {
+    if (!ctx || !out) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    if (W < 8 || H < 1 || W > kMaxW || H > kMaxH) return fail(CDS_ERR_UNSUPPORTED, "image size outside 8..2000 x 1..1000");
+    if (capacity_images <= 0 || capacity_pixels <= 0) return fail(CDS_ERR_INVALID_ARGUMENT, "capacities must be positive");
+    CDS_HIP(hipSetDevice(ctx->device));
+    cds_sparse_library *sl = new cds_sparse_library();
+    sl->ctx = ctx; sl->W = W; sl->H = H; sl->cap_images = capacity_images; sl->cap_px = capacity_pixels;
+    hipError_t e = hipMalloc(&sl->d_px, (size_t)capacity_pixels * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&sl->d_img_off, (size_t)(capacity_images + 1) * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(&sl->d_rowptr, (size_t)capacity_images * (H + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(sl->d_img_off, 0, sizeof(uint64_t), ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        if (sl->d_px) hipFree(sl->d_px);
+        if (sl->d_img_off) hipFree(sl->d_img_off);
+        if (sl->d_rowptr) hipFree(sl->d_rowptr);
+        delete sl;
+        return hip_fail(e, "hipMalloc(sparse library)");
+    }
+    *out = sl;
+    return CDS_OK;
+}
+
+void cds_sparse_library_destroy(cds_sparse_library *sl) {
+    if (!sl) return;
+    hipSetDevice(sl->ctx->device);
+    hipStreamSynchronize(sl->ctx->stream);
+    if (sl->stage) cds_library_destroy(sl->stage);
+    if (sl->d_px) hipFree(sl->d_px);
+    if (sl->d_img_off) hipFree(sl->d_img_off);
+    if (sl->d_rowptr) hipFree(sl->d_rowptr);
+    if (sl->d_tmp) hipFree(sl->d_tmp);
+    delete sl;
+}
+
+int64_t cds_sparse_library_size(const cds_sparse_library *sl) { return sl ? sl->n_images : 0; }
+int64_t cds_sparse_library_pixels(const cds_sparse_library *sl) { return sl ? sl->n_px : 0; }
+
+int cds_sparse_library_clear(cds_sparse_library *sl) {
+    if (!sl) return fail(CDS_ERR_INVALID_ARGUMENT, "sparse library is NULL");
+    std::lock_guard<std::mutex> lk(sl->mu);
+    sl->n_images = 0;
+    sl->n_px = 0;
+    return CDS_OK;
+}
+
+static int sparse_append_locked(cds_sparse_library *sl, const cds_library *src, int64_t first, int64_t count) {
+    cds_context *ctx = sl->ctx;
+    hipStream_t st = ctx->stream;
+    // one launch covers at most 2^32 / 64 image rows (one wave each)
+    const int64_t max_batch = std::max<int64_t>(1, (int64_t)(0xffffffffu / 256u) * 4 / sl->H);
+    if (sl->tmp_images < std::min(count, max_batch)) {
+        if (sl->d_tmp) hipFree(sl->d_tmp);
+        sl->d_tmp = nullptr;
+        sl->tmp_images = 0;
+        const int64_t n = std::min(count, max_batch);
+        CDS_HIP(hipMalloc(&sl->d_tmp, (size_t)n * sizeof(uint32_t) + sizeof(uint64_t)));
+        sl->tmp_images = n;
+    }
+    for (int64_t done = 0; done < count;) {
+        const int64_t n = std::min(max_batch, count - done);
+        BuildParams p{};
+        p.rgb = src->d_rgb + (size_t)(first + done) * src->img_stride;
+        p.img_stride = src->img_stride; p.pitch = src->pitch; p.W = src->W; p.H = src->H;
+        p.count = n; p.dst_first = sl->n_images;
+        p.px = sl->d_px; p.img_off = sl->d_img_off; p.rowptr = sl->d_rowptr;
+        p.tmp = sl->d_tmp;
+        p.total = reinterpret_cast<uint64_t *>(sl->d_tmp + sl->tmp_images);
+        const unsigned row_blocks = (unsigned)((n * sl->H + 3) / 4);
+        hipLaunchKernelGGL(sparse_rows_kernel<false>, dim3(row_blocks), dim3(256), 0, st, p);
+        CDS_HIP(hipGetLastError());
+        hipLaunchKernelGGL(sparse_rowscan_kernel, dim3((unsigned)n), dim3(256), 0, st, p);
+        CDS_HIP(hipGetLastError());
+        hipLaunchKernelGGL(sparse_imgscan_kernel, dim3(1), dim3(1024), 0, st, p);
+        CDS_HIP(hipGetLastError());
+        uint64_t total = 0;
+        CDS_HIP(hipMemcpyAsync(&total, p.total, sizeof total, hipMemcpyDeviceToHost, st));
+        CDS_HIP(hipStreamSynchronize(st));
+        if (sl->n_px + (int64_t)total > sl->cap_px) {
+            char buf[200];
+            snprintf(buf, sizeof buf, "sparse library is full: %lld records held, %lld more needed, capacity %lld", (long long)sl->n_px,
+                     (long long)total, (long long)sl->cap_px);
+            return fail(CDS_ERR_OUT_OF_MEMORY, buf);
+        }
+        hipLaunchKernelGGL(sparse_rows_kernel<true>, dim3(row_blocks), dim3(256), 0, st, p);
+        CDS_HIP(hipGetLastError());
+        sl->n_images += n;
+        sl->n_px += (int64_t)total;
+        done += n;
+    }
+    CDS_HIP(hipStreamSynchronize(st));
+    return CDS_OK;
+}
+
+int cds_sparse_library_append(cds_sparse_library *sl, const cds_library *src, int64_t first, int64_t count) {
+    if (!sl || !src) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (first < 0 || count < 0 || first + count > src->capacity) return fail(CDS_ERR_INVALID_ARGUMENT, "slot range outside the source library");
+    if (src->W != sl->W || src->H != sl->H) return fail(CDS_ERR_INVALID_ARGUMENT, "image size of the source library differs");
+    if (src->ctx != sl->ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "libraries belong to different contexts");
+    if (count == 0) return CDS_OK;
+    std::lock_guard<std::mutex> lk(sl->mu);
+    if (sl->n_images + count > sl->cap_images) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (images)");
+    CDS_HIP(hipSetDevice(sl->ctx->device));
+    return sparse_append_locked(sl, src, first, count);
+}
+
+int cds_sparse_library_append_host(cds_sparse_library *sl, int64_t count, const uint8_t *rgb) {
+    if (!sl) return fail(CDS_ERR_INVALID_ARGUMENT, "sparse library is NULL");
+    if (count < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "count is negative");
+    if (count == 0) return CDS_OK;
+    if (!rgb) return fail(CDS_ERR_INVALID_ARGUMENT, "rgb is NULL");
+    std::lock_guard<std::mutex> lk(sl->mu);
+    if (sl->n_images + count > sl->cap_images) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (images)");
+    CDS_HIP(hipSetDevice(sl->ctx->device));
+    const int64_t stage_n = 64;  // dense staging slots (132 MB at 1210 x 566)
+    if (!sl->stage) {
+        int rc = cds_library_create(sl->ctx, sl->W, sl->H, stage_n, &sl->stage);
+        if (rc) return rc;
+    }
+    const size_t img_bytes = (size_t)3 * sl->W * sl->H;
+    for (int64_t done = 0; done < count; done += stage_n) {
+        const int64_t n = std::min(stage_n, count - done);
+        int rc = cds_library_upload(sl->stage, 0, n, rgb + (size_t)done * img_bytes);
+        if (rc) return rc;
+        rc = sparse_append_locked(sl, sl->stage, 0, n);
+        if (rc) return rc;
+    }
+    return CDS_OK;
+}
+
+int cds_sparse_library_image_records(const cds_sparse_library *sl, int64_t index, uint32_t *records, int64_t capacity,
+                                     int64_t *n_records, uint32_t *row_offsets) {
+    if (!sl || !n_records) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (index < 0 || index >= sl->n_images) return fail(CDS_ERR_INVALID_ARGUMENT, "image index outside the sparse library");
+    CDS_HIP(hipSetDevice(sl->ctx->device));
+    uint64_t off[2];
+    CDS_HIP(hipMemcpy(off, sl->d_img_off + index, sizeof off, hipMemcpyDeviceToHost));
+    const int64_t n = (int64_t)(off[1] - off[0]);
+    *n_records = n;
+    if (records) {
+        if (capacity < n) return fail(CDS_ERR_INVALID_ARGUMENT, "record buffer too small");
+        CDS_HIP(hipMemcpy(records, sl->d_px + off[0], (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    if (row_offsets) CDS_HIP(hipMemcpy(row_offsets, sl->d_rowptr + (size_t)index * (sl->H + 1), (size_t)(sl->H + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CDS_OK;
+}
+
+int cds_search_sparse_device(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, int32_t *d_scores) {
+    if (!d_scores && count > 0) return fail(CDS_ERR_INVALID_ARGUMENT, "d_scores is NULL");
+    return sparse_search_impl(ms, sl, first, count, d_scores, nullptr, getenv("CDS_TIME_KERNELS") != nullptr);
+}
+
+static int sparse_search_host(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, int32_t *scores,
+                              uint8_t *mirrored, int32_t *counts) {
+    if (!ms || !sl) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    int rc = sparse_check_range(sl, first, count);
+    if (rc) return rc;
+    if (count == 0) return CDS_OK;
+    CDS_HIP(hipSetDevice(ms->ctx->device));
+    const size_t n = (size_t)ms->n_masks * count;
+    int32_t *d_scores = nullptr, *d_counts = nullptr;
+    CDS_HIP(hipMalloc(&d_scores, n * sizeof(int32_t)));
+    if (counts) {
+        hipError_t e = hipMalloc(&d_counts, n * CDS_N_TRANSFORMS * sizeof(int32_t));
+        if (e != hipSuccess) {
+            hipFree(d_scores);
+            return hip_fail(e, "hipMalloc(counts)");
+        }
+    }
+    rc = sparse_search_impl(ms, sl, first, count, d_scores, d_counts, true);
+    if (rc == CDS_OK) {
+        std::vector<int32_t> packed(n);
+        hipError_t e = hipMemcpyAsync(packed.data(), d_scores, n * sizeof(int32_t), hipMemcpyDeviceToHost, ms->ctx->stream);
+        if (e == hipSuccess && counts)
+            e = hipMemcpyAsync(counts, d_counts, n * CDS_N_TRANSFORMS * sizeof(int32_t), hipMemcpyDeviceToHost, ms->ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ms->ctx->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "copy scores");
+        else
+            for (size_t i = 0; i < n; i++) {
+                if (scores) scores[i] = packed[i] & 0x7fffffff;
+                if (mirrored) mirrored[i] = (uint8_t)((uint32_t)packed[i] >> 31);
+            }
+    }
+    hipFree(d_scores);
+    if (d_counts) hipFree(d_counts);
+    return rc;
+}
+
+int cds_search_sparse(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, int32_t *scores,
+                      uint8_t *mirrored) {
+    return sparse_search_host(ms, sl, first, count, scores, mirrored, nullptr);
+}
+
+int cds_search_sparse_counts(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, int32_t *counts) {
+    if (!counts && count > 0) return fail(CDS_ERR_INVALID_ARGUMENT, "counts is NULL");
+    return sparse_search_host(ms, sl, first, count, nullptr, nullptr, counts);
+}
+
+}  // extern "C"

@@ -42,6 +42,7 @@ extern "C" {
 
 typedef struct cds_context cds_context;   /* one GPU: device, default stream, tables          */
 typedef struct cds_library cds_library;   /* a resident shard of target MIPs (+ variants)      */
+typedef struct cds_sparse_library cds_sparse_library; /* a resident shard of targets kept as signal-pixel lists */
 typedef struct cds_maskset cds_maskset;   /* n prepared PixelMatchColorDepthSearchAlgorithm    */
 typedef struct cds_shapeset cds_shapeset; /* n prepared Shape2DMatchColorDepthSearchAlgorithm  */
 
@@ -131,6 +132,40 @@ int cds_score_pair(const cds_maskset *ms, int32_t mask_index, const uint8_t *tar
  * ColorMIPSearch.isMatch (API/cds/ColorMIPSearch.java:42-45). Pure host arithmetic. */
 float cds_pixel_match_normalized(int32_t score, int32_t query_size);
 int cds_is_match(int32_t score, int32_t query_size, double pct_positive_pixels);
+
+/* ---- sparse target library (pixel-match scan only) -------------------------------------------------
+ * A color-depth MIP is a few percent signal on black, and a pixel without a strict maximum channel has no hue
+ * class and matches nothing (API/cds/AbstractColorDepthSearchAlgorithm.java:195-225, 227-232).  A sparse library
+ * keeps per image only its signal pixels (4 bytes each: x, hue class, second and maximum channel -- independent of
+ * every search parameter) in row-major order: ~4 % of the dense bytes, so a 1 M-image library fits one GPU.
+ * It replaces the same host-side MIP cache (tools cmd/CachedMIPsUtils.java:60-100) for searches that need the
+ * pixel-match score only; the shape scorer keeps reading dense slots + variants.  Results of cds_search_sparse*
+ * are identical to cds_search* on the same images (tests/test_sparse_gpu.py).
+ * capacity_pixels = total signal-pixel records (+ 1 per image row without signal). */
+int cds_sparse_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t capacity_images, int64_t capacity_pixels,
+                              cds_sparse_library **out);
+void cds_sparse_library_destroy(cds_sparse_library *slib);
+/* Append slots [first, first+count) of a resident dense library (device -> device); the images get the next
+ * indices size() .. size()+count-1.  CDS_ERR_OUT_OF_MEMORY when a capacity would be exceeded (nothing is added
+ * from the failing batch on). */
+int cds_sparse_library_append(cds_sparse_library *slib, const cds_library *src, int64_t first, int64_t count);
+/* Append `count` host images (packed RGB, pitch 3*W) through internal dense staging slots. */
+int cds_sparse_library_append_host(cds_sparse_library *slib, int64_t count, const uint8_t *rgb);
+int64_t cds_sparse_library_size(const cds_sparse_library *slib);   /* images held  */
+int64_t cds_sparse_library_pixels(const cds_sparse_library *slib); /* records held */
+int cds_sparse_library_clear(cds_sparse_library *slib);
+/* Diagnostic: the records of one image (bit 31 first of its row | x << 20 | class << 16 | second << 8 | max) and
+ * its H+1 row offsets; either output may be NULL; *n_records is always set. */
+int cds_sparse_library_image_records(const cds_sparse_library *slib, int64_t index, uint32_t *records, int64_t capacity,
+                                     int64_t *n_records, uint32_t *row_offsets);
+/* The scan over images [first, first+count) of a sparse library: same outputs as cds_search / cds_search_device /
+ * cds_search_counts. */
+int cds_search_sparse(const cds_maskset *ms, const cds_sparse_library *slib, int64_t first, int64_t count,
+                      int32_t *scores, uint8_t *mirrored);
+int cds_search_sparse_device(const cds_maskset *ms, const cds_sparse_library *slib, int64_t first, int64_t count,
+                             int32_t *d_scores);
+int cds_search_sparse_counts(const cds_maskset *ms, const cds_sparse_library *slib, int64_t first, int64_t count,
+                             int32_t *counts);
 
 /* Average device time (ms) of the scan kernel launches of the last cds_search*_ call on this mask
  * set, measured with hipEvents on the launch stream, and the number of launches. */

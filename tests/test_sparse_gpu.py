@@ -1,0 +1,365 @@
+"""GPU parity tests of kernel 1 over a SPARSE resident library (cds_sparse_library, cds_search_sparse*) through the C ABI:
+the record stream against a numpy model of its specification, the reference's known answers on its own fixture images,
+oracle parity (all 18 per-transform counts) on synthetic libraries, random geometries and the edge cases of the
+reference's semantics, and equality with the dense scan at sizes the oracle cannot check.  Bar: bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden import expected as E
+
+pytestmark = pytest.mark.gpu
+
+W, H = 1210, 566
+
+
+@pytest.fixture(scope="module")
+def cds():
+    from colormipsearch_amd import cds as m
+    m.default_context()  # fails loudly without a gfx950 GPU
+    return m
+
+
+def sparse_of(cds, images, w=None, h=None, slack=0):
+    images = np.ascontiguousarray(images, dtype=np.uint8)
+    if images.ndim == 3:
+        images = images[None]
+    n, hh, ww, _ = images.shape
+    sl = cds.SparseLibrary(ww, hh, n + slack, int((images.max(axis=3) > 0).sum()) + n * hh + 64)
+    sl.append(images)
+    return sl
+
+
+def records_model(img):
+    """The specification of the record stream (include/cds_hip.h, cds_internal.hpp): per row, x ascending, the pixels with
+    a strict maximum channel as  x << 20 | class << 16 | second << 8 | max,  bit 31 on the first record of a row; a row
+    without such a pixel holds the single filler record 1 << 31."""
+    img = img.astype(np.int64)
+    r, g, b = img[..., 0], img[..., 1], img[..., 2]
+    mx = img.max(axis=2)
+    md = np.median(img, axis=2).astype(np.int64)
+    cls = np.zeros(mx.shape, dtype=np.int64)
+    bmax, gmax, rmax = (b > r) & (b > g), (g > b) & (g > r), (r > b) & (r > g)
+    cls[bmax & (r > g)] = 1          # BR
+    cls[bmax & ~(r > g)] = 2         # BG
+    cls[gmax & (b > r)] = 3          # GB
+    cls[gmax & ~(b > r)] = 4         # GR
+    cls[rmax & (g > b)] = 5          # RG
+    cls[rmax & ~(g > b)] = 6         # RB
+    out, rows = [], [0]
+    for y in range(img.shape[0]):
+        xs = np.flatnonzero(cls[y] > 0)
+        if len(xs) == 0:
+            out.append(np.array([1 << 31], dtype=np.int64))
+        else:
+            rec = (xs << 20) | (cls[y, xs] << 16) | (md[y, xs] << 8) | mx[y, xs]
+            rec[0] |= 1 << 31
+            out.append(rec)
+        rows.append(rows[-1] + len(out[-1]))
+    return np.concatenate(out).astype(np.uint32), np.array(rows, dtype=np.uint32)
+
+
+def test_record_stream_matches_its_specification(cds, fixtures, oracle):
+    rng = np.random.default_rng(5)
+    imgs = [fixtures["lm_VT016795"], oracle.synth_image(0xC0FFEE, 4, 0), np.zeros((H, W, 3), dtype=np.uint8),
+            oracle.synth_image(0xC0FFEE, 2, 1)]
+    ties = np.zeros((H, W, 3), dtype=np.uint8)   # no strict maximum anywhere except one pixel per kind of class
+    ties[5, 5:50] = (90, 90, 10)
+    ties[6, 5:50] = (128, 128, 128)
+    ties[7, W - 1] = (1, 0, 0)
+    ties[H - 1, 0] = (0, 0, 255)
+    ties[9, 3:9] = [(10, 5, 20), (5, 10, 20), (5, 20, 10), (10, 20, 5), (20, 10, 5), (20, 5, 10)]
+    imgs.append(ties)
+    imgs.append(rng.integers(0, 4, size=(H, W, 3)).astype(np.uint8))   # small values: many ties, zero numerators
+    sl = sparse_of(cds, np.stack(imgs))
+    assert len(sl) == len(imgs)
+    total = 0
+    for i, img in enumerate(imgs):
+        rec, rows = sl.image_records(i)
+        want_rec, want_rows = records_model(img)
+        assert np.array_equal(rows, want_rows), i
+        assert np.array_equal(rec, want_rec), i
+        total += len(rec)
+    assert sl.pixels == total
+
+
+def test_append_batches_capacity_and_clear(cds, oracle):
+    dense = cds.Library(W, H, 6)
+    dense.generate_synthetic(0xC0FFEE, 20, 0, 6, kind=0)
+    imgs = dense.download(0, 6)
+    n_rec = [len(records_model(im)[0]) for im in imgs]
+    sl = cds.SparseLibrary(W, H, 6, sum(n_rec[:5]) + 10)
+    sl.append_from(dense, 0, 2)
+    sl.append(imgs[2:4])
+    sl.append_from(dense, 4, 1)
+    assert len(sl) == 5 and sl.pixels == sum(n_rec[:5])
+    for i in range(5):
+        assert np.array_equal(sl.image_records(i)[0], records_model(imgs[i])[0]), i
+    with pytest.raises(cds.CdsError, match="full"):      # record capacity
+        sl.append_from(dense, 5, 1)
+    assert len(sl) == 5
+    sl.clear()
+    assert len(sl) == 0 and sl.pixels == 0
+    sl.append_from(dense, 3, 3)
+    assert np.array_equal(sl.image_records(2)[0], records_model(imgs[5])[0])
+    with pytest.raises(cds.CdsError):                    # image capacity
+        sl.append_from(dense, 0, 4)
+    with pytest.raises(ValueError):
+        sl.append(np.zeros((1, 10, 10, 3), dtype=np.uint8))
+
+
+# ---- the reference's JUnit answers ------------------------------------------------------------------
+def test_reference_known_answers(cds, fixtures):
+    # PixelMatchColorDepthSearchAlgorithmTest.pixelMatchScore (:33-53) and multiplePixelScores (:56-153)
+    e = E.PIXEL_MATCH_DIRECT
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(fixtures[e["mask"]], 20, True, None, 0, False, 20, 0.01, 2, e["rects"])
+    s, m = alg.searchSparseLibrary(sparse_of(cds, fixtures[e["target"]]))
+    assert (int(s[0, 0]), bool(m[0, 0])) == (87, False)
+    for mask, target, expected, mirrored in E.PIXEL_MATCH_PROVIDER:
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(fixtures[mask], 20, True, None, 0, False, 20, 0.01, 2, E.STD_RECTS)
+        s, m = alg.searchSparseLibrary(sparse_of(cds, fixtures[target]))
+        assert (int(s[0, 0]), bool(m[0, 0])) == (expected, mirrored), (mask, target)
+
+
+@pytest.mark.parametrize("lds_kb", [None, 24, 160])
+def test_fixture_matrix_all_transforms(cds, fixtures, oracle, lds_kb, monkeypatch):
+    """3 EM masks x 4 LM targets, every per-transform count, 4 parameter combinations; one slab, the default layout and
+    many slabs per mask."""
+    if lds_kb:
+        monkeypatch.setenv("CDS_SPARSE_LDS_KB", str(lds_kb))
+    masks = np.stack([fixtures[k] for k in ("em_12191", "em_12191_FL", "em_LPLC2")])
+    tkeys = ("lm_BJD", "lm_GMR", "lm_VT016795", "lm_VT033614")
+    targets = np.stack([fixtures[k] for k in tkeys])
+    sl = sparse_of(cds, targets)
+    for xy, mirror in ((2, True), (2, False), (0, True), (0, False)):
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, mirror, None, 0, False, 20, 0.01, xy, E.STD_RECTS)
+        scores, mir = alg.searchSparseLibrary(sl)
+        counts = alg.searchSparseLibraryCounts(sl)
+        for m in range(3):
+            q = oracle.PixelMatchQuery(masks[m], 20, 20, 0.01, xy, mirror, E.STD_RECTS)
+            for t in range(len(tkeys)):
+                s, mm, c = q.score(targets[t])
+                assert np.array_equal(counts[m, t], c), (xy, mirror, m, t, counts[m, t], c)
+                assert (int(scores[m, t]), bool(mir[m, t])) == (s, mm), (xy, mirror, m, t)
+
+
+# ---- synthetic libraries ------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,n", [(0, 48), (1, 6)])
+def test_synthetic_library_parity(cds, oracle, kind, n):
+    """BASELINE config 2 at a size the oracle finishes in seconds: 1 mask x n targets, xyShift 2, mirror."""
+    rects = cds.label_regions(W)
+    mask = oracle.synth_image(0xBADC0DE, 0, 2)
+    lib = cds.Library(W, H, n)
+    lib.generate_synthetic(0xC0FFEE, 0, 0, n, kind=kind)
+    targets = lib.download(0, n)
+    sl = cds.SparseLibrary(W, H, n, n * W * H)
+    sl.append_from(lib)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    scores, mir = alg.searchSparseLibrary(sl)
+    q = oracle.PixelMatchQuery(mask, 20, 20, 0.01, 2, True, rects)
+    want_s, want_m = q.scan(targets, n_threads=8)
+    assert np.array_equal(scores[0], want_s)
+    assert np.array_equal(mir[0], want_m.astype(bool))
+    if kind == 1:
+        assert scores.max() > 0  # dense targets do hit
+
+
+def test_self_match_mirror_and_sub_ranges(cds, oracle):
+    rects = cds.label_regions(W)
+    mask = oracle.synth_image(0xBADC0DE, 3, 2)
+    targets = np.stack([mask, np.fliplr(mask), np.roll(mask, 2, axis=1), np.roll(mask, -2, axis=0), np.zeros_like(mask)] +
+                       [oracle.synth_image(0xC0FFEE, 60 + i, 0) for i in range(5)])
+    sl = sparse_of(cds, targets)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    scores, mir = alg.searchSparseLibrary(sl)
+    P = alg.getQuerySize()
+    q = oracle.PixelMatchQuery(mask, 20, 20, 0.01, 2, True, rects)
+    for t in range(len(targets)):
+        s, m, _ = q.score(targets[t])
+        assert (int(scores[0, t]), bool(mir[0, t])) == (s, m)
+    assert scores[0, 0] <= P and scores[0, 0] > 0.9 * P and not mir[0, 0]
+    assert mir[0, 1] and scores[0, 4] == 0
+    part, pm = alg.searchSparseLibrary(sl, 3, 4)
+    assert np.array_equal(part, scores[:, 3:7]) and np.array_equal(pm, mir[:, 3:7])
+    empty, _ = alg.searchSparseLibrary(sl, 2, 0)
+    assert empty.shape == (1, 0)
+
+
+def test_batched_masks_and_parameter_sweep(cds, oracle):
+    rects = cds.label_regions(W)
+    n_masks, n_t = 5, 12
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(n_masks)])
+    targets = np.stack([oracle.synth_image(0xC0FFEE, 100 + i, 0) for i in range(n_t - 2)] + [masks[1], np.fliplr(masks[2])])
+    sl = sparse_of(cds, targets)
+    for (mthr, dthr, ztol, xy, mirror) in ((20, 20, 0.01, 2, True), (100, 100, 0.02, 0, False), (20, 50, 0.3, 2, False)):
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, mthr, mirror, None, 0, False, dthr, ztol, xy, rects)
+        scores, mir = alg.searchSparseLibrary(sl)
+        for m in range(n_masks):
+            q = oracle.PixelMatchQuery(masks[m], mthr, dthr, ztol, xy, mirror, rects)
+            ws, wm = q.scan(targets, n_threads=8)
+            assert np.array_equal(scores[m], ws), (m, mthr, dthr, ztol, xy, mirror)
+            assert np.array_equal(mir[m], wm.astype(bool))
+
+
+def test_wide_masks_and_many_colours(cds, oracle):
+    """(a) a whole-frame mask (strokes all over the image: the bounding box is the frame), (b) a very wide image,
+    (c) a mask with thousands of distinct colours: its interval table does not fit the LDS table and is read from L2."""
+    rects = cds.label_regions(W)
+    mask = oracle.synth_image(0xC0FFEE, 9001, 0)
+    targets = np.stack([oracle.synth_image(0xC0FFEE, i, 0) for i in (9001, 9002, 9003)] + [np.fliplr(mask), oracle.synth_image(0xC0FFEE, 3, 1)])
+    sl = sparse_of(cds, targets)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    counts = alg.searchSparseLibraryCounts(sl)
+    q = oracle.PixelMatchQuery(mask, 20, 20, 0.01, 2, True, rects)
+    for t in range(len(targets)):
+        assert np.array_equal(counts[0, t], q.score(targets[t])[2]), t
+    w2, h2 = 1600, 64
+    rng = np.random.default_rng(11)
+    lut = oracle.depth_lut()
+    m2 = np.zeros((h2, w2, 3), dtype=np.uint8)
+    for x0 in (3, 700, 1500):
+        m2[10:50, x0:x0 + 40] = lut[rng.integers(0, 256, size=(40, 40))]
+    t2 = np.stack([m2, np.fliplr(m2), lut[rng.integers(0, 256, size=(h2, w2))].astype(np.uint8)])
+    sl2 = sparse_of(cds, t2)
+    a2 = cds.PixelMatchColorDepthSearchAlgorithm(m2, 20, True, None, 0, False, 20, 0.01, 2, [])
+    c2 = a2.searchSparseLibraryCounts(sl2)
+    q2 = oracle.PixelMatchQuery(m2, 20, 20, 0.01, 2, True, [])
+    for t in range(len(t2)):
+        assert np.array_equal(c2[0, t], q2.score(t2[t])[2]), t
+    w3, h3 = 400, 200
+    m3 = np.zeros((h3, w3, 3), dtype=np.uint8)
+    m3[20:180, 50:350] = rng.integers(0, 256, size=(160, 300, 3))
+    t3 = np.stack([m3, np.fliplr(m3), rng.integers(0, 256, size=(h3, w3, 3)).astype(np.uint8), np.roll(m3, 2, axis=0)])
+    sl3 = sparse_of(cds, t3)
+    a3 = cds.PixelMatchColorDepthSearchAlgorithm(m3, 20, True, None, 0, False, 20, 0.02, 2, [])
+    c3 = a3.searchSparseLibraryCounts(sl3)
+    q3 = oracle.PixelMatchQuery(m3, 20, 20, 0.02, 2, True, [])
+    for t in range(len(t3)):
+        assert np.array_equal(c3[0, t], q3.score(t3[t])[2]), t
+
+
+# ---- edge cases of the reference's semantics ------------------------------------------------------------
+@pytest.mark.parametrize("lds_kb", [None, 8])
+def test_mask_touching_every_border(cds, oracle, lds_kb, monkeypatch):
+    """Shifted positions falling off the image are skipped (-1, PixelMatch...Algorithm.java:132-144,241-243),
+    mirrored columns use the full width; also a small non-standard geometry."""
+    if lds_kb:
+        monkeypatch.setenv("CDS_SPARSE_LDS_KB", str(lds_kb))
+        monkeypatch.setenv("CDS_SPARSE_THREADS", "64")
+    w, h = 64, 40
+    rng = np.random.default_rng(7)
+    lut = oracle.depth_lut()
+    mask = np.zeros((h, w, 3), dtype=np.uint8)
+    for (y, x) in [(0, 0), (0, w - 1), (h - 1, 0), (h - 1, w - 1), (1, 1), (h // 2, w // 2)]:
+        mask[y, x] = lut[rng.integers(0, 256)]
+    mask[0, 5:40] = lut[40]
+    mask[h - 1, 10:60] = lut[200]
+    mask[5:35, 0] = lut[100]
+    mask[3:30, w - 1] = lut[150]
+    targets = np.stack([mask, np.fliplr(mask), np.roll(np.roll(mask, 2, 0), -2, 1),
+                        lut[rng.integers(0, 256, size=(h, w))].astype(np.uint8)])
+    sl = sparse_of(cds, targets)
+    for xy, mirror in ((2, True), (0, True), (2, False)):
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, mirror, None, 0, False, 20, 0.01, xy, [])
+        counts = alg.searchSparseLibraryCounts(sl)
+        q = oracle.PixelMatchQuery(mask, 20, 20, 0.01, xy, mirror, [])
+        for t in range(len(targets)):
+            assert np.array_equal(counts[0, t], q.score(targets[t])[2]), (xy, mirror, t)
+
+
+@pytest.mark.parametrize("threads,lds_kb", [(None, None), (256, 12)])
+def test_random_geometry_and_parameter_sweep(cds, oracle, threads, lds_kb, monkeypatch):
+    """Seeded random sweep over image sizes, mask counts / shapes, thresholds, tolerances, shift and mirror settings:
+    all 18 per-transform counts of every (mask, target) pair against the oracle, in the default layout and with small
+    workgroups / many slabs."""
+    if threads:
+        monkeypatch.setenv("CDS_SPARSE_THREADS", str(threads))
+        monkeypatch.setenv("CDS_SPARSE_LDS_KB", str(lds_kb))
+    rng = np.random.default_rng(int(os.environ.get("CDS_TEST_SWEEP_SEED", "20261004")))
+    lut = oracle.depth_lut()
+
+    def blobs(w, h, n, dense):
+        img = np.zeros((h, w, 3), dtype=np.uint8)
+        for _ in range(n):
+            bw, bh = int(rng.integers(1, max(2, w // 3))), int(rng.integers(1, max(2, h // 3)))
+            x0, y0 = int(rng.integers(0, w - bw + 1)), int(rng.integers(0, h - bh + 1))
+            if dense:
+                img[y0:y0 + bh, x0:x0 + bw] = rng.integers(0, 256, size=(bh, bw, 3))
+            else:
+                z = rng.integers(0, 256, size=(bh, bw))
+                br = rng.uniform(0.3, 1.0, size=(bh, bw, 1))
+                img[y0:y0 + bh, x0:x0 + bw] = (lut[z] * br).astype(np.uint8)
+        return img
+
+    for case in range(int(os.environ.get("CDS_TEST_SWEEP_CASES", "40"))):
+        w, h = int(rng.integers(24, 420)), int(rng.integers(8, 150))
+        n_masks = int(rng.choice([1, 1, 2, 3]))
+        masks = np.stack([blobs(w, h, int(rng.integers(1, 5)), False) for _ in range(n_masks)])
+        targets = [blobs(w, h, int(rng.integers(1, 8)), bool(rng.integers(0, 2))) for _ in range(4)]
+        targets += [masks[0], np.fliplr(masks[-1]), np.roll(masks[0], 2, axis=1), np.zeros_like(masks[0])]
+        targets = np.stack(targets)
+        mthr, dthr = int(rng.choice([0, 20, 60, 150])), int(rng.choice([0, 20, 90]))
+        ztol = float(rng.choice([0.0, 0.01, 0.02, 0.1, 0.5]))
+        xy, mirror = int(rng.choice([0, 2])), bool(rng.integers(0, 2))
+        rects = [(0, 0, w // 4, h // 5)] if rng.integers(0, 2) else []
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, mthr, mirror, None, 0, False, dthr, ztol, xy, rects)
+        sl = sparse_of(cds, targets)
+        counts = alg.searchSparseLibraryCounts(sl)
+        scores, mir = alg.searchSparseLibrary(sl)
+        for m in range(n_masks):
+            q = oracle.PixelMatchQuery(masks[m], mthr, dthr, ztol, xy, mirror, rects)
+            for t in range(len(targets)):
+                s, mi, c = q.score(targets[t])
+                info = (case, w, h, n_masks, m, t, mthr, dthr, ztol, xy, mirror)
+                assert np.array_equal(counts[m, t], c), info
+                assert scores[m, t] == s and bool(mir[m, t]) == mi, info
+
+
+def test_empty_classless_masks_and_errors(cds, oracle, fixtures):
+    rects = cds.label_regions(W)
+    black = np.zeros((H, W, 3), dtype=np.uint8)
+    gray = black.copy()
+    gray[200:220, 400:500] = 128          # r == g == b: no hue class, never matches, but counts in the query size
+    target = oracle.synth_image(0xC0FFEE, 1, 0)
+    sl = sparse_of(cds, np.stack([target, gray]))
+    for mask, size in ((black, 0), (gray, 2000)):
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+        assert alg.getQuerySize() == size
+        s, m = alg.searchSparseLibrary(sl)
+        assert not s.any() and not m.any()
+    mixed = np.stack([black, oracle.synth_image(0xBADC0DE, 1, 2), gray])     # empty masks inside a set
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mixed, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    s, m = alg.searchSparseLibrary(sl)
+    ws, wm = oracle.PixelMatchQuery(mixed[1], 20, 20, 0.01, 2, True, rects).scan(np.stack([target, gray]))
+    assert not s[0].any() and not s[2].any() and np.array_equal(s[1], ws) and np.array_equal(m[1], wm.astype(bool))
+    small = sparse_of(cds, np.zeros((1, 100, 200, 3), dtype=np.uint8))
+    with pytest.raises(ValueError, match="Invalid image size"):                           # PixelMatch...:171-175
+        alg.searchSparseLibrary(small)
+    with pytest.raises(ValueError):
+        alg.searchSparseLibrary(sl, 1, 5)
+
+
+def test_equals_dense_scan_at_scale(cds, oracle):
+    """At a library size the oracle cannot check directly: the sparse scan equals the dense scan target by target
+    (scores and flags), is deterministic, and a permuted library gives the permuted scores."""
+    rects = cds.label_regions(W)
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(2)])
+    n = 4096
+    lib = cds.Library(W, H, n)
+    lib.generate_synthetic(0xC0FFEE, 0, 0, n, kind=0)
+    sl = cds.SparseLibrary(W, H, n, 45000 * n)
+    sl.append_from(lib, 0, 1000)
+    sl.append_from(lib, 1000, n - 1000)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    d_s, d_m = alg.searchLibrary(lib)
+    s1, m1 = alg.searchSparseLibrary(sl)
+    s2, m2 = alg.searchSparseLibrary(sl)
+    assert np.array_equal(s1, d_s) and np.array_equal(m1, d_m)
+    assert np.array_equal(s1, s2) and np.array_equal(m1, m2)
+    assert (s1 > 0).sum() > 100
+    sl2 = cds.SparseLibrary(W, H, 64, 45000 * 64)
+    for k in range(64):
+        sl2.append_from(lib, 1063 - k, 1)
+    s3, _ = alg.searchSparseLibrary(sl2)
+    assert np.array_equal(s3[:, ::-1], s1[:, 1000:1064])
