@@ -85,6 +85,7 @@ SIGNATURES = {
     "cds_sparse_library_destroy": (None, [_vp]),
     "cds_sparse_library_append": (_i, [_vp, _vp, _i64, _i64]),
     "cds_sparse_library_append_host": (_i, [_vp, _i64, _u8p]),
+    "cds_sparse_library_layout": (_i, [_vp, _i32p, _i32p]),
     "cds_sparse_library_size": (_i64, [_vp]),
     "cds_sparse_library_pixels": (_i64, [_vp]),
     "cds_sparse_library_clear": (_i, [_vp]),

@@ -209,6 +209,9 @@ class SparseLibrary:
         capi.check(self._lib.cds_sparse_library_create(self.ctx._h, self.width, self.height, self.capacity_images,
                                                        self.capacity_pixels, ctypes.byref(h)))
         self._h = h
+        ns, sw = ctypes.c_int32(), ctypes.c_int32()
+        capi.check(self._lib.cds_sparse_library_layout(self._h, ctypes.byref(ns), ctypes.byref(sw)))
+        self.n_strips, self.strip_width = ns.value, sw.value
 
     def close(self):
         if getattr(self, "_h", None):
@@ -244,11 +247,11 @@ class SparseLibrary:
         capi.check(self._lib.cds_sparse_library_append_host(self._h, imgs.shape[0], capi.as_u8p(imgs)))
 
     def image_records(self, index):
-        """(records uint32[n], row_offsets uint32[H+1]) of one image -- diagnostic."""
+        """(records uint32[n], cell offsets uint32[n_strips, H+1]) of one image -- diagnostic."""
         n = ctypes.c_int64()
         capi.check(self._lib.cds_sparse_library_image_records(self._h, int(index), None, 0, ctypes.byref(n), None))
         rec = np.zeros(n.value, dtype=np.uint32)
-        rows = np.zeros(self.height + 1, dtype=np.uint32)
+        rows = np.zeros((self.n_strips, self.height + 1), dtype=np.uint32)
         u32p = ctypes.POINTER(ctypes.c_uint32)
         capi.check(self._lib.cds_sparse_library_image_records(self._h, int(index), rec.ctypes.data_as(u32p), n.value,
                                                               ctypes.byref(n), rows.ctypes.data_as(u32p)))

@@ -141,13 +141,14 @@ namespace cds {
 // Record of one signal pixel (a pixel with a strict maximum channel -- every other pixel has no hue class and can never
 // match, AbstractColorDepthSearchAlgorithm.java:195-225): the hue class and the two channel values its ratio is made of.
 //   bit 31 first record of its image row | bits 30..20 x | bits 18..16 hue class 1..6 | bits 15..8 second channel | bits 7..0 max
-// A row without signal pixels holds one filler record (bit 31 only), so "row = rows started so far" holds everywhere.
+// An image is stored strip by strip (up to 4 column strips), a strip row by row, a row by ascending x.  A (strip, row) cell
+// without signal pixels holds one filler record (bit 31 only), so "row = rows started so far" holds everywhere.
 constexpr uint32_t kRecRowFlag = 0x80000000u;
 constexpr int kRecXShift = 20;
 constexpr int kRecClsShift = 16;
 
 // One mask prepared for the sparse scan: the mask's bounding box cut into slabs of `slab_rows` mask rows; per slab one
-// ready-to-copy LDS image [plane u16 (slab_rows + 8) x pitch | near bitmap u32 (slab_rows + 4) x nwpr]:
+// ready-to-copy LDS image [plane u16 or u8 (slab_rows + 8) x pitch | near bitmap u32 (slab_rows + 4) x nwpr]:
 //   plane[(my - slab_y0) + 4][(mx - xlo) + 4] = 1-based index of the mask pixel's interval record (0 = no mask pixel);
 //   near bit (ty - (slab_y0 - 2), tx - (xlo - 2)) = some transform maps target pixel (tx, ty) onto a mask pixel of the slab.
 struct SparseMaskPlan {
@@ -159,6 +160,7 @@ struct SparseMaskPlan {
     int slab_bytes = 0;   // multiple of 16
     int n_iv = 0;         // interval records (index 0 = the empty record) -- iv table has n_iv entries
     bool iv_in_lds = true;
+    bool plane8 = false;  // one byte per plane cell (n_iv <= 256)
     size_t slabs_off = 0; // byte offset of this mask's slab images in cds_maskset::d_sp_slabs
     size_t iv_off = 0;    // element offset of its interval table in cds_maskset::d_sp_iv
     size_t lds_bytes = 0; // dynamic LDS of one workgroup
@@ -167,16 +169,18 @@ struct SparseMaskPlan {
 struct SparseScanParams {
     const uint32_t *px;       // record arena
     const uint64_t *img_off;  // [n+1] first record of every image
-    const uint32_t *rowptr;   // [n][H+1] record offsets of the rows inside their image
+    const uint32_t *rowptr;   // [n][nstrips][H+1] record offsets of the (strip, row) cells inside their image
     int64_t first, count;
     int W, H;
+    int nstrips, strip_w;     // column strips of the record layout
     const uint8_t *slabs;
     const uint4 *iv;
-    int n_iv, iv_in_lds;
+    int n_iv, iv_in_lds, plane8;
     int xlo, cols, ylo, nrows, pitch, nwpr, slab_rows, n_slabs, near_off, slab_bytes;
     int thr;
     int group;                // targets a wave takes per grab
-    uint32_t *work;           // [n_slabs] next target of every slab (zero before the launch)
+    int nparts;               // partitions of the targets, each with its own work counter
+    uint32_t *work;           // [n_slabs][nparts] x 32 dwords: next target of the partition (zero before the launch)
     int32_t *out;             // [count] score | mirrored << 31 (written directly when there is one slab and no partial)
     int32_t *partial;         // [n_slabs][count][18] per-transform counts of every slab, or NULL
 };
@@ -186,11 +190,12 @@ struct SparseScanParams {
 struct cds_sparse_library {
     cds_context *ctx = nullptr;
     int W = 0, H = 0;
+    int nstrips = 1, strip_w = 0;   // an image is stored strip by strip (column strips), a strip row by row
     int64_t cap_images = 0, cap_px = 0;
     int64_t n_images = 0, n_px = 0;
     uint32_t *d_px = nullptr;
     uint64_t *d_img_off = nullptr;  // [cap_images + 1]
-    uint32_t *d_rowptr = nullptr;   // [cap_images][H + 1]
+    uint32_t *d_rowptr = nullptr;   // [cap_images][nstrips][H + 1]
     uint32_t *d_tmp = nullptr;      // append scratch: per-image totals of one batch
     int64_t tmp_images = 0;
     cds_library *stage = nullptr;   // dense staging slots of cds_sparse_library_append_host

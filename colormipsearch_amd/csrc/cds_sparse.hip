@@ -32,6 +32,7 @@
 #include <thread>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <unordered_map>
 
 #include "cds_internal.hpp"
@@ -42,6 +43,7 @@ constexpr int SP_QCAP = 128;                          // queue entries per wave 
 constexpr int SP_QBYTES = 2 * (SP_QCAP * 4 + SP_QCAP * 2);  // two queues of (u32 record, u16 plane offset)
 constexpr int SP_MAX_IV_LDS = 2048;                   // interval records kept in LDS (32 KB); larger tables are read from L2
 constexpr int SP_MAX_SLABS = 256;
+constexpr int SP_MAX_PARTS = 64;                      // work counters per slab (one per partition of the targets, 128 B apart)
 constexpr int SP_PAD = 4;                             // zero rows / columns around a slab's plane (two shifts of 2)
 
 // =================================================================================================
@@ -51,6 +53,7 @@ struct BuildParams {
     const uint8_t *rgb;  // first source slot
     size_t img_stride;
     int pitch, W, H;
+    int nstrips, strip_w;  // column strips of the record layout (strip_w is a multiple of 4 pixels)
     int64_t count;       // images of this batch
     int64_t dst_first;   // index of the batch's first image in the sparse library
     uint32_t *px;
@@ -69,8 +72,9 @@ __device__ __forceinline__ uint32_t px_record(uint32_t r, uint32_t g, uint32_t b
     return mx > md ? (cls << kRecClsShift) | (md << 8) | mx : 0u;
 }
 
-// One wave per image row.  FILL = false: records of the row (at least 1: the filler) -> rowptr[img][row + 1];
-// FILL = true: write them (x ascending) at img_off[img] + rowptr[img][row].
+// One wave per image row.  An image is stored strip by strip (column strips of strip_w pixels), a strip row by row, a row
+// by ascending x; rp = rowptr[img] is [nstrips][H + 1].  FILL = false: records of every (strip, row) cell (at least 1:
+// the filler) -> rp[k][row + 1]; FILL = true: write them at img_off[img] + rp[k][row].
 template <bool FILL>
 __global__ __launch_bounds__(256) void sparse_rows_kernel(BuildParams p) {
     const int lane = threadIdx.x & 63;
@@ -79,45 +83,49 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(BuildParams p) {
     const int64_t img = wid / p.H;
     const int row = (int)(wid - img * p.H);
     const uint8_t *rowp = p.rgb + (size_t)img * p.img_stride + (size_t)row * p.pitch;
-    uint32_t *rp = p.rowptr + (size_t)(p.dst_first + img) * (p.H + 1);
-    uint32_t *dst = nullptr;
-    if (FILL) dst = p.px + p.img_off[p.dst_first + img] + rp[row];
-    const int gpr = p.pitch / 12;  // 4-pixel groups per row (the padding columns are black)
-    int n = 0;
-    for (int g0 = 0; g0 < gpr; g0 += 64) {
-        const int g = g0 + lane;
-        uint32_t a = 0, b = 0, c = 0;
-        if (g < gpr) {
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(rowp + (size_t)g * 12);
-            a = q[0], b = q[1], c = q[2];
-        }
-        uint32_t rec[4];
-        rec[0] = px_record(a & 255, (a >> 8) & 255, (a >> 16) & 255);
-        rec[1] = px_record(a >> 24, b & 255, (b >> 8) & 255);
-        rec[2] = px_record((b >> 16) & 255, b >> 24, c & 255);
-        rec[3] = px_record((c >> 8) & 255, (c >> 16) & 255, c >> 24);
-        int below = 0, all = 0;
+    uint32_t *rp = p.rowptr + (size_t)(p.dst_first + img) * p.nstrips * (p.H + 1);
+    const int gpr = p.pitch / 12;   // 4-pixel groups per row (the padding columns are black)
+    const int gps = p.strip_w / 4;  // groups per strip
+    for (int k = 0; k < p.nstrips; k++) {
+        uint32_t *dst = nullptr;
+        if (FILL) dst = p.px + p.img_off[p.dst_first + img] + rp[(size_t)k * (p.H + 1) + row];
+        const int gend = min(gpr, (k + 1) * gps);
+        int n = 0;
+        for (int g0 = k * gps; g0 < gend; g0 += 64) {
+            const int g = g0 + lane;
+            uint32_t a = 0, b = 0, c = 0;
+            if (g < gend) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(rowp + (size_t)g * 12);
+                a = q[0], b = q[1], c = q[2];
+            }
+            uint32_t rec[4];
+            rec[0] = px_record(a & 255, (a >> 8) & 255, (a >> 16) & 255);
+            rec[1] = px_record(a >> 24, b & 255, (b >> 8) & 255);
+            rec[2] = px_record((b >> 16) & 255, b >> 24, c & 255);
+            rec[3] = px_record((c >> 8) & 255, (c >> 16) & 255, c >> 24);
+            int below = 0, all = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const unsigned long long bal = __ballot(rec[j] != 0);
-            below += __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-            all += __popcll(bal);
-        }
-        if (FILL) {
-            int pos = n + below;
+            for (int j = 0; j < 4; j++) {
+                const unsigned long long bal = __ballot(rec[j] != 0);
+                below += __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+                all += __popcll(bal);
+            }
+            if (FILL) {
+                int pos = n + below;
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (rec[j]) {
-                    dst[pos] = rec[j] | ((uint32_t)(4 * g + j) << kRecXShift) | (pos == 0 ? kRecRowFlag : 0u);
-                    pos++;
-                }
+                for (int j = 0; j < 4; j++)
+                    if (rec[j]) {
+                        dst[pos] = rec[j] | ((uint32_t)(4 * g + j) << kRecXShift) | (pos == 0 ? kRecRowFlag : 0u);
+                        pos++;
+                    }
+            }
+            n += all;
         }
-        n += all;
-    }
-    if (!FILL) {
-        if (lane == 0) rp[row + 1] = (uint32_t)(n > 0 ? n : 1);
-    } else if (n == 0 && lane == 0) {
-        dst[0] = kRecRowFlag;  // row filler
+        if (!FILL) {
+            if (lane == 0) rp[(size_t)k * (p.H + 1) + row + 1] = (uint32_t)(n > 0 ? n : 1);
+        } else if (n == 0 && lane == 0) {
+            dst[0] = kRecRowFlag;  // filler of an empty cell
+        }
     }
 }
 
@@ -130,33 +138,35 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
     return v;
 }
 
-// One workgroup (256 threads) per image: rowptr[img][1..H] (record counts) -> exclusive offsets in place, total -> tmp[img].
+// One workgroup (256 threads) per image: rowptr[img][k][1..H] (record counts) -> exclusive offsets in place, running on
+// from strip to strip (rowptr[img][k][H] = rowptr[img][k + 1][0] = end of strip k); image total -> tmp[img].
 __global__ __launch_bounds__(256) void sparse_rowscan_kernel(BuildParams p) {
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t *rp = p.rowptr + (size_t)(p.dst_first + blockIdx.x) * (p.H + 1);
+    uint32_t *rp0 = p.rowptr + (size_t)(p.dst_first + blockIdx.x) * p.nstrips * (p.H + 1);
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    // the counts sit one slot to the right of the offsets they turn into: read a tile, barrier, write it
-    for (int base = 0; base < p.H; base += 256) {
-        const int i = base + (int)threadIdx.x;
-        const uint32_t v = i < p.H ? rp[i + 1] : 0u;
-        const uint32_t inc = wave_incl_scan(v, lane);
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        uint32_t off = carry_s;
-        for (int w = 0; w < wave; w++) off += wsum[w];
-        const uint32_t excl = off + inc - v;
-        __syncthreads();  // every count of the tile has been read, carry_s and wsum have been consumed
-        if (i < p.H) rp[i] = excl;
-        if (threadIdx.x == 255) carry_s = off + inc;
-        __syncthreads();
+    for (int k = 0; k < p.nstrips; k++) {
+        uint32_t *rp = rp0 + (size_t)k * (p.H + 1);
+        // the counts sit one slot to the right of the offsets they turn into: read a tile, barrier, write it
+        for (int base = 0; base < p.H; base += 256) {
+            const int i = base + (int)threadIdx.x;
+            const uint32_t v = i < p.H ? rp[i + 1] : 0u;
+            const uint32_t inc = wave_incl_scan(v, lane);
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            uint32_t off = carry_s;
+            for (int w = 0; w < wave; w++) off += wsum[w];
+            const uint32_t excl = off + inc - v;
+            __syncthreads();  // every count of the tile has been read, carry_s and wsum have been consumed
+            if (i < p.H) rp[i] = excl;
+            if (threadIdx.x == 255) carry_s = off + inc;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) rp[p.H] = carry_s;
     }
-    if (threadIdx.x == 0) {
-        rp[p.H] = carry_s;
-        p.tmp[blockIdx.x] = carry_s;
-    }
+    if (threadIdx.x == 0) p.tmp[blockIdx.x] = carry_s;
 }
 
 // One workgroup (1024 threads): img_off[dst_first + i + 1] = img_off[dst_first] + sum of tmp[0..i]; batch total -> *total.
@@ -192,17 +202,20 @@ __global__ __launch_bounds__(1024) void sparse_imgscan_kernel(BuildParams p) {
 // =================================================================================================
 //                                       the sparse scan
 // =================================================================================================
-template <bool XY2, bool MIRROR, bool IVLDS>
+// P8: the plane holds one byte per pixel (a mask with at most 255 distinct interval records) instead of two.
+template <bool XY2, bool MIRROR, bool IVLDS, bool P8>
 __global__ __launch_bounds__(1024, 8) void sparse_scan_kernel(SparseScanParams p) {
     extern __shared__ uint4 lds4[];
     constexpr int NS = XY2 ? 9 : 1, NSX = XY2 ? 3 : 1, NO = MIRROR ? 2 : 1, NC = NS * NO;
     constexpr int HALO = XY2 ? 2 : 0;
+    constexpr int NB = 4;  // record blocks (64 records each) in flight per wave
+    typedef typename std::conditional<P8, uint8_t, uint16_t>::type plane_t;
     uint8_t *lds = reinterpret_cast<uint8_t *>(lds4);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint4 *ivt = lds4;
     uint8_t *slab = lds + (IVLDS ? (size_t)p.n_iv * 16 : 0);
-    const uint16_t *plane = reinterpret_cast<const uint16_t *>(slab);
+    const plane_t *plane = reinterpret_cast<const plane_t *>(slab);
     const uint32_t *nearb = reinterpret_cast<const uint32_t *>(slab + p.near_off);
     uint8_t *qb = slab + p.slab_bytes + (size_t)wave * SP_QBYTES;
     uint32_t *qrec0 = reinterpret_cast<uint32_t *>(qb), *qrec1 = qrec0 + SP_QCAP;
@@ -223,24 +236,69 @@ __global__ __launch_bounds__(1024, 8) void sparse_scan_kernel(SparseScanParams p
         const int ys0 = p.ylo + s * p.slab_rows;  // first mask row of the slab
         const int rows_s = min(p.slab_rows, p.nrows - s * p.slab_rows);
         const int ra = max(ys0 - HALO, 0), rb = min(ys0 + rows_s + HALO, p.H);  // target rows [ra, rb)
-        const int ry0 = ys0 - 2, cx0 = p.xlo - 2, cm0 = p.W - 1 - cx0;
-        const unsigned wnear = (unsigned)(p.cols + 4);
+        const int ry0 = ys0 - 2;
+        const uint32_t cx0 = (uint32_t)(p.xlo - 2), cm0 = (uint32_t)(p.W - 1) - cx0;
+        const uint32_t wnear = (uint32_t)(p.cols + 4);  // bit `wnear` of every bitmap row exists and is 0: the clamp target
+        const uint32_t pitch = (uint32_t)p.pitch, nwpr = (uint32_t)p.nwpr, poff = 2u * (uint32_t)p.pitch + 2u;
+        // column strips of the library that the mask's plain window [xlo - 2, xhi + 2] and its mirror image can touch
+        int wlo = p.xlo - HALO, whi = p.xlo + p.cols - 1 + HALO;
+        if (MIRROR) {
+            const int mlo = p.W - 1 - whi, mhi = p.W - 1 - wlo;
+            wlo = min(wlo, mlo), whi = max(whi, mhi);
+        }
+        const int ks0 = max(wlo, 0) / p.strip_w, nsv = min(whi, p.W - 1) / p.strip_w - ks0 + 1;
 
-        for (;;) {
-            uint32_t tb = 0;
-            if (lane == 0) tb = atomicAdd(&p.work[s], (uint32_t)p.group);
-            tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
-            if ((int64_t)tb >= p.count) break;
-            const int64_t te = min((int64_t)tb + p.group, p.count);
-            for (int64_t t = tb; t < te; t++) {
-                const int64_t ti = p.first + t;
-                const uint32_t *P = p.px + p.img_off[ti];
-                const uint32_t *rp = p.rowptr + (size_t)ti * (p.H + 1);
-                const uint32_t a = rp[ra], b = rp[rb];
+        // The targets are dealt in `nparts` contiguous partitions, each with its own counter (an atomic on ONE address
+        // retires every ~8 ns chip-wide: 8 K waves drawing small grabs from a single counter would wait for each other);
+        // a workgroup starts at its own partition and moves on round-robin when one is exhausted.
+        for (int pi = 0; pi < p.nparts; pi++) {
+            const int part = (int)((blockIdx.x + (unsigned)pi) % (unsigned)p.nparts);
+            const int64_t pbeg = p.count * part / p.nparts, pend = p.count * (part + 1) / p.nparts;
+            uint32_t *ctr = p.work + ((size_t)s * p.nparts + part) * 32;
+            for (;;) {
+                uint32_t tb = 0;
+                if (lane == 0) tb = atomicAdd(ctr, (uint32_t)p.group);
+                tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
+                const int64_t t0 = pbeg + tb;
+                if (t0 >= pend) break;
+                const int ng = (int)min((int64_t)p.group, pend - t0);  // targets of this grab
+                // A grab is a sequence of RUNS: (target g, visited strip k) -> one contiguous record range.  The headers of
+                // all runs come in one round trip: lane r holds run r (g = r / nsv, strip ks0 + r % nsv); ng * nsv <= 64.
+                const int nruns = ng * nsv;
+                uint64_t h_off = 0;
+                uint32_t h_a = 0, h_b = 0;
+                if (lane < nruns) {
+                    const int g = lane / nsv, k = ks0 + lane - g * nsv;
+                    const int64_t ti = p.first + t0 + g;
+                    const uint32_t *rp = p.rowptr + ((size_t)ti * p.nstrips + k) * (p.H + 1);
+                    h_off = p.img_off[ti];
+                    h_a = rp[ra];
+                    h_b = rp[rb];
+                }
+                auto header = [&](int r, const uint32_t *&P, uint32_t &a, uint32_t &b) {
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h_off, r);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h_off >> 32), r);
+                    P = p.px + (((uint64_t)hi << 32) | lo);
+                    a = (uint32_t)__builtin_amdgcn_readlane((int)h_a, r);
+                    b = (uint32_t)__builtin_amdgcn_readlane((int)h_b, r);
+                };
+                // NB unconditional loads (index clamped to the range's last record; lanes beyond the range are zeroed when
+                // the block is examined): a conditional load would make hipcc wait with vmcnt(0) at the first use of the
+                // CURRENT blocks, i.e. for the prefetch it has just issued
+                auto load_blocks = [&](const uint32_t *P, uint32_t i, uint32_t b, uint32_t (&r)[NB]) {
+#pragma unroll
+                    for (int j = 0; j < NB; j++) r[j] = P[min(i + 64u * j + (uint32_t)lane, b - 1u)];
+                };
+                const uint32_t *P;
+                uint32_t a, b;
+                header(0, P, a, b);
+                uint32_t cur[NB], nxt[NB];
+                load_blocks(P, a, b, cur);
                 int c[NC];
 #pragma unroll
                 for (int k = 0; k < NC; k++) c[k] = 0;
                 int qh0 = 0, qt0 = 0, qh1 = 0, qt1 = 0;  // queue heads / tails (monotonic, wave-uniform)
+                int kin = 0;                             // strip of the current run, relative to ks0
 
                 // evaluate up to 64 queued pixels of one orientation: every lane busy
                 auto round = [&](const uint32_t *qrec, const uint16_t *qoff, int &qh, const int qt, int *cc) {
@@ -253,24 +311,30 @@ __global__ __launch_bounds__(1024, 8) void sparse_scan_kernel(SparseScanParams p
                     const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
                     uint32_t code = (((r >> kRecClsShift) & 7u) << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
                     code = valid ? code : 0u;  // 0 lies in no interval
-                    const uint16_t *c0 = plane + off;
+                    const plane_t *c0 = plane + off - (XY2 ? 2 : 0);  // (column offsets 0, 2, 4 below)
+                    uint32_t idx[NS];
 #pragma unroll
                     for (int iy = 0; iy < NSX; iy++) {
-                        const uint16_t *rowp = XY2 ? c0 + (1 - iy) * 2 * p.pitch : c0;  // mask row = target row - dy
-                        uint32_t idx[NSX];
+                        const plane_t *rowp = XY2 ? c0 + (1 - iy) * 2 * (int)pitch : c0;  // mask row = target row - dy
 #pragma unroll
-                        for (int ix = 0; ix < NSX; ix++) idx[ix] = rowp[XY2 ? (1 - ix) * 2 : 0];  // mask column = target column - dx
+                        for (int ix = 0; ix < NSX; ix++) idx[ix * NSX + iy] = rowp[XY2 ? (2 - ix) * 2 : 0];  // mask column = target column - dx
+                    }
 #pragma unroll
-                        for (int ix = 0; ix < NSX; ix++) {
-                            const uint4 iv = IVLDS ? ivt[idx[ix]] : p.iv[idx[ix]];
-                            const bool m = ((code - iv.x) <= iv.y) | ((code - iv.z) <= iv.w);
-                            cc[ix * NSX + iy] += __popcll(__ballot(m));
+                    for (int k0 = 0; k0 < NS; k0 += 3) {
+                        uint4 iv[3];
+#pragma unroll
+                        for (int k = 0; k < 3 && k0 + k < NS; k++) iv[k] = IVLDS ? ivt[idx[k0 + k]] : p.iv[idx[k0 + k]];
+#pragma unroll
+                        for (int k = 0; k < 3 && k0 + k < NS; k++) {
+                            // the OR is taken on the wave masks (s_or_b64), not on per-lane booleans
+                            const unsigned long long mb = __ballot((code - iv[k].x) <= iv[k].y) | __ballot((code - iv[k].z) <= iv[k].w);
+                            cc[k0 + k] += __popcll(mb);
                         }
                     }
                     qh += n;
                 };
-                auto append = [&](uint32_t *qrec, uint16_t *qoff, int &qt, const bool hit, const uint32_t r, const int off) {
-                    const unsigned long long hb = __ballot(hit);
+                auto append = [&](uint32_t *qrec, uint16_t *qoff, int &qt, const unsigned long long hb, const bool hit, const uint32_t r,
+                                  const uint32_t off) {
                     if (hb) {  // wave-uniform
                         const int slot = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0))) & (SP_QCAP - 1);
                         if (hit) {
@@ -281,61 +345,82 @@ __global__ __launch_bounds__(1024, 8) void sparse_scan_kernel(SparseScanParams p
                     }
                 };
 
-                int yrun = ra - 1;  // rows started before the current block, minus one
-                uint32_t rec = (a + (uint32_t)lane < b) ? P[a + lane] : 0u;
-                for (uint32_t i = a; i < b; i += 64) {  // wave-uniform
-                    const uint32_t inext = i + 64 + (uint32_t)lane;
-                    const uint32_t nxt = inext < b ? P[inext] : 0u;  // in flight during this block
-                    const uint32_t fl = rec >> 31;
-                    const unsigned long long fb = __ballot(fl != 0);
-                    const int y = yrun + __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0)) + (int)fl;
-                    yrun += __popcll(fb);
-                    const int d = (int)(rec & 255u), x = (int)((rec >> kRecXShift) & 2047u);
-                    const bool pass = d > p.thr;
-                    const int ry = y - ry0;  // row of the near bitmap; the plane row is ry + 2
-                    {
-                        const int cx = x - cx0;
-                        const bool inw = (unsigned)cx < wnear;
-                        const int cc = inw ? cx : 0;
-                        const uint32_t w = nearb[ry * p.nwpr + (cc >> 5)];
-                        const bool hit = pass && inw && ((w >> (cc & 31)) & 1u);
-                        append(qrec0, qoff0, qt0, hit, rec, (ry + 2) * p.pitch + cx + 2);
-                        if (qt0 - qh0 >= 64) round(qrec0, qoff0, qh0, qt0, c);
-                    }
-                    if (MIRROR) {
-                        const int cx = cm0 - x;  // the mask column a mirrored probe of this pixel lands on, bitmap-relative
-                        const bool inw = (unsigned)cx < wnear;
-                        const int cc = inw ? cx : 0;
-                        const uint32_t w = nearb[ry * p.nwpr + (cc >> 5)];
-                        const bool hit = pass && inw && ((w >> (cc & 31)) & 1u);
-                        append(qrec1, qoff1, qt1, hit, rec, (ry + 2) * p.pitch + cx + 2);
-                        if (qt1 - qh1 >= 64) round(qrec1, qoff1, qh1, qt1, c + NS);
-                    }
-                    rec = nxt;
-                }
-                while (qt0 > qh0) round(qrec0, qoff0, qh0, qt0, c);
-                if (MIRROR)
-                    while (qt1 > qh1) round(qrec1, qoff1, qh1, qt1, c + NS);
-
-                if (p.partial) {  // per-transform counts of this slab: lane k holds transform k (the 18-entry layout of the ABI)
-                    int v = 0;
+                for (int r = 0; r < nruns; r++) {  // wave-uniform
+                    const uint32_t *Pn = P;
+                    uint32_t an = 0, bn = 0;
+                    if (r + 1 < nruns) header(r + 1, Pn, an, bn);
+                    int yrel = ra - 1 - ry0;  // (rows started before the current block) - 1, relative to the near bitmap
+                    for (uint32_t i = a; i < b; i += 64 * NB) {  // wave-uniform
+                        // the next NB blocks -- of this run, or the first ones of the grab's next run -- are in flight while
+                        // these are examined (always NB loads, so that the wait for the current blocks is a counted one:
+                        // the last iteration of the grab's last run re-reads its own blocks)
+                        {
+                            const bool more = i + 64 * NB < b, other = r + 1 < nruns;
+                            const uint32_t *Pq = more ? P : (other ? Pn : P);
+                            const uint32_t iq = more ? i + 64 * NB : (other ? an : i), bq = more ? b : (other ? bn : b);
+                            load_blocks(Pq, iq, bq, nxt);
+                        }
 #pragma unroll
-                    for (int k = 0; k < NS; k++) {
-                        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[k])), "n"(k));
-                        if (MIRROR) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[NS + k])), "n"(9 + k));
-                    }
-                    if (lane < CDS_N_TRANSFORMS) p.partial[((size_t)s * p.count + t) * CDS_N_TRANSFORMS + lane] = v;
-                } else {
-                    int best = 0, bm = 0;
+                        for (int j = 0; j < NB; j++) {
+                            if (i + 64u * j >= b) break;  // wave-uniform
+                            const uint32_t rec = (i + 64u * j + (uint32_t)lane < b) ? cur[j] : 0u;
+                            const unsigned long long fb = __ballot((int)rec < 0);
+                            const uint32_t ry = (uint32_t)(yrel + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0))) + (rec >> 31);
+                            yrel += __popcll(fb);
+                            const uint32_t x = (rec >> kRecXShift) & 2047u;
+                            const bool pass = (int)(rec & 255u) > p.thr;
+                            const uint32_t rowi = __umul24(ry, nwpr);
+                            // both bitmap words are requested before either is looked at; a column outside the bitmap is
+                            // clamped to the guard bit (always 0) instead of being branched around
+                            const uint32_t cxp = min(x - cx0, wnear), cxm = MIRROR ? min(cm0 - x, wnear) : 0u;
+                            const uint32_t wp = nearb[rowi + (cxp >> 5)];
+                            const uint32_t wm = MIRROR ? nearb[rowi + (cxm >> 5)] : 0u;
+                            uint32_t prow;  // plane offset of column cx0 in the pixel's row: (ry + 2) * pitch + 2
+                            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(prow) : "v"(ry), "s"(pitch), "v"(poff));  // (one SGPR per VOP3)
+                            {
+                                const bool hit = (((wp >> (cxp & 31u)) & 1u) != 0) & pass;
+                                append(qrec0, qoff0, qt0, __ballot(hit), hit, rec, prow + cxp);
+                                if (qt0 - qh0 >= 64) round(qrec0, qoff0, qh0, qt0, c);
+                            }
+                            if (MIRROR) {
+                                const bool hit = (((wm >> (cxm & 31u)) & 1u) != 0) & pass;
+                                append(qrec1, qoff1, qt1, __ballot(hit), hit, rec, prow + cxm);
+                                if (qt1 - qh1 >= 64) round(qrec1, qoff1, qh1, qt1, c + NS);
+                            }
+                        }
 #pragma unroll
-                    for (int k = 0; k < NS; k++) best = max(best, c[k]);
-                    if (MIRROR) {
-#pragma unroll
-                        for (int k = 0; k < NS; k++) bm = max(bm, c[NS + k]);
+                        for (int j = 0; j < NB; j++) cur[j] = nxt[j];
                     }
-                    int32_t packed = best;
-                    if (MIRROR && bm > best) packed = (int32_t)((uint32_t)bm | 0x80000000u);
-                    if (lane == 0) p.out[t] = packed;
+                    P = Pn, a = an, b = bn;
+                    if (++kin < nsv) continue;  // more strips of this target
+                    kin = 0;
+                    const int64_t t = t0 + r / nsv;
+                    while (qt0 > qh0) round(qrec0, qoff0, qh0, qt0, c);
+                    if (MIRROR)
+                        while (qt1 > qh1) round(qrec1, qoff1, qh1, qt1, c + NS);
+                    if (p.partial) {  // per-transform counts of this slab: lane k holds transform k (the 18-entry layout of the ABI)
+                        int v = 0;
+#pragma unroll
+                        for (int k = 0; k < NS; k++) {
+                            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[k])), "n"(k));
+                            if (MIRROR) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[NS + k])), "n"(9 + k));
+                        }
+                        if (lane < CDS_N_TRANSFORMS) p.partial[((size_t)s * p.count + t) * CDS_N_TRANSFORMS + lane] = v;
+                    } else {
+                        int best = 0, bm = 0;
+#pragma unroll
+                        for (int k = 0; k < NS; k++) best = max(best, c[k]);
+                        if (MIRROR) {
+#pragma unroll
+                            for (int k = 0; k < NS; k++) bm = max(bm, c[NS + k]);
+                        }
+                        int32_t packed = best;
+                        if (MIRROR && bm > best) packed = (int32_t)((uint32_t)bm | 0x80000000u);
+                        if (lane == 0) p.out[t] = packed;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NC; k++) c[k] = 0;
+                    qh0 = qt0 = qh1 = qt1 = 0;
                 }
             }
         }
@@ -361,8 +446,8 @@ __global__ __launch_bounds__(256) void sparse_finalize_kernel(const int32_t *par
 // =================================================================================================
 //                                   host: mask plans
 // =================================================================================================
-static size_t slab_image_bytes(int R, int pitch, int nwpr, int *near_off) {
-    const size_t plane = (size_t)round_up((R + 2 * SP_PAD) * pitch * 2, 16);
+static size_t slab_image_bytes(int R, int pitch, int nwpr, int esize, int *near_off) {
+    const size_t plane = (size_t)round_up((R + 2 * SP_PAD) * pitch * esize, 16);
     if (near_off) *near_off = (int)plane;
     return plane + (size_t)round_up((R + 4) * nwpr * 4, 16);
 }
@@ -416,7 +501,7 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
         }
         pl.xlo = xlo, pl.cols = xhi - xlo + 1, pl.ylo = ylo, pl.nrows = yhi - ylo + 1;
         pl.pitch = round_up(pl.cols + 2 * SP_PAD, 8);
-        pl.nwpr = (pl.cols + 4 + 31) / 32;
+        pl.nwpr = (pl.cols + 4 + 1 + 31) / 32;  // + the guard bit behind the last column
         // distinct interval records of this mask; index 0 = the empty record
         std::unordered_map<Key, uint32_t, KeyHash> dict;
         std::vector<uint4> &tab = iv_of[m];
@@ -438,11 +523,17 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
         }
         pl.n_iv = (int)tab.size();
         pl.iv_in_lds = pl.n_iv <= SP_MAX_IV_LDS;
+        pl.plane8 = pl.n_iv <= 256 && !getenv("CDS_SPARSE_PLANE16");
+        const int esize = pl.plane8 ? 1 : 2;
         const size_t fixed = (pl.iv_in_lds ? (size_t)pl.n_iv * 16 : 0) + (size_t)(threads / 64) * SP_QBYTES;
         auto fits = [&](int R, size_t bud) {
-            return fixed + slab_image_bytes(R, pl.pitch, pl.nwpr, nullptr) <= bud && (R + 2 * SP_PAD) * pl.pitch <= 65535;
+            return fixed + slab_image_bytes(R, pl.pitch, pl.nwpr, esize, nullptr) <= bud && (R + 2 * SP_PAD) * pl.pitch <= 65535;
         };
+        // 80 KB = two workgroups of 1024 threads per CU.  A mask that fits ONE slab when a workgroup takes the whole LDS
+        // (one workgroup per CU, 4 waves per SIMD) but needs several at 80 KB is laid out as one slab: no halo rows read
+        // twice, no partial counts (measured on the benchmark mask: 0.816 vs 0.843 ms per 65,536 targets)
         size_t bud = budget;
+        if (!getenv("CDS_SPARSE_LDS_KB") && !fits(pl.nrows, bud) && fits(pl.nrows, ctx->lds_per_block)) bud = ctx->lds_per_block;
         if (!fits(1, bud)) bud = ctx->lds_per_block;
         if (!fits(1, bud)) {
             pl.n_slabs = -1;
@@ -459,20 +550,21 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
         }
         R = (pl.nrows + pl.n_slabs - 1) / pl.n_slabs;
         pl.slab_rows = R;
-        pl.slab_bytes = (int)slab_image_bytes(R, pl.pitch, pl.nwpr, &pl.near_off);
+        pl.slab_bytes = (int)slab_image_bytes(R, pl.pitch, pl.nwpr, esize, &pl.near_off);
         pl.lds_bytes = fixed + (size_t)pl.slab_bytes;
         std::vector<uint8_t> &slabs = slab_of[m];
         slabs.assign((size_t)pl.n_slabs * pl.slab_bytes, 0);
-        const int prow_n = R + 2 * SP_PAD;
         for (int s = 0; s < pl.n_slabs; s++) {
             uint8_t *img = slabs.data() + (size_t)s * pl.slab_bytes;
-            uint16_t *plane = reinterpret_cast<uint16_t *>(img);
+            uint16_t *plane16 = reinterpret_cast<uint16_t *>(img);
             uint32_t *nearb = reinterpret_cast<uint32_t *>(img + pl.near_off);
             const int ys0 = ylo + s * R;
             for (size_t i = 0; i < L.size(); i++) {
                 const int rr = L[i].y - ys0;
                 if (rr < 0 || rr >= R) continue;
-                plane[(size_t)(rr + SP_PAD) * pl.pitch + (L[i].x - xlo) + SP_PAD] = pidx[i];
+                const size_t cell = (size_t)(rr + SP_PAD) * pl.pitch + (L[i].x - xlo) + SP_PAD;
+                if (pl.plane8) img[cell] = (uint8_t)pidx[i];
+                else plane16[cell] = pidx[i];
                 // the target pixels that reach this mask pixel under some shift: (x + dx, y + dy)
                 for (int dy = xy2 ? -2 : 0; dy <= (xy2 ? 2 : 0); dy += 2)
                     for (int dx = xy2 ? -2 : 0; dx <= (xy2 ? 2 : 0); dx += 2) {
@@ -480,8 +572,7 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
                         nearb[(size_t)ry * pl.nwpr + (cx >> 5)] |= 1u << (cx & 31);
                     }
             }
-            (void)prow_n;
-        }
+                    }
     };
     {
         const unsigned hc = std::thread::hardware_concurrency();
@@ -507,7 +598,7 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
     if (slab_total > 0) {
         e = hipMalloc(&ms->d_sp_slabs, slab_total);
         if (e == hipSuccess) e = hipMalloc(&ms->d_sp_iv, iv_total * sizeof(uint4));
-        if (e == hipSuccess) e = hipMalloc(&ms->d_sp_work, SP_MAX_SLABS * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&ms->d_sp_work, (size_t)SP_MAX_SLABS * SP_MAX_PARTS * 32 * sizeof(uint32_t));
         for (size_t m = 0; m < n_masks && e == hipSuccess; m++) {
             if (slab_of[m].empty()) continue;
             e = hipMemcpy(ms->d_sp_slabs + ms->sp_plans[m].slabs_off, slab_of[m].data(), slab_of[m].size(), hipMemcpyHostToDevice);
@@ -524,7 +615,8 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
 
 template <bool XY2, bool MIRROR>
 static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t lds_bytes, int threads, hipStream_t st) {
-    auto kern = p.iv_in_lds ? sparse_scan_kernel<XY2, MIRROR, true> : sparse_scan_kernel<XY2, MIRROR, false>;
+    auto kern = p.plane8 ? sparse_scan_kernel<XY2, MIRROR, true, true>   // (<= 255 records: the table is in LDS)
+                : p.iv_in_lds ? sparse_scan_kernel<XY2, MIRROR, true, false> : sparse_scan_kernel<XY2, MIRROR, false, false>;
     CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     // persistent grid: as many workgroups as fit (LDS and the 2048 threads of a CU), every one visits every slab
     int per_cu = (int)std::min<size_t>((size_t)(2048 / threads), ctx->lds_per_block / std::max<size_t>(lds_bytes, 1));
@@ -572,8 +664,11 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
     hipStream_t st = ctx->stream;
     std::lock_guard<std::mutex> lk(ms->sp_mu);
     const int threads = sparse_threads();
-    int group = count >= 65536 ? 4 : (count >= 4096 ? 2 : 1);
+    int group = count >= 4096 ? 2 : 1;  // (grabs are cheap since the counters are partitioned; small grabs balance the tail)
     if (const char *e = getenv("CDS_SPARSE_GROUP")) group = std::max(1, atoi(e));
+    group = std::min(group, 64 / sl->nstrips);  // a grab's run headers (targets x visited strips) live in the lanes of one wave
+    int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(SP_MAX_PARTS, count / (64 * (int64_t)group)));
+    if (const char *e = getenv("CDS_SPARSE_PARTS")) nparts = std::max(1, std::min(SP_MAX_PARTS, atoi(e)));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int32_t *partial = nullptr;
     auto cleanup = [&]() {
@@ -613,18 +708,20 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
         SparseScanParams p{};
         p.px = sl->d_px; p.img_off = sl->d_img_off; p.rowptr = sl->d_rowptr;
         p.first = first; p.count = count; p.W = sl->W; p.H = sl->H;
+        p.nstrips = sl->nstrips; p.strip_w = sl->strip_w;
         p.slabs = ms->d_sp_slabs + pl.slabs_off;
         p.iv = ms->d_sp_iv + pl.iv_off;
-        p.n_iv = pl.n_iv; p.iv_in_lds = pl.iv_in_lds ? 1 : 0;
+        p.n_iv = pl.n_iv; p.iv_in_lds = pl.iv_in_lds ? 1 : 0; p.plane8 = pl.plane8 ? 1 : 0;
         p.xlo = pl.xlo; p.cols = pl.cols; p.ylo = pl.ylo; p.nrows = pl.nrows; p.pitch = pl.pitch; p.nwpr = pl.nwpr;
         p.slab_rows = pl.slab_rows; p.n_slabs = pl.n_slabs; p.near_off = pl.near_off; p.slab_bytes = pl.slab_bytes;
         p.thr = std::max(0, ms->params.data_threshold);  // a pixel whose maximum is 0 is black and has no hue class anyway
         p.group = group;
+        p.nparts = nparts;
         p.work = ms->d_sp_work;
         p.out = out;
         const bool use_partial = cnt != nullptr || pl.n_slabs > 1;
         p.partial = use_partial ? partial : nullptr;
-        SP_HIP(hipMemsetAsync(ms->d_sp_work, 0, (size_t)pl.n_slabs * sizeof(uint32_t), st));
+        SP_HIP(hipMemsetAsync(ms->d_sp_work, 0, (size_t)pl.n_slabs * nparts * 32 * sizeof(uint32_t), st));
         rc = launch_sparse(ctx, p, pl.lds_bytes, threads, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
         if (rc) {
             cleanup();
@@ -668,9 +765,18 @@ int cds_sparse_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t ca
     CDS_HIP(hipSetDevice(ctx->device));
     cds_sparse_library *sl = new cds_sparse_library();
     sl->ctx = ctx; sl->W = W; sl->H = H; sl->cap_images = capacity_images; sl->cap_px = capacity_pixels;
+    // up to 4 column strips, each a multiple of 4 pixels and at least 64 wide (a scan reads only the strips its mask's
+    // column window -- and the window's mirror image -- can touch)
+    sl->strip_w = std::max(64, round_up((W + 3) / 4, 4));
+    if (const char *e = getenv("CDS_SPARSE_STRIP_W")) sl->strip_w = std::max(4, round_up(atoi(e), 4));
+    sl->nstrips = (W + sl->strip_w - 1) / sl->strip_w;
+    if (sl->nstrips > 16) {
+        delete sl;
+        return fail(CDS_ERR_INVALID_ARGUMENT, "CDS_SPARSE_STRIP_W is too small for this image width");
+    }
     hipError_t e = hipMalloc(&sl->d_px, (size_t)capacity_pixels * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&sl->d_img_off, (size_t)(capacity_images + 1) * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMalloc(&sl->d_rowptr, (size_t)capacity_images * (H + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&sl->d_rowptr, (size_t)capacity_images * sl->nstrips * (H + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(sl->d_img_off, 0, sizeof(uint64_t), ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -694,6 +800,13 @@ void cds_sparse_library_destroy(cds_sparse_library *sl) {
     if (sl->d_rowptr) hipFree(sl->d_rowptr);
     if (sl->d_tmp) hipFree(sl->d_tmp);
     delete sl;
+}
+
+int cds_sparse_library_layout(const cds_sparse_library *sl, int32_t *n_strips, int32_t *strip_width) {
+    if (!sl) return fail(CDS_ERR_INVALID_ARGUMENT, "sparse library is NULL");
+    if (n_strips) *n_strips = sl->nstrips;
+    if (strip_width) *strip_width = sl->strip_w;
+    return CDS_OK;
 }
 
 int64_t cds_sparse_library_size(const cds_sparse_library *sl) { return sl ? sl->n_images : 0; }
@@ -725,6 +838,7 @@ static int sparse_append_locked(cds_sparse_library *sl, const cds_library *src, 
         BuildParams p{};
         p.rgb = src->d_rgb + (size_t)(first + done) * src->img_stride;
         p.img_stride = src->img_stride; p.pitch = src->pitch; p.W = src->W; p.H = src->H;
+        p.nstrips = sl->nstrips; p.strip_w = sl->strip_w;
         p.count = n; p.dst_first = sl->n_images;
         p.px = sl->d_px; p.img_off = sl->d_img_off; p.rowptr = sl->d_rowptr;
         p.tmp = sl->d_tmp;
@@ -804,7 +918,9 @@ int cds_sparse_library_image_records(const cds_sparse_library *sl, int64_t index
         if (capacity < n) return fail(CDS_ERR_INVALID_ARGUMENT, "record buffer too small");
         CDS_HIP(hipMemcpy(records, sl->d_px + off[0], (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
-    if (row_offsets) CDS_HIP(hipMemcpy(row_offsets, sl->d_rowptr + (size_t)index * (sl->H + 1), (size_t)(sl->H + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (row_offsets)
+        CDS_HIP(hipMemcpy(row_offsets, sl->d_rowptr + (size_t)index * sl->nstrips * (sl->H + 1), (size_t)sl->nstrips * (sl->H + 1) * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost));
     return CDS_OK;
 }
 

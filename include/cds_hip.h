@@ -141,7 +141,7 @@ int cds_is_match(int32_t score, int32_t query_size, double pct_positive_pixels);
  * It replaces the same host-side MIP cache (tools cmd/CachedMIPsUtils.java:60-100) for searches that need the
  * pixel-match score only; the shape scorer keeps reading dense slots + variants.  Results of cds_search_sparse*
  * are identical to cds_search* on the same images (tests/test_sparse_gpu.py).
- * capacity_pixels = total signal-pixel records (+ 1 per image row without signal). */
+ * capacity_pixels = total signal-pixel records (+ 1 per empty (strip, row) cell: at most 4 * H per image). */
 int cds_sparse_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t capacity_images, int64_t capacity_pixels,
                               cds_sparse_library **out);
 void cds_sparse_library_destroy(cds_sparse_library *slib);
@@ -151,11 +151,14 @@ void cds_sparse_library_destroy(cds_sparse_library *slib);
 int cds_sparse_library_append(cds_sparse_library *slib, const cds_library *src, int64_t first, int64_t count);
 /* Append `count` host images (packed RGB, pitch 3*W) through internal dense staging slots. */
 int cds_sparse_library_append_host(cds_sparse_library *slib, int64_t count, const uint8_t *rgb);
+/* Record layout: an image is stored in n_strips column strips of strip_width pixels (the last may be narrower), a strip
+ * row by row, a row by ascending x; a (strip, row) cell without signal pixels holds one filler record. */
+int cds_sparse_library_layout(const cds_sparse_library *slib, int32_t *n_strips, int32_t *strip_width);
 int64_t cds_sparse_library_size(const cds_sparse_library *slib);   /* images held  */
 int64_t cds_sparse_library_pixels(const cds_sparse_library *slib); /* records held */
 int cds_sparse_library_clear(cds_sparse_library *slib);
-/* Diagnostic: the records of one image (bit 31 first of its row | x << 20 | class << 16 | second << 8 | max) and
- * its H+1 row offsets; either output may be NULL; *n_records is always set. */
+/* Diagnostic: the records of one image (bit 31 first of its cell | x << 20 | class << 16 | second << 8 | max) and
+ * its n_strips x (H+1) cell offsets; either output may be NULL; *n_records is always set. */
 int cds_sparse_library_image_records(const cds_sparse_library *slib, int64_t index, uint32_t *records, int64_t capacity,
                                      int64_t *n_records, uint32_t *row_offsets);
 /* The scan over images [first, first+count) of a sparse library: same outputs as cds_search / cds_search_device /

@@ -26,16 +26,18 @@ def sparse_of(cds, images, w=None, h=None, slack=0):
     if images.ndim == 3:
         images = images[None]
     n, hh, ww, _ = images.shape
-    sl = cds.SparseLibrary(ww, hh, n + slack, int((images.max(axis=3) > 0).sum()) + n * hh + 64)
+    sl = cds.SparseLibrary(ww, hh, n + slack, int((images.max(axis=3) > 0).sum()) + 4 * n * hh + 64)
     sl.append(images)
     return sl
 
 
-def records_model(img):
-    """The specification of the record stream (include/cds_hip.h, cds_internal.hpp): per row, x ascending, the pixels with
-    a strict maximum channel as  x << 20 | class << 16 | second << 8 | max,  bit 31 on the first record of a row; a row
-    without such a pixel holds the single filler record 1 << 31."""
+def records_model(img, n_strips=1, strip_w=None):
+    """The specification of the record stream (include/cds_hip.h, cds_internal.hpp): strip by strip (column strips of
+    strip_w pixels), row by row, x ascending, the pixels with a strict maximum channel as
+    x << 20 | class << 16 | second << 8 | max,  bit 31 on the first record of a (strip, row) cell; a cell without such a
+    pixel holds the single filler record 1 << 31."""
     img = img.astype(np.int64)
+    strip_w = strip_w or img.shape[1]
     r, g, b = img[..., 0], img[..., 1], img[..., 2]
     mx = img.max(axis=2)
     md = np.median(img, axis=2).astype(np.int64)
@@ -47,17 +49,20 @@ def records_model(img):
     cls[gmax & ~(b > r)] = 4         # GR
     cls[rmax & (g > b)] = 5          # RG
     cls[rmax & ~(g > b)] = 6         # RB
-    out, rows = [], [0]
-    for y in range(img.shape[0]):
-        xs = np.flatnonzero(cls[y] > 0)
-        if len(xs) == 0:
-            out.append(np.array([1 << 31], dtype=np.int64))
-        else:
-            rec = (xs << 20) | (cls[y, xs] << 16) | (md[y, xs] << 8) | mx[y, xs]
-            rec[0] |= 1 << 31
+    out, offs, pos = [], np.zeros((n_strips, img.shape[0] + 1), dtype=np.uint32), 0
+    for k in range(n_strips):
+        for y in range(img.shape[0]):
+            offs[k, y] = pos
+            xs = np.flatnonzero(cls[y, k * strip_w:(k + 1) * strip_w] > 0) + k * strip_w
+            if len(xs) == 0:
+                rec = np.array([1 << 31], dtype=np.int64)
+            else:
+                rec = (xs << 20) | (cls[y, xs] << 16) | (md[y, xs] << 8) | mx[y, xs]
+                rec[0] |= 1 << 31
             out.append(rec)
-        rows.append(rows[-1] + len(out[-1]))
-    return np.concatenate(out).astype(np.uint32), np.array(rows, dtype=np.uint32)
+            pos += len(rec)
+        offs[k, img.shape[0]] = pos
+    return np.concatenate(out).astype(np.uint32), offs
 
 
 def test_record_stream_matches_its_specification(cds, fixtures, oracle):
@@ -77,7 +82,7 @@ def test_record_stream_matches_its_specification(cds, fixtures, oracle):
     total = 0
     for i, img in enumerate(imgs):
         rec, rows = sl.image_records(i)
-        want_rec, want_rows = records_model(img)
+        want_rec, want_rows = records_model(img, sl.n_strips, sl.strip_width)
         assert np.array_equal(rows, want_rows), i
         assert np.array_equal(rec, want_rec), i
         total += len(rec)
@@ -88,21 +93,24 @@ def test_append_batches_capacity_and_clear(cds, oracle):
     dense = cds.Library(W, H, 6)
     dense.generate_synthetic(0xC0FFEE, 20, 0, 6, kind=0)
     imgs = dense.download(0, 6)
-    n_rec = [len(records_model(im)[0]) for im in imgs]
+    probe = cds.SparseLibrary(W, H, 1, 16)
+    ns, sw = probe.n_strips, probe.strip_width
+    assert (ns, sw) == (4, 304)
+    n_rec = [len(records_model(im, ns, sw)[0]) for im in imgs]
     sl = cds.SparseLibrary(W, H, 6, sum(n_rec[:5]) + 10)
     sl.append_from(dense, 0, 2)
     sl.append(imgs[2:4])
     sl.append_from(dense, 4, 1)
     assert len(sl) == 5 and sl.pixels == sum(n_rec[:5])
     for i in range(5):
-        assert np.array_equal(sl.image_records(i)[0], records_model(imgs[i])[0]), i
+        assert np.array_equal(sl.image_records(i)[0], records_model(imgs[i], ns, sw)[0]), i
     with pytest.raises(cds.CdsError, match="full"):      # record capacity
         sl.append_from(dense, 5, 1)
     assert len(sl) == 5
     sl.clear()
     assert len(sl) == 0 and sl.pixels == 0
     sl.append_from(dense, 3, 3)
-    assert np.array_equal(sl.image_records(2)[0], records_model(imgs[5])[0])
+    assert np.array_equal(sl.image_records(2)[0], records_model(imgs[5], ns, sw)[0])
     with pytest.raises(cds.CdsError):                    # image capacity
         sl.append_from(dense, 0, 4)
     with pytest.raises(ValueError):

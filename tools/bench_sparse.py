@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--kind", type=int, default=0)
     ap.add_argument("--check", type=int, default=1)
+    ap.add_argument("--sweep", default="")
     args = ap.parse_args()
     ctx = cds.Context(0)
     stream = torch.cuda.current_stream()
@@ -34,7 +35,7 @@ def main():
     n, st = args.targets, min(args.stage, args.targets)
     dense = cds.Library(W, H, st, context=ctx)
     per_img = 46000 if args.kind == 0 else W * H + H
-    sl = cds.SparseLibrary(W, H, n, per_img * n if args.kind else 22000 * n + 4_000_000, context=ctx)
+    sl = cds.SparseLibrary(W, H, n, per_img * n if args.kind else 24000 * n + 4_000_000, context=ctx)
     t0 = time.time()
     tg = ta = 0.0
     for first in range(0, n, st):
@@ -64,7 +65,7 @@ def main():
     e1.record(stream)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.reps
-    out = {"targets": n, "masks": args.masks, "kind": args.kind, "records": sl.pixels, "bytes_per_target": 4 * sl.pixels / n + 4 * (H + 1) + 8,
+    out = {"targets": n, "masks": args.masks, "kind": args.kind, "records": sl.pixels, "bytes_per_target": 4 * sl.pixels / n + 4 * sl.n_strips * (H + 1) + 8,
            "build_s": round(build_s, 3), "generate_s": round(tg, 3), "append_s": round(ta, 3),
            "scan_ms": ms, "comparisons_per_s": args.masks * n / (ms * 1e-3),
            "env": {k: v for k, v in os.environ.items() if k.startswith("CDS_SPARSE")}}
@@ -84,6 +85,26 @@ def main():
     print(json.dumps(out))
     if args.check and not out["equals_dense_scan"]:
         raise SystemExit("sparse scan differs from the dense scan")
+    # --sweep "THREADS:LDS_KB:GROUP:WGS,..." : re-time the scan under other layouts (the mask set is rebuilt per entry)
+    for item in [x for x in args.sweep.split(",") if x]:
+        th, kb, grp, wgs = (item.split(":") + ["", "", "", ""])[:4]
+        for k, v in (("CDS_SPARSE_THREADS", th), ("CDS_SPARSE_LDS_KB", kb), ("CDS_SPARSE_GROUP", grp), ("CDS_SPARSE_WGS_PER_CU", wgs)):
+            if v:
+                os.environ[k] = v
+            else:
+                os.environ.pop(k, None)
+        a2 = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects, context=ctx)
+        s2 = torch.empty_like(scores)
+        a2.searchSparseLibraryDevice(sl, 0, n, s2.data_ptr())
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(args.reps):
+            a2.searchSparseLibraryDevice(sl, 0, n, s2.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms2 = e0.elapsed_time(e1) / args.reps
+        print(json.dumps({"sweep": item, "scan_ms": round(ms2, 4), "comparisons_per_s": round(args.masks * n / (ms2 * 1e-3)),
+                          "same": bool(torch.equal(s2, scores))}), flush=True)
 
 
 if __name__ == "__main__":
