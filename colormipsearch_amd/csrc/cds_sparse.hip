@@ -203,8 +203,11 @@ __global__ __launch_bounds__(1024) void sparse_imgscan_kernel(BuildParams p) {
 //                                       the sparse scan
 // =================================================================================================
 // P8: the plane holds one byte per pixel (a mask with at most 255 distinct interval records) instead of two.
-template <bool XY2, bool MIRROR, bool IVLDS, bool P8>
-__global__ __launch_bounds__(1024, 8) void sparse_scan_kernel(SparseScanParams p) {
+// WPE: waves per SIMD the register budget is sized for -- 8 (64 VGPRs) when two workgroups share a CU, 4 (128 VGPRs) when a
+// workgroup's LDS image takes more than half the CU: the latter keeps all nine interval records of a round and the bitmap
+// words of four pixel blocks in flight (a wave's time is its chain of LDS round trips, not instruction issue).
+template <bool XY2, bool MIRROR, bool IVLDS, bool P8, int WPE>
+__global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams p) {
     extern __shared__ uint4 lds4[];
     constexpr int NS = XY2 ? 9 : 1, NSX = XY2 ? 3 : 1, NO = MIRROR ? 2 : 1, NC = NS * NO;
     constexpr int HALO = XY2 ? 2 : 0;
@@ -239,7 +242,18 @@ __global__ __launch_bounds__(1024, 8) void sparse_scan_kernel(SparseScanParams p
         const int ry0 = ys0 - 2;
         const uint32_t cx0 = (uint32_t)(p.xlo - 2), cm0 = (uint32_t)(p.W - 1) - cx0;
         const uint32_t wnear = (uint32_t)(p.cols + 4);  // bit `wnear` of every bitmap row exists and is 0: the clamp target
-        const uint32_t pitch = (uint32_t)p.pitch, nwpr = (uint32_t)p.nwpr, poff = 2u * (uint32_t)p.pitch + 2u;
+        const uint32_t pitch = (uint32_t)p.pitch;
+        // The per-pixel constants live in VGPRs (uniform values, pinned by the asm so that hipcc does not move them back):
+        // the kernel's scalar registers are needed for the 18 counters, the queue state and the loop state, and every
+        // scalar spilled to a VGPR lane comes back as a v_readlane inside the 64-pixel loop.
+        uint32_t v_thr, v_cx0, v_cm0, v_wnear, v_nwpr, v_pitch, poff;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_thr) : "s"(p.thr));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_cx0) : "s"(cx0));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_cm0) : "s"(cm0));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_wnear) : "s"(wnear));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_nwpr) : "s"(p.nwpr));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_pitch) : "s"(p.pitch));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(poff) : "s"(2 * p.pitch + 2));
         // column strips of the library that the mask's plain window [xlo - 2, xhi + 2] and its mirror image can touch
         int wlo = p.xlo - HALO, whi = p.xlo + p.cols - 1 + HALO;
         if (MIRROR) {
@@ -253,15 +267,15 @@ __global__ __launch_bounds__(1024, 8) void sparse_scan_kernel(SparseScanParams p
         // a workgroup starts at its own partition and moves on round-robin when one is exhausted.
         for (int pi = 0; pi < p.nparts; pi++) {
             const int part = (int)((blockIdx.x + (unsigned)pi) % (unsigned)p.nparts);
-            const int64_t pbeg = p.count * part / p.nparts, pend = p.count * (part + 1) / p.nparts;
+            const uint32_t pbeg = (uint32_t)(p.count * part / p.nparts), pend = (uint32_t)(p.count * (part + 1) / p.nparts);  // count < 2^31
             uint32_t *ctr = p.work + ((size_t)s * p.nparts + part) * 32;
             for (;;) {
                 uint32_t tb = 0;
                 if (lane == 0) tb = atomicAdd(ctr, (uint32_t)p.group);
                 tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
-                const int64_t t0 = pbeg + tb;
-                if (t0 >= pend) break;
-                const int ng = (int)min((int64_t)p.group, pend - t0);  // targets of this grab
+                if (tb >= pend - pbeg) break;
+                const uint32_t t0 = pbeg + tb;
+                const int ng = (int)min((uint32_t)p.group, pend - t0);  // targets of this grab
                 // A grab is a sequence of RUNS: (target g, visited strip k) -> one contiguous record range.  The headers of
                 // all runs come in one round trip: lane r holds run r (g = r / nsv, strip ks0 + r % nsv); ng * nsv <= 64.
                 const int nruns = ng * nsv;
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(1024, 8) void sparse_scan_kernel(SparseScanParams p
                 uint32_t h_a = 0, h_b = 0;
                 if (lane < nruns) {
                     const int g = lane / nsv, k = ks0 + lane - g * nsv;
-                    const int64_t ti = p.first + t0 + g;
+                    const int64_t ti = p.first + (int64_t)(t0 + (uint32_t)g);
                     const uint32_t *rp = p.rowptr + ((size_t)ti * p.nstrips + k) * (p.H + 1);
                     h_off = p.img_off[ti];
                     h_a = rp[ra];
@@ -298,10 +312,11 @@ __global__ __launch_bounds__(1024, 8) void sparse_scan_kernel(SparseScanParams p
 #pragma unroll
                 for (int k = 0; k < NC; k++) c[k] = 0;
                 int qh0 = 0, qt0 = 0, qh1 = 0, qt1 = 0;  // queue heads / tails (monotonic, wave-uniform)
+                int ql0 = 64, ql1 = 64;                  // head + 64: a full round is due when the tail reaches it
                 int kin = 0;                             // strip of the current run, relative to ks0
 
                 // evaluate up to 64 queued pixels of one orientation: every lane busy
-                auto round = [&](const uint32_t *qrec, const uint16_t *qoff, int &qh, const int qt, int *cc) {
+                auto round = [&](const uint32_t *qrec, const uint16_t *qoff, int &qh, int &ql, const int qt, int *cc) {
                     const int n = min(qt - qh, 64);
                     __builtin_amdgcn_wave_barrier();
                     const int e = (qh + lane) & (SP_QCAP - 1);
@@ -319,85 +334,106 @@ __global__ __launch_bounds__(1024, 8) void sparse_scan_kernel(SparseScanParams p
 #pragma unroll
                         for (int ix = 0; ix < NSX; ix++) idx[ix * NSX + iy] = rowp[XY2 ? (2 - ix) * 2 : 0];  // mask column = target column - dx
                     }
+                    constexpr int GS = WPE <= 4 ? 9 : 3;  // interval records in flight together
 #pragma unroll
-                    for (int k0 = 0; k0 < NS; k0 += 3) {
-                        uint4 iv[3];
+                    for (int k0 = 0; k0 < NS; k0 += GS) {
+                        uint4 iv[GS];
 #pragma unroll
-                        for (int k = 0; k < 3 && k0 + k < NS; k++) iv[k] = IVLDS ? ivt[idx[k0 + k]] : p.iv[idx[k0 + k]];
+                        for (int k = 0; k < GS && k0 + k < NS; k++) iv[k] = IVLDS ? ivt[idx[k0 + k]] : p.iv[idx[k0 + k]];
 #pragma unroll
-                        for (int k = 0; k < 3 && k0 + k < NS; k++) {
+                        for (int k = 0; k < GS && k0 + k < NS; k++) {
                             // the OR is taken on the wave masks (s_or_b64), not on per-lane booleans
                             const unsigned long long mb = __ballot((code - iv[k].x) <= iv[k].y) | __ballot((code - iv[k].z) <= iv[k].w);
                             cc[k0 + k] += __popcll(mb);
                         }
                     }
                     qh += n;
+                    ql = qh + 64;
                 };
+                // (no wave-uniform test of hb around this: hipcc already skips an all-false `if (hit)` with s_cbranch_execz, and the
+                // scalar unit -- one per CU, shared by the four SIMDs -- is the busier pipe of this kernel: tools/valubench)
                 auto append = [&](uint32_t *qrec, uint16_t *qoff, int &qt, const unsigned long long hb, const bool hit, const uint32_t r,
                                   const uint32_t off) {
-                    if (hb) {  // wave-uniform
+                    if (hit) {
                         const int slot = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0))) & (SP_QCAP - 1);
-                        if (hit) {
-                            qrec[slot] = r;
-                            qoff[slot] = (uint16_t)off;
-                        }
-                        qt += __popcll(hb);
+                        qrec[slot] = r;
+                        qoff[slot] = (uint16_t)off;
                     }
+                    qt += __popcll(hb);
                 };
 
                 for (int r = 0; r < nruns; r++) {  // wave-uniform
-                    const uint32_t *Pn = P;
-                    uint32_t an = 0, bn = 0;
-                    if (r + 1 < nruns) header(r + 1, Pn, an, bn);
                     int yrel = ra - 1 - ry0;  // (rows started before the current block) - 1, relative to the near bitmap
                     for (uint32_t i = a; i < b; i += 64 * NB) {  // wave-uniform
+                        const uint32_t rem = b - i;  // records of this run from block 0 of this iteration on
                         // the next NB blocks -- of this run, or the first ones of the grab's next run -- are in flight while
                         // these are examined (always NB loads, so that the wait for the current blocks is a counted one:
                         // the last iteration of the grab's last run re-reads its own blocks)
                         {
-                            const bool more = i + 64 * NB < b, other = r + 1 < nruns;
-                            const uint32_t *Pq = more ? P : (other ? Pn : P);
-                            const uint32_t iq = more ? i + 64 * NB : (other ? an : i), bq = more ? b : (other ? bn : b);
+                            const uint32_t *Pq = P;
+                            uint32_t iq = i, bq = b;
+                            if (rem > 64 * NB) iq = i + 64 * NB;
+                            else if (r + 1 < nruns) header(r + 1, Pq, iq, bq);  // (read from the header lanes only now: no scalars held)
                             load_blocks(Pq, iq, bq, nxt);
                         }
-#pragma unroll
-                        for (int j = 0; j < NB; j++) {
-                            if (i + 64u * j >= b) break;  // wave-uniform
-                            const uint32_t rec = (i + 64u * j + (uint32_t)lane < b) ? cur[j] : 0u;
-                            const unsigned long long fb = __ballot((int)rec < 0);
-                            const uint32_t ry = (uint32_t)(yrel + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0))) + (rec >> 31);
+                        // phase 1 of a block: row, columns and the two near-bitmap words of its pixels; a column outside the
+                        // bitmap is clamped to the guard bit (always 0) instead of being branched around.  phase 2: queue the hits,
+                        // evaluate a full queue.  With the 128-VGPR budget (WPE 4) phase 1 of all NB blocks comes first, so
+                        // the 2 * NB bitmap words are requested together; with 64 VGPRs the blocks go one at a time.
+                        uint32_t rec[NB], cxp[NB], cxm[NB], wp[NB], wm[NB], prow[NB], passbit[NB];
+                        auto phase1 = [&](int j) {
+                            rec[j] = (64u * j + (uint32_t)lane < rem) ? cur[j] : 0u;  // (a block beyond the run: all zero, no flags, no hits)
+                            const unsigned long long fb = __ballot((int)rec[j] < 0);
+                            const uint32_t ry = (uint32_t)(yrel + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0))) + (rec[j] >> 31);
                             yrel += __popcll(fb);
-                            const uint32_t x = (rec >> kRecXShift) & 2047u;
-                            const bool pass = (int)(rec & 255u) > p.thr;
-                            const uint32_t rowi = __umul24(ry, nwpr);
-                            // both bitmap words are requested before either is looked at; a column outside the bitmap is
-                            // clamped to the guard bit (always 0) instead of being branched around
-                            const uint32_t cxp = min(x - cx0, wnear), cxm = MIRROR ? min(cm0 - x, wnear) : 0u;
-                            const uint32_t wp = nearb[rowi + (cxp >> 5)];
-                            const uint32_t wm = MIRROR ? nearb[rowi + (cxm >> 5)] : 0u;
-                            uint32_t prow;  // plane offset of column cx0 in the pixel's row: (ry + 2) * pitch + 2
-                            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(prow) : "v"(ry), "s"(pitch), "v"(poff));  // (one SGPR per VOP3)
+                            const uint32_t x = (rec[j] >> kRecXShift) & 2047u;
+                            passbit[j] = (rec[j] & 255u) > v_thr ? 1u : 0u;
+                            const uint32_t rowi = __umul24(ry, v_nwpr);
+                            cxp[j] = min(x - v_cx0, v_wnear);
+                            cxm[j] = MIRROR ? min(v_cm0 - x, v_wnear) : 0u;
+                            wp[j] = nearb[rowi + (cxp[j] >> 5)];
+                            wm[j] = MIRROR ? nearb[rowi + (cxm[j] >> 5)] : 0u;
+                            // plane offset of column cx0 in the pixel's row: (ry + 2) * pitch + 2
+                            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(prow[j]) : "v"(ry), "v"(v_pitch), "v"(poff));
+                        };
+                        auto phase2 = [&](int j) {
                             {
-                                const bool hit = (((wp >> (cxp & 31u)) & 1u) != 0) & pass;
-                                append(qrec0, qoff0, qt0, __ballot(hit), hit, rec, prow + cxp);
-                                if (qt0 - qh0 >= 64) round(qrec0, qoff0, qh0, qt0, c);
+                                const bool hit = ((wp[j] >> (cxp[j] & 31u)) & passbit[j]) != 0;  // (one value for the ballot and the branch)
+                                append(qrec0, qoff0, qt0, __ballot(hit), hit, rec[j], prow[j] + cxp[j]);
+                                if (qt0 >= ql0) round(qrec0, qoff0, qh0, ql0, qt0, c);
                             }
                             if (MIRROR) {
-                                const bool hit = (((wm >> (cxm & 31u)) & 1u) != 0) & pass;
-                                append(qrec1, qoff1, qt1, __ballot(hit), hit, rec, prow + cxm);
-                                if (qt1 - qh1 >= 64) round(qrec1, qoff1, qh1, qt1, c + NS);
+                                const bool hit = ((wm[j] >> (cxm[j] & 31u)) & passbit[j]) != 0;
+                                append(qrec1, qoff1, qt1, __ballot(hit), hit, rec[j], prow[j] + cxm[j]);
+                                if (qt1 >= ql1) round(qrec1, qoff1, qh1, ql1, qt1, c + NS);
+                            }
+                        };
+                        if (WPE <= 4) {
+#pragma unroll
+                            for (int j = 0; j < NB; j++) phase1(j);
+#pragma unroll
+                            for (int j = 0; j < NB; j++) {
+                                if (rem <= 64u * j) break;  // wave-uniform
+                                phase2(j);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < NB; j++) {
+                                if (rem <= 64u * j) break;  // wave-uniform
+                                phase1(j);
+                                phase2(j);
                             }
                         }
 #pragma unroll
                         for (int j = 0; j < NB; j++) cur[j] = nxt[j];
                     }
-                    P = Pn, a = an, b = bn;
+                    if (r + 1 < nruns) header(r + 1, P, a, b);
                     if (++kin < nsv) continue;  // more strips of this target
                     kin = 0;
-                    const int64_t t = t0 + r / nsv;
-                    while (qt0 > qh0) round(qrec0, qoff0, qh0, qt0, c);
+                    const uint32_t t = t0 + (uint32_t)(r / nsv);
+                    while (qt0 > qh0) round(qrec0, qoff0, qh0, ql0, qt0, c);
                     if (MIRROR)
-                        while (qt1 > qh1) round(qrec1, qoff1, qh1, qt1, c + NS);
+                        while (qt1 > qh1) round(qrec1, qoff1, qh1, ql1, qt1, c + NS);
                     if (p.partial) {  // per-transform counts of this slab: lane k holds transform k (the 18-entry layout of the ABI)
                         int v = 0;
 #pragma unroll
@@ -421,6 +457,7 @@ __global__ __launch_bounds__(1024, 8) void sparse_scan_kernel(SparseScanParams p
 #pragma unroll
                     for (int k = 0; k < NC; k++) c[k] = 0;
                     qh0 = qt0 = qh1 = qt1 = 0;
+                    ql0 = ql1 = 64;
                 }
             }
         }
@@ -615,8 +652,11 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
 
 template <bool XY2, bool MIRROR>
 static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t lds_bytes, int threads, hipStream_t st) {
-    auto kern = p.plane8 ? sparse_scan_kernel<XY2, MIRROR, true, true>   // (<= 255 records: the table is in LDS)
-                : p.iv_in_lds ? sparse_scan_kernel<XY2, MIRROR, true, false> : sparse_scan_kernel<XY2, MIRROR, false, false>;
+    const bool wide = lds_bytes > ctx->lds_per_block / 2 && !getenv("CDS_SPARSE_WPE8");  // one workgroup per CU: 4 waves per SIMD, 128 VGPRs
+    auto kern = wide ? (p.plane8 ? sparse_scan_kernel<XY2, MIRROR, true, true, 4>   // (<= 255 records: the table is in LDS)
+                        : p.iv_in_lds ? sparse_scan_kernel<XY2, MIRROR, true, false, 4> : sparse_scan_kernel<XY2, MIRROR, false, false, 4>)
+                     : (p.plane8 ? sparse_scan_kernel<XY2, MIRROR, true, true, 8>
+                        : p.iv_in_lds ? sparse_scan_kernel<XY2, MIRROR, true, false, 8> : sparse_scan_kernel<XY2, MIRROR, false, false, 8>);
     CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     // persistent grid: as many workgroups as fit (LDS and the 2048 threads of a CU), every one visits every slab
     int per_cu = (int)std::min<size_t>((size_t)(2048 / threads), ctx->lds_per_block / std::max<size_t>(lds_bytes, 1));

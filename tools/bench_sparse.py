@@ -24,7 +24,8 @@ def main():
     ap.add_argument("--targets", type=int, default=65536)
     ap.add_argument("--stage", type=int, default=16384)
     ap.add_argument("--masks", type=int, default=1)
-    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--kind", type=int, default=0)
     ap.add_argument("--check", type=int, default=1)
     ap.add_argument("--sweep", default="")
@@ -56,7 +57,8 @@ def main():
     rects = cds.label_regions(W)
     alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects, context=ctx)
     scores = torch.empty(args.masks * n, dtype=torch.int32, device="cuda")
-    alg.searchSparseLibraryDevice(sl, 0, n, scores.data_ptr())
+    for _ in range(args.warmup):
+        alg.searchSparseLibraryDevice(sl, 0, n, scores.data_ptr())
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
@@ -95,7 +97,8 @@ def main():
                 os.environ.pop(k, None)
         a2 = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects, context=ctx)
         s2 = torch.empty_like(scores)
-        a2.searchSparseLibraryDevice(sl, 0, n, s2.data_ptr())
+        for _ in range(max(1, args.warmup // 2)):
+            a2.searchSparseLibraryDevice(sl, 0, n, s2.data_ptr())
         torch.cuda.synchronize()
         e0.record(stream)
         for _ in range(args.reps):
