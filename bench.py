@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- mask x target-MIP comparisons/sec of the pixel-match scan on MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1]): 1 mask x 1M synthetic 1210x566 RGB targets, xyShift 2, mirror on,
-production thresholds (maskThreshold 20, dataThreshold 20, pixColorFluctuation 1 -> zTolerance 0.01, label
-regions excluded).  1M full frames are 2.06 TB and do not fit one GPU's 288 GB, so a STEP is one pass of the
-scan kernel over one HBM-resident chunk of `--chunk` targets (default 65,536 = 135 GB; 16 steps = 1,048,576
-comparisons).  The chunk is generated on the device before the timed region (inputs resident in HBM); every
-step re-scans it (135 GB >> 256 MiB Infinity Cache, so no step is served from cache).
+Workload (BASELINE.json configs[1]): 1 mask x 1M synthetic 1210x566 RGB targets, xyShift 2, mirror on, production
+thresholds (maskThreshold 20, dataThreshold 20, pixColorFluctuation 1 -> zTolerance 0.01, label regions excluded).
+The whole library (`--targets`, default 1,048,576 per GPU) is RESIDENT in HBM as a sparse library (signal-pixel records,
+~82 KB per target instead of 2.06 MB of packed RGB: DESIGN.md section 3); it is generated on the device, through dense
+staging slots, before the timed region.  A STEP is one scan of the whole resident library with the benchmark mask =
+`--targets` comparisons per GPU (the library is far larger than the 256 MiB Infinity Cache, so no step is served from cache).
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): the library is sharded by target index, every rank
-scans its own resident chunk (weak scaling), and each step ends with ONE RCCL gather of the per-target score
-array (int32, score | mirrored<<31) to rank 0 -- the only collective on the path.
+Multi-GPU (--gpus N, launched by torch.distributed.run): the library is sharded by target index, every rank scans its own
+resident shard (weak scaling: N x 1M targets = configs[3] at N = 8), and each step ends with ONE RCCL gather of the
+per-target score array (int32, score | mirrored<<31) to rank 0 -- the only collective on the path.
 
-Prints one JSON line (rank 0): the contract fields plus `roofline` (scan kernel, HBM-bound) and
-`cpu_baseline` (the C oracle = restatement of the reference's Java loops, timed on the host cores).
+Prints one JSON line (rank 0): the contract fields plus `roofline`, `cpu_baseline` (the C oracle = restatement of the
+reference's Java loops, timed on the host cores) and `aux` (the same scan over the dense packed-RGB layout; a 128-mask
+batch).  Any disagreement between the GPU paths or with the oracle makes the run fail (value null, exit code 1).
 """
 import argparse
 import json
@@ -48,13 +49,14 @@ def usable_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chunk", type=int, default=65536, help="resident targets per GPU = comparisons per step per GPU")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--targets", type=int, default=1 << 20, help="resident targets per GPU = comparisons per step per GPU")
+    ap.add_argument("--stage", type=int, default=8192, help="dense staging slots used while the library is generated")
     ap.add_argument("--kind", type=int, default=0, help="0 sparse-lut targets (default), 1 dense-uniform")
     ap.add_argument("--cpu-sample", type=int, default=0, help="targets in the cpu_baseline sample (0 = 8000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-aux", action="store_true", help="skip the secondary (batched-mask) measurement")
+    ap.add_argument("--no-aux", action="store_true", help="skip the secondary measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,15 +89,19 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     # ---- inputs, resident in HBM before the timed region ----
-    chunk = args.chunk
-    nbytes = cds.Library.bytes_required(W, H, chunk)
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)     # torch owns the HBM (plumbing)
-    buf.zero_()
-    lib = cds.Library(W, H, chunk, context=ctx, device_buffer=buf)
+    n = args.targets
+    stage_n = min(args.stage, n)
+    dense = cds.Library(W, H, stage_n, context=ctx)             # dense staging slots (packed RGB rows)
+    cap_px = (W * H + 4 * H) * n if args.kind == 1 else 24000 * n + 4_000_000
+    slib = cds.SparseLibrary(W, H, n, cap_px, context=ctx)      # the resident library
     t0 = time.time()
-    lib.generate_synthetic(LIB_SEED, rank * chunk, 0, chunk, kind=args.kind)   # this rank's shard of the library
+    for first in range(0, n, stage_n):                          # this rank's shard: library indices rank*n + [0, n)
+        c = min(stage_n, n - first)
+        dense.generate_synthetic(LIB_SEED, rank * n + first, 0, c, kind=args.kind)
+        slib.append_from(dense, 0, c)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
+    lib_bytes = 4 * slib.pixels + n * (4 * slib.n_strips * (H + 1) + 8)
     mlib = cds.Library(W, H, 1, context=ctx)
     mlib.generate_synthetic(MASK_SEED, 0, 0, 1, kind=2)
     mask = mlib.download(0, 1)[0]
@@ -106,16 +112,13 @@ def main():
     rows = min(H, int(ys.max() - ys.min() + 1) + 2 * XY_SHIFT)
     alg_bytes_per_target = rows * 3 * W          # R x 3630 B
 
-    scores = torch.empty(chunk, dtype=torch.int32, device=dev)
-    gathered = [torch.empty(chunk, dtype=torch.int32, device=dev) for _ in range(world)] if (use_dist and rank == 0) else None
-
-    def step():
-        alg.searchLibraryDevice(lib, 0, chunk, scores.data_ptr())
-        if use_dist:
-            dist.gather(scores, gathered, dst=0)
+    scores = torch.empty(n, dtype=torch.int32, device=dev)
+    gathered = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(world)] if (use_dist and rank == 0) else None
 
     for _ in range(args.warmup):
-        step()
+        alg.searchSparseLibraryDevice(slib, 0, n, scores.data_ptr())
+        if use_dist:
+            dist.gather(scores, gathered, dst=0)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     if use_dist:
@@ -124,7 +127,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record(stream)
-        alg.searchLibraryDevice(lib, 0, chunk, scores.data_ptr())
+        alg.searchSparseLibraryDevice(slib, 0, n, scores.data_ptr())
         ev[k][1].record(stream)
         if use_dist:
             dist.gather(scores, gathered, dst=0)
@@ -137,22 +140,23 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # scan kernel only (one launch per step)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # the scan of one step (one kernel launch), on the launch stream
 
     host_scores = scores.cpu().numpy()
     sc, mir = host_scores & 0x7FFFFFFF, (host_scores >> 31) & 1
+    failed = []
 
     out = None
     if rank == 0:
-        total = world * chunk * args.steps
-        achieved = alg_bytes_per_target * chunk / (kern_ms * 1e-3) / 1e9
+        total = world * n * args.steps
+        achieved = alg_bytes_per_target * n / (kern_ms * 1e-3) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")   # PMC-derived HBM bytes per launch, if collected
+        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")   # PMC-derived HBM bytes per target of the sparse scan, if collected
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("chunk") == chunk and tj.get("kind") == args.kind:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("kind") == args.kind and tj.get("layout") == "sparse":
+                    traffic = tj.get("hbm_bytes_per_target") * n
             except Exception:
                 traffic = None
         out = {
@@ -170,19 +174,22 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "1 mask x 1M synthetic 1210x566 RGB targets, xyShift=2, mirror on (BASELINE configs[1]); "
-                            f"step = scan of one HBM-resident chunk of {chunk} targets per GPU",
-                "targets_per_step_per_gpu": chunk,
+                            f"step = scan of the whole HBM-resident library of {n} targets per GPU (sparse layout)",
+                "targets_per_step_per_gpu": n,
+                "library_layout": "sparse (signal-pixel records, 4 column strips)",
+                "library_bytes_per_gpu": lib_bytes,
+                "library_bytes_per_target": round(lib_bytes / n, 1),
                 "target_kind": "sparse-lut" if args.kind == 0 else "dense-uniform",
                 "mask_pixels": P,
                 "mask_rows_touched": rows,
                 "params": {"maskThreshold": MASK_THR, "dataThreshold": DATA_THR, "zTolerance": ZTOL, "xyShift": XY_SHIFT, "mirror": MIRROR},
                 "parallelism": f"target-shard x{world}" + (", 1 RCCL gather of int32 scores per step" if world > 1 else ""),
                 "library_generation_s": round(gen_s, 3),
-                "nonzero_scores_in_chunk": int((sc > 0).sum()),
+                "nonzero_scores": int((sc > 0).sum()),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "cds::scan_kernel<xy2,mirror,single-mask>",
+                "kernel": "cds::sparse_scan_kernel<xy2,mirror>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -190,10 +197,11 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_target": alg_bytes_per_target,
                 "kernel_ms_per_launch": kern_ms,
-                # the kernel fetches only the column window of each row, so real traffic < algorithmic bytes
                 "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
-                "note": "achieved = algorithmic bytes (mask rows x 3630 B per target, SURVEY 8d) / kernel time; the kernel "
-                        "fetches only the mask's column window of those rows, so the PMC traffic is lower and frac may exceed 1",
+                "note": "achieved = SURVEY 8(d) algorithmic bytes (mask rows x 3630 B of packed RGB per target) / kernel time.  "
+                        "The library is stored sparse, so the kernel reads ~40x fewer bytes than that (traffic) and frac exceeds 1: "
+                        "this kernel is bound by its waves' LDS round trips and by instruction issue, not by HBM (DESIGN.md "
+                        "section 4b); the HBM-streaming variant of the same scan is under aux.dense_layout.",
             },
         }
 
@@ -201,10 +209,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cds_oracle as O
         cores = usable_cores()
-        # bounded sample: the first n_s targets of the chunk (16.4 GB of host memory at 8000), scanned repeatedly until
-        # ~1 s of wall time = ~cores x 1 s of CPU work has been measured
-        n_s = min(args.cpu_sample or 8000, chunk)   # 80 partitions of 100
-        sample = lib.download(0, n_s)
+        # bounded sample: the first n_s targets of the library as dense images (16.4 GB of host memory at 8000), scanned
+        # repeatedly until ~1 s of wall time = ~cores x 1 s of CPU work has been measured
+        n_s = min(args.cpu_sample or 8000, n, stage_n)   # 80 partitions of 100
+        dense.generate_synthetic(LIB_SEED, 0, 0, n_s, kind=args.kind)
+        sample = dense.download(0, n_s)
         q = O.PixelMatchQuery(mask, MASK_THR, DATA_THR, ZTOL, XY_SHIFT, MIRROR, rects)
         q.scan(sample[: min(64, n_s)], n_threads=cores, partition=4)   # warm the thread pool / page in
         passes, dt = 0, 0.0
@@ -228,40 +237,79 @@ def main():
             "unit": "comparisons/s",
             "cores": cores,
             "kind": "port",
-            "sample": f"first {n_s} targets of the same chunk, same mask and parameters, C oracle (-O2, f64 predicate, "
-                      f"18 gather passes per pair) on {cores} threads of {cpu_model}, target partitions of 100: {passes} passes of "
-                      f"{dt:.2f} s wall = {passes * dt * cores:.0f} core-seconds; scores equal to the GPU's: {ok}",
+            "sample": f"first {n_s} targets of the same library (as dense images), same mask and parameters, C oracle (-O2, f64 "
+                      f"predicate, 18 gather passes per pair) on {cores} threads of {cpu_model}, target partitions of 100: {passes} "
+                      f"passes of {dt:.2f} s wall = {passes * dt * cores:.0f} core-seconds; scores equal to the GPU's: {ok}",
             "single_thread_value": n1 / dt1,
         }
         if not ok:
             out["cpu_baseline"]["parity_failure"] = True
-    # ---- secondary measurement (not `value`): BASELINE configs[2] in miniature -- 128 masks share one pass over the first
-    # 16,384 resident targets (the production shape: many masks against one library)
-    if rank == 0 and world == 1 and not args.no_aux and chunk >= 16384:
-        n_m, n_t = 128, 16384
+            failed.append("GPU scores differ from the CPU oracle's on the sampled targets")
+        del sample
+
+    # ---- secondary measurements (not `value`) ----
+    if rank == 0 and world == 1 and not args.no_aux:
+        aux = {}
+        # (a) the same scan over the DENSE layout (packed RGB rows streamed from HBM, cds::scan_kernel): the first stage_n targets
+        n_d = stage_n
+        dense.generate_synthetic(LIB_SEED, 0, 0, n_d, kind=args.kind)
+        dsc = torch.empty(n_d, dtype=torch.int32, device=dev)
+        for _ in range(2):
+            alg.searchLibraryDevice(dense, 0, n_d, dsc.data_ptr())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(5):
+            alg.searchLibraryDevice(dense, 0, n_d, dsc.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        dms = e0.elapsed_time(e1) / 5
+        same_d = bool(torch.equal(dsc, scores[:n_d]))
+        d_ach = alg_bytes_per_target * n_d / (dms * 1e-3) / 1e9
+        aux["dense_layout"] = {"workload": f"1 mask x {n_d} targets resident as packed RGB rows (2,064,768 B each)", "kernel": "cds::scan_kernel<xy2,mirror,single-mask>",
+                               "comparisons_per_s": n_d / (dms * 1e-3), "ms_per_pass": dms,
+                               "roofline": {"bound": "hbm", "achieved": d_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d_ach / HBM_PEAK_GBS,
+                                            "algorithmic_bytes_per_target": alg_bytes_per_target},
+                               "scores_equal_sparse_scan": same_d}
+        if not same_d:
+            failed.append("dense-layout scan disagrees with the sparse scan")
+        # (b) BASELINE configs[2] in miniature: 128 masks against the first 65,536 resident targets (one launch per mask over
+        # the sparse library); and the dense batch kernel (128 masks share one pass over dense rows) over 16,384 / stage_n
+        n_m, n_t = 128, min(65536, n)
         mlib2 = cds.Library(W, H, n_m, context=ctx)
         mlib2.generate_synthetic(MASK_SEED, 0, 0, n_m, kind=2)
         batch = cds.PixelMatchColorDepthSearchAlgorithm(mlib2.download(0, n_m), MASK_THR, MIRROR, None, 0, False, DATA_THR, ZTOL,
                                                         XY_SHIFT, rects, context=ctx)
         bscores = torch.empty(n_m * n_t, dtype=torch.int32, device=dev)
-        batch.searchLibraryDevice(lib, 0, n_t, bscores.data_ptr())
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        batch.searchSparseLibraryDevice(slib, 0, n_t, bscores.data_ptr())
         e0.record(stream)
         for _ in range(2):
-            batch.searchLibraryDevice(lib, 0, n_t, bscores.data_ptr())
+            batch.searchSparseLibraryDevice(slib, 0, n_t, bscores.data_ptr())
         e1.record(stream)
         torch.cuda.synchronize()
         bms = e0.elapsed_time(e1) / 2
-        same = bool(torch.equal(bscores[:n_t], scores[:n_t]))   # mask 0 of the batch is the benchmark mask
-        out["aux"] = {"workload": f"{n_m} masks x {n_t} resident targets in one batched pass (BASELINE configs[2] shape)",
-                      "comparisons_per_s": n_m * n_t / (bms * 1e-3), "ms_per_pass": bms,
-                      "mask0_scores_equal_single_mask_scan": same}
-    failed = []
+        same_b = bool(torch.equal(bscores[:n_t], scores[:n_t]))   # mask 0 of the batch is the benchmark mask
+        n_t2 = min(16384, n_d)
+        b2 = torch.empty(n_m * n_t2, dtype=torch.int32, device=dev)
+        batch.searchLibraryDevice(dense, 0, n_t2, b2.data_ptr())
+        e0.record(stream)
+        for _ in range(2):
+            batch.searchLibraryDevice(dense, 0, n_t2, b2.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        b2ms = e0.elapsed_time(e1) / 2
+        same_b2 = bool(torch.equal(b2.view(n_m, n_t2), bscores.view(n_m, n_t)[:, :n_t2]))
+        aux["mask_batch"] = {"workload": f"{n_m} masks x {n_t} resident targets (BASELINE configs[2] shape), sparse layout, one launch per mask",
+                             "comparisons_per_s": n_m * n_t / (bms * 1e-3), "ms_per_pass": bms,
+                             "mask0_scores_equal_single_mask_scan": same_b,
+                             "dense_batch_kernel": {"workload": f"{n_m} masks x {n_t2} dense targets in one batched pass",
+                                                    "comparisons_per_s": n_m * n_t2 / (b2ms * 1e-3), "ms_per_pass": b2ms,
+                                                    "scores_equal_sparse_scan": same_b2}}
+        if not same_b:
+            failed.append("mask-batch scan disagrees with the single-mask scan")
+        if not same_b2:
+            failed.append("dense batch kernel disagrees with the sparse scan")
+        out["aux"] = aux
     if rank == 0:
-        if out.get("cpu_baseline", {}).get("parity_failure"):
-            failed.append("GPU scores differ from the CPU oracle's on the sampled targets")
-        if out.get("aux", {}).get("mask0_scores_equal_single_mask_scan") is False:
-            failed.append("batched-mask scan disagrees with the single-mask scan")
         if failed:
             out["value"] = None     # a wrong result is not a measurement
             out["parity_failure"] = failed
