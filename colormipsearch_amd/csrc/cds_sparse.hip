@@ -40,7 +40,7 @@
 namespace cds {
 
 constexpr int SP_QCAP = 128;                          // queue entries per wave and orientation (appends <= 64, drained at >= 64)
-constexpr int SP_QBYTES = 2 * (SP_QCAP * 4 + SP_QCAP * 2);  // two queues of (u32 record, u16 plane offset)
+constexpr int SP_QBYTES = 2 * SP_QCAP * 8;            // two queues of (u32 record, u32 plane offset): one 8-byte LDS access per entry
 constexpr int SP_MAX_IV_LDS = 2048;                   // interval records kept in LDS (32 KB); larger tables are read from L2
 constexpr int SP_MAX_SLABS = 256;
 constexpr int SP_MAX_PARTS = 64;                      // work counters per slab (one per partition of the targets, 128 B apart)
@@ -221,8 +221,7 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
     const plane_t *plane = reinterpret_cast<const plane_t *>(slab);
     const uint32_t *nearb = reinterpret_cast<const uint32_t *>(slab + p.near_off);
     uint8_t *qb = slab + p.slab_bytes + (size_t)wave * SP_QBYTES;
-    uint32_t *qrec0 = reinterpret_cast<uint32_t *>(qb), *qrec1 = qrec0 + SP_QCAP;
-    uint16_t *qoff0 = reinterpret_cast<uint16_t *>(qrec1 + SP_QCAP), *qoff1 = qoff0 + SP_QCAP;
+    uint2 *q0 = reinterpret_cast<uint2 *>(qb), *q1 = q0 + SP_QCAP;
     if (IVLDS)
         for (int i = threadIdx.x; i < p.n_iv; i += blockDim.x) ivt[i] = p.iv[i];
     const int safe_off = SP_PAD * p.pitch + SP_PAD;  // an in-range plane offset for idle lanes
@@ -316,13 +315,13 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                 int kin = 0;                             // strip of the current run, relative to ks0
 
                 // evaluate up to 64 queued pixels of one orientation: every lane busy
-                auto round = [&](const uint32_t *qrec, const uint16_t *qoff, int &qh, int &ql, const int qt, int *cc) {
+                auto round = [&](const uint2 *q, int &qh, int &ql, const int qt, int *cc) {
                     const int n = min(qt - qh, 64);
                     __builtin_amdgcn_wave_barrier();
-                    const int e = (qh + lane) & (SP_QCAP - 1);
                     const bool valid = lane < n;
-                    const uint32_t r = qrec[e];
-                    const int off = valid ? (int)qoff[e] : safe_off;
+                    const uint2 ent = q[(qh + lane) & (SP_QCAP - 1)];
+                    const uint32_t r = ent.x;
+                    const int off = valid ? (int)ent.y : safe_off;
                     const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
                     uint32_t code = (((r >> kRecClsShift) & 7u) << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
                     code = valid ? code : 0u;  // 0 lies in no interval
@@ -352,12 +351,10 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                 };
                 // (no wave-uniform test of hb around this: hipcc already skips an all-false `if (hit)` with s_cbranch_execz, and the
                 // scalar unit -- one per CU, shared by the four SIMDs -- is the busier pipe of this kernel: tools/valubench)
-                auto append = [&](uint32_t *qrec, uint16_t *qoff, int &qt, const unsigned long long hb, const bool hit, const uint32_t r,
-                                  const uint32_t off) {
+                auto append = [&](uint2 *q, int &qt, const unsigned long long hb, const bool hit, const uint32_t r, const uint32_t off) {
                     if (hit) {
                         const int slot = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0))) & (SP_QCAP - 1);
-                        qrec[slot] = r;
-                        qoff[slot] = (uint16_t)off;
+                        q[slot] = make_uint2(r, off);
                     }
                     qt += __popcll(hb);
                 };
@@ -399,13 +396,13 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                         auto phase2 = [&](int j) {
                             {
                                 const bool hit = ((wp[j] >> (cxp[j] & 31u)) & passbit[j]) != 0;  // (one value for the ballot and the branch)
-                                append(qrec0, qoff0, qt0, __ballot(hit), hit, rec[j], prow[j] + cxp[j]);
-                                if (qt0 >= ql0) round(qrec0, qoff0, qh0, ql0, qt0, c);
+                                append(q0, qt0, __ballot(hit), hit, rec[j], prow[j] + cxp[j]);
+                                if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
                             }
                             if (MIRROR) {
                                 const bool hit = ((wm[j] >> (cxm[j] & 31u)) & passbit[j]) != 0;
-                                append(qrec1, qoff1, qt1, __ballot(hit), hit, rec[j], prow[j] + cxm[j]);
-                                if (qt1 >= ql1) round(qrec1, qoff1, qh1, ql1, qt1, c + NS);
+                                append(q1, qt1, __ballot(hit), hit, rec[j], prow[j] + cxm[j]);
+                                if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
                             }
                         };
                         if (WPE <= 4) {
@@ -431,9 +428,9 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                     if (++kin < nsv) continue;  // more strips of this target
                     kin = 0;
                     const uint32_t t = t0 + (uint32_t)(r / nsv);
-                    while (qt0 > qh0) round(qrec0, qoff0, qh0, ql0, qt0, c);
+                    while (qt0 > qh0) round(q0, qh0, ql0, qt0, c);
                     if (MIRROR)
-                        while (qt1 > qh1) round(qrec1, qoff1, qh1, ql1, qt1, c + NS);
+                        while (qt1 > qh1) round(q1, qh1, ql1, qt1, c + NS);
                     if (p.partial) {  // per-transform counts of this slab: lane k holds transform k (the 18-entry layout of the ABI)
                         int v = 0;
 #pragma unroll
@@ -564,7 +561,7 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
         const int esize = pl.plane8 ? 1 : 2;
         const size_t fixed = (pl.iv_in_lds ? (size_t)pl.n_iv * 16 : 0) + (size_t)(threads / 64) * SP_QBYTES;
         auto fits = [&](int R, size_t bud) {
-            return fixed + slab_image_bytes(R, pl.pitch, pl.nwpr, esize, nullptr) <= bud && (R + 2 * SP_PAD) * pl.pitch <= 65535;
+            return fixed + slab_image_bytes(R, pl.pitch, pl.nwpr, esize, nullptr) <= bud;
         };
         // 80 KB = two workgroups of 1024 threads per CU.  A mask that fits ONE slab when a workgroup takes the whole LDS
         // (one workgroup per CU, 4 waves per SIMD) but needs several at 80 KB is laid out as one slab: no halo rows read
