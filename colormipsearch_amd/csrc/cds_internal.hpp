@@ -180,6 +180,7 @@ struct SparseScanParams {
     int thr;
     int group;                // targets a wave takes per grab
     int nparts;               // partitions of the targets, each with its own work counter
+    uint32_t psize;           // targets per partition (the last one may hold fewer)
     uint32_t *work;           // [n_slabs][nparts] x 32 dwords: next target of the partition (zero before the launch)
     int32_t *out;             // [count] score | mirrored << 31 (written directly when there is one slab and no partial)
     int32_t *partial;         // [n_slabs][count][18] per-transform counts of every slab, or NULL

@@ -266,8 +266,11 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
         // a workgroup starts at its own partition and moves on round-robin when one is exhausted.
         for (int pi = 0; pi < p.nparts; pi++) {
             const int part = (int)((blockIdx.x + (unsigned)pi) % (unsigned)p.nparts);
-            const uint32_t pbeg = (uint32_t)(p.count * part / p.nparts), pend = (uint32_t)(p.count * (part + 1) / p.nparts);  // count < 2^31
+            const uint32_t pbeg = (uint32_t)part * p.psize, pend = min(pbeg + p.psize, (uint32_t)p.count);  // count < 2^31
+            if (pbeg >= pend) continue;
             uint32_t *ctr = p.work + ((size_t)s * p.nparts + part) * 32;
+            // (a partition other workgroups have already drained is recognised by a plain read: no atomic round trip)
+            if (pi > 0 && __builtin_nontemporal_load(ctr) >= pend - pbeg) continue;
             for (;;) {
                 uint32_t tb = 0;
                 if (lane == 0) tb = atomicAdd(ctr, (uint32_t)p.group);
@@ -341,7 +344,9 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                         for (int k = 0; k < GS && k0 + k < NS; k++) iv[k] = IVLDS ? ivt[idx[k0 + k]] : p.iv[idx[k0 + k]];
 #pragma unroll
                         for (int k = 0; k < GS && k0 + k < NS; k++) {
-                            // the OR is taken on the wave masks (s_or_b64), not on per-lane booleans
+                            // the OR is taken on the wave masks (s_or_b64), not on per-lane booleans.  (Counting in per-lane VGPR
+                            // counters -- v_addc of the compare, one DPP sum per target -- was measured slower: 138 vs 146 M
+                            // comparisons/s; the vector pipe is the tighter one.)
                             const unsigned long long mb = __ballot((code - iv[k].x) <= iv[k].y) | __ballot((code - iv[k].z) <= iv[k].w);
                             cc[k0 + k] += __popcll(mb);
                         }
@@ -704,7 +709,7 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
     int group = count >= 4096 ? 2 : 1;  // (grabs are cheap since the counters are partitioned; small grabs balance the tail)
     if (const char *e = getenv("CDS_SPARSE_GROUP")) group = std::max(1, atoi(e));
     group = std::min(group, 64 / sl->nstrips);  // a grab's run headers (targets x visited strips) live in the lanes of one wave
-    int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(SP_MAX_PARTS, count / (64 * (int64_t)group)));
+    int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(SP_MAX_PARTS, count / 2048));
     if (const char *e = getenv("CDS_SPARSE_PARTS")) nparts = std::max(1, std::min(SP_MAX_PARTS, atoi(e)));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int32_t *partial = nullptr;
@@ -754,6 +759,7 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
         p.thr = std::max(0, ms->params.data_threshold);  // a pixel whose maximum is 0 is black and has no hue class anyway
         p.group = group;
         p.nparts = nparts;
+        p.psize = (uint32_t)((count + nparts - 1) / nparts);
         p.work = ms->d_sp_work;
         p.out = out;
         const bool use_partial = cnt != nullptr || pl.n_slabs > 1;
