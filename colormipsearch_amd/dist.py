@@ -68,9 +68,11 @@ def sharded_search(local_scan, n_masks, n_total, device, group=None, dst=0):
 
 
 class ShardedLibrary:
-    """This rank's shard of an n_total-target library, resident in its GPU's HBM (cds.Library over torch memory)."""
+    """This rank's shard of an n_total-target library, resident in its GPU's HBM: dense slots (cds.Library over torch
+    memory) or, with sparse=True, a cds.SparseLibrary (signal-pixel records; pixel-match scan only) filled through
+    `stage` dense staging slots."""
 
-    def __init__(self, width, height, n_total, context=None, group=None):
+    def __init__(self, width, height, n_total, context=None, group=None, sparse=False, records_per_target=24000, stage=1024):
         from . import cds
         self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
@@ -78,9 +80,15 @@ class ShardedLibrary:
         self.begin, self.end = shard_range(self.n_total, self.rank, self.world)
         self.ctx = context or cds.default_context()
         self.device = torch.device("cuda", self.ctx.device)
+        self.sparse = bool(sparse)
         n_local = max(1, self.end - self.begin)
-        self._buf = torch.zeros(cds.Library.bytes_required(width, height, n_local), dtype=torch.uint8, device=self.device)
-        self.library = cds.Library(width, height, n_local, context=self.ctx, device_buffer=self._buf)
+        n_dense = min(n_local, int(stage)) if self.sparse else n_local
+        self._buf = torch.zeros(cds.Library.bytes_required(width, height, n_dense), dtype=torch.uint8, device=self.device)
+        self.library = cds.Library(width, height, n_dense, context=self.ctx, device_buffer=self._buf)   # dense slots / staging
+        self.sparse_library = None
+        if self.sparse:
+            self.sparse_library = cds.SparseLibrary(width, height, n_local, int(records_per_target) * n_local + 4 * height * n_local,
+                                                    context=self.ctx)
 
     @property
     def n_local(self):
@@ -88,15 +96,35 @@ class ShardedLibrary:
 
     def generate_synthetic(self, seed, kind=0, with_variants=False):
         """Every rank regenerates its own index range of the same global stream."""
-        if self.n_local:
+        if not self.n_local:
+            return
+        if not self.sparse:
             self.library.generate_synthetic(seed, self.begin, 0, self.n_local, kind=kind, with_variants=with_variants)
+            return
+        self.sparse_library.clear()
+        for first in range(0, self.n_local, self.library.capacity):
+            c = min(self.library.capacity, self.n_local - first)
+            self.library.generate_synthetic(seed, self.begin + first, 0, c, kind=kind)
+            self.sparse_library.append_from(self.library, 0, c)
+
+    def upload(self, images):
+        """This rank's shard from host images uint8[n_local, H, W, 3]."""
+        if self.sparse:
+            self.sparse_library.clear()
+            self.sparse_library.append(images)
+        else:
+            self.library.upload(0, images)
 
     def search(self, algorithm, dst=0):
         """All masks of `algorithm` x the whole sharded library: gathered packed scores on rank dst."""
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
         def local_scan(out):
-            if self.n_local:
+            if not self.n_local:
+                return
+            if self.sparse:
+                algorithm.searchSparseLibraryDevice(self.sparse_library, 0, self.n_local, out.data_ptr())
+            else:
                 algorithm.searchLibraryDevice(self.library, 0, self.n_local, out.data_ptr())
 
         return sharded_search(local_scan, algorithm.n_masks, self.n_total, self.device, group=self.group, dst=dst)

@@ -51,15 +51,45 @@ class CDMatch:
         return cds.calculate2DShapeScore(self.gradientAreaGap, self.highExpressionArea) if self.hasGradScore() else -1
 
 
+def java_string_hash(s: str) -> int:
+    """java.lang.String.hashCode: s[0]*31^(n-1) + ... + s[n-1] over UTF-16 code units, as a signed 32-bit int."""
+    h = 0
+    b = s.encode("utf-16-be")
+    for i in range(0, len(b), 2):
+        h = (31 * h + ((b[i] << 8) | b[i + 1])) & 0xFFFFFFFF
+    return h
+
+
+def java_hashmap_order(keys: Sequence[str]) -> List[int]:
+    """Iteration order of a java.util.HashMap<String, ?> into which the DISTINCT `keys` were put in this order: the
+    permutation of range(len(keys)) that entrySet() yields.  Collectors.groupingBy collects into a HashMap
+    (ItemsHandling.java:86-96), and the stable sort that follows (:97-103) leaves groups of equal score in this order --
+    so it decides which of several tied lines / samples survive a topResults cut.
+    Model: hash = h ^ (h >>> 16), bucket = hash & (capacity - 1); capacity 16, doubled while size > 0.75 * capacity;
+    a bucket keeps insertion order (resize splits preserve it).  Not modelled: a bucket that Java turns into a tree
+    (>= 8 colliding keys at capacity >= 64) iterates with the tree root first."""
+    n = len(keys)
+    cap = 16
+    while n > (cap * 3) // 4:
+        cap *= 2
+    def bucket(k):
+        h = java_string_hash(k)
+        return (h ^ (h >> 16)) & (cap - 1)
+    return sorted(range(n), key=lambda i: (bucket(keys[i]), i))
+
+
 def selectTopRankedElements(items: Sequence, groupingCriteria, scoreExtractor, topResults: int, limitSubResults: int):
     """ItemsHandling.selectTopRankedElements (API/results/ItemsHandling.java:80-109): group, sort each group by
-    descending score (stable), optionally cut each group, rank the groups by their best score (stable), cut."""
+    descending score (stable), optionally cut each group, rank the groups by their best score (stable over the
+    HashMap's iteration order, see java_hashmap_order), cut."""
     groups = {}
     for it in items:
         key = groupingCriteria(it)
         if key is None or str(key).strip() == "":
             key = "UNKNOWN"
-        groups.setdefault(key, []).append(it)
+        groups.setdefault(str(key), []).append(it)
+    names = list(groups)
+    groups = {names[i]: groups[names[i]] for i in java_hashmap_order(names)}
     ranked = []
     for key, lst in groups.items():
         lst = sorted(lst, key=lambda v: -float(scoreExtractor(v)))
@@ -116,22 +146,27 @@ class MatchTable:
 
 
 def _group_codes(names):
-    """Integer code per item for a grouping attribute; blank / missing -> "UNKNOWN" (ItemsHandling.java:84-88)."""
+    """(integer code per item, key string per code) for a grouping attribute; blank / missing -> "UNKNOWN"
+    (ItemsHandling.java:84-88)."""
     keys = np.array(["UNKNOWN" if (n is None or str(n).strip() == "") else str(n) for n in names], dtype=object)
-    _, codes = np.unique(keys, return_inverse=True)
-    return codes.astype(np.int64)
+    uniq, codes = np.unique(keys, return_inverse=True)
+    return codes.astype(np.int64), [str(k) for k in uniq]
 
 
-def _top_ranked(idx, group, score, top_results, limit_sub_results):
+def _top_ranked(idx, group, score, top_results, limit_sub_results, group_keys):
     """Vectorised selectTopRankedElements over the items `idx` (their order = the input order): returns the kept items, groups
-    ranked by their best score (descending, ties in first-occurrence order), items inside a group by descending score (ties
-    in input order) -- exactly the order the list version produces."""
+    ranked by their best score (descending, ties in the reference's HashMap iteration order: java_hashmap_order), items
+    inside a group by descending score (ties in input order) -- exactly the order the list version produces."""
     if len(idx) == 0:
         return idx
     g, sc = group[idx], score[idx].astype(np.float64)
     first = np.full(g.max() + 1, len(idx), dtype=np.int64)
-    np.minimum.at(first, g, np.arange(len(idx)))                      # first occurrence of each group (dict insertion order)
-    order = np.lexsort((np.arange(len(idx)), -sc, first[g]))         # by group (insertion order), then score desc, stable
+    np.minimum.at(first, g, np.arange(len(idx)))                      # first occurrence of each group = insertion into the map
+    present = np.flatnonzero(first < len(idx))
+    present = present[np.argsort(first[present], kind="stable")]      # the distinct groups in insertion order
+    hm = java_hashmap_order([group_keys[c] for c in present])
+    first[present[np.asarray(hm, dtype=np.int64)]] = np.arange(len(present))   # first[] now = position in the map's iteration
+    order = np.lexsort((np.arange(len(idx)), -sc, first[g]))         # by group (map order), then score desc, stable
     g_sorted = g[order]
     starts = np.flatnonzero(np.r_[True, g_sorted[1:] != g_sorted[:-1]])
     rank_in_group = np.arange(len(idx)) - np.repeat(starts, np.diff(np.r_[starts, len(idx)]))
@@ -149,21 +184,40 @@ def _top_ranked(idx, group, score, top_results, limit_sub_results):
 
 
 class GpuColorMIPSearchProcessor:
-    """masks: uint8[n_masks,H,W,3]; the targets live in a `cds.Library` (+ `targets` metadata, one NeuronInfo per slot)."""
+    """masks: uint8[n_masks,H,W,3]; the targets live in a `cds.Library` (+ `targets` metadata, one NeuronInfo per slot).
+
+    With `sparse_library` (a `cds.SparseLibrary` holding targets first..first+count-1 as signal-pixel records) the
+    pixel-match scan runs over it -- the layout a production-size library is resident in -- and the dense `library` only
+    has to hold the targets the shape scorer is asked about (with their gradient / zgap variants): `dense_slots[t]` = the
+    dense slot of target t, default first + t.  This is the reference's own split: every target is scanned
+    (colorDepthSearch), a few hundred per mask are loaded again with their variants (CalculateGradientScoresCmd)."""
 
     def __init__(self, colorMIPSearch: cds.ColorMIPSearch, library: cds.Library, targets: Optional[List[NeuronInfo]] = None,
-                 first=0, count=None):
+                 first=0, count=None, sparse_library=None, dense_slots=None):
         self.colorMIPSearch = colorMIPSearch
         self.library = library
+        self.sparse_library = sparse_library
         self.first = int(first)
-        self.count = library.capacity - self.first if count is None else int(count)
+        if count is None:
+            count = (len(sparse_library) if sparse_library is not None else library.capacity) - self.first
+        self.count = int(count)
+        self.dense_slots = None if dense_slots is None else np.asarray(dense_slots, dtype=np.int64)
         self.targets = targets or [NeuronInfo(str(i), f"line{i}", f"sample{i}") for i in range(self.count)]
         assert len(self.targets) == self.count
+
+    def _scan(self, alg):
+        if self.sparse_library is not None:
+            return alg.searchSparseLibrary(self.sparse_library, self.first, self.count)
+        return alg.searchLibrary(self.library, self.first, self.count)
+
+    def _slots(self, target_index):
+        t = np.asarray(target_index, dtype=np.int64)
+        return (self.first + t) if self.dense_slots is None else self.dense_slots[t]
 
     # ---- colorDepthSearch -------------------------------------------------------------------------
     def findAllColorDepthMatches(self, masks) -> List[CDMatch]:
         alg = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold(masks)
-        scores, mirrored = alg.searchLibrary(self.library, self.first, self.count)
+        scores, mirrored = self._scan(alg)
         sizes = alg.getQuerySizes()
         out = []
         for m in range(alg.n_masks):
@@ -178,7 +232,7 @@ class GpuColorMIPSearchProcessor:
     def findAllColorDepthMatchesTable(self, masks) -> MatchTable:
         """findAllColorDepthMatches in columnar form (same rows, same order)."""
         alg = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold(masks)
-        scores, mirrored = alg.searchLibrary(self.library, self.first, self.count)
+        scores, mirrored = self._scan(alg)
         sizes = np.asarray(alg.getQuerySizes())
         mi, ti, sc, ra, mr = [], [], [], [], []
         for m in range(alg.n_masks):
@@ -192,18 +246,19 @@ class GpuColorMIPSearchProcessor:
 
     def selectBestMatchesTable(self, table: MatchTable, topLineMatches, topSamplesPerLine, topMatchesPerSample) -> MatchTable:
         """selectBestMatches in columnar form: per mask top lines -> top samples per line -> top matches per sample."""
-        lines = _group_codes([t.publishedName for t in self.targets])[table.targetIndex]
-        samples = _group_codes([t.neuronId for t in self.targets])[table.targetIndex]
+        lcode, lkeys = _group_codes([t.publishedName for t in self.targets])
+        scode, skeys = _group_codes([t.neuronId for t in self.targets])
+        lines, samples = lcode[table.targetIndex], scode[table.targetIndex]
         score = table.matchingPixels
         out = []
         for m in np.unique(table.maskIndex):                     # ascending mask order, as the list version
             idx = np.flatnonzero(table.maskIndex == m)
-            kept_lines = _top_ranked(idx, lines, score, topLineMatches, -1)
+            kept_lines = _top_ranked(idx, lines, score, topLineMatches, -1, lkeys)
             # per kept line (in rank order) the sample ranking
             lcodes = lines[kept_lines]
             bounds = np.flatnonzero(np.r_[True, lcodes[1:] != lcodes[:-1]])
             for a, b in zip(bounds, np.r_[bounds[1:], len(kept_lines)]):
-                out.append(_top_ranked(kept_lines[a:b], samples, score, topSamplesPerLine, topMatchesPerSample))
+                out.append(_top_ranked(kept_lines[a:b], samples, score, topSamplesPerLine, topMatchesPerSample, skeys))
         return table.take(np.concatenate(out) if out else np.zeros(0, dtype=np.int64))
 
     def calculateGradientScoresTable(self, masks, table: MatchTable, queryThreshold, mirrorMask=True, roiMask=None,
@@ -217,7 +272,7 @@ class GpuColorMIPSearchProcessor:
             return table
         alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, queryThreshold, mirrorMask, roiMask, excludedRegions,
                                                         context=self.library.ctx)
-        gap, high, _ = alg.scoreLibraryPairs(self.library, table.maskIndex.astype(np.int32), (self.first + table.targetIndex).astype(np.int64))
+        gap, high, _ = alg.scoreLibraryPairs(self.library, table.maskIndex.astype(np.int32), self._slots(table.targetIndex))
         table.gradientAreaGap[:] = gap
         table.highExpressionArea[:] = high
         grad = table.gradScores()
@@ -254,7 +309,7 @@ class GpuColorMIPSearchProcessor:
         alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, queryThreshold, mirrorMask, roiMask, excludedRegions,
                                                         context=self.library.ctx)
         pm = np.array([mt.maskIndex for mt in matches], dtype=np.int32)
-        ps = np.array([self.first + mt.targetIndex for mt in matches], dtype=np.int64)
+        ps = self._slots([mt.targetIndex for mt in matches])
         gap, high, mir = alg.scoreLibraryPairs(self.library, pm, ps)
         for mt, g, h in zip(matches, gap, high):
             # "only set the scores that were actually calculated" (CalculateGradientScoresCmd.java:564-570); the

@@ -35,6 +35,13 @@ def test_sharded_library_search_single_rank(oracle):
             ws, wm = oracle.PixelMatchQuery(masks[m], 20, 20, 0.01, 2, True, rects).scan(targets, n_threads=8)
             assert np.array_equal(scores[m], ws) and np.array_equal(mirrored[m], wm.astype(bool))
         assert scores.max() > 0
+        # the same shard as a sparse resident library, generated through 10 staging slots (3 batches): identical gather
+        sshard = cdist.ShardedLibrary(W, H, n, context=shard.ctx, sparse=True, records_per_target=W * H, stage=10)
+        sshard.generate_synthetic(0xC0FFEE, kind=1)
+        assert len(sshard.sparse_library) == n
+        packed2 = sshard.search(alg)
+        torch.cuda.synchronize()
+        assert torch.equal(packed2, packed)
     finally:
         shard.ctx.reset_stream()
         dist.destroy_process_group()

@@ -67,8 +67,35 @@ def test_vectorised_ranking_equals_list_version():
         top, lim = int(rng.integers(-1, 5)), int(rng.integers(-1, 4))
         ref = P.selectTopRankedElements(list(range(n)), lambda i: f"g{groups[i]}", lambda i: scores[i], top, lim)
         want = [i for _, _, items in ref for i in items]
-        got = P._top_ranked(np.arange(n), groups.astype(np.int64), scores, top, lim).tolist()
+        got = P._top_ranked(np.arange(n), groups.astype(np.int64), scores, top, lim, [f"g{k}" for k in range(6)]).tolist()
         assert got == want, (trial, n, top, lim)
+
+
+def test_tied_groups_follow_java_hashmap_order():
+    """Groups of equal best score keep the iteration order of the HashMap that Collectors.groupingBy builds
+    (ItemsHandling.java:86-103): bucket = (h ^ h >>> 16) & (capacity - 1) of String.hashCode, insertion order inside a bucket."""
+    assert P.java_string_hash("Aa") == P.java_string_hash("BB") == 2112          # the classic colliding pair
+    assert P.java_string_hash("line7") == 102977219 and P.java_string_hash("") == 0
+    assert P.java_string_hash("R_\u00e9") == ((ord("R") * 31 + ord("_")) * 31 + 0xE9)   # UTF-16 code units
+    # "a", "b", "c" hash to buckets 1, 2, 3 of the 16-bucket table whatever the insertion order; "q" (113) shares bucket 1
+    # with "a" (97) and keeps its insertion position relative to it; "Aa" / "BB" collide completely
+    assert P.java_hashmap_order(["c", "b", "a"]) == [2, 1, 0]
+    assert P.java_hashmap_order(["q", "c", "a"]) == [0, 2, 1]
+    assert P.java_hashmap_order(["BB", "Aa"]) == [0, 1] and P.java_hashmap_order(["Aa", "BB"]) == [0, 1]
+    # 13 keys make the table grow to 32 buckets: "g16".."g28" spread differently than in 16
+    keys = [f"g{i}" for i in range(16, 29)]
+    def bucket32(k):
+        h = P.java_string_hash(k)
+        return (h ^ (h >> 16)) & 31
+    assert P.java_hashmap_order(keys) == sorted(range(13), key=lambda i: (bucket32(keys[i]), i))
+    # tied lines at a topResults cut: the survivors are the first in HashMap order, not the first seen
+    names = ["c", "b", "a", "c", "b", "a"]
+    items = list(range(6))
+    ranked = P.selectTopRankedElements(items, lambda i: names[i], lambda i: 5, 2, -1)
+    assert [k for k, _, _ in ranked] == ["a", "b"]
+    codes, keys = P._group_codes(names)
+    got = P._top_ranked(np.arange(6), codes, np.full(6, 5), 2, -1, keys).tolist()
+    assert got == [2, 5, 1, 4]
 
 
 @pytest.mark.gpu
@@ -127,3 +154,18 @@ def test_pipeline_equals_oracle_pipeline(oracle):
     assert [key(a)[:5] for a in best_t.to_matches()] == [key(b)[:5] for b in best]
     scored_t = proc.calculateGradientScoresTable(masks, best_t, 20, True, None, cds.label_regions)
     assert [key(a) for a in scored_t.to_matches()] == [key(b) for b in scored]
+    # production split: the scan over a sparse resident library, the shape scorer over dense slots that hold only the
+    # selected targets (in another order) with their variants
+    slib = cds.SparseLibrary(W, H, n_t, 40000 * n_t)
+    slib.append_from(lib)
+    chosen = sorted({mt.targetIndex for mt in best})[::-1]
+    small = cds.Library(W, H, len(chosen))
+    small.upload(0, targets[chosen])
+    small.upload_variants(0, grads[chosen], zgaps[chosen])
+    slot_of = np.full(n_t, -1, dtype=np.int64)
+    slot_of[chosen] = np.arange(len(chosen))
+    proc2 = P.GpuColorMIPSearchProcessor(search, small, infos, sparse_library=slib, dense_slots=slot_of)
+    matches2 = proc2.findAllColorDepthMatches(masks)
+    assert [key(a)[:5] for a in matches2] == [key(b)[:5] for b in matches]
+    scored2 = proc2.calculateGradientScores(masks, proc2.selectBestMatches(matches2, 3, 2, 1), 20, True, None, cds.label_regions)
+    assert [key(a) for a in scored2] == [key(b) for b in scored]
