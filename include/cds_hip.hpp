@@ -88,6 +88,25 @@ private:
     int64_t cap_;
 };
 
+// Resident shard of targets kept as signal-pixel records (pixel-match scan only): ~4 % of the dense bytes.
+class SparseLibrary {
+public:
+    SparseLibrary(Context &ctx, int width, int height, int64_t capacityImages, int64_t capacityPixels) {
+        check(cds_sparse_library_create(ctx.handle(), width, height, capacityImages, capacityPixels, &lib_));
+    }
+    ~SparseLibrary() { cds_sparse_library_destroy(lib_); }
+    SparseLibrary(const SparseLibrary &) = delete;
+    SparseLibrary &operator=(const SparseLibrary &) = delete;
+    cds_sparse_library *handle() const { return lib_; }
+    int64_t size() const { return cds_sparse_library_size(lib_); }
+    int64_t pixels() const { return cds_sparse_library_pixels(lib_); }
+    void appendFrom(const Library &dense, int64_t first, int64_t count) { check(cds_sparse_library_append(lib_, dense.handle(), first, count)); }
+    void append(int64_t count, const uint8_t *rgb) { check(cds_sparse_library_append_host(lib_, count, rgb)); }
+    void clear() { check(cds_sparse_library_clear(lib_)); }
+private:
+    cds_sparse_library *lib_ = nullptr;
+};
+
 struct ColorDepthMatchScore {  // API/cds/ColorDepthMatchScore.java:5-22
     virtual ~ColorDepthMatchScore() = default;
     virtual int getScore() const = 0;
@@ -158,6 +177,11 @@ public:
         scores.assign((size_t)count, 0);
         mirrored.assign((size_t)count, 0);
         check(cds_search(ms_, lib.handle(), first, count, scores.data(), mirrored.data()));
+    }
+    void searchLibrary(const SparseLibrary &lib, int64_t first, int64_t count, std::vector<int32_t> &scores, std::vector<uint8_t> &mirrored) const {
+        scores.assign((size_t)count, 0);
+        mirrored.assign((size_t)count, 0);
+        check(cds_search_sparse(ms_, lib.handle(), first, count, scores.data(), mirrored.data()));
     }
 private:
     ImageArray query_;

@@ -35,6 +35,15 @@ int main() {
         pm->searchLibrary(lib, 0, 4, scores, mirrored);
         if (scores[0] != self.getScore() || scores[3] != mir.getScore() || !mirrored[3] || mirrored[0]) return 4;
 
+        // the same four targets as a sparse resident library: identical scores
+        cds::SparseLibrary slib(ctx, W, H, 4, (int64_t)4 * W * H);
+        slib.appendFrom(lib, 0, 3);
+        slib.append(1, flipped.rgb.data());
+        std::vector<int32_t> s2;
+        std::vector<uint8_t> m2;
+        pm->searchLibrary(slib, 0, 4, s2, m2);
+        if (slib.size() != 4 || s2 != scores || m2 != mirrored) return 7;
+
         cds::ColorMIPSearch search(1.0, 20, std::move(provider));
         if (!search.isMatch(self)) return 5;
 
