@@ -491,6 +491,143 @@ int refresh_zslice(cds_library *lib, int64_t first, int64_t count) {
 
 using namespace cds;
 
+// ---------------------------------------------------------------------------------------------
+// Shape-mask preparation on the device (ColorDepthSearchAlgorithmProviderFactory.java:91-125).
+// Q = clearRegion(mask); QM = gray(Q) > 2; S(q) = slice number; QH = (maxFilter20(Q) is black) && gray(maxFilter60(Q)) > 0.
+// The two max filters are never materialised: "D20 black" <=> no pixel with a non-zero channel inside the r=20 kernel, and
+// gray_nogamma(D60) > 0 <=> mr + mg + mb >= 2 for the channel maxima over the r=60 kernel ((int)(s/3. + 0.5) > 0 <=> s >= 2,
+// checked for s = 1, 2 in the reference's double arithmetic: 0.8333 -> 0, 1.1667 -> 1) <=> some channel reaches 2, or two
+// channels reach 1.  So seven binary dilations by ImageJ's kernel (rows dy = -k..k with half-widths hw[dy]) suffice, and a
+// dilation is "some row of the kernel has a set pixel within hw[dy] of x" = a lookup of that row's horizontal-distance map.
+// ---------------------------------------------------------------------------------------------
+struct PrepParams {
+    const uint8_t *masks;  // [n][H][3W]
+    const uint8_t *roi;    // [H][W] or NULL
+    int W, H, wp, n, mirror, nrects;
+    cds_rect rects[CDS_MAX_RECTS];
+    int k60, k20;
+    const int *hw60, *hw20;
+    uint8_t *flags;        // [n][H][W]  bit c: channel c >= 1, bit 3+c: channel c >= 2, bit 6: any channel >= 1  (of Q)
+    uint8_t *hd;           // [n][7][H][W] horizontal distance to the nearest pixel with that flag in the same row, 255 = none within 62
+    uint16_t *planes;      // [n][2][H][wp]
+    int *acc;              // [n][16]: 0 ya 1 yb 2 gx0 3 gx1 4 hx0 5 hx1 (min / max accumulators), 8.. bbox of Q: bx0 by0 bx1 by1
+    uint32_t *rowflags;    // [n][H]
+    unsigned long long *sums;  // [n][2] sum QM, sum QH
+    const uint8_t *slice_lut;
+};
+constexpr int kHdMax = 62;  // distances beyond the largest half-width (61) are all the same
+
+__global__ __launch_bounds__(256) void prep_flags_kernel(PrepParams p) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, m = blockIdx.z;
+    if (x >= p.W) return;
+    const uint8_t *s = p.masks + ((size_t)m * p.H + y) * 3 * p.W + 3 * x;
+    int r = s[0], g = s[1], b = s[2];
+    if (dev_in_rects(p.rects, p.nrects, x, y)) r = g = b = 0;
+    const int f = (r >= 1) | (g >= 1) << 1 | (b >= 1) << 2 | (r >= 2) << 3 | (g >= 2) << 4 | (b >= 2) << 5 | ((r | g | b) != 0) << 6;
+    p.flags[((size_t)m * p.H + y) * p.W + x] = (uint8_t)f;
+    if (f) {
+        int *a = p.acc + (size_t)m * 16;
+        atomicMin(a + 8, x); atomicMin(a + 9, y); atomicMax(a + 10, x + 1); atomicMax(a + 11, y + 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void prep_hdist_kernel(PrepParams p) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, m = blockIdx.z;
+    if (x >= p.W) return;
+    const int *a = p.acc + (size_t)m * 16;
+    uint8_t *out = p.hd + (((size_t)m * 7) * p.H + y) * p.W + x;
+    const size_t pstride = (size_t)p.H * p.W;
+    int dist[7];
+#pragma unroll
+    for (int q = 0; q < 7; q++) dist[q] = 255;
+    if (y >= a[9] && y < a[11] && x >= a[8] - kHdMax && x < a[10] + kHdMax) {  // rows / columns without signal keep 255
+        const uint8_t *row = p.flags + ((size_t)m * p.H + y) * p.W;
+        int found = 0;
+        for (int d = 0; d < kHdMax && found != 0x7f; d++) {
+            const int xl = x - d, xr = x + d;
+            const int f = (xl >= 0 ? row[xl] : 0) | (xr < p.W ? row[xr] : 0);
+            const int nf = f & ~found;
+            if (nf) {
+#pragma unroll
+                for (int q = 0; q < 7; q++)
+                    if ((nf >> q) & 1) dist[q] = d;
+                found |= nf;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 7; q++) out[(size_t)q * pstride] = (uint8_t)dist[q];
+}
+
+// rgbToGrayNoGammaCorrection(pv, 255) -- ColorTransformation.java:40-54 (doubles, no contraction: -ffp-contract=off)
+__device__ __forceinline__ int dev_gray_nogamma(int r, int g, int b) {
+    if ((r | g | b) == 0) return 0;
+    const double w = 1 / 3.;
+    double s = r * w;
+    s = s + g * w;
+    s = s + b * w;
+    s = s + 0.5;
+    return (int)((255.f / 255) * s);
+}
+
+__global__ __launch_bounds__(256) void prep_plane_kernel(PrepParams p) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, m = blockIdx.z;
+    if (x >= p.W) return;
+    int *a = p.acc + (size_t)m * 16;
+    const int bx0 = a[8], by0 = a[9], bx1 = a[10], by1 = a[11];
+    const uint8_t *s = p.masks + ((size_t)m * p.H + y) * 3 * p.W + 3 * x;
+    int r = s[0], g = s[1], b = s[2];
+    if (dev_in_rects(p.rects, p.nrects, x, y)) r = g = b = 0;
+    const int qm = dev_gray_nogamma(r, g, b) > 2;                                   // Factory:108
+    int qh = 0;
+    if (bx1 > bx0 && x >= bx0 - p.k60 && x < bx1 + p.k60 && y >= by0 - p.k60 && y < by1 + p.k60) {
+        const uint8_t *hd = p.hd + ((size_t)m * 7) * p.H * p.W + x;
+        const size_t pstride = (size_t)p.H * p.W;
+        bool d20black = true;                                                        // Factory:101-106
+        for (int dy = -p.k20; dy <= p.k20 && d20black; dy++) {
+            const int yy = y + dy;
+            if (yy < by0 || yy >= by1) continue;
+            if (hd[6 * pstride + (size_t)yy * p.W] <= p.hw20[dy + p.k20]) d20black = false;
+        }
+        if (d20black) {
+            int got = 0;  // bit q: flag q occurs inside the r = 60 kernel
+            for (int dy = -p.k60; dy <= p.k60 && !((got & 0x38) != 0 || __popc(got & 7) >= 2); dy++) {
+                const int yy = y + dy;
+                if (yy < by0 || yy >= by1) continue;
+                const int h = p.hw60[dy + p.k60];
+                const uint8_t *q = hd + (size_t)yy * p.W;
+#pragma unroll
+                for (int c = 0; c < 6; c++) got |= (q[c * pstride] <= h) << c;
+            }
+            qh = (got & 0x38) != 0 || __popc(got & 7) >= 2;
+        }
+    }
+    const int sq = (r | g | b) ? dev_slice(p.slice_lut, r, g, b, -1) : 0;
+    const uint16_t v = (uint16_t)(sq | (qm ? kPlaneQM : 0) | (qh ? kPlaneQH : 0));
+    // sums over the whole frame, before the ROI (Shape2DMatch...Test.java:53-54 checks them on the un-mirrored, un-masked images)
+    const unsigned long long bm = __ballot(qm), bh = __ballot(qh);
+    if ((threadIdx.x & 63) == 0) {
+        if (bm) atomicAdd(p.sums + 2 * m, (unsigned long long)__popcll(bm));
+        if (bh) atomicAdd(p.sums + 2 * m + 1, (unsigned long long)__popcll(bh));
+    }
+    if (!v) return;
+    // identity orientation: value at x; mirrored orientation: the same value seen at W-1-x; the ROI (cleared in the excluded
+    // regions, Factory:96-100) is applied after mirroring
+    uint16_t *p0 = p.planes + ((size_t)m * 2) * p.H * p.wp, *p1 = p0 + (size_t)p.H * p.wp;
+    uint32_t *rfl = p.rowflags + (size_t)m * p.H;
+    auto put = [&](uint16_t *pl, int xx) {
+        if (p.roi && (p.roi[(size_t)y * p.W + xx] == 0 || dev_in_rects(p.rects, p.nrects, xx, y))) return;
+        pl[(size_t)y * p.wp + xx] = v;
+        atomicMin(a + 0, y); atomicMax(a + 1, y + 1);
+        uint32_t fl = 0;
+        if (v & (kPlaneS | kPlaneQM)) { atomicMin(a + 2, xx); atomicMax(a + 3, xx + 1); fl |= 1; }
+        if (v & kPlaneQH) { atomicMin(a + 4, xx); atomicMax(a + 5, xx + 1); fl |= 2; }
+        atomicOr(rfl + y, fl);
+    };
+    put(p0, x);
+    if (p.mirror) put(p1, p.W - 1 - x);
+}
+
 struct cds_shapeset {
     cds_context *ctx = nullptr;
     int W = 0, H = 0, wp = 0, n_masks = 0, thr = 0, mirror = 0, nrects = 0;
@@ -576,71 +713,95 @@ int cds_shapeset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_
     if (rc) return rc;
     const size_t N = (size_t)W * H;
     const int wp = round_up(W, 4);
-    std::vector<uint8_t> Q(3 * N), d60(3 * N), d20(3 * N);
-    std::vector<uint16_t> planes((size_t)n_masks * 2 * H * wp, 0);
-    std::vector<int> boxes((size_t)n_masks * 8, 0);
-    std::vector<uint8_t> rowflags((size_t)n_masks * H, 0);
     cds_shapeset *ss = new cds_shapeset();
     ss->ctx = ctx; ss->W = W; ss->H = H; ss->wp = wp; ss->n_masks = n_masks; ss->thr = query_threshold; ss->mirror = mirror != 0;
     ss->nrects = n_excluded;
     for (int i = 0; i < n_excluded; i++) ss->rects[i] = excluded[i];
     ss->qm_sum.assign((size_t)n_masks, 0);
     ss->qh_sum.assign((size_t)n_masks, 0);
-    for (int m = 0; m < n_masks; m++) {
-        const uint8_t *img = masks_rgb + (size_t)m * 3 * N;
-        // Q = clearRegion(mask)  (Factory:92,100)
-        for (int y = 0; y < H; y++)
-            for (int x = 0; x < W; x++) {
-                size_t i = 3 * ((size_t)y * W + x);
-                bool ex = in_rects_host(excluded, n_excluded, x, y);
-                Q[i] = ex ? 0 : img[i]; Q[i + 1] = ex ? 0 : img[i + 1]; Q[i + 2] = ex ? 0 : img[i + 2];
-            }
-        // unsafeMaxFilter(60) / (20) of Q on the GPU  (Factory:102-104)
-        rc = max_filter_host(ctx, Q.data(), W, H, 60, -1, nullptr, 0, d60.data());
-        if (rc == CDS_OK) rc = max_filter_host(ctx, Q.data(), W, H, 20, -1, nullptr, 0, d20.data());
-        if (rc) { delete ss; return rc; }
-        uint16_t *p0 = planes.data() + (size_t)m * 2 * H * wp, *p1 = p0 + (size_t)H * wp;
-        int ya = H, yb = 0, gx0 = W, gx1 = 0, hx0 = W, hx1 = 0;
-        uint8_t *rfl = rowflags.data() + (size_t)m * H;
-        auto mark = [&](int x, int y, uint16_t v) {
-            ya = std::min(ya, y); yb = std::max(yb, y + 1);
-            if (v & (kPlaneS | kPlaneQM)) { gx0 = std::min(gx0, x); gx1 = std::max(gx1, x + 1); rfl[y] |= 1; }
-            if (v & kPlaneQH) { hx0 = std::min(hx0, x); hx1 = std::max(hx1, x + 1); rfl[y] |= 2; }
-        };
-        for (int y = 0; y < H; y++)
-            for (int x = 0; x < W; x++) {
-                size_t i = (size_t)y * W + x;
-                int r = Q[3 * i], g = Q[3 * i + 1], b = Q[3 * i + 2];
-                int qm = gray_nogamma(r, g, b) > 2;                                   // Factory:108
-                int p2black = (d20[3 * i] | d20[3 * i + 1] | d20[3 * i + 2]) == 0;
-                int qh = p2black ? (gray_nogamma(d60[3 * i], d60[3 * i + 1], d60[3 * i + 2]) > 0) : 0;  // Factory:101-106
-                ss->qm_sum[(size_t)m] += qm;
-                ss->qh_sum[(size_t)m] += qh;
-                uint16_t v = (uint16_t)(host_slice_number(r, g, b) | (qm ? kPlaneQM : 0) | (qh ? kPlaneQH : 0));
-                if (!v) continue;
-                // identity orientation: value at x; mirrored orientation: the same value seen at W-1-x;
-                // the ROI (already cleared in the excluded regions, Factory:96-100) is applied after mirroring
-                const int xm = W - 1 - x;
-                auto roi_in = [&](int xx) { return !roi || (roi[(size_t)y * W + xx] != 0 && !in_rects_host(excluded, n_excluded, xx, y)); };
-                if (roi_in(x)) { p0[(size_t)y * wp + x] = v; mark(x, y, v); }
-                if (mirror && roi_in(xm)) { p1[(size_t)y * wp + xm] = v; mark(xm, y, v); }
-            }
-        if (yb <= ya) ya = yb = 0;
-        if (gx1 <= gx0) gx0 = gx1 = 0;
-        if (hx1 <= hx0) hx0 = hx1 = 0;
-        if (hx1 == 0 && gx1 > 0) { hx0 = gx0; hx1 = gx0; }   // empty QH window inside the gap window
-        if (gx1 == 0 && hx1 > 0) { gx0 = hx0; gx1 = hx0; }
-        int *bxm = boxes.data() + (size_t)8 * m;
-        bxm[0] = ya; bxm[1] = yb; bxm[2] = gx0; bxm[3] = gx1; bxm[4] = hx0; bxm[5] = hx1;
+    CDS_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<int> hw60, hw20;
+    const int k60 = line_radii(60, hw60), k20 = line_radii(20, hw20);
+    if (k60 >= kHdMax) { delete ss; return fail(CDS_ERR_UNSUPPORTED, "max-filter radius beyond the distance maps"); }
+    const int batch = std::min(n_masks, 32);   // masks prepared per round of launches (5.5 MB of scratch each)
+    uint8_t *d_masks = nullptr, *d_roi = nullptr, *d_flags = nullptr, *d_hd = nullptr;
+    int *d_hw = nullptr, *d_acc = nullptr;
+    uint32_t *d_rfl = nullptr;
+    unsigned long long *d_sums = nullptr;
+    auto cleanup = [&]() {
+        for (void *q : {(void *)d_masks, (void *)d_roi, (void *)d_flags, (void *)d_hd, (void *)d_hw, (void *)d_acc, (void *)d_rfl, (void *)d_sums})
+            if (q) hipFree(q);
+    };
+#define SP_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); cds_shapeset_destroy(ss); return hip_fail(_e, #call); } } while (0)
+    SP_HIP(hipMalloc(&ss->d_planes, (size_t)n_masks * 2 * H * wp * sizeof(uint16_t)));
+    SP_HIP(hipMalloc(&ss->d_boxes, (size_t)n_masks * 8 * sizeof(int)));
+    SP_HIP(hipMalloc(&ss->d_rowflags, (size_t)n_masks * H));
+    SP_HIP(hipMemsetAsync(ss->d_planes, 0, (size_t)n_masks * 2 * H * wp * sizeof(uint16_t), st));
+    SP_HIP(hipMalloc(&d_masks, (size_t)batch * 3 * N));
+    SP_HIP(hipMalloc(&d_flags, (size_t)batch * N));
+    SP_HIP(hipMalloc(&d_hd, (size_t)batch * 7 * N));
+    SP_HIP(hipMalloc(&d_hw, (hw60.size() + hw20.size()) * sizeof(int)));
+    SP_HIP(hipMalloc(&d_acc, (size_t)batch * 16 * sizeof(int)));
+    SP_HIP(hipMalloc(&d_rfl, (size_t)batch * H * sizeof(uint32_t)));
+    SP_HIP(hipMalloc(&d_sums, (size_t)batch * 2 * sizeof(unsigned long long)));
+    SP_HIP(hipMemcpyAsync(d_hw, hw60.data(), hw60.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    SP_HIP(hipMemcpyAsync(d_hw + hw60.size(), hw20.data(), hw20.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    if (roi) {
+        SP_HIP(hipMalloc(&d_roi, N));
+        SP_HIP(hipMemcpyAsync(d_roi, roi, N, hipMemcpyHostToDevice, st));
     }
-    hipSetDevice(ctx->device);
-    hipError_t e = hipMalloc(&ss->d_planes, planes.size() * 2);
-    if (e == hipSuccess) e = hipMalloc(&ss->d_boxes, boxes.size() * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(&ss->d_rowflags, rowflags.size());
-    if (e == hipSuccess) e = hipMemcpy(ss->d_rowflags, rowflags.data(), rowflags.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(ss->d_planes, planes.data(), planes.size() * 2, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(ss->d_boxes, boxes.data(), boxes.size() * sizeof(int), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { cds_shapeset_destroy(ss); return hip_fail(e, "shapeset upload"); }
+    std::vector<int> acc_init((size_t)batch * 16), acc((size_t)batch * 16), boxes((size_t)n_masks * 8, 0);
+    for (int i = 0; i < batch; i++) {
+        int *q = acc_init.data() + (size_t)16 * i;
+        for (int j = 0; j < 16; j++) q[j] = 0;
+        q[0] = H; q[2] = W; q[4] = W; q[8] = W; q[9] = H;   // the minima start at the far end
+    }
+    std::vector<uint32_t> rfl((size_t)batch * H);
+    std::vector<unsigned long long> sums((size_t)batch * 2);
+    std::vector<uint8_t> rowflags((size_t)n_masks * H, 0);
+    for (int m0 = 0; m0 < n_masks; m0 += batch) {
+        const int nb = std::min(batch, n_masks - m0);
+        SP_HIP(hipMemcpyAsync(d_masks, masks_rgb + (size_t)m0 * 3 * N, (size_t)nb * 3 * N, hipMemcpyHostToDevice, st));
+        SP_HIP(hipMemcpyAsync(d_acc, acc_init.data(), (size_t)nb * 16 * sizeof(int), hipMemcpyHostToDevice, st));
+        SP_HIP(hipMemsetAsync(d_rfl, 0, (size_t)nb * H * sizeof(uint32_t), st));
+        SP_HIP(hipMemsetAsync(d_sums, 0, (size_t)nb * 2 * sizeof(unsigned long long), st));
+        PrepParams p{};
+        p.masks = d_masks; p.roi = d_roi; p.W = W; p.H = H; p.wp = wp; p.n = nb; p.mirror = mirror != 0; p.nrects = n_excluded;
+        for (int i = 0; i < n_excluded; i++) p.rects[i] = excluded[i];
+        p.k60 = k60; p.k20 = k20; p.hw60 = d_hw; p.hw20 = d_hw + hw60.size();
+        p.flags = d_flags; p.hd = d_hd; p.planes = ss->d_planes + (size_t)m0 * 2 * H * wp; p.acc = d_acc; p.rowflags = d_rfl; p.sums = d_sums;
+        p.slice_lut = ctx->d_slice_lut;
+        const dim3 grid((W + 255) / 256, H, nb);
+        hipLaunchKernelGGL(prep_flags_kernel, grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL(prep_hdist_kernel, grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL(prep_plane_kernel, grid, dim3(256), 0, st, p);
+        SP_HIP(hipGetLastError());
+        SP_HIP(hipMemcpyAsync(acc.data(), d_acc, (size_t)nb * 16 * sizeof(int), hipMemcpyDeviceToHost, st));
+        SP_HIP(hipMemcpyAsync(rfl.data(), d_rfl, (size_t)nb * H * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        SP_HIP(hipMemcpyAsync(sums.data(), d_sums, (size_t)nb * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        SP_HIP(hipStreamSynchronize(st));
+        for (int i = 0; i < nb; i++) {
+            const int m = m0 + i;
+            const int *q = acc.data() + (size_t)16 * i;
+            int ya = q[0], yb = q[1], gx0 = q[2], gx1 = q[3], hx0 = q[4], hx1 = q[5];
+            if (yb <= ya) ya = yb = 0;
+            if (gx1 <= gx0) gx0 = gx1 = 0;
+            if (hx1 <= hx0) hx0 = hx1 = 0;
+            if (hx1 == 0 && gx1 > 0) { hx0 = gx0; hx1 = gx0; }   // empty QH window inside the gap window
+            if (gx1 == 0 && hx1 > 0) { gx0 = hx0; gx1 = hx0; }
+            int *bxm = boxes.data() + (size_t)8 * m;
+            bxm[0] = ya; bxm[1] = yb; bxm[2] = gx0; bxm[3] = gx1; bxm[4] = hx0; bxm[5] = hx1;
+            for (int y = 0; y < H; y++) rowflags[(size_t)m * H + y] = (uint8_t)rfl[(size_t)i * H + y];
+            ss->qm_sum[(size_t)m] = (int64_t)sums[(size_t)2 * i];
+            ss->qh_sum[(size_t)m] = (int64_t)sums[(size_t)2 * i + 1];
+        }
+    }
+    SP_HIP(hipMemcpyAsync(ss->d_rowflags, rowflags.data(), rowflags.size(), hipMemcpyHostToDevice, st));
+    SP_HIP(hipMemcpyAsync(ss->d_boxes, boxes.data(), boxes.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    SP_HIP(hipStreamSynchronize(st));
+#undef SP_HIP
+    cleanup();
     *out = ss;
     return CDS_OK;
 }

@@ -153,7 +153,13 @@ def _group_codes(names):
     return codes.astype(np.int64), [str(k) for k in uniq]
 
 
-def _top_ranked(idx, group, score, top_results, limit_sub_results, group_keys):
+def _key_hashes(group_keys):
+    """Spread hash (h ^ h >>> 16) of every group key, once per key list (int64 array)."""
+    h = np.array([java_string_hash(k) for k in group_keys], dtype=np.int64)
+    return h ^ (h >> 16)
+
+
+def _top_ranked(idx, group, score, top_results, limit_sub_results, group_keys, key_hashes=None):
     """Vectorised selectTopRankedElements over the items `idx` (their order = the input order): returns the kept items, groups
     ranked by their best score (descending, ties in the reference's HashMap iteration order: java_hashmap_order), items
     inside a group by descending score (ties in input order) -- exactly the order the list version produces."""
@@ -164,8 +170,13 @@ def _top_ranked(idx, group, score, top_results, limit_sub_results, group_keys):
     np.minimum.at(first, g, np.arange(len(idx)))                      # first occurrence of each group = insertion into the map
     present = np.flatnonzero(first < len(idx))
     present = present[np.argsort(first[present], kind="stable")]      # the distinct groups in insertion order
-    hm = java_hashmap_order([group_keys[c] for c in present])
-    first[present[np.asarray(hm, dtype=np.int64)]] = np.arange(len(present))   # first[] now = position in the map's iteration
+    if key_hashes is None:
+        key_hashes = _key_hashes(group_keys)
+    cap = 16
+    while len(present) > (cap * 3) // 4:
+        cap *= 2
+    hm = np.lexsort((np.arange(len(present)), key_hashes[present] & (cap - 1)))   # java_hashmap_order, vectorised
+    first[present[hm]] = np.arange(len(present))                       # first[] now = position in the map's iteration
     order = np.lexsort((np.arange(len(idx)), -sc, first[g]))         # by group (map order), then score desc, stable
     g_sorted = g[order]
     starts = np.flatnonzero(np.r_[True, g_sorted[1:] != g_sorted[:-1]])
@@ -181,6 +192,38 @@ def _top_ranked(idx, group, score, top_results, limit_sub_results, group_keys):
     sel = keep & (pos_of_group[gi] >= 0)
     final = np.lexsort((np.arange(len(idx))[sel], pos_of_group[gi][sel]))
     return idx[order][sel][final]
+
+
+def _rank_groups(outer, code, key_hashes, score, seq, n_outer):
+    """One level of selectTopRankedElements for MANY lists at once.  Items carry `outer` (which list they belong to, 0..n_outer-1),
+    `code` (their group key), `score` and `seq` (their position in their list).  Returns per item (rank of its group inside
+    its list, rank of the item inside its group): groups by best score descending, ties in the HashMap iteration order of that
+    list's distinct keys (java_hashmap_order: bucket of the key's hash at the capacity the list's key count leads to, then
+    insertion order = first appearance in the list); items by score descending, ties by position."""
+    n = len(outer)
+    pair, grp = np.unique(outer.astype(np.int64) * (int(code.max()) + 1 if n else 1) + code, return_inverse=True)
+    ng = len(pair)
+    g_outer = np.zeros(ng, dtype=np.int64); g_outer[grp] = outer
+    g_code = np.zeros(ng, dtype=np.int64); g_code[grp] = code
+    sc = score.astype(np.float64)
+    best = np.full(ng, -np.inf); np.maximum.at(best, grp, sc)
+    first = np.full(ng, np.iinfo(np.int64).max, dtype=np.int64); np.minimum.at(first, grp, seq)
+    ndist = np.bincount(g_outer, minlength=n_outer)
+    cap = np.full(n_outer, 16, dtype=np.int64)
+    while True:
+        grow = ndist > (cap * 3) // 4
+        if not grow.any():
+            break
+        cap[grow] *= 2
+    bucket = key_hashes[g_code] & (cap[g_outer] - 1)
+    order = np.lexsort((first, bucket, -best, g_outer))
+    starts = np.r_[0, np.cumsum(ndist)][:-1]
+    grank = np.empty(ng, dtype=np.int64); grank[order] = np.arange(ng) - starts[g_outer[order]]
+    io = np.lexsort((seq, -sc, grp))
+    gsize = np.bincount(grp, minlength=ng)
+    gstart = np.r_[0, np.cumsum(gsize)][:-1]
+    irank = np.empty(n, dtype=np.int64); irank[io] = np.arange(n) - gstart[grp[io]]
+    return grank[grp], irank
 
 
 class GpuColorMIPSearchProcessor:
@@ -245,21 +288,33 @@ class GpuColorMIPSearchProcessor:
         return MatchTable(cat(mi, np.int32), cat(ti, np.int64), cat(sc, np.int32), cat(ra, np.float32), cat(mr, bool))
 
     def selectBestMatchesTable(self, table: MatchTable, topLineMatches, topSamplesPerLine, topMatchesPerSample) -> MatchTable:
-        """selectBestMatches in columnar form: per mask top lines -> top samples per line -> top matches per sample."""
+        """selectBestMatches in columnar form, all masks at once: per mask top lines -> top samples per line -> top matches per
+        sample (two levels of ItemsHandling.selectTopRankedElements; same rows in the same order as the list version)."""
+        n = len(table)
+        if n == 0:
+            return table.take(np.zeros(0, dtype=np.int64))
         lcode, lkeys = _group_codes([t.publishedName for t in self.targets])
         scode, skeys = _group_codes([t.neuronId for t in self.targets])
         lines, samples = lcode[table.targetIndex], scode[table.targetIndex]
         score = table.matchingPixels
-        out = []
-        for m in np.unique(table.maskIndex):                     # ascending mask order, as the list version
-            idx = np.flatnonzero(table.maskIndex == m)
-            kept_lines = _top_ranked(idx, lines, score, topLineMatches, -1, lkeys)
-            # per kept line (in rank order) the sample ranking
-            lcodes = lines[kept_lines]
-            bounds = np.flatnonzero(np.r_[True, lcodes[1:] != lcodes[:-1]])
-            for a, b in zip(bounds, np.r_[bounds[1:], len(kept_lines)]):
-                out.append(_top_ranked(kept_lines[a:b], samples, score, topSamplesPerLine, topMatchesPerSample, skeys))
-        return table.take(np.concatenate(out) if out else np.zeros(0, dtype=np.int64))
+        masks, mcode = np.unique(table.maskIndex, return_inverse=True)          # lists of level 1: one per mask, ascending
+        mstart = np.r_[0, np.cumsum(np.bincount(mcode))][:-1]
+        order0 = np.lexsort((np.arange(n), mcode))                               # items of a mask in table order
+        seq0 = np.empty(n, dtype=np.int64); seq0[order0] = np.arange(n) - mstart[mcode[order0]]
+        lrank, lirank = _rank_groups(mcode, lines, _key_hashes(lkeys), score, seq0, len(masks))
+        keep = np.ones(n, dtype=bool) if topLineMatches <= 0 else lrank < topLineMatches
+        idx = np.flatnonzero(keep)
+        # level 2: one list per kept (mask, line), its items in the order level 1 left them in (score descending, stable)
+        pair, pcode = np.unique(mcode[idx] * (int(lrank.max()) + 1) + lrank[idx], return_inverse=True)
+        srank, sirank = _rank_groups(pcode, samples[idx], _key_hashes(skeys), score[idx], lirank[idx], len(pair))
+        keep2 = np.ones(len(idx), dtype=bool)
+        if topSamplesPerLine > 0:
+            keep2 &= srank < topSamplesPerLine
+        if topMatchesPerSample > 0:
+            keep2 &= sirank < topMatchesPerSample
+        sel = np.flatnonzero(keep2)
+        final = np.lexsort((sirank[sel], srank[sel], pcode[sel]))                 # mask, line rank, sample rank, item rank
+        return table.take(idx[sel][final])
 
     def calculateGradientScoresTable(self, masks, table: MatchTable, queryThreshold, mirrorMask=True, roiMask=None,
                                      excludedRegions=cds.label_regions) -> MatchTable:

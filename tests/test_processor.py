@@ -71,6 +71,26 @@ def test_vectorised_ranking_equals_list_version():
         assert got == want, (trial, n, top, lim)
 
 
+def test_columnar_selection_equals_list_selection():
+    """selectBestMatchesTable (all masks, lines and samples in a few sorts) == selectBestMatches (the reference's nested
+    loops) on random match lists with many ties, blank names and every combination of cuts."""
+    rng = np.random.default_rng(3)
+    for trial in range(300):
+        nt, nm = int(rng.integers(1, 60)), int(rng.integers(1, 4))
+        infos = [P.NeuronInfo(str(i), f"L{rng.integers(0, 7)}" if rng.integers(0, 9) else " ", f"S{rng.integers(0, 9)}") for i in range(nt)]
+        proc = P.GpuColorMIPSearchProcessor.__new__(P.GpuColorMIPSearchProcessor)   # (selection needs the metadata only)
+        proc.targets = infos
+        rows = [(m, t, int(rng.integers(1, 6))) for m in range(nm) for t in range(nt) if rng.integers(0, 3)]
+        if not rows:
+            continue
+        table = P.MatchTable(np.array([r[0] for r in rows], dtype=np.int32), np.array([r[1] for r in rows], dtype=np.int64),
+                             np.array([r[2] for r in rows], dtype=np.int32), np.zeros(len(rows), dtype=np.float32), np.zeros(len(rows), dtype=bool))
+        a, b, c = int(rng.integers(-1, 5)), int(rng.integers(-1, 4)), int(rng.integers(-1, 3))
+        want = [(m.maskIndex, m.targetIndex) for m in proc.selectBestMatches(table.to_matches(), a, b, c)]
+        got = proc.selectBestMatchesTable(table, a, b, c)
+        assert list(zip(got.maskIndex.tolist(), got.targetIndex.tolist())) == want, (trial, a, b, c)
+
+
 def test_tied_groups_follow_java_hashmap_order():
     """Groups of equal best score keep the iteration order of the HashMap that Collectors.groupingBy builds
     (ItemsHandling.java:86-103): bucket = (h ^ h >>> 16) & (capacity - 1) of String.hashCode, insertion order inside a bucket."""
