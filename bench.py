@@ -308,6 +308,35 @@ def main():
             failed.append("mask-batch scan disagrees with the single-mask scan")
         if not same_b2:
             failed.append("dense batch kernel disagrees with the sparse scan")
+        # (c) the reference's own fixture images and known answers ("in every benchmark binary"): the JUnit pairs
+        # of PixelMatchColorDepthSearchAlgorithmTest through the sparse scan, the dense scan and the shape scorer
+        fpath = os.path.join(ROOT, "tests", "golden", "cds_fixtures.npz")
+        if os.path.exists(fpath):
+            from tests.golden import expected as E
+            with np.load(fpath) as z:
+                fx = {k: z[k] for k in z.files}
+            tkeys = sorted({t for _, t, _, _ in E.PIXEL_MATCH_PROVIDER})
+            tg = np.stack([fx[k] for k in tkeys])
+            fl = cds.Library(W, H, len(tkeys), context=ctx)
+            fl.upload(0, tg)
+            fs = cds.SparseLibrary(W, H, len(tkeys), int((tg.max(axis=3) > 0).sum()) + 4 * H * len(tkeys) + 64, context=ctx)
+            fs.append_from(fl)
+            got, ok_f = [], True
+            for mk, tk, want_s, want_m in E.PIXEL_MATCH_PROVIDER:
+                a = cds.PixelMatchColorDepthSearchAlgorithm(fx[mk], 20, True, None, 0, False, 20, 0.01, 2, E.STD_RECTS, context=ctx)
+                t = tkeys.index(tk)
+                s1, m1 = a.searchSparseLibrary(fs, t, 1)
+                s2, m2 = a.searchLibrary(fl, t, 1)
+                got.append([mk, tk, int(s1[0, 0]), bool(m1[0, 0])])
+                ok_f &= (int(s1[0, 0]), bool(m1[0, 0])) == (want_s, want_m) == (int(s2[0, 0]), bool(m2[0, 0]))
+            sk = E.SHAPE_SCORES[2]   # the pair with a ZGapImage file: (mask, target, grad, zgap, gaps, highExpression, score, mirrored)
+            fl.upload_variants(tkeys.index(sk[1]), fx[sk[2]][None], fx[sk[3]][None])
+            sh = cds.Shape2DMatchColorDepthSearchAlgorithm(fx[sk[0]], 20, True, None, E.STD_RECTS, context=ctx)
+            gap, high, smir = sh.scoreLibraryPairs(fl, [0], [tkeys.index(sk[1])])
+            ok_f &= (int(gap[0]), int(high[0]), bool(smir[0])) == (sk[4], sk[5], sk[7])
+            aux["reference_fixtures"] = {"pixel_match": got, "shape": [int(gap[0]), int(high[0]), bool(smir[0])], "equal_to_reference_junit_values": bool(ok_f)}
+            if not ok_f:
+                failed.append("reference fixture pairs do not give the reference's JUnit values")
         out["aux"] = aux
     if rank == 0:
         if failed:
