@@ -40,6 +40,10 @@ class PixMatchParams(ctypes.Structure):
                 ("z_tolerance", ctypes.c_double), ("xy_shift", ctypes.c_int32), ("mirror", ctypes.c_int32)]
 
 
+class ImageInfo(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("channels", ctypes.c_int32), ("bits", ctypes.c_int32)]
+
+
 _vp = ctypes.c_void_p
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 _u16p = ctypes.POINTER(ctypes.c_uint16)
@@ -90,6 +94,9 @@ SIGNATURES = {
     "cds_sparse_library_pixels": (_i64, [_vp]),
     "cds_sparse_library_clear": (_i, [_vp]),
     "cds_sparse_library_image_records": (_i, [_vp, _i64, _u32p, _i64, _i64p, _u32p]),
+    "cds_image_probe": (_i, [_u8p, ctypes.c_size_t, ctypes.POINTER(ImageInfo)]),
+    "cds_image_decode": (_i, [_u8p, ctypes.c_size_t, _vp, ctypes.c_size_t]),
+    "cds_sparse_library_append_files": (_i, [_vp, ctypes.POINTER(ctypes.c_char_p), _i64, _i32]),
     "cds_search_sparse": (_i, [_vp, _vp, _i64, _i64, _i32p, _u8p]),
     "cds_search_sparse_device": (_i, [_vp, _vp, _i64, _i64, _vp]),
     "cds_search_sparse_counts": (_i, [_vp, _vp, _i64, _i64, _i32p]),

@@ -246,6 +246,13 @@ class SparseLibrary:
             raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "image size does not match the library")
         capi.check(self._lib.cds_sparse_library_append_host(self._h, imgs.shape[0], capi.as_u8p(imgs)))
 
+    def append_files(self, paths, threads=0):
+        """Append 8-bit RGB image files (TIFF / PNG, the library's size): decoded natively on `threads` host threads
+        (0 = all cores), two batches in flight (decode || upload + conversion)."""
+        paths = [os.fsencode(p) for p in paths]
+        arr = (ctypes.c_char_p * max(1, len(paths)))(*paths)
+        capi.check(self._lib.cds_sparse_library_append_files(self._h, arr, len(paths), int(threads)))
+
     def image_records(self, index):
         """(records uint32[n], cell offsets uint32[n_strips, H+1]) of one image -- diagnostic."""
         n = ctypes.c_int64()

@@ -1,0 +1,492 @@
+// cds_imageio.hip -- host side only: MIP file decoding and threaded library ingest.
+//
+// Replaces, for the files the reference's pipeline reads (color-depth MIPs: 8-bit RGB TIFF or PNG; gradient images: 8/16-bit
+// gray PNG or TIFF), ImageArrayUtils.readImageArray (API/imageprocessing/ImageArrayUtils.java:98-121, which hands TIFFs to
+// ImageJ's Opener / LocalTiffDecoder.java and everything else to ImageIO) and its PackBits strip reader
+// (packBitsUncompress :229-258).  Supported: baseline TIFF (II / MM, strips, chunky, 8- or 16-bit samples, 1 / 3 / 4 samples per
+// pixel, compression none / PackBits 32773 / LZW 5 / Deflate 8, 32946, predictor 2) and non-interlaced PNG (gray 8/16, RGB 8,
+// RGBA 8, palette 8).  Everything else is refused with a message (no silent fallback).
+// cds_sparse_library_append_files decodes on `threads` host threads, two batches in flight: one being decoded while the
+// previous one is uploaded and turned into signal-pixel records on the GPU.
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "cds_internal.hpp"
+
+namespace cds {
+
+struct ImgInfo {
+    int W = 0, H = 0, channels = 0, bits = 0;  // channels of the DECODED image (alpha dropped, palette expanded)
+};
+
+struct Reader {
+    const uint8_t *p;
+    size_t n;
+    bool le;
+    bool ok(size_t off, size_t len) const { return off <= n && len <= n - off; }
+    uint16_t u16(size_t off) const { return le ? (uint16_t)(p[off] | p[off + 1] << 8) : (uint16_t)(p[off] << 8 | p[off + 1]); }
+    uint32_t u32(size_t off) const {
+        return le ? (uint32_t)p[off] | (uint32_t)p[off + 1] << 8 | (uint32_t)p[off + 2] << 16 | (uint32_t)p[off + 3] << 24
+                  : (uint32_t)p[off] << 24 | (uint32_t)p[off + 1] << 16 | (uint32_t)p[off + 2] << 8 | (uint32_t)p[off + 3];
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ TIFF
+struct TiffDir {
+    uint32_t W = 0, H = 0, bits = 8, compression = 1, photometric = 2, spp = 1, rows_per_strip = 0xffffffffu, planar = 1, predictor = 1;
+    std::vector<uint32_t> offsets, counts;
+    bool tiled = false;
+};
+
+static bool tiff_values(const Reader &r, size_t entry, std::vector<uint32_t> &out, std::string &err) {
+    const uint16_t type = r.u16(entry + 2);
+    const uint32_t count = r.u32(entry + 4);
+    const size_t size = type == 1 || type == 2 || type == 6 || type == 7 ? 1 : type == 3 || type == 8 ? 2 : type == 4 || type == 9 ? 4 : 0;
+    if (!size) {
+        err = "unsupported TIFF field type";
+        return false;
+    }
+    if (count > (1u << 24)) {
+        err = "implausible TIFF field count";
+        return false;
+    }
+    size_t off = entry + 8;
+    if ((size_t)count * size > 4) {
+        off = r.u32(entry + 8);
+        if (!r.ok(off, (size_t)count * size)) {
+            err = "TIFF field data outside the file";
+            return false;
+        }
+    }
+    out.resize(count);
+    for (uint32_t i = 0; i < count; i++) out[i] = size == 1 ? r.p[off + i] : size == 2 ? r.u16(off + 2 * (size_t)i) : r.u32(off + 4 * (size_t)i);
+    return true;
+}
+
+static bool tiff_parse(const uint8_t *data, size_t n, Reader &r, TiffDir &d, std::string &err) {
+    if (n < 8) {
+        err = "file too short";
+        return false;
+    }
+    r.p = data; r.n = n;
+    if (data[0] == 'I' && data[1] == 'I') r.le = true;
+    else if (data[0] == 'M' && data[1] == 'M') r.le = false;
+    else {
+        err = "not a TIFF";
+        return false;
+    }
+    if (r.u16(2) != 42) {
+        err = r.u16(2) == 43 ? "BigTIFF is not supported" : "not a TIFF";
+        return false;
+    }
+    const size_t ifd = r.u32(4);
+    if (!r.ok(ifd, 2)) {
+        err = "TIFF directory outside the file";
+        return false;
+    }
+    const int ne = r.u16(ifd);
+    if (!r.ok(ifd + 2, (size_t)ne * 12)) {
+        err = "TIFF directory outside the file";
+        return false;
+    }
+    std::vector<uint32_t> v;
+    for (int i = 0; i < ne; i++) {
+        const size_t e = ifd + 2 + (size_t)i * 12;
+        const int tag = r.u16(e);
+        switch (tag) {
+            case 256: case 257: case 258: case 259: case 262: case 273: case 277: case 278: case 279: case 284: case 317:
+                if (!tiff_values(r, e, v, err)) return false;
+                if (v.empty()) continue;
+                break;
+            case 322: case 323: case 324: case 325: d.tiled = true; continue;
+            default: continue;
+        }
+        switch (tag) {
+            case 256: d.W = v[0]; break;
+            case 257: d.H = v[0]; break;
+            case 258:
+                d.bits = v[0];
+                for (uint32_t b : v)
+                    if (b != v[0]) {
+                        err = "TIFF samples of different widths";
+                        return false;
+                    }
+                break;
+            case 259: d.compression = v[0]; break;
+            case 262: d.photometric = v[0]; break;
+            case 273: d.offsets = v; break;
+            case 277: d.spp = v[0]; break;
+            case 278: d.rows_per_strip = v[0]; break;
+            case 279: d.counts = v; break;
+            case 284: d.planar = v[0]; break;
+            case 317: d.predictor = v[0]; break;
+        }
+    }
+    if (d.tiled) { err = "tiled TIFFs are not supported"; return false; }
+    if (d.W == 0 || d.H == 0 || d.W > 65535 || d.H > 65535) { err = "TIFF without a valid size"; return false; }
+    if (d.bits != 8 && d.bits != 16) { err = "TIFF bits per sample must be 8 or 16"; return false; }
+    if (d.spp != 1 && d.spp != 3 && d.spp != 4) { err = "TIFF samples per pixel must be 1, 3 or 4"; return false; }
+    if (d.spp >= 3 && d.bits != 8) { err = "16-bit colour TIFFs are not supported"; return false; }
+    if (d.planar != 1 && d.spp > 1) { err = "planar TIFFs are not supported"; return false; }
+    if (d.photometric == 3) { err = "palette TIFFs are not supported"; return false; }
+    if (d.photometric > 2) { err = "unsupported TIFF photometric interpretation"; return false; }
+    if (d.compression != 1 && d.compression != 5 && d.compression != 8 && d.compression != 32946 && d.compression != 32773) {
+        err = "unsupported TIFF compression " + std::to_string(d.compression);
+        return false;
+    }
+    if (d.predictor != 1 && d.predictor != 2) { err = "unsupported TIFF predictor"; return false; }
+    if (d.offsets.empty() || d.offsets.size() != d.counts.size()) {
+        // ImageJ writes uncompressed single-strip files without StripByteCounts
+        if (d.offsets.size() == 1 && d.counts.empty() && d.compression == 1) d.counts.assign(1, (uint32_t)std::min<size_t>(n - d.offsets[0], 0xffffffffu));
+        else { err = "TIFF strip tables missing or inconsistent"; return false; }
+    }
+    if (d.rows_per_strip == 0 || d.rows_per_strip > d.H) d.rows_per_strip = d.H;
+    if ((size_t)(d.H + d.rows_per_strip - 1) / d.rows_per_strip != d.offsets.size()) { err = "TIFF strip count does not match the image height"; return false; }
+    return true;
+}
+
+static bool packbits_decode(const uint8_t *in, size_t n, uint8_t *out, size_t want) {
+    size_t i = 0, o = 0;
+    while (o < want && i < n) {
+        const int8_t c = (int8_t)in[i++];
+        if (c >= 0) {
+            size_t len = (size_t)c + 1;
+            if (i + len > n) len = n - i;
+            if (o + len > want) len = want - o;
+            memcpy(out + o, in + i, len);
+            i += (size_t)c + 1;
+            o += len;
+        } else if (c != -128) {
+            size_t len = (size_t)(1 - c);
+            if (i >= n) break;
+            if (o + len > want) len = want - o;
+            memset(out + o, in[i++], len);
+            o += len;
+        }
+    }
+    return o == want;
+}
+
+// TIFF LZW (MSB-first codes, 9..12 bits, ClearCode 256, EoiCode 257, "early change" like every current writer: the code
+// width grows as soon as the entry just added is number 2^bits - 2)
+static bool lzw_decode(const uint8_t *in, size_t n, uint8_t *out, size_t want) {
+    struct Entry { uint16_t prev; uint8_t ch, first; uint16_t len; };
+    std::vector<Entry> tab(4096);
+    for (int i = 0; i < 256; i++) tab[i] = {0xffff, (uint8_t)i, (uint8_t)i, 1};
+    int next = 258, bits = 9, old = -1;
+    uint32_t acc = 0;
+    int nacc = 0;
+    size_t i = 0, o = 0;
+    auto emit = [&](int code) {  // the string of `code`, written backwards; clipped at `want`
+        const size_t len = tab[code].len;
+        int c = code;
+        for (size_t k = len; k-- > 0;) {
+            if (o + k < want) out[o + k] = tab[c].ch;
+            c = tab[c].prev;
+        }
+        o = std::min(o + len, want);
+    };
+    auto add = [&](int prefix, uint8_t ch) {
+        if (next < 4096) {
+            tab[next] = {(uint16_t)prefix, ch, tab[prefix].first, (uint16_t)(tab[prefix].len + 1)};
+            next++;
+            if (next >= (1 << bits) - 1 && bits < 12) bits++;
+        }
+    };
+    while (o < want) {
+        while (nacc < bits && i < n) { acc = (acc << 8) | in[i++]; nacc += 8; }
+        if (nacc < bits) break;
+        const int code = (int)((acc >> (nacc - bits)) & ((1u << bits) - 1));
+        nacc -= bits;
+        if (code == 257) break;
+        if (code == 256) { next = 258; bits = 9; old = -1; continue; }
+        if (old < 0) {
+            if (code >= 256) return false;
+            emit(code);
+        } else if (code < next) {
+            emit(code);
+            add(old, tab[code].first);
+        } else if (code == next && next < 4096) {
+            add(old, tab[old].first);   // KwKwK: the entry being defined right now
+            emit(code);
+        } else {
+            return false;
+        }
+        old = code;
+    }
+    return o == want;
+}
+
+static bool tiff_decode(const uint8_t *data, size_t n, const ImgInfo &info, void *outv, std::string &err) {
+    Reader r{};
+    TiffDir d;
+    if (!tiff_parse(data, n, r, d, err)) return false;
+    const size_t bps = d.bits / 8, src_px = (size_t)d.spp * bps, row_bytes = (size_t)d.W * src_px;
+    std::vector<uint8_t> strip;
+    uint8_t *out = static_cast<uint8_t *>(outv);
+    const size_t dst_px = (size_t)info.channels * bps;
+    for (size_t s = 0; s < d.offsets.size(); s++) {
+        const size_t y0 = s * d.rows_per_strip, rows = std::min<size_t>(d.rows_per_strip, d.H - y0), want = rows * row_bytes;
+        if (!r.ok(d.offsets[s], d.counts[s])) { err = "TIFF strip outside the file"; return false; }
+        const uint8_t *src = data + d.offsets[s];
+        const size_t len = d.counts[s];
+        strip.resize(want);
+        bool ok = true;
+        switch (d.compression) {
+            case 1: ok = len >= want; if (ok) memcpy(strip.data(), src, want); break;
+            case 32773: ok = packbits_decode(src, len, strip.data(), want); break;
+            case 5: ok = lzw_decode(src, len, strip.data(), want); break;
+            default: {
+                uLongf got = (uLongf)want;
+                ok = uncompress(strip.data(), &got, src, (uLong)len) == Z_OK && got == want;
+            }
+        }
+        if (!ok) { err = "TIFF strip " + std::to_string(s) + " is truncated or corrupt"; return false; }
+        for (size_t yy = 0; yy < rows; yy++) {
+            uint8_t *row = strip.data() + yy * row_bytes;
+            if (d.predictor == 2) {
+                if (bps == 1) {
+                    for (size_t k = d.spp; k < row_bytes; k++) row[k] = (uint8_t)(row[k] + row[k - d.spp]);
+                } else {
+                    // 16-bit gray: samples in file byte order
+                    uint16_t prev = r.le ? (uint16_t)(row[0] | row[1] << 8) : (uint16_t)(row[0] << 8 | row[1]);
+                    for (size_t x = 1; x < d.W; x++) {
+                        uint8_t *q = row + 2 * x;
+                        uint16_t v = r.le ? (uint16_t)(q[0] | q[1] << 8) : (uint16_t)(q[0] << 8 | q[1]);
+                        v = (uint16_t)(v + prev);
+                        prev = v;
+                        if (r.le) { q[0] = (uint8_t)v; q[1] = (uint8_t)(v >> 8); } else { q[0] = (uint8_t)(v >> 8); q[1] = (uint8_t)v; }
+                    }
+                }
+            }
+            uint8_t *dst = out + (y0 + yy) * (size_t)d.W * dst_px;
+            if (bps == 2) {  // gray 16: to host order, WhiteIsZero inverted
+                uint16_t *o16 = reinterpret_cast<uint16_t *>(dst);
+                for (size_t x = 0; x < d.W; x++) {
+                    const uint8_t *q = row + 2 * x;
+                    uint16_t v = r.le ? (uint16_t)(q[0] | q[1] << 8) : (uint16_t)(q[0] << 8 | q[1]);
+                    o16[x] = d.photometric == 0 ? (uint16_t)~v : v;
+                }
+            } else if (d.spp == 1) {
+                for (size_t x = 0; x < d.W; x++) dst[x] = d.photometric == 0 ? (uint8_t)~row[x] : row[x];
+            } else if (d.spp == 3) {
+                memcpy(dst, row, row_bytes);
+            } else {  // RGBA -> RGB
+                for (size_t x = 0; x < d.W; x++) { dst[3 * x] = row[4 * x]; dst[3 * x + 1] = row[4 * x + 1]; dst[3 * x + 2] = row[4 * x + 2]; }
+            }
+        }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ PNG
+static const uint8_t kPngSig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+
+struct PngHead {
+    uint32_t W = 0, H = 0;
+    int depth = 0, ctype = 0, interlace = 0;
+};
+
+static bool png_head(const uint8_t *data, size_t n, PngHead &h, std::string &err) {
+    if (n < 33 || memcmp(data, kPngSig, 8) != 0) { err = "not a PNG"; return false; }
+    Reader r{data, n, false};
+    if (r.u32(8) != 13 || memcmp(data + 12, "IHDR", 4) != 0) { err = "PNG without IHDR"; return false; }
+    h.W = r.u32(16); h.H = r.u32(20); h.depth = data[24]; h.ctype = data[25]; h.interlace = data[28];
+    if (h.W == 0 || h.H == 0 || h.W > 65535 || h.H > 65535) { err = "PNG without a valid size"; return false; }
+    if (h.interlace) { err = "interlaced PNGs are not supported"; return false; }
+    const bool ok = (h.ctype == 0 && (h.depth == 8 || h.depth == 16)) || ((h.ctype == 2 || h.ctype == 6 || h.ctype == 3) && h.depth == 8);
+    if (!ok) { err = "unsupported PNG colour type / bit depth"; return false; }
+    return true;
+}
+
+static bool png_decode(const uint8_t *data, size_t n, const ImgInfo &info, void *outv, std::string &err) {
+    PngHead h;
+    if (!png_head(data, n, h, err)) return false;
+    Reader r{data, n, false};
+    std::vector<uint8_t> idat, plte;
+    for (size_t off = 8; off + 12 <= n;) {
+        const uint32_t len = r.u32(off);
+        if (!r.ok(off + 8, (size_t)len + 4)) { err = "PNG chunk outside the file"; return false; }
+        if (memcmp(data + off + 4, "IDAT", 4) == 0) idat.insert(idat.end(), data + off + 8, data + off + 8 + len);
+        else if (memcmp(data + off + 4, "PLTE", 4) == 0) plte.assign(data + off + 8, data + off + 8 + len);
+        else if (memcmp(data + off + 4, "IEND", 4) == 0) break;
+        off += (size_t)len + 12;
+    }
+    const int src_ch = h.ctype == 0 || h.ctype == 3 ? 1 : h.ctype == 2 ? 3 : 4;
+    const size_t bpp = (size_t)src_ch * h.depth / 8, stride = (size_t)h.W * bpp;
+    std::vector<uint8_t> raw((stride + 1) * h.H);
+    uLongf got = (uLongf)raw.size();
+    if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size()) { err = "PNG data is truncated or corrupt"; return false; }
+    if (h.ctype == 3 && plte.size() < 3) { err = "palette PNG without PLTE"; return false; }
+    std::vector<uint8_t> prev(stride, 0), cur(stride);
+    uint8_t *out = static_cast<uint8_t *>(outv);
+    for (size_t y = 0; y < h.H; y++) {
+        const uint8_t *line = raw.data() + y * (stride + 1);
+        const int ft = line[0];
+        const uint8_t *s = line + 1;
+        for (size_t i = 0; i < stride; i++) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int v = s[i];
+            switch (ft) {
+                case 0: break;
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) >> 1; break;
+                case 4: {
+                    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                    v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                    break;
+                }
+                default: err = "PNG filter type out of range"; return false;
+            }
+            cur[i] = (uint8_t)v;
+        }
+        if (h.ctype == 0 && h.depth == 16) {
+            uint16_t *o16 = reinterpret_cast<uint16_t *>(out) + y * h.W;
+            for (size_t x = 0; x < h.W; x++) o16[x] = (uint16_t)(cur[2 * x] << 8 | cur[2 * x + 1]);
+        } else if (h.ctype == 0) {
+            memcpy(out + y * h.W, cur.data(), h.W);
+        } else if (h.ctype == 2) {
+            memcpy(out + y * stride, cur.data(), stride);
+        } else if (h.ctype == 6) {
+            uint8_t *d = out + y * (size_t)h.W * 3;
+            for (size_t x = 0; x < h.W; x++) { d[3 * x] = cur[4 * x]; d[3 * x + 1] = cur[4 * x + 1]; d[3 * x + 2] = cur[4 * x + 2]; }
+        } else {
+            uint8_t *d = out + y * (size_t)h.W * 3;
+            for (size_t x = 0; x < h.W; x++) {
+                const size_t k = (size_t)cur[x] * 3;
+                if (k + 3 > plte.size()) { err = "PNG palette index out of range"; return false; }
+                d[3 * x] = plte[k]; d[3 * x + 1] = plte[k + 1]; d[3 * x + 2] = plte[k + 2];
+            }
+        }
+        prev.swap(cur);
+    }
+    (void)info;
+    return true;
+}
+
+static bool image_probe(const uint8_t *data, size_t n, ImgInfo &info, std::string &err) {
+    if (n >= 8 && memcmp(data, kPngSig, 8) == 0) {
+        PngHead h;
+        if (!png_head(data, n, h, err)) return false;
+        info.W = (int)h.W; info.H = (int)h.H; info.bits = h.depth; info.channels = h.ctype == 0 ? 1 : 3;
+        return true;
+    }
+    Reader r{};
+    TiffDir d;
+    if (!tiff_parse(data, n, r, d, err)) return false;
+    info.W = (int)d.W; info.H = (int)d.H; info.bits = (int)d.bits; info.channels = d.spp == 1 ? 1 : 3;
+    return true;
+}
+
+static bool image_decode(const uint8_t *data, size_t n, const ImgInfo &info, void *out, std::string &err) {
+    if (n >= 8 && memcmp(data, kPngSig, 8) == 0) return png_decode(data, n, info, out, err);
+    return tiff_decode(data, n, info, out, err);
+}
+
+static bool read_file(const char *path, std::vector<uint8_t> &buf, std::string &err) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { err = std::string("cannot open ") + path; return false; }
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 0) { fclose(f); err = std::string("cannot read ") + path; return false; }
+    buf.resize((size_t)sz);
+    const size_t got = sz ? fread(buf.data(), 1, (size_t)sz, f) : 0;
+    fclose(f);
+    if (got != (size_t)sz) { err = std::string("cannot read ") + path; return false; }
+    return true;
+}
+
+}  // namespace cds
+
+using namespace cds;
+
+extern "C" {
+
+int cds_image_probe(const uint8_t *data, size_t size, cds_image_info *info) {
+    if (!data || !info) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    ImgInfo i;
+    std::string err;
+    if (!image_probe(data, size, i, err)) return fail(CDS_ERR_INVALID_ARGUMENT, err);
+    info->width = i.W; info->height = i.H; info->channels = i.channels; info->bits = i.bits;
+    return CDS_OK;
+}
+
+int cds_image_decode(const uint8_t *data, size_t size, void *out, size_t out_bytes) {
+    if (!data || !out) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    ImgInfo i;
+    std::string err;
+    if (!image_probe(data, size, i, err)) return fail(CDS_ERR_INVALID_ARGUMENT, err);
+    const size_t need = (size_t)i.W * i.H * i.channels * (i.bits / 8);
+    if (out_bytes < need) return fail(CDS_ERR_INVALID_ARGUMENT, "output buffer too small");
+    if (!image_decode(data, size, i, out, err)) return fail(CDS_ERR_INVALID_ARGUMENT, err);
+    return CDS_OK;
+}
+
+int cds_sparse_library_append_files(cds_sparse_library *sl, const char *const *paths, int64_t count, int32_t threads) {
+    if (!sl || (count > 0 && !paths)) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (count < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "count is negative");
+    if (count == 0) return CDS_OK;
+    if (cds_sparse_library_size(sl) + count > sl->cap_images) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (images)");
+    const int nthreads = std::max(1, std::min(threads > 0 ? threads : (int)std::thread::hardware_concurrency(), 64));
+    const int64_t batch = 64;  // = the dense staging slots of cds_sparse_library_append_host
+    const size_t img_bytes = (size_t)3 * sl->W * sl->H;
+    std::vector<uint8_t> buf[2];
+    buf[0].resize((size_t)std::min(batch, count) * img_bytes);
+    if (count > batch) buf[1].resize((size_t)std::min(batch, count - batch) * img_bytes);
+    std::string first_err;
+    std::mutex err_mu;
+    auto decode_batch = [&](int64_t b0, int64_t nb, uint8_t *dst) {
+        std::atomic<int64_t> next{0};
+        auto worker = [&]() {
+            std::vector<uint8_t> file;
+            for (int64_t i = next.fetch_add(1); i < nb; i = next.fetch_add(1)) {
+                std::string err;
+                ImgInfo info;
+                bool ok = read_file(paths[b0 + i], file, err) && image_probe(file.data(), file.size(), info, err);
+                if (ok && (info.W != sl->W || info.H != sl->H || info.channels != 3 || info.bits != 8)) {
+                    err = "is not an 8-bit RGB image of the library's size";
+                    ok = false;
+                }
+                if (ok) ok = image_decode(file.data(), file.size(), info, dst + (size_t)i * img_bytes, err);
+                if (!ok) {
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    if (first_err.empty()) first_err = std::string(paths[b0 + i]) + ": " + err;
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < std::min<int64_t>(nthreads, nb); t++) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+    };
+    // batch k is decoded by the pool while batch k-1 is uploaded and converted on the GPU by one more thread
+    int rc_gpu = CDS_OK;
+    std::string gpu_err;
+    std::thread gpu;
+    for (int64_t b0 = 0, k = 0; b0 < count; b0 += batch, k++) {
+        const int64_t nb = std::min(batch, count - b0);
+        decode_batch(b0, nb, buf[k & 1].data());
+        if (gpu.joinable()) gpu.join();
+        if (!first_err.empty()) return fail(CDS_ERR_INVALID_ARGUMENT, first_err);
+        if (rc_gpu) return fail(rc_gpu, gpu_err);
+        const uint8_t *src = buf[k & 1].data();
+        gpu = std::thread([sl, nb, src, &rc_gpu, &gpu_err]() {
+            rc_gpu = cds_sparse_library_append_host(sl, nb, src);
+            if (rc_gpu) gpu_err = cds_last_error();   // (the message is thread-local: carry it over)
+        });
+    }
+    if (gpu.joinable()) gpu.join();
+    if (rc_gpu) return fail(rc_gpu, gpu_err);
+    return CDS_OK;
+}
+
+}  // extern "C"

@@ -1,8 +1,10 @@
 """Data formats on either side of the hot path -- host I/O glue only.
 
 * reading MIPs: the reference decodes TIFF (PackBits / LZW / raw) and PNG/JPG files or zip entries into ImageArrays
-  (API/imageprocessing/ImageArrayUtils.java:98-121, API/mips/NeuronMIPUtils.java:177-199); here Pillow does the decode
-  (pixel-identical to ImageJ for the reference's fixtures) and yields the arrays the C ABI takes;
+  (API/imageprocessing/ImageArrayUtils.java:98-121, API/mips/NeuronMIPUtils.java:177-199); here the native decoder of
+  libcds_hip.so (csrc/cds_imageio.hip: strip TIFF raw / PackBits / LZW / Deflate, PNG) does it -- pixel-identical to Pillow
+  and to ImageJ on the reference's fixtures -- with Pillow as the reader of everything else; whole directories of MIP files
+  go into a sparse resident library through `cds.SparseLibrary.append_files` (threaded decode overlapped with the upload);
 * a packed shard format: one header line (JSON) + the raw uint8[n,H,W,3] pixels, written once and memory-mapped for
   large sequential uploads into a `cds.Library` -- for real libraries decode + PCIe dominate, not the scan;
 * match results as JSON records with the field names of the reference's CDMatchEntity files
@@ -37,16 +39,55 @@ def _open(file_data):
     return file_data
 
 
-def read_mip(file_data):
-    """-> uint8[H,W,3] (R,G,B), the byte layout of the reference's ColorImageArray."""
+def _bytes(file_data):
+    src = _open(file_data)
+    if isinstance(src, io.BytesIO):
+        return src.getvalue()
+    with open(src, "rb") as f:
+        return f.read()
+
+
+def decode_image(data):
+    """Native decode (libcds_hip.so: cds_image_probe / cds_image_decode -- strip TIFF raw / PackBits / LZW / Deflate, PNG):
+    bytes -> uint8[H,W,3], uint8[H,W] or uint16[H,W].  Raises ValueError for anything the native decoder refuses."""
+    import ctypes
+    from . import capi
+    lib = capi.load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    info = capi.ImageInfo()
+    capi.check(lib.cds_image_probe(capi.as_u8p(buf), buf.size, ctypes.byref(info)))
+    shape = (info.height, info.width, 3) if info.channels == 3 else (info.height, info.width)
+    out = np.empty(shape, dtype=np.uint16 if info.bits == 16 else np.uint8)
+    capi.check(lib.cds_image_decode(capi.as_u8p(buf), buf.size, out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+    return out
+
+
+def read_mip(file_data, native=True):
+    """-> uint8[H,W,3] (R,G,B), the byte layout of the reference's ColorImageArray.  The native decoder handles the formats
+    the reference's libraries come in; other files (JPEG, tiled TIFF, ...) go through Pillow."""
+    if native:
+        from .capi import CdsError
+        try:
+            a = decode_image(_bytes(file_data))
+            return a if a.ndim == 3 else np.ascontiguousarray(np.repeat(a.astype(np.uint8)[:, :, None], 3, axis=2))
+        except (CdsError, ImportError):
+            pass
     with _pil().open(_open(file_data)) as im:
         return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
 
 
-def read_gradient(file_data):
+def read_gradient(file_data, native=True):
     """-> uint16[H,W]: GRAY16 as is, GRAY8 widened (ImageArray.get semantics)."""
-    with _pil().open(_open(file_data)) as im:
-        a = np.asarray(im)
+    a = None
+    if native:
+        from .capi import CdsError
+        try:
+            a = decode_image(_bytes(file_data))
+        except (CdsError, ImportError):
+            a = None
+    if a is None:
+        with _pil().open(_open(file_data)) as im:
+            a = np.asarray(im)
     if a.ndim != 2:
         raise ValueError(f"gradient image must be grayscale, got shape {a.shape}")
     return np.ascontiguousarray(a.astype(np.uint16))

@@ -161,6 +161,22 @@ int cds_sparse_library_clear(cds_sparse_library *slib);
  * its n_strips x (H+1) cell offsets; either output may be NULL; *n_records is always set. */
 int cds_sparse_library_image_records(const cds_sparse_library *slib, int64_t index, uint32_t *records, int64_t capacity,
                                      int64_t *n_records, uint32_t *row_offsets);
+/* ---- MIP files (host side) ------------------------------------------------------------------------
+ * Decoding of the files the reference's pipeline reads -- replaces ImageArrayUtils.readImageArray
+ * (API/imageprocessing/ImageArrayUtils.java:98-121; ImageJ's TIFF opener / LocalTiffDecoder.java, packBitsUncompress :229-258,
+ * ImageIO for PNG).  Supported: baseline strip TIFF (8/16-bit, 1/3/4 samples, none / PackBits / LZW / Deflate, predictor 2)
+ * and non-interlaced PNG (gray 8/16, RGB(A) 8, palette 8); anything else fails with a message.
+ * Decoded layout: channels == 3 -> packed RGB u8 (alpha dropped, palette expanded); channels == 1 -> u8 or host-order u16. */
+typedef struct cds_image_info {
+    int32_t width, height, channels, bits;
+} cds_image_info;
+int cds_image_probe(const uint8_t *data, size_t size, cds_image_info *info);
+int cds_image_decode(const uint8_t *data, size_t size, void *out, size_t out_bytes);
+/* Append `count` image files (8-bit RGB, the library's size) to a sparse library: decoded on `threads` host threads
+ * (<= 0: all cores) while the previous batch of 64 is uploaded and converted on the GPU.  Fails at the first file that
+ * cannot be read / decoded (its path is in cds_last_error()); batches appended before it stay. */
+int cds_sparse_library_append_files(cds_sparse_library *slib, const char *const *paths, int64_t count, int32_t threads);
+
 /* The scan over images [first, first+count) of a sparse library: same outputs as cds_search / cds_search_device /
  * cds_search_counts. */
 int cds_search_sparse(const cds_maskset *ms, const cds_sparse_library *slib, int64_t first, int64_t count,

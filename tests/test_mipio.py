@@ -25,6 +25,74 @@ def test_image_files_and_zip_entries_round_trip(tmp_path, fixtures):
     assert np.array_equal(mipio.read_mip((str(zp), "dir/a.tif")), img)
 
 
+def test_native_decoder_equals_pillow(tmp_path, fixtures):
+    """csrc/cds_imageio.hip against Pillow on every container / compression / pixel type it claims, on real MIP content
+    (the reference's fixtures) and on noise (long literal runs, LZW table resets), plus its refusals."""
+    PIL = pytest.importorskip("PIL.Image")
+    from colormipsearch_amd.capi import CdsError
+    rng = np.random.default_rng(8)
+    rgb = [fixtures["lm_VT016795"], fixtures["em_LPLC2"], rng.integers(0, 256, size=(97, 131, 3)).astype(np.uint8),
+           np.zeros((33, 40, 3), dtype=np.uint8), np.repeat(rng.integers(0, 256, size=(50, 1, 3)), 300, axis=1).astype(np.uint8)]
+    k = 0
+    for img in rgb:
+        for fmt, kw in (("tif", dict(compression="raw")), ("tif", dict(compression="packbits")), ("tif", dict(compression="tiff_lzw")),
+                        ("tif", dict(compression="tiff_adobe_deflate")), ("tif", dict(compression="tiff_lzw", tiffinfo={317: 2})),
+                        ("png", {}), ("png", dict(compress_level=1))):
+            p = tmp_path / f"i{k}.{fmt}"
+            k += 1
+            PIL.fromarray(img, "RGB").save(p, **kw)
+            got = mipio.decode_image(open(p, "rb").read())
+            assert got.dtype == np.uint8 and np.array_equal(got, img), (p, kw)
+            assert np.array_equal(mipio.read_mip(str(p)), img)
+    # gray 8 / 16 (gradient images), RGBA and palette inputs
+    g16, g8 = fixtures["grad_BJD"], (fixtures["grad_BJD"] >> 2).astype(np.uint8)
+    for arr, fmt, kw in ((g16, "png", {}), (g16, "tif", dict(compression="tiff_lzw")), (g16, "tif", dict(compression="raw")),
+                         (g16, "tif", dict(compression="tiff_adobe_deflate", tiffinfo={317: 2})), (g8, "png", {}), (g8, "tif", dict(compression="packbits"))):
+        p = tmp_path / f"g{k}.{fmt}"
+        k += 1
+        PIL.fromarray(arr).save(p, **kw)
+        got = mipio.decode_image(open(p, "rb").read())
+        assert got.dtype == arr.dtype and np.array_equal(got, arr), (p, kw)
+        assert np.array_equal(mipio.read_gradient(str(p)), arr.astype(np.uint16))
+    rgba = np.dstack([rgb[2], rng.integers(0, 256, size=rgb[2].shape[:2]).astype(np.uint8)])
+    for fmt in ("png", "tif"):
+        p = tmp_path / f"a.{fmt}"
+        PIL.fromarray(rgba, "RGBA").save(p)
+        assert np.array_equal(mipio.decode_image(open(p, "rb").read()), rgb[2])
+    pal = PIL.fromarray(rgb[4], "RGB").quantize(32)
+    pal.save(tmp_path / "p.png")
+    assert np.array_equal(mipio.decode_image(open(tmp_path / "p.png", "rb").read()), np.asarray(pal.convert("RGB")))
+    # refusals: not an image, truncated data, JPEG (Pillow takes over in read_mip)
+    with pytest.raises(CdsError):
+        mipio.decode_image(b"hello world, this is not an image")
+    data = open(tmp_path / "i1.tif", "rb").read()
+    with pytest.raises(CdsError):
+        mipio.decode_image(data[: len(data) // 2])
+    PIL.fromarray(rgb[2], "RGB").save(tmp_path / "j.jpg")
+    with pytest.raises(CdsError):
+        mipio.decode_image(open(tmp_path / "j.jpg", "rb").read())
+    assert mipio.read_mip(str(tmp_path / "j.jpg")).shape == rgb[2].shape
+
+
+def test_native_decoder_on_the_reference_files(fixtures):
+    """The reference's own test images (when the reference tree is present), decoded natively == the committed pixel fixtures."""
+    import glob, os
+    root = "/root/reference/colormipsearch-api/src/test/resources/colormipsearch/api"
+    if not os.path.isdir(root):
+        pytest.skip("reference tree not present")
+    want = {"12191_JRC2018U.tif": "em_12191", "12191_JRC2018U_FL.tif": "em_12191_FL", "1752016801-LPLC2-RT_18U.tif": "em_LPLC2"}
+    for f, key in want.items():
+        assert np.array_equal(mipio.decode_image(open(os.path.join(root, "cdsearch/ems", f), "rb").read()), fixtures[key]), f
+    for f in glob.glob(os.path.join(root, "cdsearch/grad/BJD*.png")):
+        assert np.array_equal(mipio.decode_image(open(f, "rb").read()), fixtures["grad_BJD"])
+    PIL = pytest.importorskip("PIL.Image")
+    for f in glob.glob(os.path.join(root, "imageprocessing/*.tif")) + glob.glob(os.path.join(root, "cdsearch/*/*.tif")):
+        with PIL.open(f) as im:
+            ref = np.asarray(im.convert("RGB"))
+        assert np.array_equal(mipio.read_mip(f), ref), f
+        assert np.array_equal(mipio.decode_image(open(f, "rb").read()), ref), f   # (all of them are within the native decoder's range)
+
+
 def test_shard_round_trip(tmp_path, fixtures):
     imgs = np.stack([fixtures[k] for k in ("lm_GMR", "lm_BJD", "em_LPLC2")])
     path = tmp_path / "lib.shard"
@@ -64,3 +132,36 @@ def test_shard_upload_and_search(tmp_path, fixtures, oracle):
     alg = cds.PixelMatchColorDepthSearchAlgorithm(fixtures["em_12191"], 20, True, None, 0, False, 20, 0.01, 2, cds.label_regions)
     scores, mir = alg.searchLibrary(lib)
     assert scores[0].tolist() == [439, 414, 426] and mir[0].tolist() == [False, False, True]   # the reference's goldens
+
+
+@pytest.mark.gpu
+def test_append_files_to_sparse_library(tmp_path, fixtures):
+    """cds_sparse_library_append_files: a directory of MIP files (mixed compressions, more than two batches) -> sparse resident
+    library -> the reference's golden scores; a broken file stops the ingest with its path in the message."""
+    PIL = pytest.importorskip("PIL.Image")
+    from colormipsearch_amd import cds
+    keys = ("lm_VT033614", "lm_BJD", "lm_VT016795", "lm_GMR")
+    comps = ("packbits", "tiff_lzw", "raw", None)
+    paths = []
+    for i in range(150):
+        k = i % 4
+        p = tmp_path / (f"t{i}.png" if comps[k] is None else f"t{i}.tif")
+        PIL.fromarray(fixtures[keys[k]], "RGB").save(p, **({} if comps[k] is None else dict(compression=comps[k])))
+        paths.append(str(p))
+    sl = cds.SparseLibrary(1210, 566, 160, 160 * 70000)
+    sl.append_files(paths, threads=8)
+    assert len(sl) == 150
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(fixtures["em_12191"], 20, True, None, 0, False, 20, 0.01, 2, cds.label_regions)
+    scores, mir = alg.searchSparseLibrary(sl)
+    want = {0: (439, False), 1: (414, False), 2: (426, True)}
+    for i in range(150):
+        if i % 4 in want:
+            assert (int(scores[0, i]), bool(mir[0, i])) == want[i % 4], i
+    bad = tmp_path / "bad.tif"
+    bad.write_bytes(open(paths[0], "rb").read()[:5000])
+    with pytest.raises(cds.CdsError, match="bad.tif"):
+        sl.append_files([paths[1], str(bad)])
+    with pytest.raises(cds.CdsError, match="size"):
+        p2 = tmp_path / "small.png"
+        PIL.fromarray(np.zeros((10, 10, 3), dtype=np.uint8), "RGB").save(p2)
+        sl.append_files([str(p2)])

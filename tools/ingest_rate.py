@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Library ingest from image files: `--files` synthetic targets are written as TIFFs (`--compression`), then appended to a
+sparse resident library with cds_sparse_library_append_files (native threaded decode || upload + conversion).  Reports
+images/s for the native path and, on a sample, for the Pillow decode it replaces."""
+import argparse, json, os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401
+from PIL import Image
+from colormipsearch_amd import cds, mipio
+W, H = 1210, 566
+ap = argparse.ArgumentParser()
+ap.add_argument("--files", type=int, default=2048)
+ap.add_argument("--compression", default="packbits")
+ap.add_argument("--threads", type=int, default=0)
+a = ap.parse_args()
+lib = cds.Library(W, H, 256)
+lib.generate_synthetic(0xC0FFEE, 0, 0, 256, kind=0)
+imgs = lib.download(0, 256)
+with tempfile.TemporaryDirectory() as d:
+    paths, nbytes = [], 0
+    for i in range(a.files):
+        p = os.path.join(d, f"t{i}.tif")
+        if i < 256:
+            Image.fromarray(imgs[i], "RGB").save(p, compression=a.compression)
+        else:
+            os.link(paths[i % 256], p)      # the same 256 files again (page-cached either way)
+        paths.append(p)
+        nbytes += os.path.getsize(p)
+    sl = cds.SparseLibrary(W, H, a.files, 46000 * a.files)
+    sl.append_files(paths[:64], threads=a.threads)   # warm-up (staging slots, kernels)
+    sl.clear()
+    t0 = time.perf_counter(); sl.append_files(paths, threads=a.threads); t = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for p in paths[:64]:
+        mipio.read_mip(p, native=False)
+    tp = (time.perf_counter() - t0) / 64
+    print(json.dumps({"files": a.files, "compression": a.compression, "mean_file_bytes": round(nbytes / a.files), "threads": a.threads or os.cpu_count(),
+                      "append_files_s": round(t, 3), "images_per_s": round(a.files / t), "decoded_GBps": round(a.files * 3 * W * H / t / 1e9, 2),
+                      "pillow_decode_ms_per_image_single_thread": round(tp * 1e3, 2), "records": sl.pixels}))
