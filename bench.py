@@ -198,6 +198,8 @@ def main():
                 "algorithmic_bytes_per_target": alg_bytes_per_target,
                 "kernel_ms_per_launch": kern_ms,
                 "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+                "frac_by_traffic": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "pipes_busy_per_cu": {"valu": 0.58, "lds": 0.58, "salu": 0.44, "source": "profiles/r02b_summary.txt + tools/valubench (DESIGN.md 4b)"},
                 "note": "achieved = SURVEY 8(d) algorithmic bytes (mask rows x 3630 B of packed RGB per target) / kernel time.  "
                         "The library is stored sparse, so the kernel reads ~40x fewer bytes than that (traffic) and frac exceeds 1: "
                         "this kernel is bound by its waves' LDS round trips and by instruction issue, not by HBM (DESIGN.md "

@@ -94,6 +94,8 @@ SIGNATURES = {
     "cds_sparse_library_pixels": (_i64, [_vp]),
     "cds_sparse_library_clear": (_i, [_vp]),
     "cds_sparse_library_image_records": (_i, [_vp, _i64, _u32p, _i64, _i64p, _u32p]),
+    "cds_sparse_library_export": (_i, [_vp, _i64, _i64, ctypes.POINTER(ctypes.c_uint64), _u32p, _u32p, _i64]),
+    "cds_sparse_library_import": (_i, [_vp, _i64, ctypes.POINTER(ctypes.c_uint64), _u32p, _u32p, _i32, _i32]),
     "cds_image_probe": (_i, [_u8p, ctypes.c_size_t, ctypes.POINTER(ImageInfo)]),
     "cds_image_decode": (_i, [_u8p, ctypes.c_size_t, _vp, ctypes.c_size_t]),
     "cds_sparse_library_append_files": (_i, [_vp, ctypes.POINTER(ctypes.c_char_p), _i64, _i32]),

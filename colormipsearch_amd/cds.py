@@ -253,6 +253,32 @@ class SparseLibrary:
         arr = (ctypes.c_char_p * max(1, len(paths)))(*paths)
         capi.check(self._lib.cds_sparse_library_append_files(self._h, arr, len(paths), int(threads)))
 
+    def export(self, first=0, count=None):
+        """(image_offsets uint64[count+1], cell_offsets uint32[count, n_strips, H+1], records uint32[n]) of images
+        [first, first+count) -- the arrays `import_arrays` takes (and mipio.write_sparse_shard stores)."""
+        count = len(self) - first if count is None else int(count)
+        u64p, u32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)
+        offs = np.zeros(count + 1, dtype=np.uint64)
+        capi.check(self._lib.cds_sparse_library_export(self._h, int(first), count, offs.ctypes.data_as(u64p), None, None, 0))
+        cells = np.zeros((count, self.n_strips, self.height + 1), dtype=np.uint32)
+        rec = np.zeros(int(offs[count]), dtype=np.uint32)
+        capi.check(self._lib.cds_sparse_library_export(self._h, int(first), count, offs.ctypes.data_as(u64p), cells.ctypes.data_as(u32p),
+                                                       rec.ctypes.data_as(u32p), rec.size))
+        return offs, cells, rec
+
+    def import_arrays(self, image_offsets, cell_offsets, records, n_strips=None, strip_width=None):
+        """Append images given as exported arrays (possibly memory-mapped)."""
+        offs = np.ascontiguousarray(image_offsets, dtype=np.uint64)
+        cells = np.ascontiguousarray(cell_offsets, dtype=np.uint32)
+        rec = np.ascontiguousarray(records, dtype=np.uint32)
+        count = len(offs) - 1
+        if cells.size != count * self.n_strips * (self.height + 1) or (count >= 0 and rec.size < int(offs[count])):
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "array sizes do not match the image count / this library's layout")
+        u64p, u32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)
+        capi.check(self._lib.cds_sparse_library_import(self._h, count, offs.ctypes.data_as(u64p), cells.ctypes.data_as(u32p), rec.ctypes.data_as(u32p),
+                                                       self.n_strips if n_strips is None else int(n_strips),
+                                                       self.strip_width if strip_width is None else int(strip_width)))
+
     def image_records(self, index):
         """(records uint32[n], cell offsets uint32[n_strips, H+1]) of one image -- diagnostic."""
         n = ctypes.c_int64()

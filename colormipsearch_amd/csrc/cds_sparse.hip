@@ -967,6 +967,60 @@ int cds_sparse_library_image_records(const cds_sparse_library *sl, int64_t index
     return CDS_OK;
 }
 
+// ---- export / import of the record arrays (a library converted once is reloaded at disk speed) -------------------------
+int cds_sparse_library_export(const cds_sparse_library *sl, int64_t first, int64_t count, uint64_t *image_offsets, uint32_t *cell_offsets,
+                              uint32_t *records, int64_t records_capacity) {
+    int rc = sparse_check_range(sl, first, count);
+    if (rc) return rc;
+    if (!image_offsets) return fail(CDS_ERR_INVALID_ARGUMENT, "image_offsets is NULL");
+    CDS_HIP(hipSetDevice(sl->ctx->device));
+    CDS_HIP(hipStreamSynchronize(sl->ctx->stream));
+    CDS_HIP(hipMemcpy(image_offsets, sl->d_img_off + first, (size_t)(count + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    const uint64_t base = image_offsets[0], n_rec = image_offsets[count] - base;
+    for (int64_t i = 0; i <= count; i++) image_offsets[i] -= base;   // relative to the first exported image
+    if (cell_offsets && count > 0)
+        CDS_HIP(hipMemcpy(cell_offsets, sl->d_rowptr + (size_t)first * sl->nstrips * (sl->H + 1), (size_t)count * sl->nstrips * (sl->H + 1) * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost));
+    if (records) {
+        if ((uint64_t)records_capacity < n_rec) return fail(CDS_ERR_INVALID_ARGUMENT, "record buffer too small");
+        if (n_rec) CDS_HIP(hipMemcpy(records, sl->d_px + base, (size_t)n_rec * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    return CDS_OK;
+}
+
+int cds_sparse_library_import(cds_sparse_library *sl, int64_t count, const uint64_t *image_offsets, const uint32_t *cell_offsets,
+                              const uint32_t *records, int32_t n_strips, int32_t strip_width) {
+    if (!sl) return fail(CDS_ERR_INVALID_ARGUMENT, "sparse library is NULL");
+    if (count < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "count is negative");
+    if (count == 0) return CDS_OK;
+    if (!image_offsets || !cell_offsets || !records) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_strips != sl->nstrips || strip_width != sl->strip_w) return fail(CDS_ERR_INVALID_ARGUMENT, "record layout (strips) differs from this library's");
+    std::lock_guard<std::mutex> lk(sl->mu);
+    if (sl->n_images + count > sl->cap_images) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (images)");
+    const uint64_t n_rec = image_offsets[count] - image_offsets[0];
+    if (sl->n_px + (int64_t)n_rec > sl->cap_px) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (records)");
+    // consistency of the untrusted tables: monotone image offsets, every image's last cell offset == its record count
+    const size_t cells = (size_t)sl->nstrips * (sl->H + 1);
+    for (int64_t i = 0; i < count; i++) {
+        if (image_offsets[i + 1] < image_offsets[i]) return fail(CDS_ERR_INVALID_ARGUMENT, "image offsets are not monotone");
+        const uint32_t *co = cell_offsets + (size_t)i * cells;
+        if (co[0] != 0 || co[cells - 1] != image_offsets[i + 1] - image_offsets[i]) return fail(CDS_ERR_INVALID_ARGUMENT, "cell offsets do not match the image's record count");
+        for (size_t c = 1; c < cells; c++)
+            if (co[c] < co[c - 1]) return fail(CDS_ERR_INVALID_ARGUMENT, "cell offsets are not monotone");
+    }
+    CDS_HIP(hipSetDevice(sl->ctx->device));
+    hipStream_t st = sl->ctx->stream;
+    std::vector<uint64_t> off((size_t)count + 1);
+    for (int64_t i = 0; i <= count; i++) off[(size_t)i] = (uint64_t)sl->n_px + (image_offsets[i] - image_offsets[0]);
+    CDS_HIP(hipMemcpyAsync(sl->d_img_off + sl->n_images, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    CDS_HIP(hipMemcpyAsync(sl->d_rowptr + (size_t)sl->n_images * cells, cell_offsets, (size_t)count * cells * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (n_rec) CDS_HIP(hipMemcpyAsync(sl->d_px + sl->n_px, records + image_offsets[0], (size_t)n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    CDS_HIP(hipStreamSynchronize(st));
+    sl->n_images += count;
+    sl->n_px += (int64_t)n_rec;
+    return CDS_OK;
+}
+
 int cds_search_sparse_device(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, int32_t *d_scores) {
     if (!d_scores && count > 0) return fail(CDS_ERR_INVALID_ARGUMENT, "d_scores is NULL");
     return sparse_search_impl(ms, sl, first, count, d_scores, nullptr, getenv("CDS_TIME_KERNELS") != nullptr);

@@ -161,6 +161,17 @@ int cds_sparse_library_clear(cds_sparse_library *slib);
  * its n_strips x (H+1) cell offsets; either output may be NULL; *n_records is always set. */
 int cds_sparse_library_image_records(const cds_sparse_library *slib, int64_t index, uint32_t *records, int64_t capacity,
                                      int64_t *n_records, uint32_t *row_offsets);
+/* Export / import of the record arrays, for persisting a converted library (colormipsearch_amd/mipio.py: sparse shard files).
+ * Export images [first, first+count): image_offsets[count+1] (record offsets relative to the first exported image),
+ * cell_offsets[count][n_strips][H+1] and the records themselves (any of the last two may be NULL; call once with NULLs to
+ * size the buffers: the record count is image_offsets[count]).  Import appends `count` images given in that form; the
+ * layout (n_strips, strip_width) must be this library's; the offset tables are validated (records are data: a wrong
+ * record can only produce wrong scores for its own image). */
+int cds_sparse_library_export(const cds_sparse_library *slib, int64_t first, int64_t count, uint64_t *image_offsets,
+                              uint32_t *cell_offsets, uint32_t *records, int64_t records_capacity);
+int cds_sparse_library_import(cds_sparse_library *slib, int64_t count, const uint64_t *image_offsets, const uint32_t *cell_offsets,
+                              const uint32_t *records, int32_t n_strips, int32_t strip_width);
+
 /* ---- MIP files (host side) ------------------------------------------------------------------------
  * Decoding of the files the reference's pipeline reads -- replaces ImageArrayUtils.readImageArray
  * (API/imageprocessing/ImageArrayUtils.java:98-121; ImageJ's TIFF opener / LocalTiffDecoder.java, packBitsUncompress :229-258,

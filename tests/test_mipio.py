@@ -165,3 +165,38 @@ def test_append_files_to_sparse_library(tmp_path, fixtures):
         p2 = tmp_path / "small.png"
         PIL.fromarray(np.zeros((10, 10, 3), dtype=np.uint8), "RGB").save(p2)
         sl.append_files([str(p2)])
+
+
+@pytest.mark.gpu
+def test_sparse_shard_round_trip(tmp_path, fixtures, oracle):
+    """A converted library written to a sparse shard file and loaded again (in several batches, into a library that already
+    holds images): identical record arrays and identical scores; inconsistent offset tables are refused."""
+    from colormipsearch_amd import cds
+    keys = ("lm_VT033614", "lm_BJD", "lm_VT016795", "lm_GMR")
+    imgs = np.stack([fixtures[k] for k in keys] + [np.zeros_like(fixtures["lm_GMR"]), oracle.synth_image(0xC0FFEE, 5, 0)])
+    sl = cds.SparseLibrary(1210, 566, 8, 8 * 70000)
+    sl.append(imgs)
+    path = tmp_path / "lib.sparse"
+    hd = mipio.write_sparse_shard(path, sl, meta=[{"mipId": str(i)} for i in range(len(imgs))])
+    assert hd["n"] == len(imgs) and hd["records"] == sl.pixels
+    sl2 = cds.SparseLibrary(1210, 566, 12, 12 * 70000)
+    sl2.append(imgs[2:3])                                   # not empty: the import appends behind it
+    assert mipio.load_sparse_shard(sl2, path, batch=4) == len(imgs)
+    assert len(sl2) == len(imgs) + 1 and sl2.pixels == sl.pixels + len(sl.image_records(2)[0])
+    for i in range(len(imgs)):
+        a, b = sl.image_records(i), sl2.image_records(i + 1)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), i
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(fixtures["em_12191"], 20, True, None, 0, False, 20, 0.01, 2, cds.label_regions)
+    s1, m1 = alg.searchSparseLibrary(sl)
+    s2, m2 = alg.searchSparseLibrary(sl2, 1, len(imgs))
+    assert np.array_equal(s1, s2) and np.array_equal(m1, m2) and s1[0, :3].tolist() == [439, 414, 426]
+    offs, cells, rec = sl.export(1, 3)
+    assert offs[0] == 0 and offs[3] == len(rec) and cells.shape == (3, sl.n_strips, 567)
+    bad = cells.copy()
+    bad[1, 0, 5] = bad[1, 0, 4] + 10**6                  # not monotone any more
+    with pytest.raises(ValueError):
+        sl2.import_arrays(offs, bad, rec)
+    with pytest.raises(ValueError):
+        sl2.import_arrays(offs, cells, rec, n_strips=2, strip_width=608)
+    with pytest.raises(ValueError):
+        mipio.open_shard(path)                            # (a sparse shard is not a dense shard)

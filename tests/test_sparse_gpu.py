@@ -26,7 +26,7 @@ def sparse_of(cds, images, w=None, h=None, slack=0):
     if images.ndim == 3:
         images = images[None]
     n, hh, ww, _ = images.shape
-    sl = cds.SparseLibrary(ww, hh, n + slack, int((images.max(axis=3) > 0).sum()) + 4 * n * hh + 64)
+    sl = cds.SparseLibrary(ww, hh, n + slack, int((images.max(axis=3) > 0).sum()) + 16 * n * hh + 64)   # (<= 16 strips: one filler per empty cell)
     sl.append(images)
     return sl
 
@@ -371,3 +371,31 @@ def test_equals_dense_scan_at_scale(cds, oracle):
         sl2.append_from(lib, 1063 - k, 1)
     s3, _ = alg.searchSparseLibrary(sl2)
     assert np.array_equal(s3[:, ::-1], s1[:, 1000:1064])
+
+
+@pytest.mark.parametrize("strip_w", [None, 64, 20])
+def test_odd_geometries_thresholds_and_strip_widths(cds, oracle, strip_w, monkeypatch):
+    """Widths that are no multiple of 4, single-row and single-column-strip images, thresholds at the ends of the byte
+    range, masks at the image corners; with the default strips, 64-pixel strips and 20-pixel strips (up to 16 runs per
+    target and slab)."""
+    if strip_w:
+        monkeypatch.setenv("CDS_SPARSE_STRIP_W", str(strip_w))
+    rng = np.random.default_rng(31)
+    lut = oracle.depth_lut()
+    for (w, h) in ((9, 1), (13, 7), (63, 5), (65, 33), (130, 2), (257, 19), (318, 40)):
+        if strip_w == 20 and w > 320:
+            continue
+        mask = np.zeros((h, w, 3), dtype=np.uint8)
+        mask[: max(1, h // 2), : max(2, w // 3)] = lut[rng.integers(0, 256, size=(max(1, h // 2), max(2, w // 3)))]
+        mask[h - 1, w - 3:] = lut[77]
+        targets = np.stack([mask, np.fliplr(mask), lut[rng.integers(0, 256, size=(h, w))].astype(np.uint8), np.zeros_like(mask),
+                            rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8)])
+        sl = sparse_of(cds, targets)
+        assert sl.n_strips == -(-w // sl.strip_width) and sl.n_strips <= 16
+        for (mthr, dthr, ztol, xy, mirror) in ((0, 0, 0.01, 2, True), (20, 254, 0.5, 2, True), (20, 255, 0.5, 0, True), (254, 20, 0.1, 2, False),
+                                               (20, 20, 0.0, 0, False)):
+            alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, mthr, mirror, None, 0, False, dthr, ztol, xy, [])
+            counts = alg.searchSparseLibraryCounts(sl)
+            q = oracle.PixelMatchQuery(mask, mthr, dthr, ztol, xy, mirror, [])
+            for t in range(len(targets)):
+                assert np.array_equal(counts[0, t], q.score(targets[t])[2]), (w, h, mthr, dthr, ztol, xy, mirror, t)
