@@ -399,3 +399,20 @@ def test_odd_geometries_thresholds_and_strip_widths(cds, oracle, strip_w, monkey
             q = oracle.PixelMatchQuery(mask, mthr, dthr, ztol, xy, mirror, [])
             for t in range(len(targets)):
                 assert np.array_equal(counts[0, t], q.score(targets[t])[2]), (w, h, mthr, dthr, ztol, xy, mirror, t)
+
+
+def test_dense_full_frame_mask(cds, oracle):
+    """Every pixel of the frame is a mask pixel (684 K of them): the plane is cut into several slabs, every record of every
+    target is near the mask; sparse and dense targets."""
+    rects = cds.label_regions(W)
+    rng = np.random.default_rng(99)
+    lut = oracle.depth_lut()
+    mask = lut[rng.integers(0, 256, size=(H, W))].astype(np.uint8)
+    targets = np.stack([oracle.synth_image(0xC0FFEE, 11, 0), oracle.synth_image(0xC0FFEE, 12, 1), mask])
+    sl = sparse_of(cds, targets)
+    q = oracle.PixelMatchQuery(mask, 20, 20, 0.01, 2, True, rects)
+    want = np.stack([q.score(t)[2] for t in targets])
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    got = alg.searchSparseLibraryCounts(sl)[0]
+    assert np.array_equal(got, want)
+    assert got[2, 4] > 0.9 * alg.getQuerySize()   # the mask against itself, unshifted
