@@ -116,6 +116,7 @@ SIGNATURES = {
     "cds_debug_intervals": (_i, [_f32p, _i32, _i32, _i32, ctypes.c_double, _u32p]),
     "cds_debug_hue_code": (ctypes.c_uint32, [_f32p, _i32, _i32, _i32, _i32]),
     "cds_debug_device_rcp": (_i, [_vp, _f32p]),
+    "cds_maskset_sparse_layout": (_i, [_vp, _i32, _i32p]),
 }
 
 _lib = None

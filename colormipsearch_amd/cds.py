@@ -554,6 +554,13 @@ class PixelMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
         capi.check(self._lib.cds_search_sparse_device(self._h, sparse_library._h, int(first), int(count),
                                                       ctypes.c_void_p(int(d_scores_ptr))))
 
+    def sparseLayout(self, mask_index=0):
+        """How the mask is laid out for the sparse scan (diagnostic): dict of slabs, rows per slab, LDS bytes, ..."""
+        out = np.zeros(8, dtype=np.int32)
+        capi.check(self._lib.cds_maskset_sparse_layout(self._h, int(mask_index), capi.as_i32p(out)))
+        keys = ("slabs", "slab_rows", "lds_bytes", "box_cols", "box_rows", "interval_records", "plane_cell_bytes", "intervals_in_lds")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def lastKernelMs(self):
         ms, n = ctypes.c_double(), ctypes.c_int32()
         capi.check(self._lib.cds_maskset_last_kernel_ms(self._h, ctypes.byref(ms), ctypes.byref(n)))

@@ -568,19 +568,26 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
         auto fits = [&](int R, size_t bud) {
             return fixed + slab_image_bytes(R, pl.pitch, pl.nwpr, esize, nullptr) <= bud;
         };
-        // 80 KB = two workgroups of 1024 threads per CU.  A mask that fits ONE slab when a workgroup takes the whole LDS
-        // (one workgroup per CU, 4 waves per SIMD) but needs several at 80 KB is laid out as one slab: no halo rows read
-        // twice, no partial counts (measured on the benchmark mask: 0.816 vs 0.843 ms per 65,536 targets)
-        size_t bud = budget;
-        if (!getenv("CDS_SPARSE_LDS_KB") && !fits(pl.nrows, bud) && fits(pl.nrows, ctx->lds_per_block)) bud = ctx->lds_per_block;
-        if (!fits(1, bud)) bud = ctx->lds_per_block;
-        if (!fits(1, bud)) {
+        // 80 KB = two workgroups of 1024 threads per CU (8 waves per SIMD, 64 VGPRs); the whole LDS = one workgroup per CU
+        // (4 waves per SIMD, 128 VGPRs: more LDS requests in flight per wave).  Fewer slabs win: every slab re-reads 4 halo rows
+        // of records, ends every target with partial rounds and adds a partial-count pass.  Measured per 262,144 targets:
+        // the benchmark mask 1 slab / 160 KB 1.9 ms vs 3 slabs / 80 KB 2.1 ms; masks with 2-byte planes (> 255 interval
+        // records) 2 slabs / 160 KB vs 7 slabs / 80 KB 3.5-4.2 ms.  So: the larger budget whenever it needs fewer slabs.
+        auto rows_for = [&](size_t bud) {
+            int R = 0;
+            while (R < pl.nrows && fits(R + 1, bud)) R++;
+            return R;
+        };
+        int R = rows_for(budget);
+        if (!getenv("CDS_SPARSE_LDS_KB") || R == 0) {
+            const int R2 = rows_for(ctx->lds_per_block);
+            if (R2 > 0 && (R == 0 || (pl.nrows + R2 - 1) / R2 < (pl.nrows + R - 1) / R)) R = R2;
+        }
+        if (R == 0) {
             pl.n_slabs = -1;
             tab.clear();
             return;
         }
-        int R = 1;
-        while (R < pl.nrows && fits(R + 1, bud)) R++;
         pl.n_slabs = (pl.nrows + R - 1) / R;
         if (pl.n_slabs > SP_MAX_SLABS) {
             pl.n_slabs = -1;
@@ -964,6 +971,15 @@ int cds_sparse_library_image_records(const cds_sparse_library *sl, int64_t index
     if (row_offsets)
         CDS_HIP(hipMemcpy(row_offsets, sl->d_rowptr + (size_t)index * sl->nstrips * (sl->H + 1), (size_t)sl->nstrips * (sl->H + 1) * sizeof(uint32_t),
                           hipMemcpyDeviceToHost));
+    return CDS_OK;
+}
+
+int cds_maskset_sparse_layout(const cds_maskset *ms, int32_t mask_index, int32_t *out8) {
+    if (!ms || !out8) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (mask_index < 0 || mask_index >= ms->n_masks || (size_t)mask_index >= ms->sp_plans.size()) return fail(CDS_ERR_INVALID_ARGUMENT, "mask_index out of range");
+    const SparseMaskPlan &pl = ms->sp_plans[(size_t)mask_index];
+    out8[0] = pl.n_slabs; out8[1] = pl.slab_rows; out8[2] = (int32_t)pl.lds_bytes; out8[3] = pl.cols;
+    out8[4] = pl.nrows; out8[5] = pl.n_iv; out8[6] = pl.plane8 ? 1 : 2; out8[7] = pl.iv_in_lds ? 1 : 0;
     return CDS_OK;
 }
 

@@ -18,6 +18,10 @@ extern "C" {
 int cds_debug_intervals(const float *rcp_table, int32_t r, int32_t g, int32_t b, double z_tolerance, uint32_t *out4);
 uint32_t cds_debug_hue_code(const float *rcp_table, int32_t r, int32_t g, int32_t b, int32_t threshold);
 int cds_debug_device_rcp(const cds_context *ctx, float *out256);
+/* How mask `mask_index` is laid out for the sparse scan: out8 = { slabs (0 = no device pixel, -1 = not representable),
+ * mask rows per slab, LDS bytes of one workgroup, bounding-box columns, bounding-box rows, interval records + 1,
+ * bytes per plane cell, interval table in LDS }. */
+int cds_maskset_sparse_layout(const cds_maskset *ms, int32_t mask_index, int32_t *out8);
 #ifdef __cplusplus
 }
 #endif
