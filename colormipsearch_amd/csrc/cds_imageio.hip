@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -22,6 +24,8 @@
 #include "cds_internal.hpp"
 
 namespace cds {
+
+constexpr uint32_t kMaxImageSide = 16384;  // (a header is untrusted input: bounds the buffers a file can make us allocate)
 
 struct ImgInfo {
     int W = 0, H = 0, channels = 0, bits = 0;  // channels of the DECODED image (alpha dropped, palette expanded)
@@ -131,7 +135,7 @@ static bool tiff_parse(const uint8_t *data, size_t n, Reader &r, TiffDir &d, std
         }
     }
     if (d.tiled) { err = "tiled TIFFs are not supported"; return false; }
-    if (d.W == 0 || d.H == 0 || d.W > 65535 || d.H > 65535) { err = "TIFF without a valid size"; return false; }
+    if (d.W == 0 || d.H == 0 || d.W > kMaxImageSide || d.H > kMaxImageSide) { err = "TIFF without a valid size (1..16384 per side)"; return false; }
     if (d.bits != 8 && d.bits != 16) { err = "TIFF bits per sample must be 8 or 16"; return false; }
     if (d.spp != 1 && d.spp != 3 && d.spp != 4) { err = "TIFF samples per pixel must be 1, 3 or 4"; return false; }
     if (d.spp >= 3 && d.bits != 8) { err = "16-bit colour TIFFs are not supported"; return false; }
@@ -300,7 +304,7 @@ static bool png_head(const uint8_t *data, size_t n, PngHead &h, std::string &err
     Reader r{data, n, false};
     if (r.u32(8) != 13 || memcmp(data + 12, "IHDR", 4) != 0) { err = "PNG without IHDR"; return false; }
     h.W = r.u32(16); h.H = r.u32(20); h.depth = data[24]; h.ctype = data[25]; h.interlace = data[28];
-    if (h.W == 0 || h.H == 0 || h.W > 65535 || h.H > 65535) { err = "PNG without a valid size"; return false; }
+    if (h.W == 0 || h.H == 0 || h.W > kMaxImageSide || h.H > kMaxImageSide) { err = "PNG without a valid size (1..16384 per side)"; return false; }
     if (h.interlace) { err = "interlaced PNGs are not supported"; return false; }
     const bool ok = (h.ctype == 0 && (h.depth == 8 || h.depth == 16)) || ((h.ctype == 2 || h.ctype == 6 || h.ctype == 3) && h.depth == 8);
     if (!ok) { err = "unsupported PNG colour type / bit depth"; return false; }
@@ -412,17 +416,27 @@ using namespace cds;
 
 extern "C" {
 
+// (no C++ exception may cross the C ABI: allocation failures inside the decoders become error codes here)
+#define CDS_NOEXCEPT_BEGIN try {
+#define CDS_NOEXCEPT_END                                                                         \
+    }                                                                                            \
+    catch (const std::bad_alloc &) { return fail(CDS_ERR_OUT_OF_MEMORY, "out of host memory"); } \
+    catch (const std::exception &e) { return fail(CDS_ERR_INVALID_ARGUMENT, e.what()); }
+
 int cds_image_probe(const uint8_t *data, size_t size, cds_image_info *info) {
     if (!data || !info) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    CDS_NOEXCEPT_BEGIN
     ImgInfo i;
     std::string err;
     if (!image_probe(data, size, i, err)) return fail(CDS_ERR_INVALID_ARGUMENT, err);
     info->width = i.W; info->height = i.H; info->channels = i.channels; info->bits = i.bits;
     return CDS_OK;
+    CDS_NOEXCEPT_END
 }
 
 int cds_image_decode(const uint8_t *data, size_t size, void *out, size_t out_bytes) {
     if (!data || !out) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    CDS_NOEXCEPT_BEGIN
     ImgInfo i;
     std::string err;
     if (!image_probe(data, size, i, err)) return fail(CDS_ERR_INVALID_ARGUMENT, err);
@@ -430,9 +444,18 @@ int cds_image_decode(const uint8_t *data, size_t size, void *out, size_t out_byt
     if (out_bytes < need) return fail(CDS_ERR_INVALID_ARGUMENT, "output buffer too small");
     if (!image_decode(data, size, i, out, err)) return fail(CDS_ERR_INVALID_ARGUMENT, err);
     return CDS_OK;
+    CDS_NOEXCEPT_END
 }
 
+static int append_files_impl(cds_sparse_library *sl, const char *const *paths, int64_t count, int32_t threads);
+
 int cds_sparse_library_append_files(cds_sparse_library *sl, const char *const *paths, int64_t count, int32_t threads) {
+    CDS_NOEXCEPT_BEGIN
+    return append_files_impl(sl, paths, count, threads);
+    CDS_NOEXCEPT_END
+}
+
+static int append_files_impl(cds_sparse_library *sl, const char *const *paths, int64_t count, int32_t threads) {
     if (!sl || (count > 0 && !paths)) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (count < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "count is negative");
     if (count == 0) return CDS_OK;
@@ -458,12 +481,18 @@ int cds_sparse_library_append_files(cds_sparse_library *sl, const char *const *p
             for (int64_t i = next.fetch_add(1); i < nb; i = next.fetch_add(1)) {
                 std::string err;
                 ImgInfo info;
-                bool ok = read_file(paths[b0 + i], file, err) && image_probe(file.data(), file.size(), info, err);
-                if (ok && (info.W != sl->W || info.H != sl->H || info.channels != 3 || info.bits != 8)) {
-                    err = "is not an 8-bit RGB image of the library's size";
+                bool ok = false;
+                try {
+                    ok = read_file(paths[b0 + i], file, err) && image_probe(file.data(), file.size(), info, err);
+                    if (ok && (info.W != sl->W || info.H != sl->H || info.channels != 3 || info.bits != 8)) {
+                        err = "is not an 8-bit RGB image of the library's size";
+                        ok = false;
+                    }
+                    if (ok) ok = image_decode(file.data(), file.size(), info, dst + (size_t)i * img_bytes, err);
+                } catch (const std::exception &e) {   // (an exception must not leave a worker thread)
+                    err = e.what();
                     ok = false;
                 }
-                if (ok) ok = image_decode(file.data(), file.size(), info, dst + (size_t)i * img_bytes, err);
                 if (!ok) {
                     std::lock_guard<std::mutex> lk(err_mu);
                     if (first_err.empty()) first_err = std::string(paths[b0 + i]) + ": " + err;

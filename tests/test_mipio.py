@@ -74,6 +74,41 @@ def test_native_decoder_equals_pillow(tmp_path, fixtures):
     assert mipio.read_mip(str(tmp_path / "j.jpg")).shape == rgb[2].shape
 
 
+def test_native_decoder_survives_corrupt_files(tmp_path):
+    """Seeded corruption of valid files (flipped bytes, truncations, garbage tails): the decoder answers with an error or
+    with pixels, never with a crash or an out-of-bounds access (the headers are untrusted input)."""
+    PIL = pytest.importorskip("PIL.Image")
+    from colormipsearch_amd.capi import CdsError
+    rng = np.random.default_rng(2026)
+    img = rng.integers(0, 256, size=(40, 52, 3)).astype(np.uint8)
+    img[10:30, 5:40] = 0
+    files = []
+    for name, kw in (("a.tif", dict(compression="packbits")), ("b.tif", dict(compression="tiff_lzw")), ("c.tif", dict(compression="raw")),
+                     ("d.tif", dict(compression="tiff_adobe_deflate")), ("e.png", {})):
+        PIL.fromarray(img, "RGB").save(tmp_path / name, **kw)
+        files.append(open(tmp_path / name, "rb").read())
+    outcomes = {"ok": 0, "error": 0}
+    for data in files:
+        for trial in range(250):
+            b = bytearray(data)
+            kind = trial % 3
+            if kind == 0:
+                for _ in range(int(rng.integers(1, 6))):
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            elif kind == 1:
+                b = b[: int(rng.integers(0, len(b)))]
+            else:
+                pos = int(rng.integers(0, len(b)))
+                b[pos:pos + 8] = bytes(rng.integers(0, 256, size=8).astype(np.uint8))
+            try:
+                out = mipio.decode_image(bytes(b))
+                assert out.size > 0
+                outcomes["ok"] += 1
+            except (CdsError, MemoryError, ValueError):
+                outcomes["error"] += 1
+    assert outcomes["ok"] > 50 and outcomes["error"] > 50, outcomes
+
+
 def test_native_decoder_on_the_reference_files(fixtures):
     """The reference's own test images (when the reference tree is present), decoded natively == the committed pixel fixtures."""
     import glob, os
