@@ -335,6 +335,8 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                         const plane_t *rowp = XY2 ? c0 + (1 - iy) * 2 * (int)pitch : c0;  // mask row = target row - dy
 #pragma unroll
                         for (int ix = 0; ix < NSX; ix++) idx[ix * NSX + iy] = rowp[XY2 ? (2 - ix) * 2 : 0];  // mask column = target column - dx
+                        // (one unaligned ds_read_b64 per kernel row instead of three byte reads -- gfx950 serves it correctly,
+                        // tools/valubench/ldsalign.hip -- was measured 1.5x SLOWER overall: 5.5 vs 3.6 ms per 524,288 targets)
                     }
                     constexpr int GS = WPE <= 4 ? 9 : 3;  // interval records in flight together
 #pragma unroll
