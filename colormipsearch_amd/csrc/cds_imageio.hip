@@ -500,7 +500,10 @@ static int append_files_impl(cds_sparse_library *sl, const char *const *paths, i
             }
         };
         std::vector<std::thread> pool;
-        for (int t = 1; t < std::min<int64_t>(nthreads, nb); t++) pool.emplace_back(worker);
+        try {
+            for (int t = 1; t < std::min<int64_t>(nthreads, nb); t++) pool.emplace_back(worker);
+        } catch (const std::exception &) {   // (fewer threads than asked for: the ones that started do the work)
+        }
         worker();
         for (auto &th : pool) th.join();
     };
@@ -508,6 +511,10 @@ static int append_files_impl(cds_sparse_library *sl, const char *const *paths, i
     int rc_gpu = CDS_OK;
     std::string gpu_err;
     std::thread gpu;
+    struct Joiner {   // (an exception leaving this function must not destroy a joinable thread)
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{gpu};
     for (int64_t b0 = 0, k = 0; b0 < count; b0 += batch, k++) {
         const int64_t nb = std::min(batch, count - b0);
         decode_batch(b0, nb, buf[k & 1].data());
