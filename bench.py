@@ -312,6 +312,41 @@ def main():
             failed.append("mask-batch scan disagrees with the single-mask scan")
         if not same_b2:
             failed.append("dense batch kernel disagrees with the sparse scan")
+        # (b2) BASELINE configs[4] in miniature: GradientAreaGap scores of the top-500 hits of 32 masks among the staging
+        # slots (their gradient / zgap variants generated on the device), one launch; with the oracle checked on 3 pairs
+        n_gm, top = 32, min(500, n_d)
+        dense.generate_synthetic(LIB_SEED, 0, 0, n_d, kind=args.kind, with_variants=True)
+        t0 = time.perf_counter()
+        shp = cds.Shape2DMatchColorDepthSearchAlgorithm(masks128[:n_gm], MASK_THR, MIRROR, None, rects, context=ctx)
+        prep_s = time.perf_counter() - t0
+        gsel = cds.PixelMatchColorDepthSearchAlgorithm(masks128[:n_gm], MASK_THR, MIRROR, None, 0, False, DATA_THR, ZTOL, XY_SHIFT, rects, context=ctx)
+        gsc = torch.empty(n_gm * n_d, dtype=torch.int32, device=dev)
+        gsel.searchSparseLibraryDevice(slib, 0, n_d, gsc.data_ptr())
+        torch.cuda.synchronize()
+        hits = (gsc.view(n_gm, n_d) & 0x7FFFFFFF).cpu().numpy()
+        ps = np.concatenate([np.argsort(-hits[m], kind="stable")[:top] for m in range(n_gm)]).astype(np.int64)   # top hits per mask
+        pm = np.repeat(np.arange(n_gm), top).astype(np.int32)
+        shp.scoreLibraryPairs(dense, pm, ps)
+        gap, high, gmir = shp.scoreLibraryPairs(dense, pm, ps)
+        gms, _ = shp.lastKernelMs()
+        ok_g = True
+        if not args.no_cpu_baseline:
+            from oracle import cds_oracle as O
+            sq = O.ShapeQuery(masks128[0], MASK_THR, MIRROR, rects)     # (one CPU mask preparation: three pairs of mask 0)
+            for i in (0, top // 2, top - 1):
+                tgt = dense.download(int(ps[i]), 1)[0]
+                gr, zg = dense.download_variants(int(ps[i]), 1)
+                og, oh, _, om = sq.score(tgt, gr[0], zg[0])
+                ok_g &= (int(gap[i]), int(high[i]), bool(gmir[i])) == (og, oh, om)
+        g_ach = len(pm) * 2081200 / (gms * 1e-3) / 1e9            # 2,081,200 B per pair at R = 170
+        aux["gradient_scores"] = {"workload": f"GradientAreaGap of the top-{top} hits of {n_gm} masks among {n_d} dense targets with variants "
+                                              f"= {len(pm)} pairs (BASELINE configs[4] shape), one launch", "kernel": "cds::gradscore_kernel",
+                                  "pairs_per_s": len(pm) / (gms * 1e-3), "kernel_ms": gms, "shape_mask_preparation_ms_per_mask": 1e3 * prep_s / n_gm,
+                                  "roofline": {"bound": "hbm", "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS,
+                                               "algorithmic_bytes_per_pair": 2081200},
+                                  "sampled_pairs_equal_oracle": bool(ok_g)}
+        if not ok_g:
+            failed.append("gradient scores differ from the CPU oracle's on the sampled pairs")
         # (c) the reference's own fixture images and known answers ("in every benchmark binary"): the JUnit pairs
         # of PixelMatchColorDepthSearchAlgorithmTest through the sparse scan, the dense scan and the shape scorer
         fpath = os.path.join(ROOT, "tests", "golden", "cds_fixtures.npz")
