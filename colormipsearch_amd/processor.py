@@ -339,6 +339,67 @@ class GpuColorMIPSearchProcessor:
                                            for p, g in zip(table.matchingPixels[rows], grad[rows])]
         return table
 
+    def calculateGradientScoresFromFilesTable(self, masks, table: MatchTable, target_files, gradient_files, zgap_files, queryThreshold,
+                                              mirrorMask=True, roiMask=None, excludedRegions=cds.label_regions, batch=256, threads=8,
+                                              zgap_radius=10) -> MatchTable:
+        """calculateGradientScoresTable for a library that is resident only as a sparse library: the targets the table names are
+        read from files the way CalculateGradientScoresCmd does it through its variant suppliers (:541-586) -- `target_files[t]`,
+        `gradient_files[t]`, `zgap_files[t]` (file_data as mipio.read_mip takes it; a missing gradient (None) leaves the pair at
+        (-1, -1) like Shape2DMatch...Algorithm.java:155-158; a missing zgap is synthesised on the device from the target as the
+        reference's tests do, Shape2DMatch...Test.java:171-174).  `batch` distinct targets at a time are decoded natively on a
+        thread pool, uploaded into a dense library of `batch` slots and scored with one launch."""
+        from concurrent.futures import ThreadPoolExecutor
+        from . import mipio
+        n = len(table)
+        table.gradientAreaGap = np.full(n, -1, dtype=np.int64)
+        table.highExpressionArea = np.full(n, -1, dtype=np.int64)
+        table.normalizedScore = np.zeros(n, dtype=np.float32)
+        if n == 0:
+            return table
+        ctx = self.library.ctx if self.library is not None else self.sparse_library.ctx
+        alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, queryThreshold, mirrorMask, roiMask, excludedRegions, context=ctx)
+        W, H = alg.width, alg.height
+        distinct = np.unique(table.targetIndex)
+        lib = cds.Library(W, H, min(int(batch), len(distinct)), context=ctx)
+        regions = cds._resolve_regions(excludedRegions, W)
+
+        def load(t):
+            g = gradient_files[t]
+            if g is None:
+                return None
+            z = zgap_files[t] if zgap_files is not None else None
+            return mipio.read_mip(target_files[t]), mipio.read_gradient(g), (None if z is None else mipio.read_mip(z))
+
+        with ThreadPoolExecutor(max_workers=max(1, int(threads))) as pool:
+            for b0 in range(0, len(distinct), lib.capacity):
+                chunk = distinct[b0:b0 + lib.capacity]
+                loaded = list(pool.map(load, [int(t) for t in chunk]))     # (the native decoder releases the GIL)
+                slot_of = {}
+                for t, item in zip(chunk, loaded):
+                    if item is None:
+                        continue
+                    k = len(slot_of)
+                    slot_of[int(t)] = k
+                    lib.upload(k, item[0][None])
+                    lib.upload_variants(k, gradients=item[1][None], zgaps=None if item[2] is None else item[2][None])
+                    if item[2] is None:
+                        lib.make_zgap_variants(k, 1, queryThreshold, zgap_radius, regions)
+                rows = np.flatnonzero(np.isin(table.targetIndex, chunk) & np.array([int(t) in slot_of for t in table.targetIndex]))
+                if len(rows) == 0:
+                    continue
+                slots = np.array([slot_of[int(t)] for t in table.targetIndex[rows]], dtype=np.int64)
+                gap, high, _ = alg.scoreLibraryPairs(lib, table.maskIndex[rows].astype(np.int32), slots)
+                table.gradientAreaGap[rows] = gap
+                table.highExpressionArea[rows] = high
+        grad = table.gradScores()
+        for m in np.unique(table.maskIndex):                     # CalculateGradientScoresCmd.normalizeScores (:616-645)
+            rows = np.flatnonzero(table.maskIndex == m)
+            max_pix = max(-1, int(table.matchingPixels[rows].max()))
+            max_grad = max(-1, int(grad[rows].max()))
+            table.normalizedScore[rows] = [np.float32(cds.calculateNormalizedScore(int(p), int(g), max_pix, max_grad))
+                                           for p, g in zip(table.matchingPixels[rows], grad[rows])]
+        return table
+
     # ---- gradientScores ---------------------------------------------------------------------------
     def selectBestMatches(self, matches: List[CDMatch], topLineMatches, topSamplesPerLine, topMatchesPerSample) -> List[CDMatch]:
         """Per mask, as CalculateGradientScoresCmd.getCDMatchesForMaskMipIDs does (:323-379)."""

@@ -189,3 +189,44 @@ def test_pipeline_equals_oracle_pipeline(oracle):
     assert [key(a)[:5] for a in matches2] == [key(b)[:5] for b in matches]
     scored2 = proc2.calculateGradientScores(masks, proc2.selectBestMatches(matches2, 3, 2, 1), 20, True, None, cds.label_regions)
     assert [key(a) for a in scored2] == [key(b) for b in scored]
+
+
+@pytest.mark.gpu
+def test_gradient_scores_from_files(tmp_path, fixtures):
+    """The file-backed gradient-score step on the reference's own images: targets resident only as a sparse library, the
+    selected targets and their GradientImage / ZGapImage variants read from TIFF / PNG files in two batches; the reference's
+    JUnit tuples come out (Shape2DMatchColorDepthSearchAlgorithmTest.java:86-132, :230-291); a target without a gradient
+    file stays at (-1, -1)."""
+    PIL = pytest.importorskip("PIL.Image")
+    from colormipsearch_amd import cds
+    from tests.golden import expected as E
+    tkeys = ["lm_VT033614", "lm_BJD", "lm_VT016795", "lm_GMR"]
+    gkeys = {"lm_VT033614": "grad_VT033614", "lm_BJD": "grad_BJD", "lm_VT016795": "grad_VT016795"}
+    tfiles, gfiles, zfiles = [], [], []
+    for i, k in enumerate(tkeys):
+        p = tmp_path / f"{k}.tif"
+        PIL.fromarray(fixtures[k], "RGB").save(p, compression="packbits")
+        tfiles.append(str(p))
+        if k in gkeys:
+            g = tmp_path / f"{k}_grad.png"
+            PIL.fromarray(fixtures[gkeys[k]]).save(g)
+            gfiles.append(str(g))
+        else:
+            gfiles.append(None)
+        zfiles.append(None)                                   # zgap synthesised from the target (as the reference's tests do)
+    masks = np.stack([fixtures["em_12191"], fixtures["em_12191_FL"]])
+    sl = cds.SparseLibrary(W, H, len(tkeys), len(tkeys) * 80000)
+    sl.append_files(tfiles, threads=4)
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(True, 20, 1, 2, cds.label_regions)
+    proc = P.GpuColorMIPSearchProcessor(cds.ColorMIPSearch(0.01, 20, provider), None, [P.NeuronInfo(k, k, k) for k in tkeys], sparse_library=sl)
+    table = proc.findAllColorDepthMatchesTable(masks)
+    pix = {(int(m), tkeys[int(t)]): int(s) for m, t, s in zip(table.maskIndex, table.targetIndex, table.matchingPixels)}
+    assert pix[(0, "lm_VT033614")] == 439 and pix[(0, "lm_BJD")] == 414 and pix[(1, "lm_VT016795")] == 483
+    scored = proc.calculateGradientScoresFromFilesTable(masks, table, tfiles, gfiles, zfiles, 20, batch=2, threads=3)
+    got = {(int(m), tkeys[int(t)]): (int(g), int(h)) for m, t, g, h in zip(scored.maskIndex, scored.targetIndex, scored.gradientAreaGap, scored.highExpressionArea)}
+    mk = {"em_12191": 0, "em_12191_FL": 1}
+    for mask, target, grad, zgap, gap, high, score, mirrored in E.SHAPE_SCORES:
+        if zgap is None and gkeys.get(target) == grad:
+            assert got[(mk[mask], target)] == (gap, high), (mask, target)
+    assert all(v == (-1, -1) for (m, t), v in got.items() if t == "lm_GMR")
+    assert (scored.normalizedScore > 0).any()
