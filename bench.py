@@ -342,7 +342,7 @@ def main():
                 ok_g &= (int(gap[i]), int(high[i]), bool(gmir[i])) == (og, oh, om)
         g_ach = len(pm) * 2081200 / (gms * 1e-3) / 1e9            # 2,081,200 B per pair at R = 170
         aux["gradient_scores"] = {"workload": f"GradientAreaGap of the top-{top} hits of {n_gm} masks among {n_d} dense targets with variants "
-                                              f"= {len(pm)} pairs (BASELINE configs[4] shape), one launch", "kernel": "cds::gradscore_kernel",
+                                              f"= {len(pm)} pairs (BASELINE configs[4] shape), one launch", "kernel": "cds::gradscore_list_kernel",
                                   "pairs_per_s": len(pm) / (gms * 1e-3), "kernel_ms": gms, "shape_mask_preparation_ms_per_mask": 1e3 * prep_s / n_gm,
                                   "roofline": {"bound": "hbm", "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS,
                                                "algorithmic_bytes_per_pair": 2081200},

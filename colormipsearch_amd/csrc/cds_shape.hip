@@ -240,6 +240,8 @@ struct ShapeParams {
     const uint8_t *rowflags;      // [n_masks][H]: bit0 row has gap bits (S(q) or queryMask), bit1 row has high-expression bits
     int thr, mirror, nrects;
     cds_rect rects[CDS_MAX_RECTS];
+    const uint32_t *glist, *hlist;  // per mask: the 4-pixel groups with gap bits / with high-expression bits (either orientation)
+    const uint32_t *list_off;       // [n_masks + 1][2]: first entry of mask m in glist / hlist
     const int32_t *pair_mask;
     const int64_t *pair_slot;     // < 0: pair has no variants, skipped (host reports -1,-1)
     int64_t n_pairs;
@@ -492,6 +494,183 @@ int refresh_zslice(cds_library *lib, int64_t first, int64_t count) {
 using namespace cds;
 
 // ---------------------------------------------------------------------------------------------
+// gradscore_list_kernel: the scorer over per-mask GROUP LISTS instead of a scan of the mask's plane windows.
+// gradscore_kernel above finds its work by reading both orientation planes of every 4-pixel group of the mask's rows
+// (~50 K groups, 800 KB from L2 per pair) although only ~25 K groups carry a high-expression bit and ~3.5 K a gap bit, and
+// those are the same for the mask's 500 pairs.  The preparation therefore lists them once (prep_lists_kernel):
+//   hlist entry = row << 17 | group << 8 | QH bits of the 4 pixels (plain) << 4 | QH bits (mirrored orientation)
+//   glist entry = row << 9 | group
+// and a pair is: (1) every hlist entry -> the target's 12-byte group; the non-black ones (a few percent) are queued and
+// counted 64 at a time (max channel > threshold, not in a label rectangle, QH bit of the orientation); (2) every glist
+// entry -> planes, gradient, zslice (plain and reversed) -> the gap arithmetic, all lanes busy, no queue.
+// One workgroup per pair, the four waves take alternate 64-entry chunks.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gradscore_list_kernel(ShapeParams p) {
+    __shared__ long long red[4][4];
+    __shared__ uint32_t hq[4][128];  // per wave: the queued high-expression entries whose target group is not black
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool even_w = (p.W & 1) == 0;
+    for (int64_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+        const int64_t slot = p.pair_slot[pi];
+        if (slot < 0) continue;  // uniform per block
+        const int m = p.pair_mask[pi];
+        const uint8_t *timg = p.rgb + (size_t)slot * p.img_stride;
+        const uint8_t *zimg = reinterpret_cast<const uint8_t *>(p.zslice) + (size_t)slot * p.grad_stride;
+        const uint8_t *gimg = reinterpret_cast<const uint8_t *>(p.grad) + (size_t)slot * p.grad_stride;
+        const uint16_t *pl0 = p.planes + (size_t)m * 2 * p.H * p.wp;
+        const uint16_t *pl1 = pl0 + (size_t)p.H * p.wp;
+        const uint32_t g0 = p.list_off[2 * m], g1 = p.list_off[2 * m + 2], h0 = p.list_off[2 * m + 1], h1 = p.list_off[2 * m + 3];
+        unsigned gap0 = 0, gap1 = 0;  // per lane < 2^31 for H*W <= 2M pixels (gap <= 65535 per pixel)
+        int high0 = 0, high1 = 0;
+        int hn = 0;  // wave-uniform: queued high-expression entries
+        auto run_high = [&](int n) {
+            if (lane < n) {
+                const uint32_t e = hq[wave][lane];
+                const int y = (int)(e >> 17), x0 = 4 * (int)((e >> 8) & 511);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(timg + (size_t)y * p.pitch + (size_t)x0 * 3);
+                const uint32_t a = src[0], b = src[1], c = src[2];
+                const int mx[4] = {max(max((int)(a & 255), (int)((a >> 8) & 255)), (int)((a >> 16) & 255)),
+                                   max(max((int)(a >> 24), (int)(b & 255)), (int)((b >> 8) & 255)),
+                                   max(max((int)((b >> 16) & 255), (int)(b >> 24)), (int)(c & 255)),
+                                   max(max((int)((c >> 8) & 255), (int)((c >> 16) & 255)), (int)(c >> 24))};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int x = x0 + j;
+                    if (x >= p.W) break;
+                    const bool sig = mx[j] > p.thr && !dev_in_rects(p.rects, p.nrects, x, y);
+                    high0 += (sig && ((e >> (4 + j)) & 1u)) ? 1 : 0;
+                    high1 += (sig && ((e >> j) & 1u)) ? 1 : 0;
+                }
+            }
+        };
+        // (1) high-expression groups
+        for (uint32_t base = h0 + 64u * wave; base < h1; base += 256) {  // wave-uniform
+            const uint32_t i = base + lane;
+            bool nonblack = false;
+            uint32_t e = 0;
+            if (i < h1) {
+                e = p.hlist[i];
+                const int y = (int)(e >> 17), gi = (int)((e >> 8) & 511);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(timg + (size_t)y * p.pitch + (size_t)gi * 12);
+                nonblack = (src[0] | src[1] | src[2]) != 0;
+            }
+            const unsigned long long bal = __ballot(nonblack);
+            if (bal) {  // wave-uniform
+                if (nonblack) hq[wave][hn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0))] = e;
+                hn += __popcll(bal);
+                if (hn >= 64) {
+                    run_high(64);
+                    const int rest = hn - 64;
+                    uint32_t mv = 0;
+                    if (lane < rest) mv = hq[wave][64 + lane];
+                    if (lane < rest) hq[wave][lane] = mv;
+                    hn = rest;
+                }
+            }
+        }
+        run_high(hn);  // hn < 64
+        // (2) gap groups
+        for (uint32_t base = g0 + 64u * wave; base < g1; base += 256) {  // wave-uniform
+            const uint32_t i = base + lane;
+            if (i < g1) {
+                const uint32_t e = p.glist[i];
+                const int y = (int)(e >> 9), x0 = 4 * (int)(e & 511);
+                const ushort4 qa = *reinterpret_cast<const ushort4 *>(pl0 + (size_t)y * p.wp + x0);
+                ushort4 qb = make_ushort4(0, 0, 0, 0);
+                if (p.mirror) qb = *reinterpret_cast<const ushort4 *>(pl1 + (size_t)y * p.wp + x0);
+                const int pa[4] = {qa.x, qa.y, qa.z, qa.w}, pb[4] = {qb.x, qb.y, qb.z, qb.w};
+                const uint16_t *zrow = reinterpret_cast<const uint16_t *>(zimg + (size_t)y * p.gpitch);
+                const ushort4 g = *reinterpret_cast<const ushort4 *>(gimg + (size_t)y * p.gpitch + (size_t)x0 * 2);
+                const ushort4 z = *reinterpret_cast<const ushort4 *>(zrow + x0);
+                const int gg[4] = {g.x, g.y, g.z, g.w}, zz[4] = {z.x, z.y, z.z, z.w};
+                int zm[4] = {0, 0, 0, 0};  // zslice at W-1-x for x = x0 .. x0+3
+                if (p.mirror) {
+                    const int xm = p.W - 4 - x0;  // element index of the reversed run (may be < 0 at the far right)
+                    if (even_w && xm >= 0) {
+                        const uint2 r = *reinterpret_cast<const uint2 *>(zrow + xm);  // xm even: 4-byte aligned
+                        zm[3] = r.x & 0xffff; zm[2] = r.x >> 16; zm[1] = r.y & 0xffff; zm[0] = r.y >> 16;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (p.W - 1 - x0 - j >= 0) zm[j] = zrow[p.W - 1 - x0 - j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (x0 + j >= p.W) break;
+                    gap0 += gap_of(pa[j], zs_of(zz[j], p.thr), gg[j]);
+                    if (p.mirror) gap1 += gap_of(pb[j], zs_of(zm[j], p.thr), gg[j]);
+                }
+            }
+        }
+        long long v[4] = {(long long)gap0, (long long)high0, (long long)gap1, (long long)high1};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            long long sv = v[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
+            if (lane == 0) red[wave][k] = sv;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            long long sv = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); w++) sv += red[w][threadIdx.x];
+            p.out[pi * 4 + threadIdx.x] = sv;
+        }
+        __syncthreads();
+    }
+}
+
+// The group lists of every mask from its two orientation planes.  FILL = false: count; FILL = true: write (a wave's entries
+// of one row are contiguous and ascending; rows arrive in any order -- the scorer only sums).
+struct ListParams {
+    const uint16_t *planes;  // [n][2][H][wp]
+    int H, wp, n;
+    uint32_t *counts;        // [n][2]: gap groups, high-expression groups   (count pass; cursor in the fill pass)
+    const uint32_t *list_off;  // [n + 1][2]
+    uint32_t *glist, *hlist;
+};
+template <bool FILL>
+__global__ __launch_bounds__(256) void prep_lists_kernel(ListParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (int64_t)p.n * p.H) return;  // wave-uniform
+    const int m = (int)(wid / p.H), y = (int)(wid - (int64_t)m * p.H);
+    const uint16_t *r0 = p.planes + ((size_t)m * 2 * p.H + y) * p.wp, *r1 = r0 + (size_t)p.H * p.wp;
+    const int ngr = p.wp / 4;
+    for (int g0 = 0; g0 < ngr; g0 += 64) {
+        const int gi = g0 + lane;
+        ushort4 qa = make_ushort4(0, 0, 0, 0), qb = make_ushort4(0, 0, 0, 0);
+        if (gi < ngr) {
+            qa = *reinterpret_cast<const ushort4 *>(r0 + 4 * gi);
+            qb = *reinterpret_cast<const ushort4 *>(r1 + 4 * gi);
+        }
+        const int all = qa.x | qa.y | qa.z | qa.w | qb.x | qb.y | qb.z | qb.w;
+        const bool has_gap = (all & (kPlaneS | kPlaneQM)) != 0, has_high = (all & kPlaneQH) != 0;
+        const unsigned long long bg = __ballot(has_gap), bh = __ballot(has_high);
+        if (bg) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(p.counts + 2 * m, (uint32_t)__popcll(bg));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (FILL && has_gap)
+                p.glist[p.list_off[2 * m] + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bg >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bg, 0))] =
+                    ((uint32_t)y << 9) | (uint32_t)gi;
+        }
+        if (bh) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(p.counts + 2 * m + 1, (uint32_t)__popcll(bh));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (FILL && has_high) {
+                const uint32_t n0 = ((qa.x >> 10) & 1u) | ((qa.y >> 10) & 1u) << 1 | ((qa.z >> 10) & 1u) << 2 | ((qa.w >> 10) & 1u) << 3;
+                const uint32_t n1 = ((qb.x >> 10) & 1u) | ((qb.y >> 10) & 1u) << 1 | ((qb.z >> 10) & 1u) << 2 | ((qb.w >> 10) & 1u) << 3;
+                p.hlist[p.list_off[2 * m + 1] + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0))] =
+                    ((uint32_t)y << 17) | ((uint32_t)gi << 8) | (n0 << 4) | n1;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Shape-mask preparation on the device (ColorDepthSearchAlgorithmProviderFactory.java:91-125).
 // Q = clearRegion(mask); QM = gray(Q) > 2; S(q) = slice number; QH = (maxFilter20(Q) is black) && gray(maxFilter60(Q)) > 0.
 // The two max filters are never materialised: "D20 black" <=> no pixel with a non-zero channel inside the r=20 kernel, and
@@ -635,6 +814,7 @@ struct cds_shapeset {
     uint16_t *d_planes = nullptr;
     int *d_boxes = nullptr;
     uint8_t *d_rowflags = nullptr;
+    uint32_t *d_glist = nullptr, *d_hlist = nullptr, *d_list_off = nullptr;  // group lists of gradscore_list_kernel
     std::vector<int64_t> qm_sum, qh_sum;
     mutable std::mutex mu;
     mutable double last_ms = 0;
@@ -799,6 +979,41 @@ int cds_shapeset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_
     }
     SP_HIP(hipMemcpyAsync(ss->d_rowflags, rowflags.data(), rowflags.size(), hipMemcpyHostToDevice, st));
     SP_HIP(hipMemcpyAsync(ss->d_boxes, boxes.data(), boxes.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    {   // the group lists of gradscore_list_kernel: count, prefix on the host, fill
+        uint32_t *d_cnt = nullptr;
+        SP_HIP(hipMalloc(&d_cnt, (size_t)n_masks * 2 * sizeof(uint32_t)));
+        auto free_cnt = [&]() { hipFree(d_cnt); };
+        ListParams lp{};
+        lp.planes = ss->d_planes; lp.H = H; lp.wp = wp; lp.n = n_masks; lp.counts = d_cnt;
+        const unsigned lblocks = (unsigned)(((int64_t)n_masks * H + 3) / 4);
+        hipError_t e = hipMemsetAsync(d_cnt, 0, (size_t)n_masks * 2 * sizeof(uint32_t), st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(prep_lists_kernel<false>, dim3(lblocks), dim3(256), 0, st, lp);
+            e = hipGetLastError();
+        }
+        std::vector<uint32_t> cnt((size_t)n_masks * 2), off((size_t)(n_masks + 1) * 2, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_cnt, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) {
+            for (int m = 0; m < n_masks; m++) {
+                off[(size_t)2 * (m + 1)] = off[(size_t)2 * m] + cnt[(size_t)2 * m];
+                off[(size_t)2 * (m + 1) + 1] = off[(size_t)2 * m + 1] + cnt[(size_t)2 * m + 1];
+            }
+            e = hipMalloc(&ss->d_glist, std::max<size_t>(1, off[(size_t)2 * n_masks]) * sizeof(uint32_t));
+        }
+        if (e == hipSuccess) e = hipMalloc(&ss->d_hlist, std::max<size_t>(1, off[(size_t)2 * n_masks + 1]) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&ss->d_list_off, off.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpyAsync(ss->d_list_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, (size_t)n_masks * 2 * sizeof(uint32_t), st);
+        if (e == hipSuccess) {
+            lp.list_off = ss->d_list_off; lp.glist = ss->d_glist; lp.hlist = ss->d_hlist;
+            hipLaunchKernelGGL(prep_lists_kernel<true>, dim3(lblocks), dim3(256), 0, st, lp);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        free_cnt();
+        if (e != hipSuccess) { cleanup(); cds_shapeset_destroy(ss); return hip_fail(e, "shape group lists"); }
+    }
     SP_HIP(hipStreamSynchronize(st));
 #undef SP_HIP
     cleanup();
@@ -812,6 +1027,9 @@ void cds_shapeset_destroy(cds_shapeset *ss) {
     if (ss->d_planes) hipFree(ss->d_planes);
     if (ss->d_boxes) hipFree(ss->d_boxes);
     if (ss->d_rowflags) hipFree(ss->d_rowflags);
+    if (ss->d_glist) hipFree(ss->d_glist);
+    if (ss->d_hlist) hipFree(ss->d_hlist);
+    if (ss->d_list_off) hipFree(ss->d_list_off);
     if (ss->pair_lib) cds_library_destroy(ss->pair_lib);
     delete ss;
 }
@@ -882,7 +1100,9 @@ int cds_gradscore(const cds_shapeset *ss, const cds_library *lib, int64_t n_pair
     GS_HIP(hipEventCreate(&ev0));
     GS_HIP(hipEventCreate(&ev1));
     GS_HIP(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(gradscore_kernel, dim3(grid), dim3(256), 0, st, p);
+    p.glist = ss->d_glist; p.hlist = ss->d_hlist; p.list_off = ss->d_list_off;
+    if (getenv("CDS_SHAPE_SCAN_KERNEL")) hipLaunchKernelGGL(gradscore_kernel, dim3(grid), dim3(256), 0, st, p);   // (the plane-window scan, for A/B runs)
+    else hipLaunchKernelGGL(gradscore_list_kernel, dim3(grid), dim3(256), 0, st, p);
     GS_HIP(hipGetLastError());
     GS_HIP(hipEventRecord(ev1, st));
     std::vector<int64_t> res((size_t)n_pairs * 4);
