@@ -241,6 +241,7 @@ struct ShapeParams {
     int thr, mirror, nrects;
     cds_rect rects[CDS_MAX_RECTS];
     const uint32_t *glist, *hlist;  // per mask: the 4-pixel groups with gap bits / with high-expression bits (either orientation)
+    const ushort4 *gl_a, *gl_b;     // the two orientations' plane values of the glist groups (parallel to glist: coalesced reads)
     const uint32_t *list_off;       // [n_masks + 1][2]: first entry of mask m in glist / hlist
     const int32_t *pair_mask;
     const int64_t *pair_slot;     // < 0: pair has no variants, skipped (host reports -1,-1)
@@ -517,8 +518,6 @@ __global__ __launch_bounds__(256) void gradscore_list_kernel(ShapeParams p) {
         const uint8_t *timg = p.rgb + (size_t)slot * p.img_stride;
         const uint8_t *zimg = reinterpret_cast<const uint8_t *>(p.zslice) + (size_t)slot * p.grad_stride;
         const uint8_t *gimg = reinterpret_cast<const uint8_t *>(p.grad) + (size_t)slot * p.grad_stride;
-        const uint16_t *pl0 = p.planes + (size_t)m * 2 * p.H * p.wp;
-        const uint16_t *pl1 = pl0 + (size_t)p.H * p.wp;
         const uint32_t g0 = p.list_off[2 * m], g1 = p.list_off[2 * m + 2], h0 = p.list_off[2 * m + 1], h1 = p.list_off[2 * m + 3];
         unsigned gap0 = 0, gap1 = 0;  // per lane < 2^31 for H*W <= 2M pixels (gap <= 65535 per pixel)
         int high0 = 0, high1 = 0;
@@ -575,9 +574,7 @@ __global__ __launch_bounds__(256) void gradscore_list_kernel(ShapeParams p) {
             if (i < g1) {
                 const uint32_t e = p.glist[i];
                 const int y = (int)(e >> 9), x0 = 4 * (int)(e & 511);
-                const ushort4 qa = *reinterpret_cast<const ushort4 *>(pl0 + (size_t)y * p.wp + x0);
-                ushort4 qb = make_ushort4(0, 0, 0, 0);
-                if (p.mirror) qb = *reinterpret_cast<const ushort4 *>(pl1 + (size_t)y * p.wp + x0);
+                const ushort4 qa = p.gl_a[i], qb = p.gl_b[i];   // (the mirrored orientation's plane is all zero without mirroring)
                 const int pa[4] = {qa.x, qa.y, qa.z, qa.w}, pb[4] = {qb.x, qb.y, qb.z, qb.w};
                 const uint16_t *zrow = reinterpret_cast<const uint16_t *>(zimg + (size_t)y * p.gpitch);
                 const ushort4 g = *reinterpret_cast<const ushort4 *>(gimg + (size_t)y * p.gpitch + (size_t)x0 * 2);
@@ -629,6 +626,7 @@ struct ListParams {
     uint32_t *counts;        // [n][2]: gap groups, high-expression groups   (count pass; cursor in the fill pass)
     const uint32_t *list_off;  // [n + 1][2]
     uint32_t *glist, *hlist;
+    ushort4 *gl_a, *gl_b;
 };
 template <bool FILL>
 __global__ __launch_bounds__(256) void prep_lists_kernel(ListParams p) {
@@ -652,9 +650,12 @@ __global__ __launch_bounds__(256) void prep_lists_kernel(ListParams p) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(p.counts + 2 * m, (uint32_t)__popcll(bg));
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (FILL && has_gap)
-                p.glist[p.list_off[2 * m] + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bg >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bg, 0))] =
-                    ((uint32_t)y << 9) | (uint32_t)gi;
+            if (FILL && has_gap) {
+                const uint32_t at = p.list_off[2 * m] + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bg >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bg, 0));
+                p.glist[at] = ((uint32_t)y << 9) | (uint32_t)gi;
+                p.gl_a[at] = qa;
+                p.gl_b[at] = qb;
+            }
         }
         if (bh) {
             uint32_t base = 0;
@@ -815,6 +816,7 @@ struct cds_shapeset {
     int *d_boxes = nullptr;
     uint8_t *d_rowflags = nullptr;
     uint32_t *d_glist = nullptr, *d_hlist = nullptr, *d_list_off = nullptr;  // group lists of gradscore_list_kernel
+    ushort4 *d_gl_a = nullptr, *d_gl_b = nullptr;
     std::vector<int64_t> qm_sum, qh_sum;
     mutable std::mutex mu;
     mutable double last_ms = 0;
@@ -1001,12 +1003,14 @@ int cds_shapeset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_
             }
             e = hipMalloc(&ss->d_glist, std::max<size_t>(1, off[(size_t)2 * n_masks]) * sizeof(uint32_t));
         }
+        if (e == hipSuccess) e = hipMalloc(&ss->d_gl_a, std::max<size_t>(1, off[(size_t)2 * n_masks]) * sizeof(ushort4));
+        if (e == hipSuccess) e = hipMalloc(&ss->d_gl_b, std::max<size_t>(1, off[(size_t)2 * n_masks]) * sizeof(ushort4));
         if (e == hipSuccess) e = hipMalloc(&ss->d_hlist, std::max<size_t>(1, off[(size_t)2 * n_masks + 1]) * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&ss->d_list_off, off.size() * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemcpyAsync(ss->d_list_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, (size_t)n_masks * 2 * sizeof(uint32_t), st);
         if (e == hipSuccess) {
-            lp.list_off = ss->d_list_off; lp.glist = ss->d_glist; lp.hlist = ss->d_hlist;
+            lp.list_off = ss->d_list_off; lp.glist = ss->d_glist; lp.hlist = ss->d_hlist; lp.gl_a = ss->d_gl_a; lp.gl_b = ss->d_gl_b;
             hipLaunchKernelGGL(prep_lists_kernel<true>, dim3(lblocks), dim3(256), 0, st, lp);
             e = hipGetLastError();
         }
@@ -1030,6 +1034,8 @@ void cds_shapeset_destroy(cds_shapeset *ss) {
     if (ss->d_glist) hipFree(ss->d_glist);
     if (ss->d_hlist) hipFree(ss->d_hlist);
     if (ss->d_list_off) hipFree(ss->d_list_off);
+    if (ss->d_gl_a) hipFree(ss->d_gl_a);
+    if (ss->d_gl_b) hipFree(ss->d_gl_b);
     if (ss->pair_lib) cds_library_destroy(ss->pair_lib);
     delete ss;
 }
@@ -1100,7 +1106,7 @@ int cds_gradscore(const cds_shapeset *ss, const cds_library *lib, int64_t n_pair
     GS_HIP(hipEventCreate(&ev0));
     GS_HIP(hipEventCreate(&ev1));
     GS_HIP(hipEventRecord(ev0, st));
-    p.glist = ss->d_glist; p.hlist = ss->d_hlist; p.list_off = ss->d_list_off;
+    p.glist = ss->d_glist; p.hlist = ss->d_hlist; p.list_off = ss->d_list_off; p.gl_a = ss->d_gl_a; p.gl_b = ss->d_gl_b;
     if (getenv("CDS_SHAPE_SCAN_KERNEL")) hipLaunchKernelGGL(gradscore_kernel, dim3(grid), dim3(256), 0, st, p);   // (the plane-window scan, for A/B runs)
     else hipLaunchKernelGGL(gradscore_list_kernel, dim3(grid), dim3(256), 0, st, p);
     GS_HIP(hipGetLastError());
