@@ -175,40 +175,12 @@ def load_sparse_shard(sparse_library, path, batch=65536):
 
 
 # ---- results ------------------------------------------------------------------------------------------
-def match_records(matches, mask_infos, target_infos):
-    out = []
-    for m in matches:
-        rec = {
-            "class": "org.janelia.colormipsearch.model.CDMatchEntity",
-            "maskImage": dict(mask_infos[m.maskIndex]),
-            "image": dict(target_infos[m.targetIndex]),
-            "mirrored": bool(m.mirrored),
-            "matchingPixels": int(m.matchingPixels),
-            "matchingPixelsRatio": float(m.matchingPixelsRatio),
-        }
-        if m.gradientAreaGap is not None:
-            rec["gradientAreaGap"] = int(m.gradientAreaGap)
-        if m.highExpressionArea is not None:
-            rec["highExpressionArea"] = int(m.highExpressionArea)
-        if m.normalizedScore is not None:
-            rec["normalizedScore"] = float(m.normalizedScore)
-        out.append(rec)
-    return out
-
-
-def write_matches_per_mask(out_dir, matches, mask_infos, target_infos):
-    """One `<mask mipId>.json` per mask, records sorted by descending matchingPixels."""
-    os.makedirs(out_dir, exist_ok=True)
-    by_mask = {}
-    for m in matches:
-        by_mask.setdefault(m.maskIndex, []).append(m)
-    paths = []
-    for mi, items in by_mask.items():
-        items = sorted(items, key=lambda v: -v.matchingPixels)
-        # the id comes from input metadata: keep it a plain file name inside out_dir
-        name = re.sub(r"[^A-Za-z0-9._-]", "_", os.path.basename(str(mask_infos[mi].get("mipId", mi)))).lstrip(".") or str(mi)
-        path = os.path.join(out_dir, f"{name}.json")
-        with open(path, "w") as f:
-            json.dump(match_records(items, mask_infos, target_infos), f, indent=1)
-        paths.append(path)
-    return paths
+def write_matches_per_mask(out_dir, matches, mask_infos, target_infos, ordering=None):
+    """One `<mask mipId>.json` per mask in the reference's result-file layout (`{"inputImage": ..., "results": [...]}`,
+    results by descending matchingPixels unless `ordering` says otherwise): see colormipsearch_amd/results.py.
+    Returns the written paths."""
+    from . import results
+    docs = results.match_entities(matches, mask_infos, target_infos)
+    w = results.JSONNeuronMatchesWriter(matchOrdering=ordering or results.by_matching_pixels_desc, perMasksOutputDir=str(out_dir))
+    w.write(docs)
+    return list(w.written)

@@ -12,7 +12,7 @@ Counterpart of the reference's
 
 The per-pair Java loop becomes: one `cds_search` per mask batch over the resident library, a vectorised match filter,
 the (host) top-N selection over the few survivors, one `cds_gradscore` over the selected pairs.  Entities are plain
-records here -- persistence (Mongo / JSON writers) stays out of scope.
+records here; `colormipsearch_amd/results.py` turns them into the reference's JSON result files (Mongo stays out of scope).
 """
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence

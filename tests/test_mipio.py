@@ -1,5 +1,6 @@
 """Host I/O glue: image decode, packed shards, result records."""
 import json
+import os
 import zipfile
 
 import numpy as np
@@ -147,11 +148,16 @@ def test_match_records_per_mask(tmp_path):
     targets = [{"mipId": "t0", "publishedName": "lineA"}, {"mipId": "t1", "publishedName": "lineB"}]
     paths = mipio.write_matches_per_mask(tmp_path / "out", matches, masks, targets)
     assert sorted(p.split("/")[-1] for p in paths) == ["m0.json", "m1.json"]
-    recs = json.load(open([p for p in paths if p.endswith("m0.json")][0]))
+    doc = json.load(open([p for p in paths if p.endswith("m0.json")][0]))
+    assert doc["inputImage"] == {"mipId": "m0", "publishedName": "em0"}
+    recs = doc["results"]
     assert [r["matchingPixels"] for r in recs] == [80, 50]
     assert recs[0]["image"]["mipId"] == "t0" and recs[0]["mirrored"] is True
     assert recs[0]["gradientAreaGap"] == 120 and recs[0]["highExpressionArea"] == 30 and recs[0]["normalizedScore"] == 77.5
     assert "gradientAreaGap" not in recs[1] and recs[1]["class"].endswith("CDMatchEntity")
+    # a hostile id stays a file inside the output directory
+    paths = mipio.write_matches_per_mask(tmp_path / "out2", matches[:1], [{"mipId": "../../x/..m"}], targets)
+    assert [os.path.relpath(p, tmp_path / "out2") for p in paths] == ["m.json"]
 
 
 @pytest.mark.gpu
