@@ -206,6 +206,9 @@ __global__ __launch_bounds__(1024) void sparse_imgscan_kernel(BuildParams p) {
 // WPE: waves per SIMD the register budget is sized for -- 8 (64 VGPRs) when two workgroups share a CU, 4 (128 VGPRs) when a
 // workgroup's LDS image takes more than half the CU: the latter keeps all nine interval records of a round and the bitmap
 // words of four pixel blocks in flight (a wave's time is its chain of LDS round trips, not instruction issue).
+#ifndef SP_EXP
+#define SP_EXP 0  // (timing experiments only: 1 = no evaluation rounds, 2 = nothing queued; scores become entry counts)
+#endif
 template <bool XY2, bool MIRROR, bool IVLDS, bool P8, int WPE>
 __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams p) {
     extern __shared__ uint4 lds4[];
@@ -320,6 +323,9 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                 // evaluate up to 64 queued pixels of one orientation: every lane busy
                 auto round = [&](const uint2 *q, int &qh, int &ql, const int qt, int *cc) {
                     const int n = min(qt - qh, 64);
+#if SP_EXP == 1
+                    qh += n; ql = qh + 64; cc[0] += n; return;
+#endif
                     __builtin_amdgcn_wave_barrier();
                     const bool valid = lane < n;
                     const uint2 ent = q[(qh + lane) & (SP_QCAP - 1)];
@@ -359,6 +365,9 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                 // (no wave-uniform test of hb around this: hipcc already skips an all-false `if (hit)` with s_cbranch_execz, and the
                 // scalar unit -- one per CU, shared by the four SIMDs -- is the busier pipe of this kernel: tools/valubench)
                 auto append = [&](uint2 *q, int &qt, const unsigned long long hb, const bool hit, const uint32_t r, const uint32_t off) {
+#if SP_EXP == 2
+                    c[0] += __popcll(hb); return;
+#endif
                     if (hit) {
                         const int slot = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0))) & (SP_QCAP - 1);
                         q[slot] = make_uint2(r, off);
