@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Scan rate on REAL images: the reference's own test MIPs (tests/golden/cds_fixtures.npz: 4 LM images, 3 EM masks),
+each LM image replicated --copies times into a resident library, scanned with each EM mask over the sparse and the dense
+layout.  Real LM MIPs carry far more signal pixels than the benchmark's synthetic targets, so the sparse scan examines
+more records per target; this prints records per target and both rates (scores checked equal)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from colormipsearch_amd import cds  # noqa: E402
+
+W, H = 1210, 566
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--copies", type=int, default=1024)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "cds_fixtures.npz"))
+    lms = [k for k in fx.keys() if k.startswith("lm_")]
+    ems = [k for k in fx.keys() if k.startswith("em_")]
+    ctx = cds.Context(0)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    n = len(lms) * args.copies
+    dense = cds.Library(W, H, n, context=ctx)
+    for i, k in enumerate(lms):          # target j = image j % 4 (interleaved, as a mixed library would be)
+        pass
+    imgs = np.stack([fx[k] for k in lms])
+    for c in range(args.copies):
+        dense.upload(c * len(lms), imgs)
+    sig = [(int((fx[k].max(axis=2) > 0).sum())) for k in lms]
+    sl = cds.SparseLibrary(W, H, n, int(sum(sig) * args.copies * 1.05) + 8 * n * H, context=ctx)
+    for first in range(0, n, 4096):
+        sl.append_from(dense, first, min(4096, n - first))
+    rects = cds.label_regions(W)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    print(json.dumps({"targets": n, "images": lms, "nonblack_pixels": dict(zip(lms, sig)), "records_per_target": sl.pixels / n,
+                      "sparse_bytes_per_target": 4 * sl.pixels / n}))
+    for mk in ems:
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(fx[mk], 20, True, None, 0, False, 20, 0.01, 2, rects, context=ctx)
+        s_sp = torch.empty(n, dtype=torch.int32, device="cuda")
+        s_de = torch.empty(n, dtype=torch.int32, device="cuda")
+        out = {"mask": mk, "mask_pixels": int(alg.getQuerySize()) if hasattr(alg, "getQuerySize") else None, "layout": alg.sparseLayout(0)}
+        for name, fn, buf in (("sparse", lambda b: alg.searchSparseLibraryDevice(sl, 0, n, b.data_ptr()), s_sp),
+                              ("dense", lambda b: alg.searchLibraryDevice(dense, 0, n, b.data_ptr()), s_de)):
+            fn(buf)
+            torch.cuda.synchronize()
+            e0.record(stream)
+            for _ in range(args.reps):
+                fn(buf)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.reps
+            out[name + "_ms"] = round(ms, 3)
+            out[name + "_comparisons_per_s"] = round(n / (ms * 1e-3))
+        out["equal"] = bool(torch.equal(s_sp, s_de))
+        out["scores_first_images"] = [int(v) & 0x7FFFFFFF for v in s_sp[: len(lms)].tolist()]
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
