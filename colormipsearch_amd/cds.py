@@ -313,6 +313,23 @@ class PixelMatchScore:
         return f"PixelMatchScore(score={self._n}, ratio={self._ratio:.6f}, mirrored={self._mirrored})"
 
 
+class CombinedMatchScore:
+    """API/cds/CombinedMatchScore.java:5-30: the (pixel matches, shape score) pair the normalisation folds its maxima in
+    (CalculateGradientScoresCmd.java:622-629)."""
+
+    def __init__(self, pixelMatches, gradScore):
+        self._px, self._grad = int(pixelMatches), int(gradScore)
+
+    def getPixelMatches(self):
+        return self._px
+
+    def getGradScore(self):
+        return self._grad
+
+    def __repr__(self):
+        return f"CombinedMatchScore(pixelMatches={self._px}, gradScore={self._grad})"
+
+
 class ShapeMatchScore:
     """API/cds/ShapeMatchScore.java:5-65 (gradient-area-gap constructor)."""
 
