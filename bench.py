@@ -13,8 +13,8 @@ resident shard (weak scaling: N x 1M targets = configs[3] at N = 8), and each st
 per-target score array (int32, score | mirrored<<31) to rank 0 -- the only collective on the path.
 
 Prints one JSON line (rank 0): the contract fields plus `roofline`, `cpu_baseline` (the C oracle = restatement of the
-reference's Java loops, timed on the host cores) and `aux` (the same scan over the dense packed-RGB layout; a 128-mask
-batch).  Any disagreement between the GPU paths or with the oracle makes the run fail (value null, exit code 1).
+reference's Java loops, timed on the host cores) and `aux` (the same scan over the dense packed-RGB layout; mask batches;
+GradientAreaGap scores of top hits; the reference's JUnit pairs; the scan rate on the reference's real test images).  Any disagreement between the GPU paths or with the oracle makes the run fail (value null, exit code 1).
 """
 import argparse
 import json
@@ -376,6 +376,48 @@ def main():
             gap, high, smir = sh.scoreLibraryPairs(fl, [0], [tkeys.index(sk[1])])
             ok_f &= (int(gap[0]), int(high[0]), bool(smir[0])) == (sk[4], sk[5], sk[7])
             aux["reference_fixtures"] = {"pixel_match": got, "shape": [int(gap[0]), int(high[0]), bool(smir[0])], "equal_to_reference_junit_values": bool(ok_f)}
+            # (d) the same scan on REAL images: the reference's LM test MIPs replicated into a resident library (they carry 2x the
+            # records of a synthetic target and all overlap the EM test masks, so far more of them reach the interval test)
+            del fl, fs
+            lkeys = sorted(k for k in fx if k.startswith("lm_"))
+            copies = max(1, stage_n // len(lkeys))
+            n_rd = copies * len(lkeys)                       # dense slots holding the images
+            reps = max(1, 32768 // n_rd)
+            n_r = n_rd * reps                                # sparse targets: the staging slots appended `reps` times
+            limgs = np.stack([fx[k] for k in lkeys])
+            for c in range(copies):
+                dense.upload(c * len(lkeys), limgs)
+            rs = cds.SparseLibrary(W, H, n_r, int((limgs.max(axis=3) > 0).sum()) * copies * reps + 8 * H * n_r + 64, context=ctx)
+            for _ in range(reps):
+                for first in range(0, n_rd, 4096):
+                    rs.append_from(dense, first, min(4096, n_rd - first))
+            real = {"workload": f"{len(lkeys)} LM test MIPs of the reference x {copies * reps} copies = {n_r} resident sparse targets ({n_rd} of them "
+                                f"also dense), xyShift=2, mirror on", "records_per_target": rs.pixels / n_r, "masks": {}}
+            ok_r = True
+            for mk in sorted(k for k in fx if k.startswith("em_")):
+                a = cds.PixelMatchColorDepthSearchAlgorithm(fx[mk], 20, True, None, 0, False, 20, 0.01, 2, E.STD_RECTS, context=ctx)
+                rsp = torch.empty(n_r, dtype=torch.int32, device=dev)
+                rde = torch.empty(n_rd, dtype=torch.int32, device=dev)
+                a.searchSparseLibraryDevice(rs, 0, n_r, rsp.data_ptr())
+                e0.record(stream)
+                for _ in range(3):
+                    a.searchSparseLibraryDevice(rs, 0, n_r, rsp.data_ptr())
+                e1.record(stream)
+                torch.cuda.synchronize()
+                rms = e0.elapsed_time(e1) / 3
+                a.searchLibraryDevice(dense, 0, n_rd, rde.data_ptr())
+                e0.record(stream)
+                a.searchLibraryDevice(dense, 0, n_rd, rde.data_ptr())
+                e1.record(stream)
+                torch.cuda.synchronize()
+                dms = e0.elapsed_time(e1)
+                same_r = bool(torch.equal(rsp.view(reps, n_rd), rde.view(1, n_rd).expand(reps, n_rd)))
+                ok_r &= same_r
+                real["masks"][mk] = {"sparse_comparisons_per_s": n_r / (rms * 1e-3), "dense_comparisons_per_s": n_rd / (dms * 1e-3),
+                                     "scores_equal": same_r}
+            aux["real_images"] = real
+            if not ok_r:
+                failed.append("sparse and dense scans disagree on the reference's images")
             if not ok_f:
                 failed.append("reference fixture pairs do not give the reference's JUnit values")
         out["aux"] = aux
