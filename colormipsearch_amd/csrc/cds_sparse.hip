@@ -206,6 +206,9 @@ __global__ __launch_bounds__(1024) void sparse_imgscan_kernel(BuildParams p) {
 // WPE: waves per SIMD the register budget is sized for -- 8 (64 VGPRs) when two workgroups share a CU, 4 (128 VGPRs) when a
 // workgroup's LDS image takes more than half the CU: the latter keeps all nine interval records of a round and the bitmap
 // words of four pixel blocks in flight (a wave's time is its chain of LDS round trips, not instruction issue).
+#ifndef SP_BAND
+#define SP_BAND 1  // 1: stage 1 tests a (4 x 8-pixel cell) x (30 hue band) map; 0: the plain near bitmap (A/B builds)
+#endif
 #ifndef SP_EXP
 #define SP_EXP 0  // (timing experiments only: 1 = no evaluation rounds, 2 = nothing queued; scores become entry counts)
 #endif
@@ -243,7 +246,11 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
         const int ra = max(ys0 - HALO, 0), rb = min(ys0 + rows_s + HALO, p.H);  // target rows [ra, rb)
         const int ry0 = ys0 - 2;
         const uint32_t cx0 = (uint32_t)(p.xlo - 2), cm0 = (uint32_t)(p.W - 1) - cx0;
+#if SP_BAND
+        const uint32_t wnear = (uint32_t)((p.cols + 4 + 7) & ~7);  // first column of the band map's guard cell (always 0): the clamp target
+#else
         const uint32_t wnear = (uint32_t)(p.cols + 4);  // bit `wnear` of every bitmap row exists and is 0: the clamp target
+#endif
         const uint32_t pitch = (uint32_t)p.pitch;
         // The per-pixel constants live in VGPRs (uniform values, pinned by the asm so that hipcc does not move them back):
         // the kernel's scalar registers are needed for the 18 counters, the queue state and the loop state, and every
@@ -394,6 +401,9 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                         // evaluate a full queue.  With the 128-VGPR budget (WPE 4) phase 1 of all NB blocks comes first, so
                         // the 2 * NB bitmap words are requested together; with 64 VGPRs the blocks go one at a time.
                         uint32_t rec[NB], cxp[NB], cxm[NB], wp[NB], wm[NB], prow[NB], passbit[NB];
+#if SP_BAND
+                        uint32_t band[NB];
+#endif
                         auto phase1 = [&](int j) {
                             rec[j] = (64u * j + (uint32_t)lane < rem) ? cur[j] : 0u;  // (a block beyond the run: all zero, no flags, no hits)
                             const unsigned long long fb = __ballot((int)rec[j] < 0);
@@ -401,22 +411,40 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                             yrel += __popcll(fb);
                             const uint32_t x = (rec[j] >> kRecXShift) & 2047u;
                             passbit[j] = (rec[j] & 255u) > v_thr ? 1u : 0u;
-                            const uint32_t rowi = __umul24(ry, v_nwpr);
                             cxp[j] = min(x - v_cx0, v_wnear);
                             cxm[j] = MIRROR ? min(v_cm0 - x, v_wnear) : 0u;
+#if SP_BAND
+                            // hue band of the pixel = class * 5 + floor(5 * ratio), the ratio as the evaluation computes it (a filler
+                            // record gives NaN -> 0 and fails the threshold anyway); the map cell = 4 rows x 8 columns
+                            const float hf = (float)((rec[j] >> 8) & 255u) * __builtin_amdgcn_rcpf((float)(rec[j] & 255u));
+                            band[j] = __umul24((rec[j] >> kRecClsShift) & 7u, 5u) + (uint32_t)(hf * 5.0f);
+                            const uint32_t rowi = __umul24(ry >> 2, v_nwpr);
+                            wp[j] = nearb[rowi + (cxp[j] >> 3)];
+                            wm[j] = MIRROR ? nearb[rowi + (cxm[j] >> 3)] : 0u;
+#else
+                            const uint32_t rowi = __umul24(ry, v_nwpr);
                             wp[j] = nearb[rowi + (cxp[j] >> 5)];
                             wm[j] = MIRROR ? nearb[rowi + (cxm[j] >> 5)] : 0u;
+#endif
                             // plane offset of column cx0 in the pixel's row: (ry + 2) * pitch + 2
                             asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(prow[j]) : "v"(ry), "v"(v_pitch), "v"(poff));
                         };
                         auto phase2 = [&](int j) {
                             {
+#if SP_BAND
+                                const bool hit = ((wp[j] >> (band[j] & 31u)) & passbit[j]) != 0;  // (one value for the ballot and the branch)
+#else
                                 const bool hit = ((wp[j] >> (cxp[j] & 31u)) & passbit[j]) != 0;  // (one value for the ballot and the branch)
+#endif
                                 append(q0, qt0, __ballot(hit), hit, rec[j], prow[j] + cxp[j]);
                                 if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
                             }
                             if (MIRROR) {
+#if SP_BAND
+                                const bool hit = ((wm[j] >> (band[j] & 31u)) & passbit[j]) != 0;
+#else
                                 const bool hit = ((wm[j] >> (cxm[j] & 31u)) & passbit[j]) != 0;
+#endif
                                 append(q1, qt1, __ballot(hit), hit, rec[j], prow[j] + cxm[j]);
                                 if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
                             }
@@ -499,8 +527,31 @@ __global__ __launch_bounds__(256) void sparse_finalize_kernel(const int32_t *par
 static size_t slab_image_bytes(int R, int pitch, int nwpr, int esize, int *near_off) {
     const size_t plane = (size_t)round_up((R + 2 * SP_PAD) * pitch * esize, 16);
     if (near_off) *near_off = (int)plane;
+#if SP_BAND
+    return plane + (size_t)round_up(((R + 4 + 3) / 4) * nwpr * 4, 16);  // band map: one word per 4-row x 8-column cell
+#else
     return plane + (size_t)round_up((R + 4) * nwpr * 4, 16);
+#endif
 }
+
+#if SP_BAND
+// Hue bands (bit = (class * 5 + floor(5 * ratio)) & 31, classes 1..6) that codes of the inclusive interval [lo, lo + len] can
+// fall in.  The band is a monotone function of the code inside a class, so the bands of the two ends bound those of
+// every code between them; the arithmetic is the kernel's (float multiply, truncating conversion).
+static uint32_t band_bits_of(uint32_t lo, uint32_t len) {
+    if (lo == 1u && len == 0u) return 0;  // the empty record
+    const uint32_t hi = lo + len;
+    uint32_t bits = 0;
+    auto u2f = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+    for (uint32_t c = lo >> 29; c <= hi >> 29; c++) {
+        const float flo = c == (lo >> 29) ? u2f((lo & 0x1FFFFFFFu) << 1) : 0.0f;
+        const float fhi = c == (hi >> 29) ? u2f(((hi & 0x1FFFFFFFu) << 1) | 1u) : 1.0f;  // (the code dropped the ratio's last bit)
+        const uint32_t b0 = (uint32_t)(flo * 5.0f), b1 = (uint32_t)(fhi * 5.0f);
+        for (uint32_t b = b0; b <= b1; b++) bits |= 1u << ((c * 5u + b) & 31u);
+    }
+    return bits;
+}
+#endif
 
 void free_sparse_plans(cds_maskset *ms) {
     if (ms->d_sp_slabs) hipFree(ms->d_sp_slabs);
@@ -550,8 +601,16 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
             ylo = std::min(ylo, q.y), yhi = std::max(yhi, q.y);
         }
         pl.xlo = xlo, pl.cols = xhi - xlo + 1, pl.ylo = ylo, pl.nrows = yhi - ylo + 1;
+#if SP_BAND
+        // columns are clamped to G = the first column of an always-empty guard cell; a pixel between the window's end and G
+        // can pass the cell test, so the plane is wide enough (and zero there) for its nine reads: columns up to G + 3
+        const int G = round_up(pl.cols + 4, 8);
+        pl.pitch = round_up(G + 4, 8);
+        pl.nwpr = G / 8 + 1;                    // band-map words per cell row, with the guard cell
+#else
         pl.pitch = round_up(pl.cols + 2 * SP_PAD, 8);
         pl.nwpr = (pl.cols + 4 + 1 + 31) / 32;  // + the guard bit behind the last column
+#endif
         // distinct interval records of this mask; index 0 = the empty record
         std::unordered_map<Key, uint32_t, KeyHash> dict;
         std::vector<uint4> &tab = iv_of[m];
@@ -611,6 +670,10 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
         pl.lds_bytes = fixed + (size_t)pl.slab_bytes;
         std::vector<uint8_t> &slabs = slab_of[m];
         slabs.assign((size_t)pl.n_slabs * pl.slab_bytes, 0);
+#if SP_BAND
+        std::vector<uint32_t> tab_bits(tab.size());
+        for (size_t k = 0; k < tab.size(); k++) tab_bits[k] = band_bits_of(tab[k].x, tab[k].y) | band_bits_of(tab[k].z, tab[k].w);
+#endif
         for (int s = 0; s < pl.n_slabs; s++) {
             uint8_t *img = slabs.data() + (size_t)s * pl.slab_bytes;
             uint16_t *plane16 = reinterpret_cast<uint16_t *>(img);
@@ -626,7 +689,11 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
                 for (int dy = xy2 ? -2 : 0; dy <= (xy2 ? 2 : 0); dy += 2)
                     for (int dx = xy2 ? -2 : 0; dx <= (xy2 ? 2 : 0); dx += 2) {
                         const int ry = rr + 2 + dy, cx = (L[i].x - xlo) + 2 + dx;  // bitmap origin = (xlo - 2, ys0 - 2)
+#if SP_BAND
+                        nearb[(size_t)(ry >> 2) * pl.nwpr + (cx >> 3)] |= tab_bits[pidx[i]];
+#else
                         nearb[(size_t)ry * pl.nwpr + (cx >> 5)] |= 1u << (cx & 31);
+#endif
                     }
             }
                     }
