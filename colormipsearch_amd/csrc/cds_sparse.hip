@@ -308,12 +308,16 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                     a = (uint32_t)__builtin_amdgcn_readlane((int)h_a, r);
                     b = (uint32_t)__builtin_amdgcn_readlane((int)h_b, r);
                 };
-                // NB unconditional loads (index clamped to the range's last record; lanes beyond the range are zeroed when
-                // the block is examined): a conditional load would make hipcc wait with vmcnt(0) at the first use of the
-                // CURRENT blocks, i.e. for the prefetch it has just issued
+                // NB unconditional loads through a buffer descriptor of the image's records [0, b): a lane beyond the run reads
+                // 0 (the hardware's range check) -- no flag, below every threshold -- so neither the index nor the record
+                // needs a per-lane clamp, and the four blocks share one offset register (immediates 0 / 256 / 512 / 768).
+                // (A conditional load would make hipcc wait with vmcnt(0) at the first use of the CURRENT blocks, i.e. for the
+                // prefetch it has just issued.)
                 auto load_blocks = [&](const uint32_t *P, uint32_t i, uint32_t b, uint32_t (&r)[NB]) {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(P), 0, (int)(b * 4u), 0x00020000);
+                    const uint32_t vo = (i + (uint32_t)lane) * 4u;
 #pragma unroll
-                    for (int j = 0; j < NB; j++) r[j] = P[min(i + 64u * j + (uint32_t)lane, b - 1u)];
+                    for (int j = 0; j < NB; j++) r[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(vo + 256u * j), 0, 0);
                 };
                 const uint32_t *P;
                 uint32_t a, b;
@@ -400,17 +404,21 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                         // bitmap is clamped to the guard bit (always 0) instead of being branched around.  phase 2: queue the hits,
                         // evaluate a full queue.  With the 128-VGPR budget (WPE 4) phase 1 of all NB blocks comes first, so
                         // the 2 * NB bitmap words are requested together; with 64 VGPRs the blocks go one at a time.
-                        uint32_t rec[NB], cxp[NB], cxm[NB], wp[NB], wm[NB], prow[NB], passbit[NB];
+                        uint32_t rec[NB], cxp[NB], cxm[NB], wp[NB], wm[NB], prow[NB];
 #if SP_BAND
                         uint32_t band[NB];
+#else
+                        uint32_t passbit[NB];
 #endif
                         auto phase1 = [&](int j) {
-                            rec[j] = (64u * j + (uint32_t)lane < rem) ? cur[j] : 0u;  // (a block beyond the run: all zero, no flags, no hits)
+                            rec[j] = cur[j];  // (lanes and whole blocks beyond the run were loaded as 0: no flags, no hits)
                             const unsigned long long fb = __ballot((int)rec[j] < 0);
                             const uint32_t ry = (uint32_t)(yrel + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0))) + (rec[j] >> 31);
                             yrel += __popcll(fb);
                             const uint32_t x = (rec[j] >> kRecXShift) & 2047u;
+#if !SP_BAND
                             passbit[j] = (rec[j] & 255u) > v_thr ? 1u : 0u;
+#endif
                             cxp[j] = min(x - v_cx0, v_wnear);
                             cxm[j] = MIRROR ? min(v_cm0 - x, v_wnear) : 0u;
 #if SP_BAND
@@ -418,6 +426,7 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                             // record gives NaN -> 0 and fails the threshold anyway); the map cell = 4 rows x 8 columns
                             const float hf = (float)((rec[j] >> 8) & 255u) * __builtin_amdgcn_rcpf((float)(rec[j] & 255u));
                             band[j] = __umul24((rec[j] >> kRecClsShift) & 7u, 5u) + (uint32_t)(hf * 5.0f);
+                            band[j] = (rec[j] & 255u) > v_thr ? band[j] : 3u;  // below the threshold: bit 3, which no band maps to
                             const uint32_t rowi = __umul24(ry >> 2, v_nwpr);
                             wp[j] = nearb[rowi + (cxp[j] >> 3)];
                             wm[j] = MIRROR ? nearb[rowi + (cxm[j] >> 3)] : 0u;
@@ -432,7 +441,7 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                         auto phase2 = [&](int j) {
                             {
 #if SP_BAND
-                                const bool hit = ((wp[j] >> (band[j] & 31u)) & passbit[j]) != 0;  // (one value for the ballot and the branch)
+                                const bool hit = __builtin_amdgcn_ubfe(wp[j], band[j], 1u) != 0;  // (one value for the ballot and the branch)
 #else
                                 const bool hit = ((wp[j] >> (cxp[j] & 31u)) & passbit[j]) != 0;  // (one value for the ballot and the branch)
 #endif
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                             }
                             if (MIRROR) {
 #if SP_BAND
-                                const bool hit = ((wm[j] >> (band[j] & 31u)) & passbit[j]) != 0;
+                                const bool hit = __builtin_amdgcn_ubfe(wm[j], band[j], 1u) != 0;
 #else
                                 const bool hit = ((wm[j] >> (cxm[j] & 31u)) & passbit[j]) != 0;
 #endif
@@ -543,10 +552,12 @@ static uint32_t band_bits_of(uint32_t lo, uint32_t len) {
     const uint32_t hi = lo + len;
     uint32_t bits = 0;
     auto u2f = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
-    for (uint32_t c = lo >> 29; c <= hi >> 29; c++) {
+    // classes 1..6 and bins 0..4 only (a record's ratio is < 1): bands 5..34, i.e. bits 5..31 and 0..2 -- bits 3 and 4 stay
+    // clear in every word, bit 3 is where the kernel sends the pixels below the data threshold
+    for (uint32_t c = std::max(1u, lo >> 29); c <= std::min(6u, hi >> 29); c++) {
         const float flo = c == (lo >> 29) ? u2f((lo & 0x1FFFFFFFu) << 1) : 0.0f;
         const float fhi = c == (hi >> 29) ? u2f(((hi & 0x1FFFFFFFu) << 1) | 1u) : 1.0f;  // (the code dropped the ratio's last bit)
-        const uint32_t b0 = (uint32_t)(flo * 5.0f), b1 = (uint32_t)(fhi * 5.0f);
+        const uint32_t b0 = (uint32_t)(flo * 5.0f), b1 = std::min(4u, (uint32_t)(fhi * 5.0f));
         for (uint32_t b = b0; b <= b1; b++) bits |= 1u << ((c * 5u + b) & 31u);
     }
     return bits;
