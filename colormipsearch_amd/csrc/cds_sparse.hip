@@ -256,11 +256,19 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
         // the kernel's scalar registers are needed for the 18 counters, the queue state and the loop state, and every
         // scalar spilled to a VGPR lane comes back as a v_readlane inside the 64-pixel loop.
         uint32_t v_thr, v_cx0, v_cm0, v_wnear, v_nwpr, v_pitch, poff;
+#if SP_BAND
+        uint32_t near_lds;  // LDS address of the band map
+        asm volatile("v_mov_b32 %0, %1" : "=v"(near_lds) : "s"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)nearb));
+#endif
         asm volatile("v_mov_b32 %0, %1" : "=v"(v_thr) : "s"(p.thr));
         asm volatile("v_mov_b32 %0, %1" : "=v"(v_cx0) : "s"(cx0));
         asm volatile("v_mov_b32 %0, %1" : "=v"(v_cm0) : "s"(cm0));
         asm volatile("v_mov_b32 %0, %1" : "=v"(v_wnear) : "s"(wnear));
+#if SP_BAND
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_nwpr) : "s"(p.nwpr * 4));  // bytes per cell row of the band map
+#else
         asm volatile("v_mov_b32 %0, %1" : "=v"(v_nwpr) : "s"(p.nwpr));
+#endif
         asm volatile("v_mov_b32 %0, %1" : "=v"(v_pitch) : "s"(p.pitch));
         asm volatile("v_mov_b32 %0, %1" : "=v"(poff) : "s"(2 * p.pitch + 2));
         // column strips of the library that the mask's plain window [xlo - 2, xhi + 2] and its mirror image can touch
@@ -427,9 +435,19 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                             const float hf = (float)((rec[j] >> 8) & 255u) * __builtin_amdgcn_rcpf((float)(rec[j] & 255u));
                             band[j] = __umul24((rec[j] >> kRecClsShift) & 7u, 5u) + (uint32_t)(hf * 5.0f);
                             band[j] = (rec[j] & 255u) > v_thr ? band[j] : 3u;  // below the threshold: bit 3, which no band maps to
-                            const uint32_t rowi = __umul24(ry >> 2, v_nwpr);
-                            wp[j] = nearb[rowi + (cxp[j] >> 3)];
-                            wm[j] = MIRROR ? nearb[rowi + (cxm[j] >> 3)] : 0u;
+                            // LDS address of the cell's word = map + (ry / 4) * row bytes + (column / 8) * 4: one mad for the row, one
+                            // shift-add per orientation (written as asm: hipcc turns (c >> 3) << 2 into shift, mask and a separate add)
+                            typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+                            uint32_t rowa, ap, am;
+                            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rowa) : "v"(ry >> 2), "v"(v_nwpr), "v"(near_lds));
+                            asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ap) : "v"(cxp[j] >> 3), "v"(rowa));
+                            wp[j] = *reinterpret_cast<lds_u32 *>((uintptr_t)ap);
+                            if (MIRROR) {
+                                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(am) : "v"(cxm[j] >> 3), "v"(rowa));
+                                wm[j] = *reinterpret_cast<lds_u32 *>((uintptr_t)am);
+                            } else {
+                                wm[j] = 0u;
+                            }
 #else
                             const uint32_t rowi = __umul24(ry, v_nwpr);
                             wp[j] = nearb[rowi + (cxp[j] >> 5)];
