@@ -217,7 +217,9 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
     extern __shared__ uint4 lds4[];
     constexpr int NS = XY2 ? 9 : 1, NSX = XY2 ? 3 : 1, NO = MIRROR ? 2 : 1, NC = NS * NO;
     constexpr int HALO = XY2 ? 2 : 0;
-    constexpr int NB = 4;  // record blocks (64 records each) in flight per wave (8 with the 128-VGPR budget: 3 % slower)
+    constexpr int NB = 4;  // record blocks (64 records each) in flight per wave.  (8 with the 128-VGPR budget: no faster, measured
+                           // twice; requests two steps ahead need three statically named register sets, i.e. the loop body three
+                           // times -- a rotation by copies makes hipcc wait for the loads it copies -- for the same <= 8 %.)
     typedef typename std::conditional<P8, uint8_t, uint16_t>::type plane_t;
     uint8_t *lds = reinterpret_cast<uint8_t *>(lds4);
     const int lane = threadIdx.x & 63;
