@@ -201,11 +201,12 @@ def main():
                 "kernel_ms_per_launch": kern_ms,
                 "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
                 "frac_by_traffic": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "pipes_busy_per_cu": {"valu": 0.58, "lds": 0.58, "salu": 0.44, "source": "profiles/r02b_summary.txt + tools/valubench (DESIGN.md 4b)"},
+                "pipes_busy_per_cu": {"valu": 0.52, "salu": 0.47, "lds": 0.23, "source": "profiles/r02e_summary.txt + tools/valubench (DESIGN.md 4b)"},
                 "note": "achieved = SURVEY 8(d) algorithmic bytes (mask rows x 3630 B of packed RGB per target) / kernel time.  "
-                        "The library is stored sparse, so the kernel reads ~40x fewer bytes than that (traffic) and frac exceeds 1: "
-                        "this kernel is bound by its waves' LDS round trips and by instruction issue, not by HBM (DESIGN.md "
-                        "section 4b); the HBM-streaming variant of the same scan is under aux.dense_layout.",
+                        "The library is stored sparse, so the kernel reads ~45x fewer bytes than that (traffic) and frac exceeds 1; "
+                        "frac_by_traffic is the share of the HBM peak the measured bytes take.  The kernel is bound by instruction "
+                        "issue (vector and scalar pipes about half busy with 4 waves per SIMD) before HBM (DESIGN.md section 4b); "
+                        "the HBM-streaming variant of the same scan is under aux.dense_layout.",
             },
         }
 
