@@ -416,3 +416,38 @@ def test_dense_full_frame_mask(cds, oracle):
     got = alg.searchSparseLibraryCounts(sl)[0]
     assert np.array_equal(got, want)
     assert got[2, 4] > 0.9 * alg.getQuerySize()   # the mask against itself, unshifted
+
+
+def test_every_target_colour_against_uniform_masks(cds, oracle):
+    """The hue-band map of stage 1 must never drop a pixel the evaluation would count.  One target holds EVERY (class, second,
+    max) combination a record can have (6 x 32,640 = 195,840 pixels in a 400 x 500 block); masks are uniform blocks of one colour
+    each -- ratios on and next to the band boundaries k/5, ratio 0, the colours next to a class change -- so every target pixel
+    meets that colour under every shift; several tolerances, all 18 counts against the oracle."""
+    hh, ww = 500, 400
+    combos = []
+    for mx in range(1, 256):
+        sec = np.arange(mx)
+        lo = np.zeros_like(sec)   # the third channel: anything not above the second one; 0 keeps the class unambiguous
+        m = np.full_like(sec, mx)
+        for order in ((2, 0, 1), (2, 1, 0), (1, 2, 0), (1, 0, 2), (0, 1, 2), (0, 2, 1)):   # (max channel, second, third)
+            px = np.zeros((len(sec), 3), dtype=np.uint8)
+            px[:, order[0]], px[:, order[1]], px[:, order[2]] = m, sec, lo
+            combos.append(px)
+    combos = np.concatenate(combos)
+    assert len(combos) == 195840
+    target = np.zeros((H, W, 3), dtype=np.uint8)
+    block = np.zeros((hh * ww, 3), dtype=np.uint8)
+    block[: len(combos)] = combos
+    y0, x0 = 40, 420
+    target[y0:y0 + hh, x0:x0 + ww] = block.reshape(hh, ww, 3)
+    sl = sparse_of(cds, target)
+    colours = [(255, 51, 0), (255, 50, 0), (255, 52, 3), (250, 100, 0), (250, 101, 7), (200, 120, 10), (0, 200, 160), (0, 201, 160),
+               (10, 100, 255), (255, 0, 0), (30, 0, 255), (0, 255, 254), (254, 255, 0), (128, 127, 3), (64, 255, 13), (21, 20, 1)]
+    for ci, col in enumerate(colours):
+        mask = np.zeros((H, W, 3), dtype=np.uint8)
+        mask[y0:y0 + hh, x0:x0 + ww] = col
+        for ztol in ((0.01, 0.05, 0.25) if ci % 4 == 0 else (0.01,)):
+            alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, ztol, 2, [])
+            counts = alg.searchSparseLibraryCounts(sl)
+            want = oracle.PixelMatchQuery(mask, 20, 20, ztol, 2, True, []).score(target)[2]
+            assert np.array_equal(counts[0, 0], want), (col, ztol, counts[0, 0].tolist(), list(want))
