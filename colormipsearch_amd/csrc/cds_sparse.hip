@@ -482,10 +482,8 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
 #pragma unroll
                             for (int j = 0; j < NB; j++) phase1(j);
 #pragma unroll
-                            for (int j = 0; j < NB; j++) {
-                                if (rem <= 64u * j) break;  // wave-uniform
-                                phase2(j);
-                            }
+                            for (int j = 0; j < NB; j++) phase2(j);  // (a block beyond the run is all zero: no hit, nothing queued -- cheaper
+                                                                     // than a scalar compare and branch per block)
                         } else {
 #pragma unroll
                             for (int j = 0; j < NB; j++) {
