@@ -114,6 +114,8 @@ SIGNATURES = {
     "cds_library_make_zgap_variants": (_i, [_vp, _i64, _i64, _i32, ctypes.c_double, _rp, _i32]),
     # include/cds_hip_debug.h
     "cds_debug_intervals": (_i, [_f32p, _i32, _i32, _i32, ctypes.c_double, _u32p]),
+    "cds_debug_band_bits": (_i, [ctypes.c_uint32, ctypes.c_uint32, _u32p]),
+    "cds_debug_band_of": (_i32, [_f32p, _i32, _i32, _i32]),
     "cds_debug_hue_code": (ctypes.c_uint32, [_f32p, _i32, _i32, _i32, _i32]),
     "cds_debug_device_rcp": (_i, [_vp, _f32p]),
     "cds_maskset_sparse_layout": (_i, [_vp, _i32, _i32p]),

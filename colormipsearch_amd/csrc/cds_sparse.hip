@@ -1195,4 +1195,19 @@ int cds_search_sparse_counts(const cds_maskset *ms, const cds_sparse_library *sl
     return sparse_search_host(ms, sl, first, count, nullptr, nullptr, counts);
 }
 
+
+#if SP_BAND
+// diagnostics of the stage-1 hue-band map (include/cds_hip_debug.h; host arithmetic identical to the kernel's)
+int cds_debug_band_bits(uint32_t lo, uint32_t len, uint32_t *bits) {
+    if (!bits) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *bits = band_bits_of(lo, len);
+    return CDS_OK;
+}
+int32_t cds_debug_band_of(const float *rcp_table, int32_t cls, int32_t second, int32_t max) {
+    if (!rcp_table || max < 0 || max > 255 || second < 0 || second > 255) return -1;
+    const float hf = (float)second * rcp_table[max];
+    return (int32_t)(((uint32_t)cls * 5u + (uint32_t)(hf * 5.0f)) & 31u);
+}
+#endif
+
 }  // extern "C"

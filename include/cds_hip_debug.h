@@ -22,6 +22,12 @@ int cds_debug_device_rcp(const cds_context *ctx, float *out256);
  * mask rows per slab, LDS bytes of one workgroup, bounding-box columns, bounding-box rows, interval records + 1,
  * bytes per plane cell, interval table in LDS }. */
 int cds_maskset_sparse_layout(const cds_maskset *ms, int32_t mask_index, int32_t *out8);
+/* Stage 1 of the sparse scan tests one bit of a per-cell word: bit cds_debug_band_of(class 1..6, second, max) of the pixel
+ * (its hue band, (class * 5 + floor(5 * ratio)) mod 32 with the ratio as the device computes it) against the union of
+ * cds_debug_band_bits(lo, len) over the intervals of the mask pixels that can reach the cell.  The property that makes the
+ * filter exact: a code inside [lo, lo + len] always has its band's bit set in cds_debug_band_bits(lo, len). */
+int cds_debug_band_bits(uint32_t lo, uint32_t len, uint32_t *bits);
+int32_t cds_debug_band_of(const float *rcp_table, int32_t cls, int32_t second, int32_t max);
 #ifdef __cplusplus
 }
 #endif

@@ -110,3 +110,49 @@ def test_hue_code_is_zero_below_threshold_and_for_ties():
     c = _codes(rcp, np.array([[0, 0, 0], [20, 20, 20], [20, 3, 1], [200, 200, 10], [21, 3, 1], [0, 0, 21]], dtype=np.uint8), 20)
     assert list(c[:4]) == [0, 0, 0, 0] and c[4] != 0 and c[5] != 0
     assert (c[4] >> 29) == 5 and (c[5] >> 29) == 2      # RG, BG (r <= g)
+
+
+@pytest.mark.parametrize("ztol", [0.0, 0.01, 0.05, 0.3])
+def test_band_map_bits_cover_every_code_of_an_interval(oracle, ztol):
+    """Stage 1 of the sparse scan drops a target pixel when its hue band's bit is clear in the cell's word.  For that to be
+    exact, every code an interval contains must have its band among cds_debug_band_bits(interval): checked for all 195,840
+    (class, second, max) target colours against the intervals of LUT, random and boundary mask colours."""
+    lib = capi.load()
+    rcp = _host_rcp()
+    p = rcp.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    # every record colour: class 1..6 (BR, BG, GB, GR, RG, RB as in cds_internal.hpp), second < max
+    orders = {1: (2, 0, 1), 2: (2, 1, 0), 3: (1, 2, 0), 4: (1, 0, 2), 5: (0, 1, 2), 6: (0, 2, 1)}   # (max channel, second, third)
+    cols, cls, sec, mxs = [], [], [], []
+    for c, order in orders.items():
+        for mx in range(1, 256):
+            s = np.arange(mx)
+            px = np.zeros((mx, 3), dtype=np.uint8)
+            px[:, order[0]], px[:, order[1]] = mx, s
+            cols.append(px), cls.append(np.full(mx, c)), sec.append(s), mxs.append(np.full(mx, mx))
+    cols, cls, sec, mxs = np.concatenate(cols), np.concatenate(cls), np.concatenate(sec), np.concatenate(mxs)
+    codes = _codes(rcp, cols, 0)
+    # (with second == third == 0 the reference's strict comparisons pick the class, e.g. (0, 0, 9) is BG, not BR: take the
+    # class from the code itself; everywhere else it is the one enumerated)
+    assert np.array_equal((codes >> 29)[sec > 0], cls.astype(np.uint32)[sec > 0])
+    cls = (codes >> 29).astype(np.int64)
+    assert cls.min() >= 1 and cls.max() <= 6
+    bands = np.array([lib.cds_debug_band_of(p, int(c), int(s), int(m)) for c, s, m in zip(cls[::7], sec[::7], mxs[::7])])
+    hf = (sec.astype(np.float32) * rcp[mxs]).astype(np.float32)
+    band_all = ((cls * 5 + (hf * np.float32(5.0)).astype(np.uint32)) & 31).astype(np.uint32)
+    assert np.array_equal(bands, band_all[::7])                          # numpy restatement == the library's arithmetic
+    assert not np.isin(band_all, (3, 4)).any()                           # bit 3 is where pixels below the threshold are sent
+    rng = np.random.default_rng(77)
+    masks = np.concatenate([oracle.depth_lut()[::3], rng.integers(0, 256, size=(120, 3)),
+                            np.array([[255, 51, 0], [255, 50, 0], [255, 102, 1], [250, 100, 0], [0, 204, 255], [0, 255, 254], [254, 255, 0],
+                                      [255, 0, 0], [30, 0, 255], [128, 127, 3], [21, 20, 1], [255, 254, 253]])]).astype(np.uint8)
+    out = np.zeros(1, dtype=np.uint32)
+    for m in masks:
+        iv = [int(v) for v in _intervals(rcp, m, ztol)]
+        bits = 0
+        for lo, ln in ((iv[0], iv[1]), (iv[2], iv[3])):
+            capi.check(lib.cds_debug_band_bits(lo, ln, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+            bits |= int(out[0])
+        assert bits & 0b11000 == 0
+        inside = (((codes - np.uint32(iv[0])) & 0xFFFFFFFF) <= iv[1]) | (((codes - np.uint32(iv[2])) & 0xFFFFFFFF) <= iv[3])
+        missed = inside & (((bits >> band_all) & 1) == 0)
+        assert not missed.any(), (m.tolist(), ztol, cols[missed][:5].tolist())
