@@ -182,29 +182,17 @@ static bool packbits_decode(const uint8_t *in, size_t n, uint8_t *out, size_t wa
 // TIFF LZW (MSB-first codes, 9..12 bits, ClearCode 256, EoiCode 257, "early change" like every current writer: the code
 // width grows as soon as the entry just added is number 2^bits - 2)
 static bool lzw_decode(const uint8_t *in, size_t n, uint8_t *out, size_t want) {
-    struct Entry { uint16_t prev; uint8_t ch, first; uint16_t len; };
-    std::vector<Entry> tab(4096);
-    for (int i = 0; i < 256; i++) tab[i] = {0xffff, (uint8_t)i, (uint8_t)i, 1};
+    // Every table string is a piece of the output already written: the entry added after emitting `code` is the previous
+    // code's string plus the first byte of this one, i.e. the bytes starting where the previous string was emitted, one
+    // longer.  So an entry is (position, length) and emitting a code is a forward copy inside the output (overlapping for
+    // the KwKwK case, hence byte order matters) -- no prefix chains to walk backwards.
+    uint32_t pos[4096];
+    uint32_t len[4096];
     int next = 258, bits = 9, old = -1;
     uint32_t acc = 0;
     int nacc = 0;
-    size_t i = 0, o = 0;
-    auto emit = [&](int code) {  // the string of `code`, written backwards; clipped at `want`
-        const size_t len = tab[code].len;
-        int c = code;
-        for (size_t k = len; k-- > 0;) {
-            if (o + k < want) out[o + k] = tab[c].ch;
-            c = tab[c].prev;
-        }
-        o = std::min(o + len, want);
-    };
-    auto add = [&](int prefix, uint8_t ch) {
-        if (next < 4096) {
-            tab[next] = {(uint16_t)prefix, ch, tab[prefix].first, (uint16_t)(tab[prefix].len + 1)};
-            next++;
-            if (next >= (1 << bits) - 1 && bits < 12) bits++;
-        }
-    };
+    size_t i = 0, o = 0, o_old = 0;
+    size_t old_len = 0;   // full (unclipped) length of the previous code's string
     while (o < want) {
         while (nacc < bits && i < n) { acc = (acc << 8) | in[i++]; nacc += 8; }
         if (nacc < bits) break;
@@ -212,19 +200,39 @@ static bool lzw_decode(const uint8_t *in, size_t n, uint8_t *out, size_t want) {
         nacc -= bits;
         if (code == 257) break;
         if (code == 256) { next = 258; bits = 9; old = -1; continue; }
-        if (old < 0) {
-            if (code >= 256) return false;
-            emit(code);
-        } else if (code < next) {
-            emit(code);
-            add(old, tab[code].first);
-        } else if (code == next && next < 4096) {
-            add(old, tab[old].first);   // KwKwK: the entry being defined right now
-            emit(code);
+        size_t L;
+        const size_t at = o;
+        if (code < 256) {
+            if (old < 0 || code < next) {
+                out[o++] = (uint8_t)code;
+                L = 1;
+            } else {
+                return false;
+            }
         } else {
-            return false;
+            if (old < 0) return false;
+            size_t src;
+            if (code < next) {
+                src = pos[code], L = len[code];
+            } else if (code == next && next < 4096) {
+                src = o_old, L = old_len + 1;   // KwKwK: the entry being defined right now
+            } else {
+                return false;
+            }
+            const size_t m = std::min(L, want - o);
+            if (src + m <= o) memcpy(out + o, out + src, m);
+            else for (size_t k = 0; k < m; k++) out[o + k] = out[src + k];
+            o += m;
+        }
+        if (old >= 0 && next < 4096) {
+            pos[next] = (uint32_t)o_old;
+            len[next] = (uint32_t)(old_len + 1);
+            next++;
+            if (next >= (1 << bits) - 1 && bits < 12) bits++;
         }
         old = code;
+        o_old = at;
+        old_len = L;
     }
     return o == want;
 }
