@@ -148,15 +148,15 @@ constexpr int kRecXShift = 20;
 constexpr int kRecClsShift = 16;
 
 // One mask prepared for the sparse scan: the mask's bounding box cut into slabs of `slab_rows` mask rows; per slab one
-// ready-to-copy LDS image [plane u16 or u8 (slab_rows + 8) x pitch | near bitmap u32 (slab_rows + 4) x nwpr]:
+// ready-to-copy LDS image [plane u16 or u8 (slab_rows + 8) x pitch | band map u32 ceil((slab_rows + 4) / 4) x nwpr (one word per 4-row x 8-column cell)]:
 //   plane[(my - slab_y0) + 4][(mx - xlo) + 4] = 1-based index of the mask pixel's interval record (0 = no mask pixel);
 //   near bit (ty - (slab_y0 - 2), tx - (xlo - 2)) = some transform maps target pixel (tx, ty) onto a mask pixel of the slab.
 struct SparseMaskPlan {
     int xlo = 0, cols = 0, ylo = 0, nrows = 0;  // bounding box of the mask's device pixels
     int pitch = 0;        // plane row pitch in u16 elements (multiple of 8, >= cols + 8)
-    int nwpr = 0;         // near-bitmap words per row
+    int nwpr = 0;         // band-map words per cell row (with the guard cell)
     int slab_rows = 0, n_slabs = 0;
-    int near_off = 0;     // byte offset of the near bitmap inside a slab image
+    int near_off = 0;     // byte offset of the band map inside a slab image
     int slab_bytes = 0;   // multiple of 16
     int n_iv = 0;         // interval records (index 0 = the empty record) -- iv table has n_iv entries
     bool iv_in_lds = true;

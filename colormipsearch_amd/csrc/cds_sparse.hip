@@ -13,19 +13,22 @@
 // ~80 KB per synthetic target instead of 2.06 MB, so a 1 M-target library (80 GB) is RESIDENT in one MI355X's 288 GB.
 //
 // The scan turns around accordingly (target-centric instead of the reference's mask-centric gather):
-//   * the MASK lives in LDS: a u16 plane over its bounding box (index of the pixel's acceptance-interval record, 0 = no
-//     mask pixel), the table of distinct interval records, and a "near" bitmap = the plane dilated by the 9 xy-shifts.
+//   * the MASK lives in LDS: a u8 / u16 plane over its bounding box (index of the pixel's acceptance-interval record,
+//     0 = no mask pixel), the table of distinct interval records, and a BAND MAP: per cell of 4 rows x 8 columns of target
+//     positions one word whose bit b says "some xy-shift maps a position of this cell onto a mask pixel that accepts a code
+//     of hue band b" (30 bands = class x floor(5 * ratio); conservative, band_bits_of below).
 //     A mask taller than the LDS budget is cut into slabs of rows; per-transform counts of the slabs are summed at the end.
-//   * a WAVE streams one target's records (coalesced dword loads, the rows a slab can reach are one contiguous run thanks
-//     to the row pointers), 64 pixels per step: row from the row-start flags (ballot + mbcnt), threshold on the max
-//     channel, one bitmap probe per orientation "can any shift of this pixel land on a mask pixel?" -- the survivors
-//     (~13 %) go to a per-wave LDS queue;
+//   * a WAVE streams one target's records (coalesced dword loads through a buffer descriptor, the rows a slab can reach in
+//     a column strip are one contiguous run thanks to the row pointers), 64 pixels per step: row from the row-start flags
+//     (ballot + mbcnt), the pixel's band (or a never-set bit below the data threshold), one band-map probe per orientation
+//     "can any shift of this pixel land on a mask pixel of a compatible colour?" -- the survivors (1.5 % when the target's
+//     colours are unrelated to the mask's, about half on overlapping real images) go to a per-wave LDS queue;
 //   * queued pixels are evaluated 64 at a time with every lane busy: hue code = class << 29 | bits(second * v_rcp_f32(max)) >> 1
 //     (the same code the dense kernel computes, so the host's interval tables apply unchanged and the integer range test
 //     is bit-exact with the reference's double arithmetic, cds_host.hip), 9 plane lookups with immediate offsets, 9
 //     interval fetches, 2 compares each, matches counted by s_bcnt1 of the ballot into wave-uniform (SGPR) counters;
 //   * no barriers, no staging, no atomics on the data path: waves are independent, targets are drawn in small groups
-//     from a global counter (persistent grid, every workgroup visits every slab), ~25 KB of HBM traffic per target.
+//     from partition counters (persistent grid, every workgroup visits every slab), ~14 KB of HBM traffic per target.
 //   * no MFMA: integer compare / count.
 #include <algorithm>
 #include <atomic>
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                 };
 
                 for (int r = 0; r < nruns; r++) {  // wave-uniform
-                    int yrel = ra - 1 - ry0;  // (rows started before the current block) - 1, relative to the near bitmap
+                    int yrel = ra - 1 - ry0;  // (rows started before the current block) - 1, relative to the band map
                     for (uint32_t i = a; i < b; i += 64 * NB) {  // wave-uniform
                         const uint32_t rem = b - i;  // records of this run from block 0 of this iteration on
                         // the next NB blocks -- of this run, or the first ones of the grab's next run -- are in flight while
