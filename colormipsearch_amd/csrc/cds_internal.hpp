@@ -150,7 +150,8 @@ constexpr int kRecClsShift = 16;
 // One mask prepared for the sparse scan: the mask's bounding box cut into slabs of `slab_rows` mask rows; per slab one
 // ready-to-copy LDS image [plane u16 or u8 (slab_rows + 8) x pitch | band map u32 ceil((slab_rows + 4) / 4) x nwpr (one word per 4-row x 8-column cell)]:
 //   plane[(my - slab_y0) + 4][(mx - xlo) + 4] = 1-based index of the mask pixel's interval record (0 = no mask pixel);
-//   near bit (ty - (slab_y0 - 2), tx - (xlo - 2)) = some transform maps target pixel (tx, ty) onto a mask pixel of the slab.
+//   band-map word of cell ((ty - (slab_y0 - 2)) / 4, (tx - (xlo - 2)) / 8), bit b = some transform maps a target position of
+//   the cell onto a mask pixel of the slab whose intervals contain a code of hue band b (cds_sparse.hip, band_bits_of).
 struct SparseMaskPlan {
     int xlo = 0, cols = 0, ylo = 0, nrows = 0;  // bounding box of the mask's device pixels
     int pitch = 0;        // plane row pitch in u16 elements (multiple of 8, >= cols + 8)
