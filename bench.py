@@ -8,17 +8,26 @@ The whole library (`--targets`, default 1,048,576 per GPU) is RESIDENT in HBM as
 staging slots, before the timed region.  A STEP is one scan of the whole resident library with the benchmark mask =
 `--targets` comparisons per GPU (the library is far larger than the 256 MiB Infinity Cache, so no step is served from cache).
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): the library is sharded by target index, every rank scans its own
-resident shard (weak scaling: N x 1M targets = configs[3] at N = 8), and each step ends with ONE RCCL gather of the
-per-target score array (int32, score | mirrored<<31) to rank 0 -- the only collective on the path.
+Multi-GPU (`--gpus N`): started directly, this script launches its N ranks itself (torch.distributed.run, before anything
+touches a GPU); under torch.distributed.run it is one of the ranks.  The library is sharded by target index, every rank
+scans its own resident shard (weak scaling: N x 1M targets = configs[3] at N = 8), and each step ends with ONE RCCL gather
+of the per-target score array (int32, score | mirrored<<31) to rank 0 -- the only collective on the path.
 
-Prints one JSON line (rank 0): the contract fields plus `roofline`, `cpu_baseline` (the C oracle = restatement of the
-reference's Java loops, timed on the host cores) and `aux` (the same scan over the dense packed-RGB layout; mask batches;
-GradientAreaGap scores of top hits; the reference's JUnit pairs; the scan rate on the reference's real test images).  Any disagreement between the GPU paths or with the oracle makes the run fail (value null, exit code 1).
+EVERY score of the last timed step is verified: each rank regenerates its shard window by window as dense images and
+compares the sparse scan with the dense-layout kernel (a second, independent implementation), and three 256-target slices
+(first window, a window whose records lie beyond 2^32 in the arena, last window) with the CPU oracle.  A flipped bit
+anywhere makes the run fail (value null, exit code 1).
+
+Prints one JSON line (rank 0): the contract fields plus `roofline` (instruction-issue bound with the HBM fraction by
+measured traffic beside it), `cpu_baseline` (the C oracle = restatement of the reference's Java loops, timed on the host
+cores) and `aux` (dense layout; BASELINE configs[2] at full size; GradientAreaGap scores of top hits; the reference's JUnit
+pairs; the scan rate on the reference's real test images).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,6 +41,7 @@ W, H = 1210, 566
 LIB_SEED, MASK_SEED = 0xC0FFEE, 0xBADC0DE
 MASK_THR, DATA_THR, ZTOL, XY_SHIFT, MIRROR = 20, 20, 0.01, 2, True
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+PMC_FILE = os.path.join(ROOT, "profiles", "scan_pmc.json")   # written by tools/summarize_profile.py from rocprofv3 --pmc passes
 
 
 def usable_cores():
@@ -46,25 +56,69 @@ def usable_cores():
     return max(1, n)
 
 
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as children (nothing in this process
+    has touched a GPU yet, and it never will) and leave with their exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def load_pmc():
+    """Per-target / per-pair hardware-counter figures of the kernels, collected by separate rocprofv3 --pmc passes of this
+    script (tools/profile_round.sh) and keyed by the SHA-256 of the kernel sources they were measured on."""
+    try:
+        j = json.load(open(PMC_FILE))
+    except Exception:
+        return None
+    stale = []
+    for rel, want in j.get("sources", {}).items():
+        try:
+            got = hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()
+        except Exception:
+            got = None
+        if got != want:
+            stale.append(rel)
+    j["stale_sources"] = stale
+    return j
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--targets", type=int, default=1 << 20, help="resident targets per GPU = comparisons per step per GPU")
-    ap.add_argument("--stage", type=int, default=8192, help="dense staging slots used while the library is generated")
+    ap.add_argument("--stage", type=int, default=8192, help="dense staging slots used while the library is generated / verified")
     ap.add_argument("--kind", type=int, default=0, help="0 sparse-lut targets (default), 1 dense-uniform")
     ap.add_argument("--cpu-sample", type=int, default=0, help="targets in the cpu_baseline sample (0 = 8000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--batch-masks", type=int, default=1024, help="masks of the configs[2] leg (aux.mask_batch)")
+    ap.add_argument("--verify-windows", type=int, default=0, help="staging-sized windows of the library compared with the dense scan "
+                    "(0 = all of them: every score of the run is checked; k >= 3 = k windows spread over the index range)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.gpus > torch.cuda.device_count():      # (device_count() does not initialise the GPU on this image)
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} visible")
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE {world}")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line, the JSON: whatever libraries print there (RCCL's version banner) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -87,6 +141,7 @@ def main():
     ctx = cds.Context(local_rank)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
 
     # ---- inputs, resident in HBM before the timed region ----
     n = args.targets
@@ -112,7 +167,7 @@ def main():
     P = alg.getQuerySize()
     ys = np.flatnonzero((mask.max(axis=2) > MASK_THR).any(axis=1))
     rows = min(H, int(ys.max() - ys.min() + 1) + 2 * XY_SHIFT)
-    alg_bytes_per_target = rows * 3 * W          # R x 3630 B
+    dense_bytes_per_target = rows * 3 * W        # R x 3630 B -- what a DENSE layout would stream
 
     # Two score buffers: the gather of step k (RCCL's own stream, waits for scan k) runs while step k + 1 scans into the
     # other buffer -- as consecutive masks of a search would; a buffer is reused only after its gather has completed.
@@ -157,29 +212,100 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # the scan of one step (one kernel launch), on the launch stream
+    rank_kern_ms = [kern_ms]
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # the scan of one step (one kernel launch), on the launch stream
+        km = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(km, torch.tensor([kern_ms], dtype=torch.float64, device=dev))
+        rank_kern_ms = [float(x.item()) for x in km]
+        if rank == 0 and not torch.equal(gathered[0], scores):
+            raise SystemExit("gathered scores differ from the local ones")
 
     host_scores = scores.cpu().numpy()
     sc, mir = host_scores & 0x7FFFFFFF, (host_scores >> 31) & 1
     failed = []
 
+    # ---- verification of the WHOLE shard: sparse scan == dense-layout scan, window by window; oracle on three slices ----
+    offs = slib.image_offsets(0, n)                               # record offsets in the arena (uint64)
+    first_beyond = int(np.searchsorted(offs[:-1], np.uint64(1) << np.uint64(32)))   # first image stored beyond 2^32 records
+    starts = list(range(0, n, stage_n))
+    if args.verify_windows >= 3 and args.verify_windows < len(starts):
+        pick = sorted({int(round(i * (len(starts) - 1) / (args.verify_windows - 1))) for i in range(args.verify_windows)})
+        beyond = [i for i, s0 in enumerate(starts) if s0 >= first_beyond]
+        if beyond and not any(starts[i] >= first_beyond for i in pick):
+            pick.append(beyond[len(beyond) // 2])
+        starts = [starts[i] for i in sorted(set(pick))]
+    dsc = torch.empty(stage_n, dtype=torch.int32, device=dev)
+    mism = torch.zeros((), dtype=torch.int64, device=dev)
+    t0 = time.time()
+    slice_at = {0: "first window", starts[-1]: "last window"}
+    mid = [s0 for s0 in starts if s0 >= first_beyond and s0 != starts[-1]]
+    if mid:
+        slice_at[mid[len(mid) // 2]] = "window beyond 2^32 records"
+    oracle_slices, q_or = [], None
+    for s0 in starts:
+        c = min(stage_n, n - s0)
+        dense.generate_synthetic(LIB_SEED, rank * n + s0, 0, c, kind=args.kind)
+        alg.searchLibraryDevice(dense, 0, c, dsc.data_ptr())
+        mism += (dsc[:c] != scores[s0:s0 + c]).sum()
+        if s0 in slice_at and rank == 0 and not args.no_cpu_baseline:
+            from oracle import cds_oracle as O
+            if q_or is None:
+                q_or = O.PixelMatchQuery(mask, MASK_THR, DATA_THR, ZTOL, XY_SHIFT, MIRROR, rects)
+            k0 = max(0, c - 256) if s0 == starts[-1] else 0          # (the last window: its last 256 targets)
+            k1 = min(c, k0 + 256)
+            imgs = dense.download(k0, k1 - k0)
+            ws, wm = q_or.scan(imgs, n_threads=usable_cores(), partition=16)
+            ok = bool(np.array_equal(ws, sc[s0 + k0:s0 + k1]) and np.array_equal(wm.astype(np.int64), mir[s0 + k0:s0 + k1].astype(np.int64)))
+            oracle_slices.append({"targets": [s0 + k0, s0 + k1], "what": slice_at[s0], "first_record_offset": int(offs[s0 + k0]),
+                                  "equal_to_oracle": ok})
+            if not ok:
+                failed.append(f"sparse scan differs from the CPU oracle on targets [{s0 + k0}, {s0 + k1})")
+            del imgs
+    n_mism = int(mism.item())
+    verified = sum(min(stage_n, n - s0) for s0 in starts)
+    if use_dist:
+        tm = torch.tensor([n_mism, verified], dtype=torch.int64, device=dev)
+        dist.all_reduce(tm)
+        n_mism, verified = int(tm[0].item()), int(tm[1].item())
+    if n_mism:
+        failed.append(f"sparse scan and dense-layout scan disagree on {n_mism} of the {verified} verified targets")
+    verification = {"targets_verified_against_dense_scan": verified, "of": world * n, "windows_per_gpu": len(starts), "mismatches": n_mism,
+                    "first_target_beyond_2^32_records": first_beyond if first_beyond < n else None,
+                    "targets_beyond_2^32_records_verified_per_gpu": sum(min(stage_n, n - s0) for s0 in starts if s0 >= first_beyond),
+                    "oracle_slices": oracle_slices, "seconds": round(time.time() - t0, 2)}
+
     out = None
     if rank == 0:
         total = world * n * args.steps
-        achieved = alg_bytes_per_target * n / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")   # PMC-derived HBM bytes per target of the sparse scan, if collected
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("kind") == args.kind and tj.get("layout") == "sparse":
-                    traffic = tj.get("hbm_bytes_per_target") * n
-            except Exception:
-                traffic = None
+        pmc = load_pmc()
+        issue_ns = ctx.valu_issue_ns()                            # measured now, on this device
+        simds = 4 * n_cus
+        roof = {"bound": "issue", "kernel": "cds::sparse_scan_kernel<xy2,mirror>", "achieved": None, "peak": simds / issue_ns,
+                "unit": "G wave64-VALU-instructions/s", "frac": None, "traffic": None,
+                "kernel_ms_per_launch": kern_ms, "targets_per_launch": n, "valu_issue_ns_per_simd": issue_ns, "simds": simds,
+                "hbm": {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None},
+                "dense_layout_bytes_per_target": dense_bytes_per_target,
+                "note": "The sparse library removed the bytes a dense scan streams (dense_layout_bytes_per_target), so the scan is bound by "
+                        "instruction issue, not HBM: frac = VALU wave-instructions per launch (PMC, counters.source) x the issue time of one "
+                        "wave64 VALU instruction per SIMD measured in this run / (SIMDs x kernel time of this run).  hbm = measured HBM "
+                        "traffic (2 x FETCH_SIZE) / kernel time against the 8 TB/s peak.  The HBM-streaming variant of the scan is aux.dense_layout."}
+        cls = (pmc or {}).get("classes", {}).get("sparse_scan_headline") if args.kind == 0 else None
+        if cls:
+            pt = cls["per_target"]
+            valu = pt["SQ_INSTS_VALU"] * n
+            roof["achieved"] = valu / (kern_ms * 1e6)             # G wave-instructions / s
+            roof["frac"] = roof["achieved"] / roof["peak"]
+            roof["traffic"] = pt["hbm_bytes"] * n
+            roof["hbm"]["achieved"] = roof["traffic"] / (kern_ms * 1e-3) / 1e9
+            roof["hbm"]["frac"] = roof["hbm"]["achieved"] / HBM_PEAK_GBS
+            roof["counters"] = {"source": f"profiles/scan_pmc.json (tag {pmc.get('tag')}): separate rocprofv3 --pmc passes of "
+                                          f"`{pmc.get('command')}`, mean of {cls.get('dispatches')} launches of {cls.get('targets_per_dispatch')} targets",
+                                "measured_in_this_run": False, "stale_sources": pmc["stale_sources"],
+                                "per_target": pt, "profile_kernel_ms_per_launch": cls.get("mean_ms")}
         out = {
             "metric": "mask x target MIP comparisons/sec at 1210x566 RGB",
             "value": total / elapsed,
@@ -208,25 +334,9 @@ def main():
                 "library_generation_s": round(gen_s, 3),
                 "nonzero_scores": int((sc > 0).sum()),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "cds::sparse_scan_kernel<xy2,mirror>",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_target": alg_bytes_per_target,
-                "kernel_ms_per_launch": kern_ms,
-                "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
-                "frac_by_traffic": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "pipes_busy_per_cu": {"valu": 0.52, "salu": 0.47, "lds": 0.23, "source": "profiles/r02e_summary.txt + tools/valubench (DESIGN.md 4b)"},
-                "note": "achieved = SURVEY 8(d) algorithmic bytes (mask rows x 3630 B of packed RGB per target) / kernel time.  "
-                        "The library is stored sparse, so the kernel reads ~45x fewer bytes than that (traffic) and frac exceeds 1; "
-                        "frac_by_traffic is the share of the HBM peak the measured bytes take.  The kernel is bound by instruction "
-                        "issue (vector and scalar pipes about half busy with 4 waves per SIMD) before HBM (DESIGN.md section 4b); "
-                        "the HBM-streaming variant of the same scan is under aux.dense_layout.",
-            },
+            "kernel_ms_per_rank": rank_kern_ms,
+            "verification": verification,
+            "roofline": roof,
         }
 
     # ---- CPU baseline: the C oracle (a restatement of the reference's Java loops), bounded sample ----
@@ -238,7 +348,7 @@ def main():
         n_s = min(args.cpu_sample or 8000, n, stage_n)   # 80 partitions of 100
         dense.generate_synthetic(LIB_SEED, 0, 0, n_s, kind=args.kind)
         sample = dense.download(0, n_s)
-        q = O.PixelMatchQuery(mask, MASK_THR, DATA_THR, ZTOL, XY_SHIFT, MIRROR, rects)
+        q = q_or or O.PixelMatchQuery(mask, MASK_THR, DATA_THR, ZTOL, XY_SHIFT, MIRROR, rects)
         q.scan(sample[: min(64, n_s)], n_threads=cores, partition=4)   # warm the thread pool / page in
         passes, dt = 0, 0.0
         while dt < 1.0 and passes < 64:
@@ -273,185 +383,209 @@ def main():
 
     # ---- secondary measurements (not `value`) ----
     if rank == 0 and world == 1 and not args.no_aux:
-        aux = {}
-        # (a) the same scan over the DENSE layout (packed RGB rows streamed from HBM, cds::scan_kernel): the first stage_n targets
-        n_d = stage_n
-        dense.generate_synthetic(LIB_SEED, 0, 0, n_d, kind=args.kind)
-        dsc = torch.empty(n_d, dtype=torch.int32, device=dev)
-        for _ in range(2):
-            alg.searchLibraryDevice(dense, 0, n_d, dsc.data_ptr())
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(5):
-            alg.searchLibraryDevice(dense, 0, n_d, dsc.data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize()
-        dms = e0.elapsed_time(e1) / 5
-        same_d = bool(torch.equal(dsc, scores[:n_d]))
-        d_ach = alg_bytes_per_target * n_d / (dms * 1e-3) / 1e9
-        aux["dense_layout"] = {"workload": f"1 mask x {n_d} targets resident as packed RGB rows (2,064,768 B each)", "kernel": "cds::scan_kernel<xy2,mirror,single-mask>",
-                               "comparisons_per_s": n_d / (dms * 1e-3), "ms_per_pass": dms,
-                               "roofline": {"bound": "hbm", "achieved": d_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d_ach / HBM_PEAK_GBS,
-                                            "algorithmic_bytes_per_target": alg_bytes_per_target},
-                               "scores_equal_sparse_scan": same_d}
-        if not same_d:
-            failed.append("dense-layout scan disagrees with the sparse scan")
-        # (b) BASELINE configs[2] (many masks x the 1M library) on a sample of masks: 16 masks against ALL resident targets, one
-        # launch per mask over the sparse library (1,024 masks are 64 such passes); and, for comparison, the dense batch
-        # kernel (128 masks share one pass over dense rows) over the staging slots
-        n_m, n_t = 16, n
-        mlib2 = cds.Library(W, H, 128, context=ctx)
-        mlib2.generate_synthetic(MASK_SEED, 0, 0, 128, kind=2)
-        masks128 = mlib2.download(0, 128)
-        batch = cds.PixelMatchColorDepthSearchAlgorithm(masks128[:n_m], MASK_THR, MIRROR, None, 0, False, DATA_THR, ZTOL, XY_SHIFT, rects, context=ctx)
-        bscores = torch.empty(n_m * n_t, dtype=torch.int32, device=dev)
-        batch.searchSparseLibraryDevice(slib, 0, n_t, bscores.data_ptr())
-        e0.record(stream)
-        for _ in range(2):
-            batch.searchSparseLibraryDevice(slib, 0, n_t, bscores.data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize()
-        bms = e0.elapsed_time(e1) / 2
-        same_b = bool(torch.equal(bscores[:n_t], scores[:n_t]))   # mask 0 of the batch is the benchmark mask
-        n_t2 = min(16384, n_d)
-        batch128 = cds.PixelMatchColorDepthSearchAlgorithm(masks128, MASK_THR, MIRROR, None, 0, False, DATA_THR, ZTOL, XY_SHIFT, rects, context=ctx)
-        b2 = torch.empty(128 * n_t2, dtype=torch.int32, device=dev)
-        batch128.searchLibraryDevice(dense, 0, n_t2, b2.data_ptr())
-        e0.record(stream)
-        for _ in range(2):
-            batch128.searchLibraryDevice(dense, 0, n_t2, b2.data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize()
-        b2ms = e0.elapsed_time(e1) / 2
-        same_b2 = bool(torch.equal(b2.view(128, n_t2)[:n_m], bscores.view(n_m, n_t)[:, :n_t2]))
-        aux["mask_batch"] = {"workload": f"{n_m} masks x {n_t} resident targets (BASELINE configs[2] on a sample of its 1,024 masks), sparse layout, one launch per mask",
-                             "comparisons_per_s": n_m * n_t / (bms * 1e-3), "ms_per_pass": bms,
-                             "mask0_scores_equal_single_mask_scan": same_b,
-                             "dense_batch_kernel": {"workload": f"128 masks x {n_t2} dense targets in one batched pass",
-                                                    "comparisons_per_s": 128 * n_t2 / (b2ms * 1e-3), "ms_per_pass": b2ms,
-                                                    "scores_equal_sparse_scan": same_b2}}
-        if not same_b:
-            failed.append("mask-batch scan disagrees with the single-mask scan")
-        if not same_b2:
-            failed.append("dense batch kernel disagrees with the sparse scan")
-        # (b2) BASELINE configs[4] in miniature: GradientAreaGap scores of the top-500 hits of 32 masks among the staging
-        # slots (their gradient / zgap variants generated on the device), one launch; with the oracle checked on 3 pairs
-        n_gm, top = 32, min(500, n_d)
-        dense.generate_synthetic(LIB_SEED, 0, 0, n_d, kind=args.kind, with_variants=True)
-        t0 = time.perf_counter()
-        shp = cds.Shape2DMatchColorDepthSearchAlgorithm(masks128[:n_gm], MASK_THR, MIRROR, None, rects, context=ctx)
-        prep_s = time.perf_counter() - t0
-        gsel = cds.PixelMatchColorDepthSearchAlgorithm(masks128[:n_gm], MASK_THR, MIRROR, None, 0, False, DATA_THR, ZTOL, XY_SHIFT, rects, context=ctx)
-        gsc = torch.empty(n_gm * n_d, dtype=torch.int32, device=dev)
-        gsel.searchSparseLibraryDevice(slib, 0, n_d, gsc.data_ptr())
-        torch.cuda.synchronize()
-        hits = (gsc.view(n_gm, n_d) & 0x7FFFFFFF).cpu().numpy()
-        ps = np.concatenate([np.argsort(-hits[m], kind="stable")[:top] for m in range(n_gm)]).astype(np.int64)   # top hits per mask
-        pm = np.repeat(np.arange(n_gm), top).astype(np.int32)
-        shp.scoreLibraryPairs(dense, pm, ps)
-        gap, high, gmir = shp.scoreLibraryPairs(dense, pm, ps)
-        gms, _ = shp.lastKernelMs()
-        ok_g = True
-        if not args.no_cpu_baseline:
-            from oracle import cds_oracle as O
-            sq = O.ShapeQuery(masks128[0], MASK_THR, MIRROR, rects)     # (one CPU mask preparation: three pairs of mask 0)
-            for i in (0, top // 2, top - 1):
-                tgt = dense.download(int(ps[i]), 1)[0]
-                gr, zg = dense.download_variants(int(ps[i]), 1)
-                og, oh, _, om = sq.score(tgt, gr[0], zg[0])
-                ok_g &= (int(gap[i]), int(high[i]), bool(gmir[i])) == (og, oh, om)
-        g_ach = len(pm) * 2081200 / (gms * 1e-3) / 1e9            # 2,081,200 B per pair at R = 170
-        aux["gradient_scores"] = {"workload": f"GradientAreaGap of the top-{top} hits of {n_gm} masks among {n_d} dense targets with variants "
-                                              f"= {len(pm)} pairs (BASELINE configs[4] shape), one launch", "kernel": "cds::gradscore_list_kernel",
-                                  "pairs_per_s": len(pm) / (gms * 1e-3), "kernel_ms": gms, "shape_mask_preparation_ms_per_mask": 1e3 * prep_s / n_gm,
-                                  "roofline": {"bound": "hbm", "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS,
-                                               "algorithmic_bytes_per_pair": 2081200},
-                                  "sampled_pairs_equal_oracle": bool(ok_g)}
-        if not ok_g:
-            failed.append("gradient scores differ from the CPU oracle's on the sampled pairs")
-        # (c) the reference's own fixture images and known answers ("in every benchmark binary"): the JUnit pairs
-        # of PixelMatchColorDepthSearchAlgorithmTest through the sparse scan, the dense scan and the shape scorer
-        fpath = os.path.join(ROOT, "tests", "golden", "cds_fixtures.npz")
-        if os.path.exists(fpath):
-            from tests.golden import expected as E
-            with np.load(fpath) as z:
-                fx = {k: z[k] for k in z.files}
-            tkeys = sorted({t for _, t, _, _ in E.PIXEL_MATCH_PROVIDER})
-            tg = np.stack([fx[k] for k in tkeys])
-            fl = cds.Library(W, H, len(tkeys), context=ctx)
-            fl.upload(0, tg)
-            fs = cds.SparseLibrary(W, H, len(tkeys), int((tg.max(axis=3) > 0).sum()) + 4 * H * len(tkeys) + 64, context=ctx)
-            fs.append_from(fl)
-            got, ok_f = [], True
-            for mk, tk, want_s, want_m in E.PIXEL_MATCH_PROVIDER:
-                a = cds.PixelMatchColorDepthSearchAlgorithm(fx[mk], 20, True, None, 0, False, 20, 0.01, 2, E.STD_RECTS, context=ctx)
-                t = tkeys.index(tk)
-                s1, m1 = a.searchSparseLibrary(fs, t, 1)
-                s2, m2 = a.searchLibrary(fl, t, 1)
-                got.append([mk, tk, int(s1[0, 0]), bool(m1[0, 0])])
-                ok_f &= (int(s1[0, 0]), bool(m1[0, 0])) == (want_s, want_m) == (int(s2[0, 0]), bool(m2[0, 0]))
-            sk = E.SHAPE_SCORES[2]   # the pair with a ZGapImage file: (mask, target, grad, zgap, gaps, highExpression, score, mirrored)
-            fl.upload_variants(tkeys.index(sk[1]), fx[sk[2]][None], fx[sk[3]][None])
-            sh = cds.Shape2DMatchColorDepthSearchAlgorithm(fx[sk[0]], 20, True, None, E.STD_RECTS, context=ctx)
-            gap, high, smir = sh.scoreLibraryPairs(fl, [0], [tkeys.index(sk[1])])
-            ok_f &= (int(gap[0]), int(high[0]), bool(smir[0])) == (sk[4], sk[5], sk[7])
-            aux["reference_fixtures"] = {"pixel_match": got, "shape": [int(gap[0]), int(high[0]), bool(smir[0])], "equal_to_reference_junit_values": bool(ok_f)}
-            # (d) the same scan on REAL images: the reference's LM test MIPs replicated into a resident library (they carry 2x the
-            # records of a synthetic target and all overlap the EM test masks, so far more of them reach the interval test)
-            del fl, fs
-            lkeys = sorted(k for k in fx if k.startswith("lm_"))
-            copies = max(1, stage_n // len(lkeys))
-            n_rd = copies * len(lkeys)                       # dense slots holding the images
-            reps = max(1, 32768 // n_rd)
-            n_r = n_rd * reps                                # sparse targets: the staging slots appended `reps` times
-            limgs = np.stack([fx[k] for k in lkeys])
-            for c in range(copies):
-                dense.upload(c * len(lkeys), limgs)
-            rs = cds.SparseLibrary(W, H, n_r, int((limgs.max(axis=3) > 0).sum()) * copies * reps + 8 * H * n_r + 64, context=ctx)
-            for _ in range(reps):
-                for first in range(0, n_rd, 4096):
-                    rs.append_from(dense, first, min(4096, n_rd - first))
-            real = {"workload": f"{len(lkeys)} LM test MIPs of the reference x {copies * reps} copies = {n_r} resident sparse targets ({n_rd} of them "
-                                f"also dense), xyShift=2, mirror on", "records_per_target": rs.pixels / n_r, "masks": {}}
-            ok_r = True
-            for mk in sorted(k for k in fx if k.startswith("em_")):
-                a = cds.PixelMatchColorDepthSearchAlgorithm(fx[mk], 20, True, None, 0, False, 20, 0.01, 2, E.STD_RECTS, context=ctx)
-                rsp = torch.empty(n_r, dtype=torch.int32, device=dev)
-                rde = torch.empty(n_rd, dtype=torch.int32, device=dev)
-                a.searchSparseLibraryDevice(rs, 0, n_r, rsp.data_ptr())
-                e0.record(stream)
-                for _ in range(3):
-                    a.searchSparseLibraryDevice(rs, 0, n_r, rsp.data_ptr())
-                e1.record(stream)
-                torch.cuda.synchronize()
-                rms = e0.elapsed_time(e1) / 3
-                a.searchLibraryDevice(dense, 0, n_rd, rde.data_ptr())
-                e0.record(stream)
-                a.searchLibraryDevice(dense, 0, n_rd, rde.data_ptr())
-                e1.record(stream)
-                torch.cuda.synchronize()
-                dms = e0.elapsed_time(e1)
-                same_r = bool(torch.equal(rsp.view(reps, n_rd), rde.view(1, n_rd).expand(reps, n_rd)))
-                ok_r &= same_r
-                real["masks"][mk] = {"sparse_comparisons_per_s": n_r / (rms * 1e-3), "dense_comparisons_per_s": n_rd / (dms * 1e-3),
-                                     "scores_equal": same_r}
-            aux["real_images"] = real
-            if not ok_r:
-                failed.append("sparse and dense scans disagree on the reference's images")
-            if not ok_f:
-                failed.append("reference fixture pairs do not give the reference's JUnit values")
-        out["aux"] = aux
+        out["aux"] = aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores, n, stage_n, dense_bytes_per_target, failed)
     if rank == 0:
         if failed:
             out["value"] = None     # a wrong result is not a measurement
             out["parity_failure"] = failed
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
-        if rank == 0 and not torch.equal(gathered[0], scores):
-            raise SystemExit("gathered scores differ from the local ones")
         dist.destroy_process_group()
     if failed:
         raise SystemExit("bench.py: parity failure: " + "; ".join(failed))
+
+
+def timed(stream, fn, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores, n, stage_n, dense_bytes_per_target, failed):
+    aux = {}
+    pmc = load_pmc() or {}
+    # (a) the same scan over the DENSE layout (packed RGB rows streamed from HBM, cds::scan_kernel): the first stage_n targets
+    n_d = stage_n
+    dense.generate_synthetic(LIB_SEED, 0, 0, n_d, kind=args.kind)
+    dsc = torch.empty(n_d, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        alg.searchLibraryDevice(dense, 0, n_d, dsc.data_ptr())
+    dms = timed(stream, lambda: alg.searchLibraryDevice(dense, 0, n_d, dsc.data_ptr()), 5)
+    same_d = bool(torch.equal(dsc, scores[:n_d]))
+    d_ach = dense_bytes_per_target * n_d / (dms * 1e-3) / 1e9
+    dcls = pmc.get("classes", {}).get("dense_scan")
+    aux["dense_layout"] = {"workload": f"1 mask x {n_d} targets resident as packed RGB rows (2,064,768 B each)", "kernel": "cds::scan_kernel<xy2,mirror,single-mask>",
+                           "comparisons_per_s": n_d / (dms * 1e-3), "ms_per_pass": dms,
+                           "roofline": {"bound": "hbm", "achieved": d_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d_ach / HBM_PEAK_GBS,
+                                        "algorithmic_bytes_per_target": dense_bytes_per_target,
+                                        "traffic": (dcls["per_target"]["hbm_bytes"] * n_d) if dcls else None,
+                                        "frac_by_traffic": (dcls["per_target"]["hbm_bytes"] * n_d / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dcls else None},
+                           "scores_equal_sparse_scan": same_d}
+    if not same_d:
+        failed.append("dense-layout scan disagrees with the sparse scan")
+
+    # (b) BASELINE configs[2] at FULL size: `--batch-masks` (1,024) masks x ALL resident targets over the sparse library;
+    # sampled masks are checked against the dense batch kernel (128 masks share one pass over dense rows) and the oracle
+    n_m, n_t = args.batch_masks, n
+    mlib2 = cds.Library(W, H, max(128, n_m), context=ctx)
+    mlib2.generate_synthetic(MASK_SEED, 0, 0, max(128, n_m), kind=2)
+    masks = mlib2.download(0, max(128, n_m))
+    del mlib2
+    t0 = time.perf_counter()
+    batch = cds.PixelMatchColorDepthSearchAlgorithm(masks[:n_m], MASK_THR, MIRROR, None, 0, False, DATA_THR, ZTOL, XY_SHIFT, rects, context=ctx)
+    prep_s = time.perf_counter() - t0
+    bscores = torch.empty(n_m * n_t, dtype=torch.int32, device=dev)
+    bms = timed(stream, lambda: batch.searchSparseLibraryDevice(slib, 0, n_t, bscores.data_ptr()), 1)
+    bview = bscores.view(n_m, n_t)
+    same_b = bool(torch.equal(bview[0], scores[:n_t]))   # mask 0 of the batch is the benchmark mask
+    n_t2 = min(16384, n_d)
+    batch128 = cds.PixelMatchColorDepthSearchAlgorithm(masks[:128], MASK_THR, MIRROR, None, 0, False, DATA_THR, ZTOL, XY_SHIFT, rects, context=ctx)
+    b2 = torch.empty(128 * n_t2, dtype=torch.int32, device=dev)
+    batch128.searchLibraryDevice(dense, 0, n_t2, b2.data_ptr())
+    b2ms = timed(stream, lambda: batch128.searchLibraryDevice(dense, 0, n_t2, b2.data_ptr()), 2)
+    k128 = min(128, n_m)
+    same_b2 = bool(torch.equal(b2.view(128, n_t2)[:k128], bview[:k128, :n_t2]))
+    # masks beyond the first 128, spread over the set: the single-mask dense kernel on the staging targets
+    sample_masks = sorted({min(n_m - 1, i) for i in (0, n_m // 3, (2 * n_m) // 3, n_m - 1)})
+    same_b3, ok_or = True, True
+    for mi in sample_masks:
+        a1 = cds.PixelMatchColorDepthSearchAlgorithm(masks[mi], MASK_THR, MIRROR, None, 0, False, DATA_THR, ZTOL, XY_SHIFT, rects, context=ctx)
+        a1.searchLibraryDevice(dense, 0, n_d, dsc.data_ptr())
+        same_b3 &= bool(torch.equal(dsc, bview[mi, :n_d]))
+        if not args.no_cpu_baseline:
+            from oracle import cds_oracle as O
+            qm = O.PixelMatchQuery(masks[mi], MASK_THR, DATA_THR, ZTOL, XY_SHIFT, MIRROR, rects)
+            ws, wm = qm.scan(dense.download(0, 128), n_threads=usable_cores(), partition=8)
+            hs = bview[mi, :128].cpu().numpy()
+            ok_or &= bool(np.array_equal(ws, hs & 0x7FFFFFFF) and np.array_equal(wm.astype(np.int64), ((hs >> 31) & 1).astype(np.int64)))
+    aux["mask_batch"] = {"workload": f"{n_m} masks x {n_t} resident targets (BASELINE configs[2]" + (" at full size" if n_m >= 1024 and n_t >= 1 << 20 else "") + "), sparse layout",
+                         "comparisons_per_s": n_m * n_t / (bms * 1e-3), "seconds_per_pass": bms * 1e-3, "mask_preparation_s": prep_s,
+                         "mask0_scores_equal_single_mask_scan": same_b,
+                         "sampled_masks": sample_masks, "sampled_masks_equal_dense_scan": same_b3,
+                         "sampled_masks_equal_oracle_on_128_targets": bool(ok_or) if not args.no_cpu_baseline else None,
+                         "dense_batch_kernel": {"workload": f"128 masks x {n_t2} dense targets in one batched pass",
+                                                "comparisons_per_s": 128 * n_t2 / (b2ms * 1e-3), "ms_per_pass": b2ms,
+                                                "scores_equal_sparse_scan": same_b2}}
+    if not same_b:
+        failed.append("mask-batch scan disagrees with the single-mask scan")
+    if not same_b2:
+        failed.append("dense batch kernel disagrees with the sparse scan")
+    if not same_b3:
+        failed.append("mask-batch scan disagrees with the dense scan on sampled masks")
+    if not ok_or:
+        failed.append("mask-batch scan disagrees with the oracle on sampled masks")
+    del batch128, b2
+
+    # (b2) BASELINE configs[4] in miniature: GradientAreaGap scores of the top-500 hits of 32 masks among the staging
+    # slots (their gradient / zgap variants generated on the device), one launch; oracle-checked on 64 random pairs of 4 masks
+    n_gm, top = min(32, n_m), min(500, n_d)
+    dense.generate_synthetic(LIB_SEED, 0, 0, n_d, kind=args.kind, with_variants=True)
+    t0 = time.perf_counter()
+    shp = cds.Shape2DMatchColorDepthSearchAlgorithm(masks[:n_gm], MASK_THR, MIRROR, None, rects, context=ctx)
+    prep_s = time.perf_counter() - t0
+    hits = (bview[:n_gm, :n_d] & 0x7FFFFFFF).cpu().numpy()
+    ps = np.concatenate([np.argsort(-hits[m], kind="stable")[:top] for m in range(n_gm)]).astype(np.int64)   # top hits per mask
+    pm = np.repeat(np.arange(n_gm), top).astype(np.int32)
+    shp.scoreLibraryPairs(dense, pm, ps)
+    gap, high, gmir = shp.scoreLibraryPairs(dense, pm, ps)
+    gms, _ = shp.lastKernelMs()
+    ok_g, n_checked = True, 0
+    if not args.no_cpu_baseline:
+        from oracle import cds_oracle as O
+        rng = np.random.default_rng(7)
+        for m in sorted({0, n_gm // 3, (2 * n_gm) // 3, n_gm - 1}):
+            sq = O.ShapeQuery(masks[m], MASK_THR, MIRROR, rects)     # (one CPU mask preparation per sampled mask)
+            for i in rng.choice(top, size=16, replace=False):
+                j = m * top + int(i)
+                tgt = dense.download(int(ps[j]), 1)[0]
+                gr, zg = dense.download_variants(int(ps[j]), 1)
+                og, oh, _, om = sq.score(tgt, gr[0], zg[0])
+                ok_g &= (int(gap[j]), int(high[j]), bool(gmir[j])) == (og, oh, om)
+                n_checked += 1
+    gcls = pmc.get("classes", {}).get("gradscore_list")
+    g_alg = len(pm) * 2081200 / (gms * 1e-3) / 1e9            # 2,081,200 B per pair at R = 170
+    g_traffic = gcls["per_pair"]["hbm_bytes"] * len(pm) if gcls else None
+    aux["gradient_scores"] = {"workload": f"GradientAreaGap of the top-{top} hits of {n_gm} masks among {n_d} dense targets with variants "
+                                          f"= {len(pm)} pairs (BASELINE configs[4] shape), one launch", "kernel": "cds::gradscore_list_kernel",
+                              "pairs_per_s": len(pm) / (gms * 1e-3), "kernel_ms": gms, "shape_mask_preparation_ms_per_mask": 1e3 * prep_s / n_gm,
+                              "roofline": {"bound": "hbm", "achieved": (g_traffic / (gms * 1e-3) / 1e9) if g_traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": (g_traffic / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS) if g_traffic else None, "traffic": g_traffic,
+                                           "traffic_source": (f"profiles/scan_pmc.json (tag {pmc.get('tag')}), 2 x FETCH_SIZE per pair; stale sources: {pmc.get('stale_sources')}") if gcls else None,
+                                           "survey_8d_bytes_per_pair": 2081200, "survey_8d_GBps": g_alg,
+                                           "note": "the list kernel reads only the groups the mask's lists select, fewer bytes than SURVEY 8(d) counts; frac is by measured traffic"},
+                              "pairs_checked_against_oracle": n_checked, "sampled_pairs_equal_oracle": bool(ok_g)}
+    if not ok_g:
+        failed.append("gradient scores differ from the CPU oracle's on the sampled pairs")
+    del bscores, bview, batch
+
+    # (c) the reference's own fixture images and known answers ("in every benchmark binary"): the JUnit pairs
+    # of PixelMatchColorDepthSearchAlgorithmTest through the sparse scan, the dense scan and the shape scorer
+    fpath = os.path.join(ROOT, "tests", "golden", "cds_fixtures.npz")
+    if os.path.exists(fpath):
+        from tests.golden import expected as E
+        with np.load(fpath) as z:
+            fx = {k: z[k] for k in z.files}
+        tkeys = sorted({t for _, t, _, _ in E.PIXEL_MATCH_PROVIDER})
+        tg = np.stack([fx[k] for k in tkeys])
+        fl = cds.Library(W, H, len(tkeys), context=ctx)
+        fl.upload(0, tg)
+        fs = cds.SparseLibrary(W, H, len(tkeys), int((tg.max(axis=3) > 0).sum()) + 4 * H * len(tkeys) + 64, context=ctx)
+        fs.append_from(fl)
+        got, ok_f = [], True
+        for mk, tk, want_s, want_m in E.PIXEL_MATCH_PROVIDER:
+            a = cds.PixelMatchColorDepthSearchAlgorithm(fx[mk], 20, True, None, 0, False, 20, 0.01, 2, E.STD_RECTS, context=ctx)
+            t = tkeys.index(tk)
+            s1, m1 = a.searchSparseLibrary(fs, t, 1)
+            s2, m2 = a.searchLibrary(fl, t, 1)
+            got.append([mk, tk, int(s1[0, 0]), bool(m1[0, 0])])
+            ok_f &= (int(s1[0, 0]), bool(m1[0, 0])) == (want_s, want_m) == (int(s2[0, 0]), bool(m2[0, 0]))
+        sk = E.SHAPE_SCORES[2]   # the pair with a ZGapImage file: (mask, target, grad, zgap, gaps, highExpression, score, mirrored)
+        fl.upload_variants(tkeys.index(sk[1]), fx[sk[2]][None], fx[sk[3]][None])
+        sh = cds.Shape2DMatchColorDepthSearchAlgorithm(fx[sk[0]], 20, True, None, E.STD_RECTS, context=ctx)
+        gap, high, smir = sh.scoreLibraryPairs(fl, [0], [tkeys.index(sk[1])])
+        ok_f &= (int(gap[0]), int(high[0]), bool(smir[0])) == (sk[4], sk[5], sk[7])
+        aux["reference_fixtures"] = {"pixel_match": got, "shape": [int(gap[0]), int(high[0]), bool(smir[0])], "equal_to_reference_junit_values": bool(ok_f)}
+        # (d) the same scan on REAL images: the reference's LM test MIPs replicated into a resident library (they carry 2x the
+        # records of a synthetic target and all overlap the EM test masks, so far more of them reach the interval test)
+        del fl, fs
+        lkeys = sorted(k for k in fx if k.startswith("lm_"))
+        copies = max(1, stage_n // len(lkeys))
+        n_rd = copies * len(lkeys)                       # dense slots holding the images
+        reps = max(1, 32768 // n_rd)
+        n_r = n_rd * reps                                # sparse targets: the staging slots appended `reps` times
+        limgs = np.stack([fx[k] for k in lkeys])
+        for c in range(copies):
+            dense.upload(c * len(lkeys), limgs)
+        rs = cds.SparseLibrary(W, H, n_r, int((limgs.max(axis=3) > 0).sum()) * copies * reps + 8 * H * n_r + 64, context=ctx)
+        for _ in range(reps):
+            for first in range(0, n_rd, 4096):
+                rs.append_from(dense, first, min(4096, n_rd - first))
+        real = {"workload": f"{len(lkeys)} LM test MIPs of the reference x {copies * reps} copies = {n_r} resident sparse targets ({n_rd} of them "
+                            f"also dense), xyShift=2, mirror on", "records_per_target": rs.pixels / n_r, "masks": {}}
+        ok_r = True
+        for mk in sorted(k for k in fx if k.startswith("em_")):
+            a = cds.PixelMatchColorDepthSearchAlgorithm(fx[mk], 20, True, None, 0, False, 20, 0.01, 2, E.STD_RECTS, context=ctx)
+            rsp = torch.empty(n_r, dtype=torch.int32, device=dev)
+            rde = torch.empty(n_rd, dtype=torch.int32, device=dev)
+            a.searchSparseLibraryDevice(rs, 0, n_r, rsp.data_ptr())
+            rms = timed(stream, lambda: a.searchSparseLibraryDevice(rs, 0, n_r, rsp.data_ptr()), 3)
+            a.searchLibraryDevice(dense, 0, n_rd, rde.data_ptr())
+            dms = timed(stream, lambda: a.searchLibraryDevice(dense, 0, n_rd, rde.data_ptr()), 1)
+            same_r = bool(torch.equal(rsp.view(reps, n_rd), rde.view(1, n_rd).expand(reps, n_rd)))
+            ok_r &= same_r
+            real["masks"][mk] = {"sparse_comparisons_per_s": n_r / (rms * 1e-3), "dense_comparisons_per_s": n_rd / (dms * 1e-3),
+                                 "scores_equal": same_r}
+        aux["real_images"] = real
+        if not ok_r:
+            failed.append("sparse and dense scans disagree on the reference's images")
+        if not ok_f:
+            failed.append("reference fixture pairs do not give the reference's JUnit values")
+    return aux
 
 
 if __name__ == "__main__":

@@ -94,6 +94,7 @@ SIGNATURES = {
     "cds_sparse_library_pixels": (_i64, [_vp]),
     "cds_sparse_library_clear": (_i, [_vp]),
     "cds_sparse_library_image_records": (_i, [_vp, _i64, _u32p, _i64, _i64p, _u32p]),
+    "cds_sparse_library_image_offsets": (_i, [_vp, _i64, _i64, ctypes.POINTER(ctypes.c_uint64)]),
     "cds_sparse_library_export": (_i, [_vp, _i64, _i64, ctypes.POINTER(ctypes.c_uint64), _u32p, _u32p, _i64]),
     "cds_sparse_library_import": (_i, [_vp, _i64, ctypes.POINTER(ctypes.c_uint64), _u32p, _u32p, _i32, _i32]),
     "cds_image_probe": (_i, [_u8p, ctypes.c_size_t, ctypes.POINTER(ImageInfo)]),
@@ -118,6 +119,7 @@ SIGNATURES = {
     "cds_debug_band_of": (_i32, [_f32p, _i32, _i32, _i32]),
     "cds_debug_hue_code": (ctypes.c_uint32, [_f32p, _i32, _i32, _i32, _i32]),
     "cds_debug_device_rcp": (_i, [_vp, _f32p]),
+    "cds_debug_valu_issue_ns": (_i, [_vp, ctypes.POINTER(ctypes.c_double)]),
     "cds_maskset_sparse_layout": (_i, [_vp, _i32, _i32p]),
 }
 

@@ -96,6 +96,12 @@ class Context:
         capi.check(self._lib.cds_debug_device_rcp(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
         return out
 
+    def valu_issue_ns(self):
+        """ns one SIMD of this device needs per wave64 VALU instruction (calibration of the issue roofline, bench.py)."""
+        v = ctypes.c_double()
+        capi.check(self._lib.cds_debug_valu_issue_ns(self._h, ctypes.byref(v)))
+        return v.value
+
     def make_zgap(self, target, threshold, radius=10, excluded_regions=None):
         """clearRegion -> mask(threshold) -> unsafeMaxFilter(radius), on the GPU."""
         img = capi.rgb_images(target)[0]
@@ -278,6 +284,13 @@ class SparseLibrary:
         capi.check(self._lib.cds_sparse_library_import(self._h, count, offs.ctypes.data_as(u64p), cells.ctypes.data_as(u32p), rec.ctypes.data_as(u32p),
                                                        self.n_strips if n_strips is None else int(n_strips),
                                                        self.strip_width if strip_width is None else int(strip_width)))
+
+    def image_offsets(self, first=0, count=None):
+        """uint64[count + 1]: absolute position of the first record of images first..first+count in the record arena."""
+        count = len(self) - first if count is None else int(count)
+        offs = np.zeros(count + 1, dtype=np.uint64)
+        capi.check(self._lib.cds_sparse_library_image_offsets(self._h, int(first), count, offs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+        return offs
 
     def image_records(self, index):
         """(records uint32[n], cell offsets uint32[n_strips, H+1]) of one image -- diagnostic."""

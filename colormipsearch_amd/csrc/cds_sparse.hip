@@ -1084,6 +1084,16 @@ int cds_sparse_library_image_records(const cds_sparse_library *sl, int64_t index
     return CDS_OK;
 }
 
+int cds_sparse_library_image_offsets(const cds_sparse_library *sl, int64_t first, int64_t count, uint64_t *offsets) {
+    int rc = sparse_check_range(sl, first, count);
+    if (rc) return rc;
+    if (!offsets) return fail(CDS_ERR_INVALID_ARGUMENT, "offsets is NULL");
+    CDS_HIP(hipSetDevice(sl->ctx->device));
+    CDS_HIP(hipStreamSynchronize(sl->ctx->stream));
+    CDS_HIP(hipMemcpy(offsets, sl->d_img_off + first, (size_t)(count + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return CDS_OK;
+}
+
 int cds_maskset_sparse_layout(const cds_maskset *ms, int32_t mask_index, int32_t *out8) {
     if (!ms || !out8) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (mask_index < 0 || mask_index >= ms->n_masks || (size_t)mask_index >= ms->sp_plans.size()) return fail(CDS_ERR_INVALID_ARGUMENT, "mask_index out of range");

@@ -161,6 +161,9 @@ int cds_sparse_library_clear(cds_sparse_library *slib);
  * its n_strips x (H+1) cell offsets; either output may be NULL; *n_records is always set. */
 int cds_sparse_library_image_records(const cds_sparse_library *slib, int64_t index, uint32_t *records, int64_t capacity,
                                      int64_t *n_records, uint32_t *row_offsets);
+/* Diagnostic: offsets[count+1] = position of the first record of images first..first+count in the library's record
+ * arena (absolute, 64-bit: a 1 M-image library holds > 2^32 records). */
+int cds_sparse_library_image_offsets(const cds_sparse_library *slib, int64_t first, int64_t count, uint64_t *offsets);
 /* Export / import of the record arrays, for persisting a converted library (colormipsearch_amd/mipio.py: sparse shard files).
  * Export images [first, first+count): image_offsets[count+1] (record offsets relative to the first exported image),
  * cell_offsets[count][n_strips][H+1] and the records themselves (any of the last two may be NULL; call once with NULLs to

@@ -28,6 +28,9 @@ int cds_maskset_sparse_layout(const cds_maskset *ms, int32_t mask_index, int32_t
  * filter exact: a code inside [lo, lo + len] always has its band's bit set in cds_debug_band_bits(lo, len). */
 int cds_debug_band_bits(uint32_t lo, uint32_t len, uint32_t *bits);
 int32_t cds_debug_band_of(const float *rcp_table, int32_t cls, int32_t second, int32_t max);
+/* Calibration of the instruction-issue roofline (bench.py): ns one SIMD needs per wave64 integer VALU instruction with 8
+ * waves resident, measured on this device with independent v_add / v_xor chains (tools/valubench/valubench.hip, mode 0). */
+int cds_debug_valu_issue_ns(cds_context *ctx, double *ns_per_wave_instruction_per_simd);
 #ifdef __cplusplus
 }
 #endif

@@ -451,3 +451,46 @@ def test_every_target_colour_against_uniform_masks(cds, oracle):
             counts = alg.searchSparseLibraryCounts(sl)
             want = oracle.PixelMatchQuery(mask, 20, 20, ztol, 2, True, []).score(target)[2]
             assert np.array_equal(counts[0, 0], want), (col, ztol, counts[0, 0].tolist(), list(want))
+
+
+def test_record_arena_beyond_2_pow_32(cds, oracle):
+    """A library whose record arena crosses 2^32 records (8,192 dense-uniform images = 5.6 G records, 22 GB): the 64-bit
+    paths -- img_off, the buffer-descriptor base of the scan, the append kernels' offsets -- are checked on the images stored
+    BEYOND 2^32: every score against the dense-layout kernel, the first and the last images beyond the line (scores and all
+    18 per-transform counts) against the oracle."""
+    rects = cds.label_regions(W)
+    n_stage, reps = 1024, 8
+    n = n_stage * reps
+    mask = oracle.synth_image(0xBADC0DE, 0, 2)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    dense = cds.Library(W, H, n_stage)
+    sl = cds.SparseLibrary(W, H, n, (W * H + 4 * H) * n)
+    for r in range(reps):
+        dense.generate_synthetic(0xC0FFEE, r * n_stage, 0, n_stage, kind=1)
+        sl.append_from(dense, 0, n_stage)
+    assert len(sl) == n and sl.pixels > 2 ** 32
+    offs = sl.image_offsets()
+    assert offs[0] == 0 and int(offs[-1]) == sl.pixels and np.all(np.diff(offs.astype(np.int64)) > 0)
+    first_beyond = int(np.searchsorted(offs[:-1], np.uint64(2 ** 32)))
+    assert 0 < first_beyond < n - n_stage          # more than a window of images lies beyond the line
+    scores, mir = alg.searchSparseLibrary(sl)
+    for r in range(reps):                          # every image, also those beyond 2^32: the dense kernel on regenerated slots
+        dense.generate_synthetic(0xC0FFEE, r * n_stage, 0, n_stage, kind=1)
+        s2, m2 = alg.searchLibrary(dense)
+        assert np.array_equal(s2[0], scores[0, r * n_stage:(r + 1) * n_stage]), r
+        assert np.array_equal(m2[0], mir[0, r * n_stage:(r + 1) * n_stage]), r
+    assert scores.max() > 0
+    q = oracle.PixelMatchQuery(mask, 20, 20, 0.01, 2, True, rects)
+    for lo in (first_beyond, n - 4):               # (the last window is still in `dense`)
+        cnt = alg.searchSparseLibraryCounts(sl, lo, 4)
+        part, pm = alg.searchSparseLibrary(sl, lo, 4)   # a sub-range whose first image starts beyond 2^32
+        for i in range(4):
+            img = oracle.synth_image(0xC0FFEE, lo + i, 1)
+            s, m, c = q.score(img)
+            assert (int(scores[0, lo + i]), bool(mir[0, lo + i])) == (s, m) == (int(part[0, i]), bool(pm[0, i])), lo + i
+            assert np.array_equal(cnt[0, i], c), lo + i
+    # the record stream of an image beyond the line equals its specification
+    img = oracle.synth_image(0xC0FFEE, n - 1, 1)
+    rec, rows = sl.image_records(n - 1)
+    want_rec, want_rows = records_model(img, sl.n_strips, sl.strip_width)
+    assert np.array_equal(rec, want_rec) and np.array_equal(rows, want_rows)

@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of tools/profile_round.sh into (1) a per-LAUNCH-CLASS text summary that by itself reproduces
+the ms per launch and the counters per unit of work, and (2) profiles/scan_pmc.json, which bench.py reads for its roofline
+block (keyed by the SHA-256 of the kernel sources the counters were measured on).
+
+A launch class = the dispatches of one kernel in one profiled command whose work size is known:
+  sparse_scan_headline  `bench.py --no-aux --no-cpu-baseline --verify-windows 3`: the LAST `--steps` dispatches of
+                        cds::sparse_scan_kernel (the timed scans of TARGETS targets; the first `--warmup` ones are dropped)
+  dense_scan            same command: cds::scan_kernel dispatches of STAGE targets (the verification windows)
+  sparse_multi          `bench.py --no-cpu-baseline --verify-windows 3`: cds::sparse_multi_kernel dispatches (aux.mask_batch:
+                        one per mask group over TARGETS targets); per (mask, target) comparison
+  gradscore_list        same command: cds::gradscore_list_kernel dispatches of PAIRS pairs (aux.gradient_scores)
+HBM bytes = 2 x FETCH_SIZE (KB x 1024): on gfx950 FETCH_SIZE reports half the bytes of a streaming read
+(MI355X_MICROARCH.md, HBM / rocprofv3 section).
+"""
+import argparse
+import collections
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCES = ["colormipsearch_amd/csrc/cds_sparse.hip", "colormipsearch_amd/csrc/cds_scan.hip", "colormipsearch_amd/csrc/cds_shape.hip",
+           "colormipsearch_amd/csrc/cds_internal.hpp"]
+
+
+def trace_rows(d):
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    return rows
+
+
+def pmc_rows(dirs):
+    """{counter: [(dispatch order, kernel name, value)]} -- one list per counter, dispatches in launch order."""
+    out = collections.defaultdict(list)
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            per = collections.defaultdict(dict)
+            for r in csv.DictReader(open(f)):
+                per[int(r["Dispatch_Id"])][r["Counter_Name"]] = (r["Kernel_Name"], float(r["Counter_Value"]), int(r["Grid_Size"]))
+            for did in sorted(per):
+                for c, (k, v, g) in per[did].items():
+                    out[c].append((did, k, v, g))
+    return out
+
+
+def pick(seq, name, last=None):
+    sel = [x for x in seq if name in x[1]]
+    return sel[-last:] if last else sel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out_dir", help="gpurun_out/TAG as written by tools/profile_round.sh")
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--targets", type=int, default=1 << 20)
+    ap.add_argument("--stage", type=int, default=8192)
+    ap.add_argument("--pairs", type=int, default=16000)
+    ap.add_argument("--write-json", default=os.path.join(ROOT, "profiles", "scan_pmc.json"))
+    a = ap.parse_args()
+    o = a.out_dir
+    lines = []
+    classes = {}
+
+    def add_class(key, kernel, cmd_tag, unit_name, units_per_dispatch, last=None, desc=""):
+        tr = [(i, r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, int(r["Grid_Size_X"]))
+              for i, r in enumerate(trace_rows(os.path.join(o, "trace_" + cmd_tag)))]
+        sel = pick(tr, kernel, last)
+        if not sel:
+            return
+        ms = [x[2] for x in sel]
+        cls = {"kernel": sel[0][1][:120], "command": cmd_tag, "dispatches": len(sel), unit_name + "_per_dispatch": units_per_dispatch,
+               "mean_ms": sum(ms) / len(ms), "min_ms": min(ms), "max_ms": max(ms), "grid_size_x": sel[0][3], "per_" + unit_name[:-1]: {}}
+        lines.append(f"== class {key}: {desc}")
+        lines.append(f"   kernel {cls['kernel']}")
+        lines.append(f"   rocprofv3 --kernel-trace: {len(sel)} dispatches, grid {sel[0][3]}, mean {cls['mean_ms']:.4f} ms (min {min(ms):.4f}, max {max(ms):.4f}); "
+                     f"{units_per_dispatch} {unit_name} per dispatch -> {units_per_dispatch / cls['mean_ms'] / 1e3:.2f} M {unit_name}/s")
+        pm = pmc_rows(glob.glob(os.path.join(o, "pmc_" + cmd_tag + "_*")))
+        for c in sorted(pm):
+            s = pick(pm[c], kernel, last)
+            if not s:
+                continue
+            mean = sum(x[2] for x in s) / len(s)
+            cls["per_" + unit_name[:-1]][c] = mean / units_per_dispatch
+            lines.append(f"   {c:24s} mean per dispatch {mean:18.1f}  (n={len(s)})   per {unit_name[:-1]} {mean / units_per_dispatch:12.3f}")
+        per = cls["per_" + unit_name[:-1]]
+        if "FETCH_SIZE" in per:
+            per["hbm_bytes"] = 2.0 * per["FETCH_SIZE"] * 1024.0
+            gbs = per["hbm_bytes"] * units_per_dispatch / (cls["mean_ms"] * 1e-3) / 1e9
+            lines.append(f"   HBM traffic = 2 x FETCH_SIZE = {per['hbm_bytes']:.1f} B per {unit_name[:-1]} = {gbs:.0f} GB/s at the traced duration = {gbs / 8000:.3f} of the 8 TB/s peak")
+        classes[key] = cls
+
+    add_class("sparse_scan_headline", "sparse_scan_kernel", "headline", "targets", a.targets, last=a.steps,
+              desc=f"the {a.steps} timed 1-mask scans of the resident library (bench.py `value`)")
+    add_class("dense_scan", "cds::scan_kernel", "headline", "targets", a.stage, desc="the dense-layout kernel over the verification windows")
+    add_class("sparse_multi", "sparse_multi_kernel", "full", "comparisons", None or 1, desc="aux.mask_batch (units filled in below)")
+    add_class("gradscore_list", "gradscore_list_kernel", "full", "pairs", a.pairs, desc="aux.gradient_scores")
+    if "sparse_multi" in classes:   # comparisons per dispatch = masks of the group x targets: not in the trace; report per dispatch
+        classes["sparse_multi"]["note"] = "per-dispatch figures; divide by (masks per group x targets) for per-comparison values"
+    for tagc in ("headline", "full"):
+        for f in glob.glob(os.path.join(o, "trace_" + tagc, "**", "*kernel_stats.csv"), recursive=True):
+            lines.append(f"== rocprofv3 --kernel-trace --stats (kernel_stats.csv), command `{tagc}` -- ALL dispatches of the run, mixed sizes")
+            lines.append(open(f).read().strip())
+    for name in ("bench_headline.json", "bench_full.json"):
+        p = os.path.join(o, name)
+        if os.path.exists(p):
+            lines.append(f"== {name}")
+            lines.append(open(p).read().strip())
+    text = "\n".join(lines) + "\n"
+    open(os.path.join(o, "summary.txt"), "w").write(text)
+    print(text)
+    if a.write_json and "sparse_scan_headline" in classes:
+        j = {"tag": a.tag, "command": "python3 bench.py --no-aux --no-cpu-baseline --verify-windows 3 (class *_headline) / --no-cpu-baseline --verify-windows 3 (others)",
+             "hbm_bytes": "2 x FETCH_SIZE x 1024 (gfx950 correction, MI355X_MICROARCH.md)",
+             "sources": {s: hashlib.sha256(open(os.path.join(ROOT, s), "rb").read()).hexdigest() for s in SOURCES},
+             "classes": classes}
+        json.dump(j, open(a.write_json, "w"), indent=1)
+        print("wrote", a.write_json, file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
