@@ -294,7 +294,7 @@ def main():
                         "wave64 VALU instruction per SIMD measured in this run / (SIMDs x kernel time of this run).  hbm = measured HBM "
                         "traffic (2 x FETCH_SIZE) / kernel time against the 8 TB/s peak.  The HBM-streaming variant of the scan is aux.dense_layout."}
         cls = (pmc or {}).get("classes", {}).get("sparse_scan_headline") if args.kind == 0 else None
-        if cls:
+        if cls and {"SQ_INSTS_VALU", "hbm_bytes"} <= set(cls.get("per_target", {})):
             pt = cls["per_target"]
             valu = pt["SQ_INSTS_VALU"] * n
             roof["achieved"] = valu / (kern_ms * 1e6)             # G wave-instructions / s
@@ -419,6 +419,8 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
     same_d = bool(torch.equal(dsc, scores[:n_d]))
     d_ach = dense_bytes_per_target * n_d / (dms * 1e-3) / 1e9
     dcls = pmc.get("classes", {}).get("dense_scan")
+    if dcls and "hbm_bytes" not in dcls.get("per_target", {}):
+        dcls = None
     aux["dense_layout"] = {"workload": f"1 mask x {n_d} targets resident as packed RGB rows (2,064,768 B each)", "kernel": "cds::scan_kernel<xy2,mirror,single-mask>",
                            "comparisons_per_s": n_d / (dms * 1e-3), "ms_per_pass": dms,
                            "roofline": {"bound": "hbm", "achieved": d_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d_ach / HBM_PEAK_GBS,
@@ -508,6 +510,8 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
                 ok_g &= (int(gap[j]), int(high[j]), bool(gmir[j])) == (og, oh, om)
                 n_checked += 1
     gcls = pmc.get("classes", {}).get("gradscore_list")
+    if gcls and "hbm_bytes" not in gcls.get("per_pair", {}):
+        gcls = None
     g_alg = len(pm) * 2081200 / (gms * 1e-3) / 1e9            # 2,081,200 B per pair at R = 170
     g_traffic = gcls["per_pair"]["hbm_bytes"] * len(pm) if gcls else None
     aux["gradient_scores"] = {"workload": f"GradientAreaGap of the top-{top} hits of {n_gm} masks among {n_d} dense targets with variants "

@@ -30,4 +30,4 @@ if [ -n "$FULL" ]; then
 fi
 cd $R && python3 tools/summarize_profile.py $OUT --tag $TAG --write-json $OUT/scan_pmc.json
 # the big per-dispatch CSVs stay on the box: only the logs, the summary and the JSON travel back
-find $OUT -name '*.csv' -size +2M -delete
+find $OUT -name '*.csv' -size +8M -delete

@@ -50,7 +50,11 @@ def pmc_rows(dirs):
 
 
 def pick(seq, name, last=None):
+    """dispatches of kernel `name` with the class's (= the largest) grid, optionally only the last `last` of them"""
     sel = [x for x in seq if name in x[1]]
+    if sel:
+        g = max(x[3] for x in sel)
+        sel = [x for x in sel if x[3] == g]
     return sel[-last:] if last else sel
 
 
