@@ -591,6 +591,12 @@ class PixelMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
         keys = ("slabs", "slab_rows", "lds_bytes", "box_cols", "box_rows", "interval_records", "plane_cell_bytes", "intervals_in_lds")
         return dict(zip(keys, (int(v) for v in out)))
 
+    def sparseGroups(self):
+        """(groups, groups scanned by the multi-mask kernel, masks in those) -- diagnostic of the multi-mask sparse scan."""
+        a, b, c = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        capi.check(self._lib.cds_maskset_sparse_groups(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
     def lastKernelMs(self):
         ms, n = ctypes.c_double(), ctypes.c_int32()
         capi.check(self._lib.cds_maskset_last_kernel_ms(self._h, ctypes.byref(ms), ctypes.byref(n)))

@@ -187,6 +187,46 @@ struct SparseScanParams {
     int32_t *partial;         // [n_slabs][count][18] per-transform counts of every slab, or NULL
 };
 
+// ---- multi-mask sparse scan: a GROUP of up to kSparseGroupMasks masks shares one pass over the records ----------------------
+// Per group, over the UNION bounding box of its masks: one u8 plane per mask (interval-record index per mask pixel, the
+// single-mask layout), the masks' interval tables (256 x 16 B each, copied to LDS) and ONE transposed band map
+//   tmap[cell row][cell column][32 hue bands] (u8): bit j = mask j of the group accepts, under some xy-shift, a code of
+//   that band at some position of the 4-row x 8-column cell
+// so that stage 1 (record -> row, band, cell) is done once per record and ONE byte per orientation names the masks it
+// can matter to.
+constexpr int kSparseGroupMasks = 8;
+constexpr int kSparseGroupIv = 3072;  // interval records of a group's masks together (48 KB of LDS); groups are cut accordingly
+struct SparseGroupPlan {
+    int first_mask = 0, n_masks = 0;
+    bool ok = false;          // representable (the masks' interval tables fit the LDS table, plane offsets < 2^20)
+    bool plane8 = false;      // every mask has <= 255 interval records: one byte per plane cell, else two
+    int xlo = 0, cols = 0, ylo = 0, nrows = 0, pitch = 0, nwpr = 0;
+    int plane_cells = 0;      // cells of one mask's plane (multiple of 16)
+    int n_iv = 0;             // interval records of the group (the masks' tables back to back)
+    int iv_base[kSparseGroupMasks] = {0, 0, 0, 0, 0, 0, 0, 0};   // first record of mask j's table
+    size_t planes_off = 0, tmap_off = 0, iv_off = 0;   // offsets into cds_maskset::d_sg_planes / d_sg_tmap (bytes) / d_sg_iv (elements)
+    size_t tmap_bytes = 0;
+};
+
+struct SparseMultiParams {
+    const uint32_t *px;
+    const uint64_t *img_off;
+    const uint32_t *rowptr;
+    int64_t first, count;
+    int W, H, nstrips, strip_w;
+    const void *planes;       // [n_masks][plane_cells] u8 or u16
+    const uint8_t *tmap;      // [cell rows][nwpr][32]
+    const uint4 *iv;          // [n_iv]
+    int n_iv, iv_base[kSparseGroupMasks];
+    int n_masks, plane_cells, tmap_bytes;
+    int xlo, cols, ylo, nrows, pitch, nwpr;
+    int thr, group, nparts;
+    uint32_t psize;
+    uint32_t *work;           // [nparts] x 32 dwords, zero before the launch
+    int32_t *out;             // score | mirrored << 31 of mask j, target t at out[j * out_stride + t]
+    int64_t out_stride;
+};
+
 }  // namespace cds
 
 struct cds_sparse_library {
@@ -224,6 +264,9 @@ struct cds_maskset {
     uint8_t *d_sp_slabs = nullptr;
     uint4 *d_sp_iv = nullptr;
     uint32_t *d_sp_work = nullptr;   // work counters of one launch
+    std::vector<cds::SparseGroupPlan> sg_plans;   // multi-mask scan: groups of consecutive masks (empty for a single mask)
+    uint8_t *d_sg_planes = nullptr, *d_sg_tmap = nullptr;
+    uint4 *d_sg_iv = nullptr;
     mutable std::mutex sp_mu;        // one sparse search at a time per mask set (the work counters are shared)
     // cds_score_pair: one resident slot + device scores, created on first use
     mutable std::mutex pair_mu;

@@ -551,6 +551,260 @@ __global__ __launch_bounds__(256) void sparse_finalize_kernel(const int32_t *par
     out[t] = bm > best ? (int32_t)((uint32_t)bm | 0x80000000u) : best;
 }
 
+
+// =================================================================================================
+//                      the multi-mask sparse scan (BASELINE configs[2]: many masks x one library)
+// =================================================================================================
+// The single-mask kernel above spends most of its instructions on work that does not depend on the mask: fetching a
+// record, finding its row (ballot + mbcnt), its hue band, its cell.  Here a GROUP of up to 8 masks shares that work
+// (reference: the masks x target-partitions loop of tools cmd/cdsprocess/LocalColorMIPSearchProcessor.java:82-116):
+//   * stage 1, once per record: row, columns (plain / mirrored), band -> ONE byte per orientation from the group's
+//     transposed band map (global memory, L2-resident: cells x 32 bands, bit j = mask j), i.e. the set of (mask, orientation)
+//     pairs the record can matter to -- 16 bits per record;
+//   * expansion: every set bit becomes an entry (record, plane offset | bit << 20) of the wave's ONE queue (a loop over
+//     "lowest set bit of every lane": as many turns as the busiest lane has bits);
+//   * stage 2, 64 entries at a time, every lane busy, the lanes of a round belonging to DIFFERENT masks: hue code, 9 plane
+//     bytes of the entry's own mask (u8 planes of all masks in global memory / L2: they do not fit LDS together), 9 interval
+//     records from the masks' tables in LDS, 2 range compares each; a match increments the wave's LDS counter of
+//     (mask, transform) -- matches are rare, so the atomics are few;
+//   * end of a target: lane j turns mask j's 18 counters into score | mirrored << 31 and clears them.
+// A group = consecutive masks, at most 8, whose interval tables together hold at most 3,072 records (a synthetic arbor
+// mask has 150-380 distinct colours, the reference's EM masks 105-389).
+// LDS per workgroup: 3,072 interval records (48 KB) + per wave a queue of 128 entries and 8 x 18 counters = 74 KB: two
+// workgroups per CU, 8 waves per SIMD (64 VGPRs) to cover the L2 round trips of the map and plane bytes.
+constexpr int SM_QCAP = 128;
+constexpr int SM_WAVE_BYTES = SM_QCAP * 8 + kSparseGroupMasks * CDS_N_TRANSFORMS * 4;
+constexpr int SM_FIXED_BYTES = kSparseGroupIv * 16 + 64;   // interval records + the masks' table bases
+static size_t multi_lds_bytes(int threads) { return (size_t)SM_FIXED_BYTES + (size_t)(threads / 64) * SM_WAVE_BYTES; }
+
+template <bool XY2, bool MIRROR, bool P8>
+__global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams p) {
+    extern __shared__ uint4 lds4[];
+    constexpr int NS = XY2 ? 9 : 1, NSX = XY2 ? 3 : 1;
+    constexpr int HALO = XY2 ? 2 : 0;
+    constexpr int NB = 4;
+    constexpr int K = kSparseGroupMasks;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // the planes and the map are read through buffer descriptors: a 32-bit offset register per access (the three columns
+    // of a plane row as instruction immediates) instead of a 64-bit address pair -- all nine plane reads of a round fit the
+    // 64-VGPR budget and are in flight together
+    constexpr uint32_t ES = P8 ? 1u : 2u;  // bytes per plane cell
+    const __amdgpu_buffer_rsrc_t planes_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.planes), 0, (int)((uint32_t)p.n_masks * (uint32_t)p.plane_cells * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t tmap_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.tmap), 0, (int)p.tmap_bytes, 0x00020000);
+    uint4 *ivt = lds4;
+    int *ivb = reinterpret_cast<int *>(lds4 + kSparseGroupIv);
+    uint8_t *wb = reinterpret_cast<uint8_t *>(lds4) + SM_FIXED_BYTES + (size_t)wave * SM_WAVE_BYTES;
+    uint2 *q = reinterpret_cast<uint2 *>(wb);
+    int *cnt = reinterpret_cast<int *>(wb + SM_QCAP * 8);
+    for (int i = threadIdx.x; i < p.n_iv; i += blockDim.x) ivt[i] = p.iv[i];
+    if (threadIdx.x < K) ivb[threadIdx.x] = p.iv_base[threadIdx.x];
+    for (int i = lane; i < K * CDS_N_TRANSFORMS; i += 64) cnt[i] = 0;
+    __syncthreads();
+    const uint32_t safe_off = (uint32_t)(SP_PAD * p.pitch + SP_PAD);  // an in-range plane offset for idle lanes
+    const int ra = max(p.ylo - HALO, 0), rb = min(p.ylo + p.nrows + HALO, p.H);  // target rows [ra, rb)
+    const int ry0 = p.ylo - 2;
+    const uint32_t cx0 = (uint32_t)(p.xlo - 2), cm0 = (uint32_t)(p.W - 1) - cx0;
+    const uint32_t wnear = (uint32_t)((p.cols + 4 + 7) & ~7);  // first column of the map's guard cell (always 0): the clamp target
+    const uint32_t pitch = (uint32_t)p.pitch, nwpr = (uint32_t)p.nwpr, poff = (uint32_t)(2 * p.pitch + 2);
+    const uint32_t thr = (uint32_t)p.thr, pcells = (uint32_t)p.plane_cells;
+    int wlo = p.xlo - HALO, whi = p.xlo + p.cols - 1 + HALO;
+    if (MIRROR) {
+        const int mlo = p.W - 1 - whi, mhi = p.W - 1 - wlo;
+        wlo = min(wlo, mlo), whi = max(whi, mhi);
+    }
+    const int ks0 = max(wlo, 0) / p.strip_w, nsv = min(whi, p.W - 1) / p.strip_w - ks0 + 1;
+
+    for (int pi = 0; pi < p.nparts; pi++) {
+        const int part = (int)((blockIdx.x + (unsigned)pi) % (unsigned)p.nparts);
+        const uint32_t pbeg = (uint32_t)part * p.psize, pend = min(pbeg + p.psize, (uint32_t)p.count);
+        if (pbeg >= pend) continue;
+        uint32_t *ctr = p.work + (size_t)part * 32;
+        if (pi > 0 && __builtin_nontemporal_load(ctr) >= pend - pbeg) continue;
+        for (;;) {
+            uint32_t tb = 0;
+            if (lane == 0) tb = atomicAdd(ctr, (uint32_t)p.group);
+            tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
+            if (tb >= pend - pbeg) break;
+            const uint32_t t0 = pbeg + tb;
+            const int ng = (int)min((uint32_t)p.group, pend - t0);
+            const int nruns = ng * nsv;  // (target, visited strip) -> one contiguous record range; lane r holds run r's header
+            uint64_t h_off = 0;
+            uint32_t h_a = 0, h_b = 0;
+            if (lane < nruns) {
+                const int g = lane / nsv, k = ks0 + lane - g * nsv;
+                const int64_t ti = p.first + (int64_t)(t0 + (uint32_t)g);
+                const uint32_t *rp = p.rowptr + ((size_t)ti * p.nstrips + k) * (p.H + 1);
+                h_off = p.img_off[ti];
+                h_a = rp[ra];
+                h_b = rp[rb];
+            }
+            auto header = [&](int r, const uint32_t *&P, uint32_t &a, uint32_t &b) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h_off, r);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h_off >> 32), r);
+                P = p.px + (((uint64_t)hi << 32) | lo);
+                a = (uint32_t)__builtin_amdgcn_readlane((int)h_a, r);
+                b = (uint32_t)__builtin_amdgcn_readlane((int)h_b, r);
+            };
+            auto load_blocks = [&](const uint32_t *P, uint32_t i, uint32_t b, uint32_t (&r)[NB]) {  // (see sparse_scan_kernel)
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(P), 0, (int)(b * 4u), 0x00020000);
+                const uint32_t vo = (i + (uint32_t)lane) * 4u;
+#pragma unroll
+                for (int j = 0; j < NB; j++) r[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(vo + 256u * j), 0, 0);
+            };
+            const uint32_t *P;
+            uint32_t a, b;
+            header(0, P, a, b);
+            uint32_t cur[NB], nxt[NB];
+            load_blocks(P, a, b, cur);
+            int qh = 0, qt = 0;  // queue head / tail (monotonic, wave-uniform)
+            int kin = 0;
+
+            // evaluate up to 64 queued (record, mask, orientation) entries: every lane busy, lanes of different masks
+            auto round = [&]() {
+                const int n = min(qt - qh, 64);
+                __builtin_amdgcn_wave_barrier();
+                const bool valid = lane < n;
+                const uint2 ent = q[(qh + lane) & (SM_QCAP - 1)];
+                const uint32_t r = ent.x;
+                const uint32_t e = valid ? ent.y : safe_off;
+                const uint32_t off = e & 0xFFFFFu, bit = e >> 20, m = bit & 7u, o = bit >> 3;
+                const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
+                uint32_t code = (((r >> kRecClsShift) & 7u) << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
+                code = valid ? code : 0u;  // 0 lies in no interval
+                // plane bytes of the entry's own mask: mask row = target row - dy, mask column = target column - dx
+                const uint4 *ivm = ivt + ivb[m];  // (requested before the plane reads: the asm below is a memory barrier to hipcc)
+                const uint32_t top = (m * pcells + off + (XY2 ? 2u * pitch - 2u : 0u)) * ES;  // byte offset of cell (row + 2, column - 2) of mask m's plane
+                uint32_t idx[NS];
+                if (XY2) {
+                    // The three cells of a plane row (columns -2, 0, +2 around the pixel = 5 consecutive cells) come with ONE
+                    // unaligned load per row -- 12 bytes of u16 cells, 8 bytes of u8 cells -- instead of three narrow ones: a gather
+                    // costs the texture addresser the same whatever its width, and the gathers are this kernel's tightest pipe.
+                    // Issued back to back, then ONE wait (hipcc splits them when it is short of registers).
+                    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const uint32_t r0 = top, r1 = top - 2u * pitch * ES, r2 = top - 4u * pitch * ES;
+                    if (P8) {
+                        u32x2 d0, d1, d2;
+                        asm volatile("buffer_load_dwordx2 %0, %3, %6, 0 offen\n\tbuffer_load_dwordx2 %1, %4, %6, 0 offen\n\t"
+                                     "buffer_load_dwordx2 %2, %5, %6, 0 offen\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(d0), "=&v"(d1), "=&v"(d2) : "v"(r0), "v"(r1), "v"(r2), "s"(planes_rs) : "memory");
+                        idx[0] = d0.y & 255u, idx[3] = (d0.x >> 16) & 255u, idx[6] = d0.x & 255u;   // idx[ix * 3 + iy]: column +4 - 2 ix, row iy
+                        idx[1] = d1.y & 255u, idx[4] = (d1.x >> 16) & 255u, idx[7] = d1.x & 255u;
+                        idx[2] = d2.y & 255u, idx[5] = (d2.x >> 16) & 255u, idx[8] = d2.x & 255u;
+                    } else {
+                        u32x3 d0, d1, d2;
+                        asm volatile("buffer_load_dwordx3 %0, %3, %6, 0 offen\n\tbuffer_load_dwordx3 %1, %4, %6, 0 offen\n\t"
+                                     "buffer_load_dwordx3 %2, %5, %6, 0 offen\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(d0), "=&v"(d1), "=&v"(d2) : "v"(r0), "v"(r1), "v"(r2), "s"(planes_rs) : "memory");
+                        idx[0] = d0.z & 0xFFFFu, idx[3] = d0.y & 0xFFFFu, idx[6] = d0.x & 0xFFFFu;
+                        idx[1] = d1.z & 0xFFFFu, idx[4] = d1.y & 0xFFFFu, idx[7] = d1.x & 0xFFFFu;
+                        idx[2] = d2.z & 0xFFFFu, idx[5] = d2.y & 0xFFFFu, idx[8] = d2.x & 0xFFFFu;
+                    }
+                } else {
+                    idx[0] = P8 ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(planes_rs, (int)top, 0, 0)
+                                : (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(planes_rs, (int)top, 0, 0);
+                }
+                int *cm = cnt + m * CDS_N_TRANSFORMS + o * 9u;
+                // compares first (interval records three at a time), the rare counter updates afterwards: an LDS atomic between
+                // the reads would pin their order and make every read a round trip of its own
+                bool hit[NS];
+#pragma unroll
+                for (int k0 = 0; k0 < NS; k0 += 3) {
+                    uint4 iv[3];
+#pragma unroll
+                    for (int k = 0; k < 3 && k0 + k < NS; k++) iv[k] = ivm[idx[k0 + k]];
+#pragma unroll
+                    for (int k = 0; k < 3 && k0 + k < NS; k++) hit[k0 + k] = ((code - iv[k].x) <= iv[k].y) | ((code - iv[k].z) <= iv[k].w);
+                }
+#pragma unroll
+                for (int k = 0; k < NS; k++)
+                    if (hit[k]) atomicAdd(&cm[k], 1);
+                qh += n;
+            };
+
+            for (int r = 0; r < nruns; r++) {  // wave-uniform
+                int yrel = ra - 1 - ry0;  // (rows started before the current block) - 1, relative to the map's first row
+                for (uint32_t i = a; i < b; i += 64 * NB) {  // wave-uniform
+                    const uint32_t rem = b - i;
+                    {   // the next NB blocks -- of this run or the first of the grab's next run -- are in flight meanwhile
+                        const uint32_t *Pq = P;
+                        uint32_t iq = i, bq = b;
+                        if (rem > 64 * NB) iq = i + 64 * NB;
+                        else if (r + 1 < nruns) header(r + 1, Pq, iq, bq);
+                        load_blocks(Pq, iq, bq, nxt);
+                    }
+                    // stage 1 of block j + 1 (row, columns, band, the two map bytes: an L2 round trip) is issued before block j's
+                    // set bits are expanded into queue entries
+                    uint32_t s_rec, s_prow, s_cxp, s_cxm, s_w;
+                    auto stage1 = [&](int j) {
+                        const uint32_t rec = cur[j];  // (lanes beyond the run were loaded as 0: no flag, below every threshold)
+                        const unsigned long long fb = __ballot((int)rec < 0);
+                        const uint32_t ry = (uint32_t)(yrel + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0))) + (rec >> 31);
+                        yrel += __popcll(fb);
+                        const uint32_t x = (rec >> kRecXShift) & 2047u;
+                        const uint32_t cxp = min(x - cx0, wnear);
+                        const uint32_t cxm = MIRROR ? min(cm0 - x, wnear) : 0u;
+                        const float hf = (float)((rec >> 8) & 255u) * __builtin_amdgcn_rcpf((float)(rec & 255u));
+                        uint32_t band = (__umul24((rec >> kRecClsShift) & 7u, 5u) + (uint32_t)(hf * 5.0f)) & 31u;
+                        band = (rec & 255u) > thr ? band : 3u;  // below the threshold: band 3, which no mask accepts
+                        const uint32_t rowc = __umul24(ry >> 2, nwpr);
+                        uint32_t w = __builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)(((rowc + (cxp >> 3)) << 5) + band), 0, 0);
+                        if (MIRROR) w |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)(((rowc + (cxm >> 3)) << 5) + band), 0, 0) << 8;
+                        s_rec = rec, s_cxp = cxp, s_cxm = cxm, s_w = w;
+                        s_prow = __umul24(ry, pitch) + poff;  // plane offset of column cx0 in the record's row
+                    };
+                    stage1(0);
+#pragma unroll
+                    for (int j = 0; j < NB; j++) {
+                        const uint32_t rec = s_rec, prow = s_prow, cxp = s_cxp, cxm = s_cxm;
+                        uint32_t w = s_w;
+                        const bool more = j + 1 < NB && rem > 64u * (j + 1);  // wave-uniform
+                        if (more) stage1(j + 1);
+                        unsigned long long bal = __ballot(w != 0);
+                        while (bal) {  // one turn per set bit of the busiest lane
+                            if (w != 0) {
+                                const uint32_t bit = (uint32_t)__builtin_ctz(w);
+                                const int slot = (qt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0))) & (SM_QCAP - 1);
+                                q[slot] = make_uint2(rec, (prow + (bit >= 8u ? cxm : cxp)) | (bit << 20));
+                                w &= w - 1u;
+                            }
+                            qt += __popcll(bal);
+                            if (qt - qh >= 64) round();
+                            bal = __ballot(w != 0);
+                        }
+                        if (!more) break;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NB; j++) cur[j] = nxt[j];
+                }
+                if (r + 1 < nruns) header(r + 1, P, a, b);
+                if (++kin < nsv) continue;  // more strips of this target
+                kin = 0;
+                const uint32_t t = t0 + (uint32_t)(r / nsv);
+                while (qt > qh) round();
+                __builtin_amdgcn_wave_barrier();
+                if (lane < p.n_masks) {
+                    const int *cl = cnt + lane * CDS_N_TRANSFORMS;
+                    int best = 0, bm = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) {
+                        best = max(best, cl[k]);
+                        bm = max(bm, cl[9 + k]);
+                    }
+                    int32_t packed = best;
+                    if (MIRROR && bm > best) packed = (int32_t)((uint32_t)bm | 0x80000000u);
+                    p.out[(int64_t)lane * p.out_stride + t] = packed;
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < K * CDS_N_TRANSFORMS; i += 64) cnt[i] = 0;
+                __builtin_amdgcn_wave_barrier();
+                qh = qt = 0;
+            }
+        }
+    }
+}
+
 // =================================================================================================
 //                                   host: mask plans
 // =================================================================================================
@@ -589,6 +843,12 @@ void free_sparse_plans(cds_maskset *ms) {
     if (ms->d_sp_slabs) hipFree(ms->d_sp_slabs);
     if (ms->d_sp_iv) hipFree(ms->d_sp_iv);
     if (ms->d_sp_work) hipFree(ms->d_sp_work);
+    if (ms->d_sg_planes) hipFree(ms->d_sg_planes);
+    if (ms->d_sg_tmap) hipFree(ms->d_sg_tmap);
+    if (ms->d_sg_iv) hipFree(ms->d_sg_iv);
+    ms->d_sg_planes = ms->d_sg_tmap = nullptr;
+    ms->d_sg_iv = nullptr;
+    ms->sg_plans.clear();
     ms->d_sp_slabs = nullptr;
     ms->d_sp_iv = nullptr;
     ms->d_sp_work = nullptr;
@@ -602,6 +862,160 @@ static int sparse_threads() {
     return t;
 }
 
+
+// distinct interval records of a mask (index 0 = the empty record) and, per mask pixel, the index of its record;
+// false when the mask has more than `limit` - 1 distinct records
+struct IvKey {
+    uint32_t a, b, c, d;
+    bool operator==(const IvKey &o) const { return a == o.a && b == o.b && c == o.c && d == o.d; }
+};
+struct IvKeyHash {
+    size_t operator()(const IvKey &k) const {
+        uint64_t h = (uint64_t)k.a * 0x9E3779B97F4A7C15ull ^ ((uint64_t)k.b << 32 | k.c) * 0xC2B2AE3D27D4EB4Full ^ k.d;
+        return (size_t)(h ^ (h >> 29));
+    }
+};
+static bool mask_dictionary(const std::vector<MaskPx> &L, size_t limit, std::vector<uint4> &tab, std::vector<uint16_t> &pidx) {
+    std::unordered_map<IvKey, uint32_t, IvKeyHash> dict;
+    tab.clear();
+    tab.push_back(make_uint4(1u, 0u, 1u, 0u));
+    pidx.resize(L.size());
+    for (size_t i = 0; i < L.size(); i++) {
+        const IvKey k{L[i].lo1, L[i].len1, L[i].lo2, L[i].len2};
+        auto it = dict.find(k);
+        if (it == dict.end()) {
+            if (tab.size() >= limit) return false;
+            it = dict.emplace(k, (uint32_t)tab.size()).first;
+            tab.push_back(make_uint4(k.a, k.b, k.c, k.d));
+        }
+        pidx[i] = (uint16_t)it->second;
+    }
+    return true;
+}
+
+// Plans of the multi-mask scan: groups of kSparseGroupMasks consecutive masks over the union of their bounding boxes.
+static int build_group_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &per_mask) {
+    const size_t n_masks = per_mask.size();
+    if (n_masks < 2 || !SP_BAND || getenv("CDS_SPARSE_NO_GROUPS")) return CDS_OK;
+#if SP_BAND
+    const bool xy2 = ms->params.xy_shift == 2;
+    constexpr int K = kSparseGroupMasks;
+    // consecutive masks, at most K, whose interval tables fit the LDS table together (sp_plans[m].n_iv = records of mask m,
+    // the empty record included; a mask without device pixels has none and joins any group)
+    for (size_t m = 0; m < n_masks;) {
+        SparseGroupPlan gp;
+        gp.first_mask = (int)m;
+        int sum = 0;
+        while (m < n_masks && gp.n_masks < K) {
+            const int niv = std::max(1, ms->sp_plans[m].n_iv);
+            if (gp.n_masks > 0 && sum + niv > kSparseGroupIv) break;
+            sum += niv;
+            gp.n_masks++;
+            m++;
+        }
+        ms->sg_plans.push_back(gp);
+    }
+    const size_t n_groups = ms->sg_plans.size();
+    std::vector<std::vector<uint8_t>> planes_of(n_groups), tmap_of(n_groups);
+    std::vector<std::vector<uint4>> iv_of(n_groups);
+    auto plan_group = [&](size_t g) {
+        SparseGroupPlan &gp = ms->sg_plans[g];
+        const size_t m0 = (size_t)gp.first_mask;
+        int xlo = ms->W, xhi = -1, ylo = ms->H, yhi = -1;
+        for (int j = 0; j < gp.n_masks; j++) {
+            if (ms->sp_plans[m0 + j].n_slabs < 0) return;  // (a mask the single-mask scan cannot lay out either)
+            for (const MaskPx &q : per_mask[m0 + j]) {
+                xlo = std::min(xlo, q.x), xhi = std::max(xhi, q.x);
+                ylo = std::min(ylo, q.y), yhi = std::max(yhi, q.y);
+            }
+        }
+        if (xhi < 0) return;  // no mask of the group can match anything: the per-mask path writes the zeros
+        gp.xlo = xlo, gp.cols = xhi - xlo + 1, gp.ylo = ylo, gp.nrows = yhi - ylo + 1;
+        const int G = round_up(gp.cols + 4, 8);  // (the single-mask geometry: guard cell at column G, plane wide enough for its reads)
+        gp.pitch = round_up(G + 4, 8);
+        gp.nwpr = G / 8 + 1;
+        if ((size_t)(gp.nrows + 2 * SP_PAD) * gp.pitch >= ((size_t)1 << 20)) return;  // plane offsets travel in 20 bits
+        gp.plane_cells = round_up((gp.nrows + 2 * SP_PAD) * gp.pitch, 16);
+        gp.tmap_bytes = (size_t)((gp.nrows + 4 + 3) / 4) * gp.nwpr * 32;
+        gp.plane8 = true;
+        for (int j = 0; j < gp.n_masks; j++) gp.plane8 = gp.plane8 && ms->sp_plans[m0 + j].n_iv <= 256;
+        const int esize = gp.plane8 ? 1 : 2;
+        std::vector<uint8_t> &planes = planes_of[g], &tmap = tmap_of[g];
+        std::vector<uint4> &ivs = iv_of[g];
+        planes.assign((size_t)gp.n_masks * gp.plane_cells * esize, 0);
+        tmap.assign(round_up((int)gp.tmap_bytes, 16), 0);
+        ivs.clear();
+        std::vector<uint4> tab;
+        std::vector<uint16_t> pidx;
+        std::vector<uint32_t> tab_bits;
+        for (int j = 0; j < gp.n_masks; j++) {
+            const std::vector<MaskPx> &L = per_mask[m0 + j];
+            if (!mask_dictionary(L, kSparseGroupIv + 1, tab, pidx) || ivs.size() + tab.size() > (size_t)kSparseGroupIv) {
+                planes.clear(), tmap.clear(), ivs.clear();
+                return;  // (a single mask with more records than the LDS table holds: scanned by the single-mask kernel)
+            }
+            gp.iv_base[j] = (int)ivs.size();
+            ivs.insert(ivs.end(), tab.begin(), tab.end());
+            tab_bits.resize(tab.size());
+            for (size_t k = 0; k < tab.size(); k++) tab_bits[k] = band_bits_of(tab[k].x, tab[k].y) | band_bits_of(tab[k].z, tab[k].w);
+            uint8_t *plane = planes.data() + (size_t)j * gp.plane_cells * esize;
+            uint16_t *plane16 = reinterpret_cast<uint16_t *>(plane);
+            for (size_t i = 0; i < L.size(); i++) {
+                const int rr = L[i].y - ylo, cc = L[i].x - xlo;
+                const size_t pc = (size_t)(rr + SP_PAD) * gp.pitch + cc + SP_PAD;
+                if (gp.plane8) plane[pc] = (uint8_t)pidx[i];
+                else plane16[pc] = pidx[i];
+                for (int dy = xy2 ? -2 : 0; dy <= (xy2 ? 2 : 0); dy += 2)
+                    for (int dx = xy2 ? -2 : 0; dx <= (xy2 ? 2 : 0); dx += 2) {
+                        const int ry = rr + 2 + dy, cx = cc + 2 + dx;  // map origin = (xlo - 2, ylo - 2)
+                        uint8_t *cell = tmap.data() + ((size_t)(ry >> 2) * gp.nwpr + (cx >> 3)) * 32;
+                        for (uint32_t bits = tab_bits[pidx[i]]; bits; bits &= bits - 1) cell[__builtin_ctz(bits)] |= (uint8_t)(1u << j);
+                    }
+            }
+        }
+        gp.n_iv = (int)ivs.size();
+        gp.ok = true;
+    };
+    {
+        const unsigned hc = std::thread::hardware_concurrency();
+        const int n_threads = std::max(1, std::min<int>((int)n_groups, (int)std::min<unsigned>(hc ? hc : 1u, 16u)));
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t g = next.fetch_add(1); g < n_groups; g = next.fetch_add(1)) plan_group(g);
+        };
+        std::vector<std::thread> pool;
+        for (int i = 1; i < n_threads; i++) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+    }
+    size_t planes_total = 0, tmap_total = 0, iv_total = 0;
+    for (size_t g = 0; g < n_groups; g++) {
+        SparseGroupPlan &gp = ms->sg_plans[g];
+        if (!gp.ok) continue;
+        gp.planes_off = planes_total, gp.tmap_off = tmap_total, gp.iv_off = iv_total;
+        planes_total += planes_of[g].size();
+        tmap_total += tmap_of[g].size();
+        iv_total += iv_of[g].size();
+    }
+    if (planes_total == 0) {
+        ms->sg_plans.clear();
+        return CDS_OK;
+    }
+    hipError_t e = hipMalloc(&ms->d_sg_planes, planes_total);
+    if (e == hipSuccess) e = hipMalloc(&ms->d_sg_tmap, tmap_total);
+    if (e == hipSuccess) e = hipMalloc(&ms->d_sg_iv, iv_total * sizeof(uint4));
+    for (size_t g = 0; g < n_groups && e == hipSuccess; g++) {
+        const SparseGroupPlan &gp = ms->sg_plans[g];
+        if (!gp.ok) continue;
+        e = hipMemcpy(ms->d_sg_planes + gp.planes_off, planes_of[g].data(), planes_of[g].size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ms->d_sg_tmap + gp.tmap_off, tmap_of[g].data(), tmap_of[g].size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ms->d_sg_iv + gp.iv_off, iv_of[g].data(), iv_of[g].size() * sizeof(uint4), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) return hip_fail(e, "sparse group plans");
+#endif
+    return CDS_OK;
+}
+
 int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &per_mask) {
     cds_context *ctx = ms->ctx;
     const bool xy2 = ms->params.xy_shift == 2;
@@ -613,16 +1027,6 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
     ms->sp_plans.assign(n_masks, SparseMaskPlan());
     std::vector<std::vector<uint8_t>> slab_of(n_masks);
     std::vector<std::vector<uint4>> iv_of(n_masks);
-    struct Key {
-        uint32_t a, b, c, d;
-        bool operator==(const Key &o) const { return a == o.a && b == o.b && c == o.c && d == o.d; }
-    };
-    struct KeyHash {
-        size_t operator()(const Key &k) const {
-            uint64_t h = (uint64_t)k.a * 0x9E3779B97F4A7C15ull ^ ((uint64_t)k.b << 32 | k.c) * 0xC2B2AE3D27D4EB4Full ^ k.d;
-            return (size_t)(h ^ (h >> 29));
-        }
-    };
     auto plan_one = [&](size_t m) {
         const std::vector<MaskPx> &L = per_mask[m];
         SparseMaskPlan &pl = ms->sp_plans[m];
@@ -644,23 +1048,12 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
         pl.nwpr = (pl.cols + 4 + 1 + 31) / 32;  // + the guard bit behind the last column
 #endif
         // distinct interval records of this mask; index 0 = the empty record
-        std::unordered_map<Key, uint32_t, KeyHash> dict;
         std::vector<uint4> &tab = iv_of[m];
-        tab.push_back(make_uint4(1u, 0u, 1u, 0u));
-        std::vector<uint16_t> pidx(L.size());
-        for (size_t i = 0; i < L.size(); i++) {
-            const Key k{L[i].lo1, L[i].len1, L[i].lo2, L[i].len2};
-            auto it = dict.find(k);
-            if (it == dict.end()) {
-                if (tab.size() >= 65535) {
-                    pl.n_slabs = -1;  // (a mask with more than 65,534 distinct interval records: use the dense scan)
-                    tab.clear();
-                    return;
-                }
-                it = dict.emplace(k, (uint32_t)tab.size()).first;
-                tab.push_back(make_uint4(k.a, k.b, k.c, k.d));
-            }
-            pidx[i] = (uint16_t)it->second;
+        std::vector<uint16_t> pidx;
+        if (!mask_dictionary(L, 65535, tab, pidx)) {
+            pl.n_slabs = -1;  // (a mask with more than 65,534 distinct interval records: use the dense scan)
+            tab.clear();
+            return;
         }
         pl.n_iv = (int)tab.size();
         pl.iv_in_lds = pl.n_iv <= SP_MAX_IV_LDS;
@@ -766,6 +1159,13 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
         free_sparse_plans(ms);
         return hip_fail(e, "sparse mask plans");
     }
+    if (slab_total > 0) {
+        const int rc = build_group_plans(ms, per_mask);
+        if (rc) {
+            free_sparse_plans(ms);
+            return rc;
+        }
+    }
     return CDS_OK;
 }
 
@@ -793,6 +1193,25 @@ static int launch_sparse(cds_context *ctx, const SparseScanParams &p, size_t lds
                          hipStream_t st) {
     if (xy2) return mirror ? launch_sparse_one<true, true>(ctx, p, lds_bytes, threads, st) : launch_sparse_one<true, false>(ctx, p, lds_bytes, threads, st);
     return mirror ? launch_sparse_one<false, true>(ctx, p, lds_bytes, threads, st) : launch_sparse_one<false, false>(ctx, p, lds_bytes, threads, st);
+}
+
+
+static int launch_sparse_multi(cds_context *ctx, const SparseMultiParams &p, int threads, bool xy2, bool mirror, bool plane8, hipStream_t st) {
+    auto kern = plane8 ? (xy2 ? (mirror ? sparse_multi_kernel<true, true, true> : sparse_multi_kernel<true, false, true>)
+                              : (mirror ? sparse_multi_kernel<false, true, true> : sparse_multi_kernel<false, false, true>))
+                       : (xy2 ? (mirror ? sparse_multi_kernel<true, true, false> : sparse_multi_kernel<true, false, false>)
+                              : (mirror ? sparse_multi_kernel<false, true, false> : sparse_multi_kernel<false, false, false>));
+    const size_t lds_bytes = multi_lds_bytes(threads);
+    CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int per_cu = (int)std::min<size_t>((size_t)(2048 / threads), ctx->lds_per_block / lds_bytes);
+    per_cu = std::max(1, per_cu);
+    if (const char *e = getenv("CDS_SPARSE_WGS_PER_CU")) per_cu = std::max(1, atoi(e));
+    const int64_t waves = threads / 64;
+    const int64_t need = (p.count + (int64_t)p.group * waves - 1) / ((int64_t)p.group * waves);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cus * per_cu, need));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, st, p);
+    CDS_HIP(hipGetLastError());
+    return CDS_OK;
 }
 
 static int sparse_check_range(const cds_sparse_library *sl, int64_t first, int64_t count) {
@@ -855,14 +1274,14 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
         SP_HIP(hipEventRecord(ev0, st));
     }
     int launches = 0;
-    for (int m = 0; m < ms->n_masks; m++) {
+    auto scan_one_mask = [&](int m) -> int {
         const SparseMaskPlan &pl = ms->sp_plans[(size_t)m];
         int32_t *out = d_scores + (size_t)m * count;
         int32_t *cnt = d_counts ? d_counts + (size_t)m * count * CDS_N_TRANSFORMS : nullptr;
         if (pl.n_slabs == 0) {  // no mask pixel can ever match
             SP_HIP(hipMemsetAsync(out, 0, (size_t)count * sizeof(int32_t), st));
             if (cnt) SP_HIP(hipMemsetAsync(cnt, 0, (size_t)count * CDS_N_TRANSFORMS * sizeof(int32_t), st));
-            continue;
+            return CDS_OK;
         }
         SparseScanParams p{};
         p.px = sl->d_px; p.img_off = sl->d_img_off; p.rowptr = sl->d_rowptr;
@@ -882,16 +1301,61 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
         const bool use_partial = cnt != nullptr || pl.n_slabs > 1;
         p.partial = use_partial ? partial : nullptr;
         SP_HIP(hipMemsetAsync(ms->d_sp_work, 0, (size_t)pl.n_slabs * nparts * 32 * sizeof(uint32_t), st));
-        rc = launch_sparse(ctx, p, pl.lds_bytes, threads, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
-        if (rc) {
+        const int lrc = launch_sparse(ctx, p, pl.lds_bytes, threads, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
+        if (lrc) {
             cleanup();
-            return rc;
+            return lrc;
         }
         if (use_partial) {
             hipLaunchKernelGGL(sparse_finalize_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, partial, pl.n_slabs, count, out, cnt);
             SP_HIP(hipGetLastError());
         }
         launches++;
+        return CDS_OK;
+    };
+    // groups of masks share one pass (sparse_multi_kernel) when the set was laid out for it and only scores are wanted
+    const char *multi_env = getenv("CDS_SPARSE_MULTI");
+    const bool use_multi = !d_counts && !ms->sg_plans.empty() && threads == 1024 && !(multi_env && atoi(multi_env) == 0);
+    if (!use_multi) {
+        for (int m = 0; m < ms->n_masks; m++) {
+            rc = scan_one_mask(m);
+            if (rc) return rc;
+        }
+    } else {
+        for (const SparseGroupPlan &gp : ms->sg_plans) {
+            if (!gp.ok) {
+                for (int m = gp.first_mask; m < gp.first_mask + gp.n_masks; m++) {
+                    rc = scan_one_mask(m);
+                    if (rc) return rc;
+                }
+                continue;
+            }
+            SparseMultiParams p{};
+            p.px = sl->d_px; p.img_off = sl->d_img_off; p.rowptr = sl->d_rowptr;
+            p.first = first; p.count = count; p.W = sl->W; p.H = sl->H;
+            p.nstrips = sl->nstrips; p.strip_w = sl->strip_w;
+            p.planes = ms->d_sg_planes + gp.planes_off;
+            p.tmap = ms->d_sg_tmap + gp.tmap_off;
+            p.tmap_bytes = (int)gp.tmap_bytes;
+            p.iv = ms->d_sg_iv + gp.iv_off;
+            p.n_masks = gp.n_masks; p.plane_cells = gp.plane_cells;
+            p.n_iv = gp.n_iv;
+            for (int j = 0; j < kSparseGroupMasks; j++) p.iv_base[j] = gp.iv_base[j];
+            p.xlo = gp.xlo; p.cols = gp.cols; p.ylo = gp.ylo; p.nrows = gp.nrows; p.pitch = gp.pitch; p.nwpr = gp.nwpr;
+            p.thr = std::max(0, ms->params.data_threshold);
+            p.group = group; p.nparts = nparts;
+            p.psize = (uint32_t)((count + nparts - 1) / nparts);
+            p.work = ms->d_sp_work;
+            p.out = d_scores + (size_t)gp.first_mask * count;
+            p.out_stride = count;
+            SP_HIP(hipMemsetAsync(ms->d_sp_work, 0, (size_t)nparts * 32 * sizeof(uint32_t), st));
+            rc = launch_sparse_multi(ctx, p, threads, ms->params.xy_shift == 2, ms->params.mirror != 0, gp.plane8, st);
+            if (rc) {
+                cleanup();
+                return rc;
+            }
+            launches++;
+        }
     }
     if (timed) {
         SP_HIP(hipEventRecord(ev1, st));
@@ -1091,6 +1555,19 @@ int cds_sparse_library_image_offsets(const cds_sparse_library *sl, int64_t first
     CDS_HIP(hipSetDevice(sl->ctx->device));
     CDS_HIP(hipStreamSynchronize(sl->ctx->stream));
     CDS_HIP(hipMemcpy(offsets, sl->d_img_off + first, (size_t)(count + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return CDS_OK;
+}
+
+int cds_maskset_sparse_groups(const cds_maskset *ms, int32_t *n_groups, int32_t *n_multi_groups, int32_t *n_multi_masks) {
+    if (!ms) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    int g = 0, gm = 0, mm = 0;
+    for (const SparseGroupPlan &gp : ms->sg_plans) {
+        g++;
+        if (gp.ok) gm++, mm += gp.n_masks;
+    }
+    if (n_groups) *n_groups = g;
+    if (n_multi_groups) *n_multi_groups = gm;
+    if (n_multi_masks) *n_multi_masks = mm;
     return CDS_OK;
 }
 

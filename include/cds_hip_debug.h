@@ -22,6 +22,9 @@ int cds_debug_device_rcp(const cds_context *ctx, float *out256);
  * mask rows per slab, LDS bytes of one workgroup, bounding-box columns, bounding-box rows, interval records + 1,
  * bytes per plane cell, interval table in LDS }. */
 int cds_maskset_sparse_layout(const cds_maskset *ms, int32_t mask_index, int32_t *out8);
+/* How the masks of a set were grouped for the multi-mask sparse scan: groups of consecutive masks, how many of them are
+ * scanned by sparse_multi_kernel (the others fall back to one launch per mask) and how many masks those hold. */
+int cds_maskset_sparse_groups(const cds_maskset *ms, int32_t *n_groups, int32_t *n_multi_groups, int32_t *n_multi_masks);
 /* Stage 1 of the sparse scan tests one bit of a per-cell word: bit cds_debug_band_of(class 1..6, second, max) of the pixel
  * (its hue band, (class * 5 + floor(5 * ratio)) mod 32 with the ratio as the device computes it) against the union of
  * cds_debug_band_bits(lo, len) over the intervals of the mask pixels that can reach the cell.  The property that makes the

@@ -494,3 +494,69 @@ def test_record_arena_beyond_2_pow_32(cds, oracle):
     rec, rows = sl.image_records(n - 1)
     want_rec, want_rows = records_model(img, sl.n_strips, sl.strip_width)
     assert np.array_equal(rec, want_rec) and np.array_equal(rows, want_rows)
+
+
+# ---- the multi-mask scan (groups of 8 masks share one pass over the records) ---------------------------------------
+def test_multi_mask_groups_equal_single_mask_scans_and_oracle(cds, oracle, fixtures, monkeypatch):
+    """19 masks = two full groups and one of 3: synthetic arbors, an EM fixture with few colours, a mask elsewhere in the
+    frame (the group's union box grows), a mask touching the borders, an empty mask and a mask of one pixel.  Targets:
+    synthetic ones, copies / mirror images / shifts of masks (full matches), a real LM image.  The scores of the multi-mask
+    kernel == those of one launch per mask (CDS_SPARSE_MULTI=0) == the oracle's, for three parameter sets."""
+    rects = cds.label_regions(W)
+    lut = oracle.depth_lut()
+    rng = np.random.default_rng(21)
+    masks = [oracle.synth_image(0xBADC0DE, i, 2) for i in range(13)]
+    masks.append(fixtures["em_12191"])
+    far = np.zeros((H, W, 3), dtype=np.uint8)
+    far[400:520, 20:140] = lut[rng.integers(0, 256, size=(120, 120))]
+    masks.append(far)
+    border = np.zeros((H, W, 3), dtype=np.uint8)
+    border[:, :3] = lut[7]; border[:, W - 3:] = lut[200]; border[:2, :] = lut[90]; border[H - 2:, :] = lut[150]
+    masks.append(border)
+    masks.append(np.zeros((H, W, 3), dtype=np.uint8))
+    one = np.zeros((H, W, 3), dtype=np.uint8)
+    one[300, 600] = lut[128]
+    masks.append(one)
+    masks.append(fixtures["em_LPLC2"])
+    masks = np.stack(masks)
+    targets = np.stack([oracle.synth_image(0xC0FFEE, 500 + i, 0) for i in range(10)] +
+                       [masks[1], np.fliplr(masks[2]), np.roll(masks[3], 2, axis=1), far, np.fliplr(border), border, one,
+                        fixtures["lm_VT016795"], oracle.synth_image(0xC0FFEE, 5, 1)])
+    sl = sparse_of(cds, targets)
+    for (mthr, dthr, ztol, xy, mirror) in ((20, 20, 0.01, 2, True), (20, 30, 0.02, 0, True), (50, 20, 0.01, 2, False)):
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, mthr, mirror, None, 0, False, dthr, ztol, xy, rects)
+        monkeypatch.delenv("CDS_SPARSE_MULTI", raising=False)
+        groups, multi_groups, multi_masks = alg.sparseGroups()
+        assert multi_groups >= 2 and multi_masks >= 16, (groups, multi_groups, multi_masks)   # (the kernel under test really runs)
+        s_multi, m_multi = alg.searchSparseLibrary(sl)
+        monkeypatch.setenv("CDS_SPARSE_MULTI", "0")
+        s_one, m_one = alg.searchSparseLibrary(sl)
+        monkeypatch.delenv("CDS_SPARSE_MULTI", raising=False)
+        assert np.array_equal(s_multi, s_one) and np.array_equal(m_multi, m_one), (mthr, dthr, ztol, xy, mirror, np.argwhere(s_multi != s_one)[:5])
+        for m in range(len(masks)):
+            q = oracle.PixelMatchQuery(masks[m], mthr, dthr, ztol, xy, mirror, rects)
+            ws, wm = q.scan(targets, n_threads=8)
+            assert np.array_equal(s_multi[m], ws), (m, mthr, dthr, ztol, xy, mirror)
+            assert np.array_equal(m_multi[m], wm.astype(bool)), m
+        part, pm = alg.searchSparseLibrary(sl, 9, 7)           # a sub-range
+        assert np.array_equal(part, s_multi[:, 9:16]) and np.array_equal(pm, m_multi[:, 9:16])
+    assert s_multi[1, 10] > 0 and s_multi[14, 13] > 0 and s_multi[16].max() == 0
+
+
+def test_multi_mask_large_library_equals_dense_batch(cds, oracle):
+    """16 masks x 4,096 synthetic targets: multi-mask sparse scan == the dense batch kernel == per-mask sparse launches."""
+    rects = cds.label_regions(W)
+    n_m, n_t = 16, 4096
+    mlib = cds.Library(W, H, n_m)
+    mlib.generate_synthetic(0xBADC0DE, 0, 0, n_m, kind=2)
+    masks = mlib.download(0, n_m)
+    dense = cds.Library(W, H, n_t)
+    dense.generate_synthetic(0xC0FFEE, 70000, 0, n_t, kind=0)
+    sl = cds.SparseLibrary(W, H, n_t, 24000 * n_t + 4 * H * n_t)
+    sl.append_from(dense)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    assert alg.sparseGroups()[2] == n_m
+    s1, m1 = alg.searchSparseLibrary(sl)
+    s2, m2 = alg.searchLibrary(dense)
+    assert np.array_equal(s1, s2) and np.array_equal(m1, m2)
+    assert (s1 > 0).sum() > 100

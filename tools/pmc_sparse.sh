@@ -28,7 +28,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         agg[row["Kernel_Name"][:48]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in agg.items():
-    if "sparse_scan" not in k:
+    if "sparse_scan" not in k and "sparse_multi" not in k:
         continue
     print("== counters of", k, "(mean per dispatch, and per target)")
     for c, v in sorted(d.items()):
