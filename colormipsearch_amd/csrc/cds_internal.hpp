@@ -190,11 +190,16 @@ struct SparseScanParams {
 // ---- multi-mask sparse scan: a GROUP of up to kSparseGroupMasks masks shares one pass over the records ----------------------
 // Per group, over the UNION bounding box of its masks: one u8 plane per mask (interval-record index per mask pixel, the
 // single-mask layout), the masks' interval tables (256 x 16 B each, copied to LDS) and ONE transposed band map
-//   tmap[cell row][cell column][32 hue bands] (u8): bit j = mask j of the group accepts, under some xy-shift, a code of
-//   that band at some position of the 4-row x 8-column cell
+//   tmap[cell row][cell column][7 x 64 hue bins] (u8): bit j = mask j of the group accepts, under some xy-shift, a code
+//   of that bin (class x floor(64 x ratio)) at some position of the 4-row x 8-column cell
 // so that stage 1 (record -> row, band, cell) is done once per record and ONE byte per orientation names the masks it
 // can matter to.
 constexpr int kSparseGroupMasks = 8;
+#ifndef SP_BINS_LOG2
+#define SP_BINS_LOG2 6
+#endif
+constexpr int kSparseGroupBinsLog2 = SP_BINS_LOG2;
+constexpr int kSparseGroupBins = 1 << kSparseGroupBinsLog2;   // hue bins per class in the group's map (7 x 64 bytes per cell; class 0 is never set)
 constexpr int kSparseGroupIv = 3072;  // interval records of a group's masks together (48 KB of LDS); groups are cut accordingly
 struct SparseGroupPlan {
     int first_mask = 0, n_masks = 0;
@@ -206,6 +211,8 @@ struct SparseGroupPlan {
     int iv_base[kSparseGroupMasks] = {0, 0, 0, 0, 0, 0, 0, 0};   // first record of mask j's table
     size_t planes_off = 0, tmap_off = 0, iv_off = 0;   // offsets into cds_maskset::d_sg_planes / d_sg_tmap (bytes) / d_sg_iv (elements)
     size_t tmap_bytes = 0;
+    size_t umap_off = 0;      // the union band map (u32 per cell) follows the fine map in d_sg_tmap
+    int umap_words = 0;       // 0: not used (it would not leave room for two workgroups per CU)
 };
 
 struct SparseMultiParams {
@@ -215,8 +222,10 @@ struct SparseMultiParams {
     int64_t first, count;
     int W, H, nstrips, strip_w;
     const void *planes;       // [n_masks][plane_cells] u8 or u16
-    const uint8_t *tmap;      // [cell rows][nwpr][32]
+    const uint8_t *tmap;      // [cell rows][nwpr][7 * kSparseGroupBins]
     const uint4 *iv;          // [n_iv]
+    const uint32_t *umap;     // [umap_words] union of the masks' coarse band maps, one word per cell
+    int umap_words;
     int n_iv, iv_base[kSparseGroupMasks];
     int n_masks, plane_cells, tmap_bytes;
     int xlo, cols, ylo, nrows, pitch, nwpr;

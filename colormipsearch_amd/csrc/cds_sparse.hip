@@ -574,8 +574,9 @@ __global__ __launch_bounds__(256) void sparse_finalize_kernel(const int32_t *par
 // workgroups per CU, 8 waves per SIMD (64 VGPRs) to cover the L2 round trips of the map and plane bytes.
 constexpr int SM_QCAP = 128;
 constexpr int SM_WAVE_BYTES = SM_QCAP * 8 + kSparseGroupMasks * CDS_N_TRANSFORMS * 4;
-constexpr int SM_FIXED_BYTES = kSparseGroupIv * 16 + 64;   // interval records + the masks' table bases
-static size_t multi_lds_bytes(int threads) { return (size_t)SM_FIXED_BYTES + (size_t)(threads / 64) * SM_WAVE_BYTES; }
+// dynamic LDS of one workgroup: interval records | the masks' table bases (64 B) | union band map | per-wave queue + counters
+static size_t multi_fixed_bytes(int n_iv, int umap_words) { return (size_t)round_up(n_iv, 4) * 16 + 64 + (size_t)round_up(umap_words, 4) * 4; }
+static size_t multi_lds_bytes(int threads, int n_iv, int umap_words) { return multi_fixed_bytes(n_iv, umap_words) + (size_t)(threads / 64) * SM_WAVE_BYTES; }
 
 template <bool XY2, bool MIRROR, bool P8>
 __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams p) {
@@ -593,11 +594,15 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
     const __amdgpu_buffer_rsrc_t planes_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.planes), 0, (int)((uint32_t)p.n_masks * (uint32_t)p.plane_cells * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t tmap_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.tmap), 0, (int)p.tmap_bytes, 0x00020000);
     uint4 *ivt = lds4;
-    int *ivb = reinterpret_cast<int *>(lds4 + kSparseGroupIv);
-    uint8_t *wb = reinterpret_cast<uint8_t *>(lds4) + SM_FIXED_BYTES + (size_t)wave * SM_WAVE_BYTES;
+    const int n_iv4 = (p.n_iv + 3) & ~3, um4 = (p.umap_words + 3) & ~3;
+    int *ivb = reinterpret_cast<int *>(lds4 + n_iv4);
+    uint32_t *umap = reinterpret_cast<uint32_t *>(ivb + 16);
+    uint8_t *wb = reinterpret_cast<uint8_t *>(umap + um4) + (size_t)wave * SM_WAVE_BYTES;
     uint2 *q = reinterpret_cast<uint2 *>(wb);
     int *cnt = reinterpret_cast<int *>(wb + SM_QCAP * 8);
     for (int i = threadIdx.x; i < p.n_iv; i += blockDim.x) ivt[i] = p.iv[i];
+    for (int i = threadIdx.x; i < p.umap_words; i += blockDim.x) umap[i] = p.umap[i];
+    const bool prefilter = p.umap_words > 0;  // (a map too large for the LDS is left out: every record then asks the L2 map)
     if (threadIdx.x < K) ivb[threadIdx.x] = p.iv_base[threadIdx.x];
     for (int i = lane; i < K * CDS_N_TRANSFORMS; i += 64) cnt[i] = 0;
     __syncthreads();
@@ -727,6 +732,41 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                 int yrel = ra - 1 - ry0;  // (rows started before the current block) - 1, relative to the map's first row
                 for (uint32_t i = a; i < b; i += 64 * NB) {  // wave-uniform
                     const uint32_t rem = b - i;
+                    // stage 1 of all NB blocks first (row, columns, bin, the map bytes of both orientations: 2 NB L2 gathers in flight
+                    // together, one wait), then the next NB record blocks are requested, then the set bits become queue entries
+                    uint32_t w4[NB], prow4[NB];
+#pragma unroll
+                    for (int j = 0; j < NB; j++) {
+                        const uint32_t rec = cur[j];  // (lanes and whole blocks beyond the run were loaded as 0: no flag, below every threshold)
+                        const unsigned long long fb = __ballot((int)rec < 0);
+                        const uint32_t ry = (uint32_t)(yrel + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0))) + (rec >> 31);
+                        yrel += __popcll(fb);
+                        const uint32_t x = (rec >> kRecXShift) & 2047u;
+                        const uint32_t cxp = min(x - cx0, wnear);
+                        const uint32_t cxm = MIRROR ? min(cm0 - x, wnear) : 0u;
+                        // hue bin = class * 64 + floor(64 * ratio) (448 per cell; class 0 = bins no mask accepts, where a pixel below
+                        // the data threshold is sent; a filler record gives NaN -> 0 and fails the threshold anyway)
+                        const float hf = (float)((rec >> 8) & 255u) * __builtin_amdgcn_rcpf((float)(rec & 255u));
+                        uint32_t bin = (((rec >> kRecClsShift) & 7u) << kSparseGroupBinsLog2) + (uint32_t)(hf * (float)kSparseGroupBins);
+                        bin = (rec & 255u) > thr ? bin : 0u;
+                        const uint32_t rowc = __umul24(ry >> 2, nwpr);
+                        // the group's UNION band map (LDS, one word per cell, the single-mask kernel's 30 coarse bands) first: only a
+                        // record that some mask of the group can accept at all asks the fine map in L2 -- the gathers are what this
+                        // kernel waits for, and their cost is the number of distinct lines the ACTIVE lanes touch
+                        const uint32_t cellp = rowc + (cxp >> 3), cellm = rowc + (cxm >> 3);
+                        bool passp = true, passm = MIRROR;
+                        if (prefilter) {
+                            uint32_t band = (__umul24((rec >> kRecClsShift) & 7u, 5u) + (uint32_t)(hf * 5.0f)) & 31u;
+                            band = (rec & 255u) > thr ? band : 3u;  // bit 3 is never set
+                            passp = __builtin_amdgcn_ubfe(umap[cellp], band, 1u) != 0;
+                            if (MIRROR) passm = __builtin_amdgcn_ubfe(umap[cellm], band, 1u) != 0;
+                        }
+                        uint32_t w = 0;
+                        if (passp) w = __builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)(__umul24(cellp, 7u * kSparseGroupBins) + bin), 0, 0);
+                        if (MIRROR && passm) w |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)(__umul24(cellm, 7u * kSparseGroupBins) + bin), 0, 0) << 8;
+                        w4[j] = w;
+                        prow4[j] = __umul24(ry, pitch) + poff;  // plane offset of column cx0 in the record's row
+                    }
                     {   // the next NB blocks -- of this run or the first of the grab's next run -- are in flight meanwhile
                         const uint32_t *Pq = P;
                         uint32_t iq = i, bq = b;
@@ -734,46 +774,24 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                         else if (r + 1 < nruns) header(r + 1, Pq, iq, bq);
                         load_blocks(Pq, iq, bq, nxt);
                     }
-                    // stage 1 of block j + 1 (row, columns, band, the two map bytes: an L2 round trip) is issued before block j's
-                    // set bits are expanded into queue entries
-                    uint32_t s_rec, s_prow, s_cxp, s_cxm, s_w;
-                    auto stage1 = [&](int j) {
-                        const uint32_t rec = cur[j];  // (lanes beyond the run were loaded as 0: no flag, below every threshold)
-                        const unsigned long long fb = __ballot((int)rec < 0);
-                        const uint32_t ry = (uint32_t)(yrel + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0))) + (rec >> 31);
-                        yrel += __popcll(fb);
-                        const uint32_t x = (rec >> kRecXShift) & 2047u;
-                        const uint32_t cxp = min(x - cx0, wnear);
-                        const uint32_t cxm = MIRROR ? min(cm0 - x, wnear) : 0u;
-                        const float hf = (float)((rec >> 8) & 255u) * __builtin_amdgcn_rcpf((float)(rec & 255u));
-                        uint32_t band = (__umul24((rec >> kRecClsShift) & 7u, 5u) + (uint32_t)(hf * 5.0f)) & 31u;
-                        band = (rec & 255u) > thr ? band : 3u;  // below the threshold: band 3, which no mask accepts
-                        const uint32_t rowc = __umul24(ry >> 2, nwpr);
-                        uint32_t w = __builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)(((rowc + (cxp >> 3)) << 5) + band), 0, 0);
-                        if (MIRROR) w |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)(((rowc + (cxm >> 3)) << 5) + band), 0, 0) << 8;
-                        s_rec = rec, s_cxp = cxp, s_cxm = cxm, s_w = w;
-                        s_prow = __umul24(ry, pitch) + poff;  // plane offset of column cx0 in the record's row
-                    };
-                    stage1(0);
 #pragma unroll
                     for (int j = 0; j < NB; j++) {
-                        const uint32_t rec = s_rec, prow = s_prow, cxp = s_cxp, cxm = s_cxm;
-                        uint32_t w = s_w;
-                        const bool more = j + 1 < NB && rem > 64u * (j + 1);  // wave-uniform
-                        if (more) stage1(j + 1);
+                        const uint32_t rec = cur[j], prow = prow4[j];
+                        uint32_t w = w4[j];
                         unsigned long long bal = __ballot(w != 0);
                         while (bal) {  // one turn per set bit of the busiest lane
                             if (w != 0) {
                                 const uint32_t bit = (uint32_t)__builtin_ctz(w);
                                 const int slot = (qt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0))) & (SM_QCAP - 1);
-                                q[slot] = make_uint2(rec, (prow + (bit >= 8u ? cxm : cxp)) | (bit << 20));
+                                const uint32_t x = (rec >> kRecXShift) & 2047u;
+                                const uint32_t cx = (MIRROR && bit >= 8u) ? min(cm0 - x, wnear) : min(x - cx0, wnear);
+                                q[slot] = make_uint2(rec, (prow + cx) | (bit << 20));
                                 w &= w - 1u;
                             }
                             qt += __popcll(bal);
                             if (qt - qh >= 64) round();
                             bal = __ballot(w != 0);
                         }
-                        if (!more) break;
                     }
 #pragma unroll
                     for (int j = 0; j < NB; j++) cur[j] = nxt[j];
@@ -863,6 +881,23 @@ static int sparse_threads() {
 }
 
 
+#if SP_BAND
+// Hue bins (class * kSparseGroupBins + floor(kSparseGroupBins * ratio), classes 1..6) that codes of the inclusive interval
+// [lo, lo + len] can fall in -- the fine-grained counterpart of band_bits_of for the multi-mask scan's map (same argument:
+// the bin is monotone in the code inside a class; the arithmetic is the kernel's).
+static void bins_of(uint32_t lo, uint32_t len, std::vector<uint16_t> &out) {
+    if (lo == 1u && len == 0u) return;  // the empty record
+    const uint32_t hi = lo + len;
+    auto u2f = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+    for (uint32_t c = std::max(1u, lo >> 29); c <= std::min(6u, hi >> 29); c++) {
+        const float flo = c == (lo >> 29) ? u2f((lo & 0x1FFFFFFFu) << 1) : 0.0f;
+        const float fhi = c == (hi >> 29) ? u2f(((hi & 0x1FFFFFFFu) << 1) | 1u) : 1.0f;  // (the code dropped the ratio's last bit)
+        const uint32_t b0 = (uint32_t)(flo * (float)kSparseGroupBins), b1 = std::min((uint32_t)kSparseGroupBins - 1u, (uint32_t)(fhi * (float)kSparseGroupBins));
+        for (uint32_t b = b0; b <= b1; b++) out.push_back((uint16_t)(c * kSparseGroupBins + b));
+    }
+}
+#endif
+
 // distinct interval records of a mask (index 0 = the empty record) and, per mask pixel, the index of its record;
 // false when the mask has more than `limit` - 1 distinct records
 struct IvKey {
@@ -936,18 +971,23 @@ static int build_group_plans(cds_maskset *ms, const std::vector<std::vector<Mask
         gp.nwpr = G / 8 + 1;
         if ((size_t)(gp.nrows + 2 * SP_PAD) * gp.pitch >= ((size_t)1 << 20)) return;  // plane offsets travel in 20 bits
         gp.plane_cells = round_up((gp.nrows + 2 * SP_PAD) * gp.pitch, 16);
-        gp.tmap_bytes = (size_t)((gp.nrows + 4 + 3) / 4) * gp.nwpr * 32;
+        gp.tmap_bytes = (size_t)((gp.nrows + 4 + 3) / 4) * gp.nwpr * 7 * kSparseGroupBins;
         gp.plane8 = true;
         for (int j = 0; j < gp.n_masks; j++) gp.plane8 = gp.plane8 && ms->sp_plans[m0 + j].n_iv <= 256;
         const int esize = gp.plane8 ? 1 : 2;
         std::vector<uint8_t> &planes = planes_of[g], &tmap = tmap_of[g];
         std::vector<uint4> &ivs = iv_of[g];
         planes.assign((size_t)gp.n_masks * gp.plane_cells * esize, 0);
-        tmap.assign(round_up((int)gp.tmap_bytes, 16), 0);
+        // the fine map, followed by the union band map (one word per cell)
+        const size_t n_cells = (size_t)((gp.nrows + 4 + 3) / 4) * gp.nwpr;
+        gp.umap_off = (size_t)round_up((int)gp.tmap_bytes, 16);
+        tmap.assign(gp.umap_off + n_cells * 4, 0);
+        uint32_t *umap = reinterpret_cast<uint32_t *>(tmap.data() + gp.umap_off);
         ivs.clear();
         std::vector<uint4> tab;
         std::vector<uint16_t> pidx;
-        std::vector<uint32_t> tab_bits;
+        std::vector<std::vector<uint16_t>> tab_bins;
+        std::vector<uint32_t> cells;   // (cell << 12 | record) pairs of the mask, deduplicated before the bins are written
         for (int j = 0; j < gp.n_masks; j++) {
             const std::vector<MaskPx> &L = per_mask[m0 + j];
             if (!mask_dictionary(L, kSparseGroupIv + 1, tab, pidx) || ivs.size() + tab.size() > (size_t)kSparseGroupIv) {
@@ -956,8 +996,14 @@ static int build_group_plans(cds_maskset *ms, const std::vector<std::vector<Mask
             }
             gp.iv_base[j] = (int)ivs.size();
             ivs.insert(ivs.end(), tab.begin(), tab.end());
-            tab_bits.resize(tab.size());
-            for (size_t k = 0; k < tab.size(); k++) tab_bits[k] = band_bits_of(tab[k].x, tab[k].y) | band_bits_of(tab[k].z, tab[k].w);
+            tab_bins.assign(tab.size(), std::vector<uint16_t>());
+            std::vector<uint32_t> tab_bits(tab.size());
+            for (size_t k = 0; k < tab.size(); k++) {
+                tab_bits[k] = band_bits_of(tab[k].x, tab[k].y) | band_bits_of(tab[k].z, tab[k].w);
+                bins_of(tab[k].x, tab[k].y, tab_bins[k]);
+                bins_of(tab[k].z, tab[k].w, tab_bins[k]);
+            }
+            cells.clear();
             uint8_t *plane = planes.data() + (size_t)j * gp.plane_cells * esize;
             uint16_t *plane16 = reinterpret_cast<uint16_t *>(plane);
             for (size_t i = 0; i < L.size(); i++) {
@@ -968,12 +1014,20 @@ static int build_group_plans(cds_maskset *ms, const std::vector<std::vector<Mask
                 for (int dy = xy2 ? -2 : 0; dy <= (xy2 ? 2 : 0); dy += 2)
                     for (int dx = xy2 ? -2 : 0; dx <= (xy2 ? 2 : 0); dx += 2) {
                         const int ry = rr + 2 + dy, cx = cc + 2 + dx;  // map origin = (xlo - 2, ylo - 2)
-                        uint8_t *cell = tmap.data() + ((size_t)(ry >> 2) * gp.nwpr + (cx >> 3)) * 32;
-                        for (uint32_t bits = tab_bits[pidx[i]]; bits; bits &= bits - 1) cell[__builtin_ctz(bits)] |= (uint8_t)(1u << j);
+                        cells.push_back((uint32_t)(((ry >> 2) * gp.nwpr + (cx >> 3)) << 12) | pidx[i]);
                     }
+            }
+            std::sort(cells.begin(), cells.end());
+            cells.erase(std::unique(cells.begin(), cells.end()), cells.end());
+            for (const uint32_t cr : cells) {
+                uint8_t *cell = tmap.data() + (size_t)(cr >> 12) * 7 * kSparseGroupBins;
+                for (const uint16_t b : tab_bins[cr & 4095u]) cell[b] |= (uint8_t)(1u << j);
+                umap[cr >> 12] |= tab_bits[cr & 4095u];
             }
         }
         gp.n_iv = (int)ivs.size();
+        gp.umap_words = (int)n_cells;
+        if (multi_lds_bytes(1024, gp.n_iv, gp.umap_words) > ms->ctx->lds_per_block / 2) gp.umap_words = 0;  // keep two workgroups per CU
         gp.ok = true;
     };
     {
@@ -1201,7 +1255,7 @@ static int launch_sparse_multi(cds_context *ctx, const SparseMultiParams &p, int
                               : (mirror ? sparse_multi_kernel<false, true, true> : sparse_multi_kernel<false, false, true>))
                        : (xy2 ? (mirror ? sparse_multi_kernel<true, true, false> : sparse_multi_kernel<true, false, false>)
                               : (mirror ? sparse_multi_kernel<false, true, false> : sparse_multi_kernel<false, false, false>));
-    const size_t lds_bytes = multi_lds_bytes(threads);
+    const size_t lds_bytes = multi_lds_bytes(threads, p.n_iv, p.umap_words);
     CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int per_cu = (int)std::min<size_t>((size_t)(2048 / threads), ctx->lds_per_block / lds_bytes);
     per_cu = std::max(1, per_cu);
@@ -1337,6 +1391,8 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
             p.planes = ms->d_sg_planes + gp.planes_off;
             p.tmap = ms->d_sg_tmap + gp.tmap_off;
             p.tmap_bytes = (int)gp.tmap_bytes;
+            p.umap = reinterpret_cast<const uint32_t *>(ms->d_sg_tmap + gp.tmap_off + gp.umap_off);
+            p.umap_words = gp.umap_words;
             p.iv = ms->d_sg_iv + gp.iv_off;
             p.n_masks = gp.n_masks; p.plane_cells = gp.plane_cells;
             p.n_iv = gp.n_iv;
