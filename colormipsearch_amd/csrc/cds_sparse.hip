@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <climits>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -583,7 +584,10 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
     extern __shared__ uint4 lds4[];
     constexpr int NS = XY2 ? 9 : 1, NSX = XY2 ? 3 : 1;
     constexpr int HALO = XY2 ? 2 : 0;
-    constexpr int NB = 4;
+    #ifndef SM_NB
+#define SM_NB 2
+#endif
+    constexpr int NB = SM_NB;
     constexpr int K = kSparseGroupMasks;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -931,7 +935,7 @@ static bool mask_dictionary(const std::vector<MaskPx> &L, size_t limit, std::vec
 // Plans of the multi-mask scan: groups of kSparseGroupMasks consecutive masks over the union of their bounding boxes.
 static int build_group_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &per_mask) {
     const size_t n_masks = per_mask.size();
-    if (n_masks < 2 || !SP_BAND || getenv("CDS_SPARSE_NO_GROUPS")) return CDS_OK;
+    if ((n_masks < 2 && !getenv("CDS_SPARSE_GROUP_SINGLE")) || !SP_BAND || getenv("CDS_SPARSE_NO_GROUPS")) return CDS_OK;
 #if SP_BAND
     const bool xy2 = ms->params.xy_shift == 2;
     constexpr int K = kSparseGroupMasks;
@@ -1274,9 +1278,10 @@ static int sparse_check_range(const cds_sparse_library *sl, int64_t first, int64
     return CDS_OK;
 }
 
-// d_scores[m * count + t]; d_counts optional [m][t][18]
+// masks [m_begin, m_end) of the set (m_end < 0: all; a range must not cut a multi-mask group, see mask_chunks):
+// d_scores[(m - m_begin) * count + t]; d_counts optional [m - m_begin][t][18]
 static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, int32_t *d_scores,
-                              int32_t *d_counts, bool timed) {
+                              int32_t *d_counts, bool timed, int m_begin = 0, int m_end = -1) {
     if (!ms || !sl) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     int rc = sparse_check_range(sl, first, count);
     if (rc) return rc;
@@ -1328,10 +1333,11 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
         SP_HIP(hipEventRecord(ev0, st));
     }
     int launches = 0;
+    if (m_end < 0) m_end = ms->n_masks;
     auto scan_one_mask = [&](int m) -> int {
         const SparseMaskPlan &pl = ms->sp_plans[(size_t)m];
-        int32_t *out = d_scores + (size_t)m * count;
-        int32_t *cnt = d_counts ? d_counts + (size_t)m * count * CDS_N_TRANSFORMS : nullptr;
+        int32_t *out = d_scores + (size_t)(m - m_begin) * count;
+        int32_t *cnt = d_counts ? d_counts + (size_t)(m - m_begin) * count * CDS_N_TRANSFORMS : nullptr;
         if (pl.n_slabs == 0) {  // no mask pixel can ever match
             SP_HIP(hipMemsetAsync(out, 0, (size_t)count * sizeof(int32_t), st));
             if (cnt) SP_HIP(hipMemsetAsync(cnt, 0, (size_t)count * CDS_N_TRANSFORMS * sizeof(int32_t), st));
@@ -1371,12 +1377,13 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
     const char *multi_env = getenv("CDS_SPARSE_MULTI");
     const bool use_multi = !d_counts && !ms->sg_plans.empty() && threads == 1024 && !(multi_env && atoi(multi_env) == 0);
     if (!use_multi) {
-        for (int m = 0; m < ms->n_masks; m++) {
+        for (int m = m_begin; m < m_end; m++) {
             rc = scan_one_mask(m);
             if (rc) return rc;
         }
     } else {
         for (const SparseGroupPlan &gp : ms->sg_plans) {
+            if (gp.first_mask < m_begin || gp.first_mask + gp.n_masks > m_end) continue;
             if (!gp.ok) {
                 for (int m = gp.first_mask; m < gp.first_mask + gp.n_masks; m++) {
                     rc = scan_one_mask(m);
@@ -1402,7 +1409,7 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
             p.group = group; p.nparts = nparts;
             p.psize = (uint32_t)((count + nparts - 1) / nparts);
             p.work = ms->d_sp_work;
-            p.out = d_scores + (size_t)gp.first_mask * count;
+            p.out = d_scores + (size_t)(gp.first_mask - m_begin) * count;
             p.out_stride = count;
             SP_HIP(hipMemsetAsync(ms->d_sp_work, 0, (size_t)nparts * 32 * sizeof(uint32_t), st));
             rc = launch_sparse_multi(ctx, p, threads, ms->params.xy_shift == 2, ms->params.mirror != 0, gp.plane8, st);
@@ -1426,6 +1433,112 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
 #undef SP_HIP
     return CDS_OK;
 }
+
+
+// =================================================================================================
+//            match list: ColorMIPSearch.isMatch + stream compaction on the device
+// =================================================================================================
+// The reference keeps a (mask, target) pair when ColorMIPSearch.isMatch holds (API/cds/ColorMIPSearch.java:42-45: score > 0
+// and (float) score / querySize > pctPositivePixels / 100) and drops the rest (tools cmd/cdsprocess/
+// AbstractColorMIPSearchProcessor.java:60-85).  A 1,024-mask x 1 M-target search produces 4 GB of scores of which a handful
+// per mask pass; here the filter and the compaction run where the scores are, and only the match list crosses PCIe.
+// isMatch is monotone in the score, so the host finds, per mask, the smallest passing score with the reference's own
+// arithmetic (cds_is_match) and the device test is an integer compare.
+struct MatchParams {
+    const int32_t *scores;     // [n_masks][count] score | mirrored << 31
+    const int32_t *min_score;  // [n_masks] smallest score that is a match (INT32_MAX: none)
+    int n_masks, mask0;
+    int64_t count;
+    int nblk;                  // blocks of 1024 targets per mask
+    uint32_t *blockcnt;        // [n_masks * nblk] matches per block -> exclusive offsets inside the chunk
+    unsigned long long *total; // [0] matches before this chunk, [1] matches of this chunk
+    cds_match *out;
+    int64_t capacity;
+};
+
+__device__ __forceinline__ int match_flags(const MatchParams &p, int m, int64_t t0, int32_t (&v)[4]) {
+    const int32_t thr = p.min_score[m];
+    int f = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t t = t0 + k;
+        v[k] = t < p.count ? p.scores[(size_t)m * p.count + t] : 0;
+        if (t < p.count && (v[k] & 0x7fffffff) >= thr) f |= 1 << k;
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(256) void match_count_kernel(MatchParams p) {
+    __shared__ int wsum[4];
+    const int m = blockIdx.x / p.nblk, b = blockIdx.x - m * p.nblk;
+    int32_t v[4];
+    const int f = match_flags(p, m, (int64_t)b * 1024 + threadIdx.x * 4, v);
+    int c = __popc(f);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) p.blockcnt[blockIdx.x] = (uint32_t)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+
+// one workgroup: blockcnt[0..n) -> exclusive offsets in place, chunk total -> total[1]
+__global__ __launch_bounds__(1024) void match_scan_kernel(MatchParams p) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = (int64_t)p.n_masks * p.nblk;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? p.blockcnt[i] : 0u;
+        const uint32_t inc = wave_incl_scan(v, lane);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (int w = 0; w < wave; w++) off += wsum[w];
+        __syncthreads();
+        if (i < n) p.blockcnt[i] = off + inc - v;
+        if (threadIdx.x == 1023) carry_s = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.total[1] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void match_fill_kernel(MatchParams p) {
+    __shared__ int wsum[4];
+    const int m = blockIdx.x / p.nblk, b = blockIdx.x - m * p.nblk;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t t0 = (int64_t)b * 1024 + threadIdx.x * 4;
+    int32_t v[4];
+    const int f = match_flags(p, m, t0, v);
+    const int c = __popc(f);
+    int inc = c;  // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int before = inc - c;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    unsigned long long pos = p.total[0] + p.blockcnt[blockIdx.x] + (unsigned long long)before;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (f & (1 << k)) {
+            if (pos < (unsigned long long)p.capacity) {
+                cds_match r;
+                r.mask = p.mask0 + m;
+                r.target = (int32_t)(t0 + k);
+                r.score = v[k];
+                p.out[pos] = r;
+            }
+            pos++;
+        }
+}
+
+__global__ void match_advance_kernel(unsigned long long *total) { total[0] += total[1]; }
 
 }  // namespace cds
 
@@ -1729,6 +1842,110 @@ static int sparse_search_host(const cds_maskset *ms, const cds_sparse_library *s
     hipFree(d_scores);
     if (d_counts) hipFree(d_counts);
     return rc;
+}
+
+int cds_search_sparse_matches(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, double pct_positive_pixels,
+                              cds_match *matches, int64_t capacity, int64_t *n_matches) {
+    if (!ms || !sl || !n_matches) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *n_matches = 0;
+    if (capacity < 0 || (capacity > 0 && !matches)) return fail(CDS_ERR_INVALID_ARGUMENT, "bad match buffer");
+    int rc = sparse_check_range(sl, first, count);
+    if (rc) return rc;
+    if (count == 0) return CDS_OK;
+    if (count >= ((int64_t)1 << 31)) return fail(CDS_ERR_UNSUPPORTED, "more than 2^31 targets in one call");
+    cds_context *ctx = ms->ctx;
+    CDS_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // smallest passing score per mask (isMatch is monotone in the score); an empty mask is skipped as the reference does
+    // ("No computation created ... because it is empty", LocalColorMIPSearchProcessor.java:88-92)
+    std::vector<int32_t> min_score((size_t)ms->n_masks, INT32_MAX);
+    for (int m = 0; m < ms->n_masks; m++) {
+        const int32_t P = ms->sizes[(size_t)m];
+        if (P <= 0 || !cds_is_match(P, P, pct_positive_pixels)) continue;
+        int32_t lo = 1, hi = P;
+        while (lo < hi) {
+            const int32_t mid = lo + (hi - lo) / 2;
+            if (cds_is_match(mid, P, pct_positive_pixels)) hi = mid; else lo = mid + 1;
+        }
+        min_score[(size_t)m] = lo;
+    }
+    // chunks of masks: at most 128 masks and fewer than 2^32 pairs each, never cutting a multi-mask group
+    int max_chunk = (int)std::max<int64_t>(1, std::min<int64_t>(128, (((int64_t)1 << 32) - 1) / count));
+    if (const char *e = getenv("CDS_MATCH_CHUNK_MASKS")) max_chunk = std::max(1, atoi(e));
+    std::vector<std::pair<int, int>> chunks;
+    if (ms->sg_plans.empty()) {
+        for (int m = 0; m < ms->n_masks; m += max_chunk) chunks.push_back({m, std::min(ms->n_masks, m + max_chunk)});
+    } else {
+        int b = 0, e = 0;
+        for (const SparseGroupPlan &gp : ms->sg_plans) {
+            if (e > b && gp.first_mask + gp.n_masks - b > max_chunk) {
+                chunks.push_back({b, e});
+                b = e;
+            }
+            e = gp.first_mask + gp.n_masks;
+        }
+        if (e > b) chunks.push_back({b, e});
+    }
+    int widest = 0;
+    for (auto &c : chunks) widest = std::max(widest, c.second - c.first);
+    const int nblk = (int)((count + 1023) / 1024);
+    int32_t *d_scores = nullptr, *d_min = nullptr;
+    uint32_t *d_blockcnt = nullptr;
+    unsigned long long *d_total = nullptr;
+    cds_match *d_out = nullptr;
+    auto cleanup = [&]() {
+        if (d_scores) hipFree(d_scores);
+        if (d_min) hipFree(d_min);
+        if (d_blockcnt) hipFree(d_blockcnt);
+        if (d_total) hipFree(d_total);
+        if (d_out) hipFree(d_out);
+    };
+#define MT_HIP(call)                         \
+    do {                                     \
+        hipError_t _e = (call);              \
+        if (_e != hipSuccess) {              \
+            cleanup();                       \
+            return cds::hip_fail(_e, #call); \
+        }                                    \
+    } while (0)
+    MT_HIP(hipMalloc(&d_scores, (size_t)widest * count * sizeof(int32_t)));
+    MT_HIP(hipMalloc(&d_min, (size_t)ms->n_masks * sizeof(int32_t)));
+    MT_HIP(hipMalloc(&d_blockcnt, (size_t)widest * nblk * sizeof(uint32_t)));
+    MT_HIP(hipMalloc(&d_total, 2 * sizeof(unsigned long long)));
+    if (capacity > 0) MT_HIP(hipMalloc(&d_out, (size_t)capacity * sizeof(cds_match)));
+    MT_HIP(hipMemcpyAsync(d_min, min_score.data(), min_score.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    MT_HIP(hipMemsetAsync(d_total, 0, 2 * sizeof(unsigned long long), st));
+    for (auto &c : chunks) {
+        rc = sparse_search_impl(ms, sl, first, count, d_scores, nullptr, false, c.first, c.second);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
+        MatchParams p{};
+        p.scores = d_scores; p.min_score = d_min + c.first; p.n_masks = c.second - c.first; p.mask0 = c.first;
+        p.count = count; p.nblk = nblk; p.blockcnt = d_blockcnt; p.total = d_total; p.out = d_out; p.capacity = capacity;
+        const unsigned grid = (unsigned)((int64_t)p.n_masks * nblk);
+        hipLaunchKernelGGL(match_count_kernel, dim3(grid), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, st, p);
+        hipLaunchKernelGGL(match_fill_kernel, dim3(grid), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(match_advance_kernel, dim3(1), dim3(1), 0, st, d_total);
+        MT_HIP(hipGetLastError());
+    }
+    unsigned long long total[2] = {0, 0};
+    MT_HIP(hipMemcpyAsync(total, d_total, sizeof total, hipMemcpyDeviceToHost, st));
+    MT_HIP(hipStreamSynchronize(st));
+    *n_matches = (int64_t)total[0];
+    if ((int64_t)total[0] > capacity) {
+        cleanup();
+        char buf[160];
+        snprintf(buf, sizeof buf, "match buffer too small: %lld matches, capacity %lld (n_matches holds the count: call again)", (long long)total[0],
+                 (long long)capacity);
+        return fail(CDS_ERR_OUT_OF_MEMORY, buf);
+    }
+    if (total[0]) MT_HIP(hipMemcpy(matches, d_out, (size_t)total[0] * sizeof(cds_match), hipMemcpyDeviceToHost));
+    cleanup();
+#undef MT_HIP
+    return CDS_OK;
 }
 
 int cds_search_sparse(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, int32_t *scores,

@@ -10,8 +10,9 @@ Counterpart of the reference's
   * `CalculateGradientScoresCmd`: shape scores of the selected pairs (:541-586) and the per-mask normalisation
     (:616-645, GradientAreaGapUtils.calculateNormalizedScore).
 
-The per-pair Java loop becomes: one `cds_search` per mask batch over the resident library, a vectorised match filter,
-the (host) top-N selection over the few survivors, one `cds_gradscore` over the selected pairs.  Entities are plain
+The per-pair Java loop becomes: one `cds_search` per mask batch over the resident library, the match filter (on the
+device together with the compaction when the library is sparse: `cds_search_sparse_matches`; vectorised on the host for
+dense slots), the (host) top-N selection over the few survivors, one `cds_gradscore` over the selected pairs.  Entities are plain
 records here; `colormipsearch_amd/results.py` turns them into the reference's JSON result files (Mongo stays out of scope).
 """
 from dataclasses import dataclass, field
@@ -258,8 +259,18 @@ class GpuColorMIPSearchProcessor:
         return (self.first + t) if self.dense_slots is None else self.dense_slots[t]
 
     # ---- colorDepthSearch -------------------------------------------------------------------------
+    def _device_match_table(self, alg) -> MatchTable:
+        """Sparse library: scan, ColorMIPSearch.isMatch and the compaction run on the device (cds_search_sparse_matches); only the
+        match list comes back (rows ordered by mask, then target -- the order of the host-side filter below)."""
+        m, t, sc, mir = alg.searchSparseLibraryMatches(self.sparse_library, self.colorMIPSearch.pctPositivePixels, self.first, self.count)
+        sizes = np.asarray(alg.getQuerySizes(), dtype=np.float64)
+        ratio = (sc.astype(np.float64) / np.maximum(sizes[m], 1.0)).astype(np.float32)
+        return MatchTable(m.astype(np.int32), t.astype(np.int64), sc.astype(np.int32), ratio, mir.astype(bool))
+
     def findAllColorDepthMatches(self, masks) -> List[CDMatch]:
         alg = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold(masks)
+        if self.sparse_library is not None:
+            return self._device_match_table(alg).to_matches()
         scores, mirrored = self._scan(alg)
         sizes = alg.getQuerySizes()
         out = []
@@ -275,6 +286,8 @@ class GpuColorMIPSearchProcessor:
     def findAllColorDepthMatchesTable(self, masks) -> MatchTable:
         """findAllColorDepthMatches in columnar form (same rows, same order)."""
         alg = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold(masks)
+        if self.sparse_library is not None:
+            return self._device_match_table(alg)
         scores, mirrored = self._scan(alg)
         sizes = np.asarray(alg.getQuerySizes())
         mi, ti, sc, ra, mr = [], [], [], [], []

@@ -200,6 +200,17 @@ int cds_search_sparse_device(const cds_maskset *ms, const cds_sparse_library *sl
 int cds_search_sparse_counts(const cds_maskset *ms, const cds_sparse_library *slib, int64_t first, int64_t count,
                              int32_t *counts);
 
+/* The scan + ColorMIPSearch.isMatch (API/cds/ColorMIPSearch.java:42-45) + compaction, all on the device: the pairs the
+ * reference keeps in findAllColorDepthMatches (tools cmd/cdsprocess/LocalColorMIPSearchProcessor.java:82-116,
+ * AbstractColorMIPSearchProcessor.java:60-85), as a list ordered by mask, then target.  score = matching pixels | mirrored << 31.
+ * A mask whose query size is 0 yields no pair.  Only the list crosses PCIe (a 1,024 x 1 M search has 4 GB of scores).
+ * CDS_ERR_OUT_OF_MEMORY when the list is longer than `capacity` -- *n_matches then holds the length needed. */
+typedef struct cds_match {
+    int32_t mask, target, score;
+} cds_match;
+int cds_search_sparse_matches(const cds_maskset *ms, const cds_sparse_library *slib, int64_t first, int64_t count,
+                              double pct_positive_pixels, cds_match *matches, int64_t capacity, int64_t *n_matches);
+
 /* Average device time (ms) of the scan kernel launches of the last cds_search*_ call on this mask
  * set, measured with hipEvents on the launch stream, and the number of launches. */
 int cds_maskset_last_kernel_ms(const cds_maskset *ms, double *avg_ms, int32_t *launches);

@@ -560,3 +560,44 @@ def test_multi_mask_large_library_equals_dense_batch(cds, oracle):
     s2, m2 = alg.searchLibrary(dense)
     assert np.array_equal(s1, s2) and np.array_equal(m1, m2)
     assert (s1 > 0).sum() > 100
+
+
+# ---- match list: ColorMIPSearch.isMatch + compaction on the device ------------------------------------------------------
+def test_device_match_list_equals_host_filter(cds, oracle, monkeypatch):
+    """cds_search_sparse_matches == scan + the host-side isMatch (oracle.is_match restates ColorMIPSearch.java:42-45) for several
+    thresholds, with an empty mask (skipped like the reference's "empty" masks), in one chunk and in chunks of 3 masks, and
+    with a buffer that is too small (the needed length is reported)."""
+    import ctypes
+    from colormipsearch_amd import capi
+    rects = cds.label_regions(W)
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(10)] + [np.zeros((H, W, 3), dtype=np.uint8)])
+    n_t = 1500                                                   # (more than one 1024-target block per mask)
+    dense = cds.Library(W, H, n_t)
+    dense.generate_synthetic(0xC0FFEE, 31000, 0, n_t, kind=0)
+    dense.upload(7, np.stack([masks[2], np.fliplr(masks[5]).copy()]))
+    sl = cds.SparseLibrary(W, H, n_t, 24000 * n_t + 4 * H * n_t)
+    sl.append_from(dense)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    scores, mir = alg.searchSparseLibrary(sl)
+    sizes = alg.getQuerySizes()
+    assert sizes[10] == 0
+    for pct in (0.0, 0.01, 0.5, 2.0, 50.0):
+        want = [(m, t, int(scores[m, t]), bool(mir[m, t])) for m in range(len(masks)) for t in range(n_t)
+                if sizes[m] > 0 and oracle.is_match(int(scores[m, t]), int(sizes[m]), pct)]
+        for chunk in (None, "3"):
+            if chunk:
+                monkeypatch.setenv("CDS_MATCH_CHUNK_MASKS", chunk)
+            else:
+                monkeypatch.delenv("CDS_MATCH_CHUNK_MASKS", raising=False)
+            m, t, s, mr = alg.searchSparseLibraryMatches(sl, pct)
+            assert list(zip(m.tolist(), t.tolist(), s.tolist(), mr.tolist())) == want, (pct, chunk, len(want), len(m))
+    monkeypatch.delenv("CDS_MATCH_CHUNK_MASKS", raising=False)
+    assert len(want) >= 2                                        # the two planted copies pass even 50 %
+    part = alg.searchSparseLibraryMatches(sl, 0.01, 5, 100)      # a sub-range: target indices are relative to `first`
+    want_p = [(m, t - 5) for m in range(len(masks)) for t in range(5, 105) if sizes[m] > 0 and oracle.is_match(int(scores[m, t]), int(sizes[m]), 0.01)]
+    assert list(zip(part[0].tolist(), part[1].tolist())) == want_p
+    buf = np.zeros((1, 3), dtype=np.int32)
+    n = ctypes.c_int64()
+    rc = capi.load().cds_search_sparse_matches(alg._h, sl._h, 0, n_t, 0.0, buf.ctypes.data_as(ctypes.c_void_p), 1, ctypes.byref(n))
+    n_all = sum(1 for mm in range(len(masks)) for tt in range(n_t) if sizes[mm] > 0 and scores[mm, tt] > 0)
+    assert rc == capi.CDS_ERR_OUT_OF_MEMORY and n.value == n_all

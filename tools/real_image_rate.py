@@ -63,7 +63,34 @@ def main():
             out[name + "_comparisons_per_s"] = round(n / (ms * 1e-3))
         out["equal"] = bool(torch.equal(s_sp, s_de))
         out["scores_first_images"] = [int(v) & 0x7FFFFFFF for v in s_sp[: len(lms)].tolist()]
+        out["groups"] = alg.sparseGroups()
+        lay = out.pop("layout")
+        out["interval_records"] = lay.get("interval_records") if isinstance(lay, dict) else None
         print(json.dumps(out), flush=True)
+    # the three masks (and shifted / flipped variants of them: 8 masks = one group) in ONE mask set: the multi-mask scan
+    # against one launch per mask
+    em = [fx[k] for k in ems]
+    masks8 = np.stack(em + [np.roll(em[0], 6, axis=1), np.roll(em[1], -8, axis=0), np.fliplr(em[2]).copy(), np.roll(em[0], 12, axis=0), np.roll(em[1], 10, axis=1)])
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(masks8, 20, True, None, 0, False, 20, 0.01, 2, rects, context=ctx)
+    res = {}
+    for name, env in (("multi", None), ("per_mask", "0")):
+        if env is None:
+            os.environ.pop("CDS_SPARSE_MULTI", None)
+        else:
+            os.environ["CDS_SPARSE_MULTI"] = env
+        buf = torch.empty(8 * n, dtype=torch.int32, device="cuda")
+        alg.searchSparseLibraryDevice(sl, 0, n, buf.data_ptr())
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(2):
+            alg.searchSparseLibraryDevice(sl, 0, n, buf.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 2
+        res[name] = buf
+        print(json.dumps({"8_masks": name, "groups": alg.sparseGroups(), "ms": round(ms, 3), "comparisons_per_s": round(8 * n / (ms * 1e-3))}), flush=True)
+    os.environ.pop("CDS_SPARSE_MULTI", None)
+    print(json.dumps({"multi_equals_per_mask": bool(torch.equal(res["multi"], res["per_mask"]))}))
 
 
 if __name__ == "__main__":
