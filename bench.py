@@ -227,6 +227,17 @@ def main():
     host_scores = scores.cpu().numpy()
     sc, mir = host_scores & 0x7FFFFFFF, (host_scores >> 31) & 1
     failed = []
+    native_comm = None
+    if use_dist and rank == 0:
+        # the same gather behind the C ABI (cds_comm over this rank's context: ncclCommInitAll + ncclGather through libcds_hip.so,
+        # what a JVM host with all GPUs in one process calls): its scores must be the ones torch.distributed gathered
+        comm = cds.Comm([ctx])
+        ns, nm, _ = comm.searchSparseLibrarySharded([alg], [slib])
+        ok = bool(np.array_equal(ns[0], sc) and np.array_equal(nm[0].astype(np.int64), mir.astype(np.int64)))
+        native_comm = {"entry": "cds_search_sparse_sharded", "contexts": len(comm), "rccl": comm.uses_rccl, "scores_equal": ok}
+        comm.close()
+        if not ok:
+            failed.append("cds_search_sparse_sharded disagrees with the local scan")
 
     # ---- verification of the WHOLE shard: sparse scan == dense-layout scan, window by window; oracle on three slices ----
     offs = slib.image_offsets(0, n)                               # record offsets in the arena (uint64)
@@ -335,6 +346,7 @@ def main():
                 "nonzero_scores": int((sc > 0).sum()),
             },
             "kernel_ms_per_rank": rank_kern_ms,
+            "native_comm": native_comm,
             "verification": verification,
             "roofline": roof,
         }

@@ -104,6 +104,11 @@ SIGNATURES = {
     "cds_search_sparse_device": (_i, [_vp, _vp, _i64, _i64, _vp]),
     "cds_search_sparse_counts": (_i, [_vp, _vp, _i64, _i64, _i32p]),
     "cds_search_sparse_matches": (_i, [_vp, _vp, _i64, _i64, ctypes.c_double, _vp, _i64, _i64p]),
+    "cds_comm_create": (_i, [ctypes.POINTER(_vp), _i32, ctypes.POINTER(_vp)]),
+    "cds_comm_destroy": (None, [_vp]),
+    "cds_comm_size": (_i32, [_vp]),
+    "cds_comm_uses_rccl": (_i32, [_vp]),
+    "cds_search_sparse_sharded": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i64p, _i32p, _u8p]),
     "cds_shapeset_create": (_i, [_vp, _i32, _u8p, _i32, _i32, _i32, _i32, _u8p, _rp, _i32, ctypes.POINTER(_vp)]),
     "cds_shapeset_destroy": (None, [_vp]),
     "cds_shapeset_mask_stats": (_i, [_vp, _i64p, _i64p]),

@@ -113,6 +113,54 @@ class Context:
         return out
 
 
+class Comm:
+    """Several GPUs of one node in ONE process (cds_comm): `contexts[r]` owns shard r of a target-sharded library.
+    `searchSparseLibrarySharded` scans every shard on its own GPU, gathers the score arrays to the first GPU with one RCCL
+    gather and returns them in library order (the reference: partitions of targets, SparkColorMIPSearchProcessor.java:50-73)."""
+
+    def __init__(self, contexts):
+        self._lib = capi.load()
+        self.contexts = list(contexts)
+        arr = (ctypes.c_void_p * len(self.contexts))(*[c._h for c in self.contexts])
+        h = ctypes.c_void_p()
+        capi.check(self._lib.cds_comm_create(arr, len(self.contexts), ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cds_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._lib.cds_comm_size(self._h))
+
+    @property
+    def uses_rccl(self):
+        return bool(self._lib.cds_comm_uses_rccl(self._h))
+
+    def searchSparseLibrarySharded(self, algorithms, sparse_libraries):
+        """algorithms[r] / sparse_libraries[r]: the replicated mask set and the shard of context r.
+        Returns (scores int32[n_masks, n_total], mirrored bool[n_masks, n_total], shard_offsets int64[n + 1])."""
+        n = len(self.contexts)
+        if len(algorithms) != n or len(sparse_libraries) != n:
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "one mask set and one shard per context")
+        ms = (ctypes.c_void_p * n)(*[a._h for a in algorithms])
+        sl = (ctypes.c_void_p * n)(*[s._h for s in sparse_libraries])
+        n_total = sum(len(s) for s in sparse_libraries)
+        n_masks = algorithms[0].n_masks
+        scores = np.zeros((n_masks, n_total), dtype=np.int32)
+        mirrored = np.zeros((n_masks, n_total), dtype=np.uint8)
+        offs = np.zeros(n + 1, dtype=np.int64)
+        capi.check(self._lib.cds_search_sparse_sharded(self._h, ms, sl, capi.as_i64p(offs), capi.as_i32p(scores), capi.as_u8p(mirrored)))
+        return scores, mirrored.astype(bool), offs
+
+
 _default_ctx = {}
 _ctx_lock = threading.Lock()
 

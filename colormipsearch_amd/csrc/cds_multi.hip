@@ -1,0 +1,233 @@
+// cds_multi.hip -- the target-sharded search over the GPUs of one node, behind the C ABI (one host process, n devices).
+//
+// Reference: the only parallel strategy of the reference is data parallelism over target partitions -- host threads in
+// tools cmd/cdsprocess/LocalColorMIPSearchProcessor.java:93-116, Spark partitions whose results are collect()-ed in
+// SparkColorMIPSearchProcessor.java:50-73.  Every (mask, target) score depends on that pair alone, so here the library
+// is cut into n shards, each resident in its own GPU's HBM (a cds_sparse_library created through that GPU's context);
+// the mask set is tiny and replicated (one cds_maskset per GPU).  A search = every GPU scans its shard (asynchronous
+// launches from one host thread), then ONE RCCL gather of the per-target score arrays (int32 score | mirrored << 31) to
+// the first GPU over xGMI, then one copy to the host -- no reduction, no ring, no other collective on the path.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1: the copy already loaded by a torch host, or ROCm's): a single-GPU host
+// does not need it.  A communicator over contexts that share a device (a one-GPU rehearsal of the sharding logic; RCCL
+// refuses duplicate devices) moves the shards' scores with device-to-device copies instead -- same layout, same result.
+#include <dlfcn.h>
+
+#include <cstring>
+#include <set>
+
+#include "cds_internal.hpp"
+
+namespace cds {
+
+// the handful of RCCL entry points this file uses (rccl/rccl.h: ncclCommInitAll :236, ncclCommDestroy :260,
+// ncclGetErrorString :339, ncclGroupStart / ncclGroupEnd, ncclGather :745)
+typedef void *rccl_comm_t;
+struct RcclApi {
+    void *handle = nullptr;
+    int (*CommInitAll)(rccl_comm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(rccl_comm_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Gather)(const void *, void *, size_t, int /*ncclDataType_t*/, int /*root*/, rccl_comm_t, hipStream_t) = nullptr;
+};
+constexpr int kNcclInt32 = 2;  // ncclInt32 (rccl.h ncclDataType_t)
+
+static RcclApi *load_rccl(std::string &why) {
+    static RcclApi api;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (api.handle) return &api;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) {
+        why = std::string("librccl.so.1 cannot be loaded: ") + (dlerror() ? dlerror() : "?");
+        return nullptr;
+    }
+    RcclApi a;
+    a.handle = h;
+    a.CommInitAll = (decltype(a.CommInitAll))dlsym(h, "ncclCommInitAll");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+    a.Gather = (decltype(a.Gather))dlsym(h, "ncclGather");
+    if (!a.CommInitAll || !a.CommDestroy || !a.GetErrorString || !a.GroupStart || !a.GroupEnd || !a.Gather) {
+        why = "librccl.so.1 lacks an entry point (ncclCommInitAll / ncclGather / ...)";
+        return nullptr;
+    }
+    api = a;
+    return &api;
+}
+
+}  // namespace cds
+
+struct cds_comm {
+    std::vector<cds_context *> ctxs;
+    bool rccl = false;
+    cds::RcclApi *api = nullptr;
+    std::vector<cds::rccl_comm_t> comms;
+    // per-shard score buffers of the last search (grown on demand) and the root's gather buffer
+    std::vector<int32_t *> d_send;
+    std::vector<size_t> send_elems;
+    int32_t *d_recv = nullptr;
+    size_t recv_elems = 0;
+    std::mutex mu;
+};
+
+using namespace cds;
+
+extern "C" {
+
+int cds_comm_create(cds_context *const *contexts, int32_t n, cds_comm **out) {
+    if (!contexts || !out) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    if (n <= 0 || n > 64) return fail(CDS_ERR_INVALID_ARGUMENT, "a communicator has 1..64 contexts");
+    std::set<int> devs;
+    for (int i = 0; i < n; i++) {
+        if (!contexts[i]) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL context");
+        devs.insert(contexts[i]->device);
+    }
+    cds_comm *c = new cds_comm();
+    c->ctxs.assign(contexts, contexts + n);
+    c->d_send.assign((size_t)n, nullptr);
+    c->send_elems.assign((size_t)n, 0);
+    const bool distinct = (int)devs.size() == n;
+    if (distinct && !getenv("CDS_COMM_NO_RCCL")) {
+        std::string why;
+        c->api = load_rccl(why);
+        if (!c->api) {
+            delete c;
+            return fail(CDS_ERR_UNSUPPORTED, why);
+        }
+        std::vector<int> devlist;
+        for (int i = 0; i < n; i++) devlist.push_back(contexts[i]->device);
+        c->comms.assign((size_t)n, nullptr);
+        const int rc = c->api->CommInitAll(c->comms.data(), n, devlist.data());
+        if (rc != 0) {
+            const std::string msg = std::string("ncclCommInitAll: ") + c->api->GetErrorString(rc);
+            delete c;
+            return fail(CDS_ERR_HIP, msg);
+        }
+        c->rccl = true;
+    }
+    *out = c;
+    return CDS_OK;
+}
+
+void cds_comm_destroy(cds_comm *c) {
+    if (!c) return;
+    for (size_t i = 0; i < c->ctxs.size(); i++) {
+        hipSetDevice(c->ctxs[i]->device);
+        hipStreamSynchronize(c->ctxs[i]->stream);
+        if (c->d_send[i]) hipFree(c->d_send[i]);
+    }
+    if (c->d_recv) {
+        hipSetDevice(c->ctxs[0]->device);
+        hipFree(c->d_recv);
+    }
+    if (c->rccl)
+        for (rccl_comm_t cm : c->comms)
+            if (cm) c->api->CommDestroy(cm);
+    delete c;
+}
+
+int32_t cds_comm_size(const cds_comm *c) { return c ? (int32_t)c->ctxs.size() : 0; }
+int32_t cds_comm_uses_rccl(const cds_comm *c) { return c && c->rccl ? 1 : 0; }
+
+int cds_search_sparse_sharded(cds_comm *c, const cds_maskset *const *masksets, const cds_sparse_library *const *slibs, int64_t *shard_offsets,
+                              int32_t *scores, uint8_t *mirrored) {
+    if (!c || !masksets || !slibs) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    const int n = (int)c->ctxs.size();
+    int n_masks = -1;
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    int64_t pad = 0;
+    for (int r = 0; r < n; r++) {
+        if (!masksets[r] || !slibs[r]) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL shard");
+        if (masksets[r]->ctx != c->ctxs[(size_t)r] || slibs[r]->ctx != c->ctxs[(size_t)r])
+            return fail(CDS_ERR_INVALID_ARGUMENT, "shard r must have been created through context r of the communicator");
+        if (n_masks < 0) n_masks = masksets[r]->n_masks;
+        if (masksets[r]->n_masks != n_masks) return fail(CDS_ERR_INVALID_ARGUMENT, "the shards' mask sets differ in size (the mask set is replicated)");
+        const int64_t nl = cds_sparse_library_size(slibs[r]);
+        off[(size_t)r + 1] = off[(size_t)r] + nl;
+        pad = std::max(pad, nl);
+    }
+    if (shard_offsets) memcpy(shard_offsets, off.data(), off.size() * sizeof(int64_t));
+    const int64_t n_total = off[(size_t)n];
+    if (n_total == 0) return CDS_OK;
+    if (!scores && !mirrored) return fail(CDS_ERR_INVALID_ARGUMENT, "no output buffer");
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t elems = (size_t)n_masks * (size_t)pad;  // every shard sends [n_masks][pad] (the gather wants equal counts)
+    for (int r = 0; r < n; r++) {
+        CDS_HIP(hipSetDevice(c->ctxs[(size_t)r]->device));
+        if (c->send_elems[(size_t)r] < elems) {
+            if (c->d_send[(size_t)r]) hipFree(c->d_send[(size_t)r]);
+            c->d_send[(size_t)r] = nullptr;
+            c->send_elems[(size_t)r] = 0;
+            CDS_HIP(hipMalloc(&c->d_send[(size_t)r], elems * sizeof(int32_t)));
+            c->send_elems[(size_t)r] = elems;
+        }
+    }
+    CDS_HIP(hipSetDevice(c->ctxs[0]->device));
+    if (c->recv_elems < elems * (size_t)n) {
+        if (c->d_recv) hipFree(c->d_recv);
+        c->d_recv = nullptr;
+        c->recv_elems = 0;
+        CDS_HIP(hipMalloc(&c->d_recv, elems * (size_t)n * sizeof(int32_t)));
+        c->recv_elems = elems * (size_t)n;
+    }
+    // 1. every GPU scans its own shard: asynchronous launches, all devices busy at once.  Shard r writes mask m's scores
+    //    at d_send[r] + m * n_local (its own row pitch); the padding is never read back
+    for (int r = 0; r < n; r++) {
+        const int64_t nl = off[(size_t)r + 1] - off[(size_t)r];
+        if (nl == 0) continue;
+        const int rc = cds_search_sparse_device(masksets[r], slibs[r], 0, nl, c->d_send[(size_t)r]);
+        if (rc) return rc;
+    }
+    // 2. ONE gather to the first GPU: RCCL over xGMI (each peer -> root transfer rides its own link), stream-ordered after
+    //    the scans; contexts sharing a device (rehearsal) copy device-to-device instead
+    if (c->rccl) {
+        int rc = c->api->GroupStart();
+        for (int r = 0; r < n && rc == 0; r++) {
+            hipSetDevice(c->ctxs[(size_t)r]->device);
+            rc = c->api->Gather(c->d_send[(size_t)r], r == 0 ? c->d_recv : nullptr, elems, kNcclInt32, 0, c->comms[(size_t)r], c->ctxs[(size_t)r]->stream);
+        }
+        const int rc2 = c->api->GroupEnd();
+        if (rc == 0) rc = rc2;
+        if (rc != 0) return fail(CDS_ERR_HIP, std::string("ncclGather: ") + c->api->GetErrorString(rc));
+    } else {
+        for (int r = 0; r < n; r++) {
+            CDS_HIP(hipSetDevice(c->ctxs[(size_t)r]->device));
+            CDS_HIP(hipStreamSynchronize(c->ctxs[(size_t)r]->stream));
+            CDS_HIP(hipMemcpyAsync(c->d_recv + (size_t)r * elems, c->d_send[(size_t)r], elems * sizeof(int32_t), hipMemcpyDeviceToDevice, c->ctxs[0]->stream));
+        }
+    }
+    // 3. root -> host, then into library order: scores[m * n_total + offset_r + t]
+    CDS_HIP(hipSetDevice(c->ctxs[0]->device));
+    std::vector<int32_t> packed(elems * (size_t)n);
+    CDS_HIP(hipMemcpyAsync(packed.data(), c->d_recv, packed.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->ctxs[0]->stream));
+    CDS_HIP(hipStreamSynchronize(c->ctxs[0]->stream));
+    for (int r = 1; r < n; r++) {  // (the peers' streams: their send buffers are free again)
+        CDS_HIP(hipSetDevice(c->ctxs[(size_t)r]->device));
+        CDS_HIP(hipStreamSynchronize(c->ctxs[(size_t)r]->stream));
+    }
+    for (int r = 0; r < n; r++) {
+        const int64_t nl = off[(size_t)r + 1] - off[(size_t)r];
+        for (int m = 0; m < n_masks; m++) {
+            const int32_t *src = packed.data() + (size_t)r * elems + (size_t)m * (size_t)nl;
+            const size_t dst = (size_t)m * (size_t)n_total + (size_t)off[(size_t)r];
+            for (int64_t t = 0; t < nl; t++) {
+                if (scores) scores[dst + (size_t)t] = src[t] & 0x7fffffff;
+                if (mirrored) mirrored[dst + (size_t)t] = (uint8_t)((uint32_t)src[t] >> 31);
+            }
+        }
+    }
+    return CDS_OK;
+}
+
+}  // extern "C"

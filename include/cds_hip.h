@@ -211,6 +211,24 @@ typedef struct cds_match {
 int cds_search_sparse_matches(const cds_maskset *ms, const cds_sparse_library *slib, int64_t first, int64_t count,
                               double pct_positive_pixels, cds_match *matches, int64_t capacity, int64_t *n_matches);
 
+/* ---- several GPUs of one node: the target-sharded search --------------------------------------------------------
+ * The reference's only parallel strategy is data parallelism over target partitions (host threads:
+ * tools cmd/cdsprocess/LocalColorMIPSearchProcessor.java:93-116; Spark partitions + collect():
+ * SparkColorMIPSearchProcessor.java:50-73).  Here: one cds_context per GPU, the library cut into one cds_sparse_library
+ * per GPU (shard r through context r), the mask set replicated (one cds_maskset per GPU, same masks and parameters).
+ * cds_search_sparse_sharded scans every shard on its own GPU at the same time, gathers the per-target score arrays to the
+ * first GPU with ONE RCCL gather over xGMI and returns them in library order:
+ *   scores[m * n_total + shard_offsets[r] + t], t = image t of shard r;  shard_offsets[n + 1] (optional output).
+ * RCCL (librccl.so.1) is bound at run time by cds_comm_create; contexts that share a device (a one-GPU rehearsal; RCCL
+ * refuses duplicate devices) are served by device-to-device copies -- cds_comm_uses_rccl tells which. */
+typedef struct cds_comm cds_comm;
+int cds_comm_create(cds_context *const *contexts, int32_t n, cds_comm **out);
+void cds_comm_destroy(cds_comm *comm);
+int32_t cds_comm_size(const cds_comm *comm);
+int32_t cds_comm_uses_rccl(const cds_comm *comm);
+int cds_search_sparse_sharded(cds_comm *comm, const cds_maskset *const *masksets, const cds_sparse_library *const *slibs,
+                              int64_t *shard_offsets, int32_t *scores, uint8_t *mirrored);
+
 /* Average device time (ms) of the scan kernel launches of the last cds_search*_ call on this mask
  * set, measured with hipEvents on the launch stream, and the number of launches. */
 int cds_maskset_last_kernel_ms(const cds_maskset *ms, double *avg_ms, int32_t *launches);

@@ -18,6 +18,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "cds_hip.h"
@@ -183,10 +184,46 @@ public:
         mirrored.assign((size_t)count, 0);
         check(cds_search_sparse(ms_, lib.handle(), first, count, scores.data(), mirrored.data()));
     }
+    // scan + ColorMIPSearch.isMatch + compaction on the device: the pairs findAllColorDepthMatches keeps (mask, target, score | mirrored << 31)
+    std::vector<cds_match> searchLibraryMatches(const SparseLibrary &lib, int64_t first, int64_t count, double pctPositivePixels) const {
+        std::vector<cds_match> out((size_t)std::max<int64_t>(1024, count / 64));
+        int64_t n = 0;
+        int rc = cds_search_sparse_matches(ms_, lib.handle(), first, count, pctPositivePixels, out.data(), (int64_t)out.size(), &n);
+        if (rc == CDS_ERR_OUT_OF_MEMORY && n > (int64_t)out.size()) {   // the list is longer than the guess: once more with the exact size
+            out.resize((size_t)n);
+            rc = cds_search_sparse_matches(ms_, lib.handle(), first, count, pctPositivePixels, out.data(), (int64_t)out.size(), &n);
+        }
+        check(rc);
+        out.resize((size_t)n);
+        return out;
+    }
 private:
     ImageArray query_;
     cds_maskset *ms_ = nullptr;
     int32_t size_ = 0;
+};
+
+// The target-sharded search over the GPUs of one node: contexts[r] owns shard r (cds_comm; one RCCL gather per search).
+class ShardedSearch {
+public:
+    explicit ShardedSearch(const std::vector<cds_context *> &contexts) { check(cds_comm_create(contexts.data(), (int32_t)contexts.size(), &comm_)); }
+    ~ShardedSearch() { cds_comm_destroy(comm_); }
+    ShardedSearch(const ShardedSearch &) = delete;
+    ShardedSearch &operator=(const ShardedSearch &) = delete;
+    int size() const { return cds_comm_size(comm_); }
+    bool usesRccl() const { return cds_comm_uses_rccl(comm_) != 0; }
+    // masksets[r] / shards[r] were created through contexts[r]; scores[m * total + offsets[r] + t]
+    void search(const std::vector<const cds_maskset *> &masksets, const std::vector<const cds_sparse_library *> &shards, int nMasks,
+                std::vector<int64_t> &offsets, std::vector<int32_t> &scores, std::vector<uint8_t> &mirrored) const {
+        offsets.assign(shards.size() + 1, 0);
+        int64_t total = 0;
+        for (const cds_sparse_library *s : shards) total += cds_sparse_library_size(s);
+        scores.assign((size_t)nMasks * (size_t)total, 0);
+        mirrored.assign((size_t)nMasks * (size_t)total, 0);
+        check(cds_search_sparse_sharded(comm_, masksets.data(), shards.data(), offsets.data(), scores.data(), mirrored.data()));
+    }
+private:
+    cds_comm *comm_ = nullptr;
 };
 
 class Shape2DMatchColorDepthSearchAlgorithm : public ColorDepthSearchAlgorithm<ShapeMatchScore> {

@@ -45,3 +45,40 @@ def test_sharded_library_search_single_rank(oracle):
     finally:
         shard.ctx.reset_stream()
         dist.destroy_process_group()
+
+
+def test_native_sharded_search_through_the_c_abi(oracle):
+    """cds_comm / cds_search_sparse_sharded (one process, one context per shard): (a) one context = the RCCL communicator
+    (ncclCommInitAll + ncclGather with one rank), (b) three contexts on the one GPU = uneven shards through the
+    device-to-device rehearsal path; both equal the single search over the whole library and the oracle."""
+    from colormipsearch_amd import cds
+    rects = cds.label_regions(W)
+    n = 41
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(3)])
+    targets = np.stack([oracle.synth_image(0xC0FFEE, 900 + i, 0) for i in range(n - 2)] + [masks[1], np.fliplr(masks[2]).copy()])
+
+    def shard_of(ctx, imgs):
+        sl = cds.SparseLibrary(W, H, max(1, len(imgs)), int((imgs.max(axis=3) > 0).sum()) + 4 * H * len(imgs) + 64, context=ctx)
+        if len(imgs):
+            sl.append(imgs)
+        return sl
+
+    want_s, want_m = [], []
+    for m in range(3):
+        ws, wm = oracle.PixelMatchQuery(masks[m], 20, 20, 0.01, 2, True, rects).scan(targets, n_threads=8)
+        want_s.append(ws), want_m.append(wm.astype(bool))
+    want_s, want_m = np.stack(want_s), np.stack(want_m)
+    for bounds in ([0, n], [0, 17, 17, n], [0, 5, 30, n]):      # 1 shard (RCCL); 3 shards, one of them empty; 3 uneven shards
+        k = len(bounds) - 1
+        ctxs = [cds.Context(0) for _ in range(k)]
+        comm = cds.Comm(ctxs)
+        assert len(comm) == k and comm.uses_rccl == (k == 1)
+        algs = [cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects, context=c) for c in ctxs]
+        libs = [shard_of(ctxs[r], targets[bounds[r]:bounds[r + 1]]) for r in range(k)]
+        s, mir, offs = comm.searchSparseLibrarySharded(algs, libs)
+        assert offs.tolist() == bounds
+        assert np.array_equal(s, want_s) and np.array_equal(mir, want_m), bounds
+        s2, _, _ = comm.searchSparseLibrarySharded(algs, libs)   # (the buffers are reused)
+        assert np.array_equal(s2, want_s)
+        comm.close()
+    assert want_s.max() > 0
