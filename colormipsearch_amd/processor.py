@@ -227,6 +227,32 @@ def _rank_groups(outer, code, key_hashes, score, seq, n_outer):
     return grank[grp], irank
 
 
+def normalizedScoresArray(pixelMatchScore, shapeScore, maxPixelMatch, maxShapeScore):
+    """GradientAreaGapUtils.calculateNormalizedScore (API/cds/GradientAreaGapUtils.java:219-235) over arrays: the same double
+    operations in the same order as cds_normalized_score (element-wise IEEE division / multiplication / min / max)."""
+    pix = np.asarray(pixelMatchScore, dtype=np.float64)
+    shape = np.asarray(shapeScore, dtype=np.float64)
+    mp = np.broadcast_to(np.asarray(maxPixelMatch, dtype=np.float64), pix.shape)
+    msh = np.broadcast_to(np.asarray(maxShapeScore, dtype=np.float64), pix.shape)
+    plain = (pix == 0) | (mp == 0) | (shape < 0) | (msh <= 0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        bounded = np.minimum(np.maximum((shape / msh) * 2.5, 0.002), 1.0)
+        out = (pix / mp) / bounded * 100
+    return np.where(plain, pix, out)
+
+
+def normalizeTable(table: "MatchTable"):
+    """CalculateGradientScoresCmd.normalizeScores (:616-645) for all masks of a table at once (normalizedScore as float32)."""
+    grad = table.gradScores()
+    masks, code = np.unique(table.maskIndex, return_inverse=True)
+    max_pix = np.full(len(masks), -1, dtype=np.int64)
+    max_grad = np.full(len(masks), -1, dtype=np.int64)
+    np.maximum.at(max_pix, code, table.matchingPixels.astype(np.int64))
+    np.maximum.at(max_grad, code, grad)
+    table.normalizedScore = normalizedScoresArray(table.matchingPixels, grad, max_pix[code], max_grad[code]).astype(np.float32)
+    return table
+
+
 class GpuColorMIPSearchProcessor:
     """masks: uint8[n_masks,H,W,3]; the targets live in a `cds.Library` (+ `targets` metadata, one NeuronInfo per slot).
 
@@ -246,8 +272,14 @@ class GpuColorMIPSearchProcessor:
             count = (len(sparse_library) if sparse_library is not None else library.capacity) - self.first
         self.count = int(count)
         self.dense_slots = None if dense_slots is None else np.asarray(dense_slots, dtype=np.int64)
-        self.targets = targets or [NeuronInfo(str(i), f"line{i}", f"sample{i}") for i in range(self.count)]
-        assert len(self.targets) == self.count
+        self._targets = targets            # (default metadata -- one line and one sample per target -- is made on first use:
+        assert targets is None or len(targets) == self.count   # a million-target library does not need a million records to be scanned)
+
+    @property
+    def targets(self):
+        if self._targets is None:
+            self._targets = [NeuronInfo(str(i), f"line{i}", f"sample{i}") for i in range(self.count)]
+        return self._targets
 
     def _scan(self, alg):
         if self.sparse_library is not None:
@@ -343,14 +375,47 @@ class GpuColorMIPSearchProcessor:
         gap, high, _ = alg.scoreLibraryPairs(self.library, table.maskIndex.astype(np.int32), self._slots(table.targetIndex))
         table.gradientAreaGap[:] = gap
         table.highExpressionArea[:] = high
-        grad = table.gradScores()
-        for m in np.unique(table.maskIndex):                     # CalculateGradientScoresCmd.normalizeScores (:616-645)
-            rows = np.flatnonzero(table.maskIndex == m)
-            max_pix = max(-1, int(table.matchingPixels[rows].max()))
-            max_grad = max(-1, int(grad[rows].max()))
-            table.normalizedScore[rows] = [np.float32(cds.calculateNormalizedScore(int(p), int(g), max_pix, max_grad))
-                                           for p, g in zip(table.matchingPixels[rows], grad[rows])]
-        return table
+        return normalizeTable(table)                             # CalculateGradientScoresCmd.normalizeScores (:616-645)
+
+    def calculateGradientScoresBatchedTable(self, masks, table: MatchTable, load_range, queryThreshold, mirrorMask=True, roiMask=None,
+                                            excludedRegions=cds.label_regions, batch=8192, library=None) -> MatchTable:
+        """calculateGradientScoresTable for a library far larger than the dense slots the shape scorer reads (BASELINE configs[4]:
+        1,024 masks x top-500 of a 1 M-target library resident as signal-pixel records): the table's pairs are visited in windows
+        of `batch` consecutive target indices; `load_range(lib, first_target, count)` makes targets first_target..+count-1
+        resident WITH their gradient / zgap variants in slots 0..count-1 of `lib` (regenerated on the device for a synthetic
+        library: `lambda lib, f, c: lib.generate_synthetic(seed, f, 0, c, kind=0, with_variants=True)`; ingested from a shard
+        or from files otherwise), one `cds_gradscore` launch per window, per-mask normalisation on the host
+        (CalculateGradientScoresCmd.java:541-586, 616-645).  The kernel time of the launches is left in
+        `self.last_gradscore = {kernel_ms, launches, pairs}`."""
+        n = len(table)
+        table.gradientAreaGap = np.full(n, -1, dtype=np.int64)
+        table.highExpressionArea = np.full(n, -1, dtype=np.int64)
+        table.normalizedScore = np.zeros(n, dtype=np.float32)
+        self.last_gradscore = {"kernel_ms": 0.0, "launches": 0, "pairs": 0}
+        if n == 0:
+            return table
+        ctx = library.ctx if library is not None else (self.library.ctx if self.library is not None else self.sparse_library.ctx)
+        alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, queryThreshold, mirrorMask, roiMask, excludedRegions, context=ctx)
+        lib = library if library is not None else cds.Library(alg.width, alg.height, int(batch), context=ctx)
+        batch = min(int(batch), lib.capacity)
+        order = np.argsort(table.targetIndex, kind="stable")
+        tsorted = table.targetIndex[order]
+        limit = self.first + self.count
+        w0 = (int(tsorted[0]) // batch) * batch
+        while w0 <= int(tsorted[-1]):
+            lo, hi = np.searchsorted(tsorted, w0), np.searchsorted(tsorted, w0 + batch)
+            if hi > lo:
+                rows = order[lo:hi]
+                load_range(lib, w0, min(batch, limit - w0))
+                gap, high, _ = alg.scoreLibraryPairs(lib, table.maskIndex[rows].astype(np.int32), table.targetIndex[rows] - w0)
+                table.gradientAreaGap[rows] = gap
+                table.highExpressionArea[rows] = high
+                ms, launches = alg.lastKernelMs()
+                self.last_gradscore["kernel_ms"] += ms * launches
+                self.last_gradscore["launches"] += launches
+                self.last_gradscore["pairs"] += len(rows)
+            w0 += batch
+        return normalizeTable(table)
 
     def calculateGradientScoresFromFilesTable(self, masks, table: MatchTable, target_files, gradient_files, zgap_files, queryThreshold,
                                               mirrorMask=True, roiMask=None, excludedRegions=cds.label_regions, batch=256, threads=8,
@@ -404,14 +469,7 @@ class GpuColorMIPSearchProcessor:
                 gap, high, _ = alg.scoreLibraryPairs(lib, table.maskIndex[rows].astype(np.int32), slots)
                 table.gradientAreaGap[rows] = gap
                 table.highExpressionArea[rows] = high
-        grad = table.gradScores()
-        for m in np.unique(table.maskIndex):                     # CalculateGradientScoresCmd.normalizeScores (:616-645)
-            rows = np.flatnonzero(table.maskIndex == m)
-            max_pix = max(-1, int(table.matchingPixels[rows].max()))
-            max_grad = max(-1, int(grad[rows].max()))
-            table.normalizedScore[rows] = [np.float32(cds.calculateNormalizedScore(int(p), int(g), max_pix, max_grad))
-                                           for p, g in zip(table.matchingPixels[rows], grad[rows])]
-        return table
+        return normalizeTable(table)                             # CalculateGradientScoresCmd.normalizeScores (:616-645)
 
     # ---- gradientScores ---------------------------------------------------------------------------
     def selectBestMatches(self, matches: List[CDMatch], topLineMatches, topSamplesPerLine, topMatchesPerSample) -> List[CDMatch]:

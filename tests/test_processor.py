@@ -118,6 +118,50 @@ def test_tied_groups_follow_java_hashmap_order():
     assert got == [2, 5, 1, 4]
 
 
+def test_vectorised_normalisation_equals_the_scalar_function():
+    """normalizedScoresArray == cds_normalized_score (GradientAreaGapUtils.java:219-235) element by element, including the
+    branches that return the pixel score unchanged (zero scores, missing shape score, non-positive maxima)."""
+    from colormipsearch_amd import cds
+    rng = np.random.default_rng(3)
+    pix = np.r_[rng.integers(0, 5000, size=400), [0, 0, 7, 7, 7, 7]]
+    shape = np.r_[rng.integers(-1, 200000, size=400), [5, -1, -1, 0, 9, 9]]
+    mp = np.r_[rng.integers(1, 5000, size=400), [10, 10, 10, 10, 0, 10]]
+    ms = np.r_[rng.integers(1, 200000, size=400), [10, 10, 10, 10, 10, -1]]
+    got = P.normalizedScoresArray(pix, shape, mp, ms)
+    want = np.array([cds.calculateNormalizedScore(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(pix, shape, mp, ms)])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_batched_gradient_scores_equal_the_resident_ones(oracle):
+    """calculateGradientScoresBatchedTable (targets regenerated window by window into a few dense slots) == the same pairs
+    scored over a library that holds every target with its variants."""
+    from colormipsearch_amd import cds
+    n_masks, n_t = 3, 50
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(n_masks)])
+    lib = cds.Library(W, H, n_t)
+    lib.generate_synthetic(0xC0FFEE, 7000, 0, n_t, kind=0, with_variants=True)
+    slib = cds.SparseLibrary(W, H, n_t, 40000 * n_t)
+    slib.append_from(lib)
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(True, 20, 1, 2, cds.label_regions)
+    proc = P.GpuColorMIPSearchProcessor(cds.ColorMIPSearch(0.0, 20, provider), lib, None, sparse_library=slib)
+    table = proc.findAllColorDepthMatchesTable(masks)
+    assert len(table) > 20
+    full = proc.calculateGradientScoresTable(masks, table.take(np.arange(len(table))), 20)
+    small = cds.Library(W, H, 16)
+    calls = []
+
+    def load(dst, first, count):
+        calls.append((first, count))
+        dst.generate_synthetic(0xC0FFEE, 7000 + first, 0, count, kind=0, with_variants=True)
+
+    batched = proc.calculateGradientScoresBatchedTable(masks, table.take(np.arange(len(table))), load, 20, batch=16, library=small)
+    assert np.array_equal(batched.gradientAreaGap, full.gradientAreaGap) and np.array_equal(batched.highExpressionArea, full.highExpressionArea)
+    assert np.array_equal(batched.normalizedScore, full.normalizedScore)
+    assert (batched.gradientAreaGap >= 0).all() and proc.last_gradscore["pairs"] == len(table)
+    assert all(f % 16 == 0 and f + c <= n_t for f, c in calls) and calls[-1] == (48, 2)
+
+
 @pytest.mark.gpu
 def test_pipeline_equals_oracle_pipeline(oracle):
     from colormipsearch_amd import cds

@@ -49,10 +49,11 @@ def pmc_rows(dirs):
     return out
 
 
-def pick(seq, name, last=None):
-    """dispatches of kernel `name` with the class's (= the largest) grid, optionally only the last `last` of them"""
+def pick(seq, name, last=None, every=False):
+    """dispatches of kernel `name` with the class's (= the largest) grid -- or every one of them --, optionally only the
+    last `last`"""
     sel = [x for x in seq if name in x[1]]
-    if sel:
+    if sel and not every:
         g = max(x[3] for x in sel)
         sel = [x for x in sel if x[3] == g]
     return sel[-last:] if last else sel
@@ -65,18 +66,44 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--targets", type=int, default=1 << 20)
     ap.add_argument("--stage", type=int, default=8192)
-    ap.add_argument("--pairs", type=int, default=16000)
+    ap.add_argument("--pairs", type=int, default=0, help="pairs scored by all gradscore launches of the `full` command (0: masks x 500 + 1)")
+    ap.add_argument("--multi-masks", type=int, default=1024)
+    ap.add_argument("--extra-multi", type=int, default=0, help="comparisons of multi-mask launches outside aux.mask_batch")
     ap.add_argument("--write-json", default=os.path.join(ROOT, "profiles", "scan_pmc.json"))
     a = ap.parse_args()
     o = a.out_dir
     lines = []
     classes = {}
 
-    def add_class(key, kernel, cmd_tag, unit_name, units_per_dispatch, last=None, desc=""):
+    def add_class(key, kernel, cmd_tag, unit_name, units_per_dispatch, last=None, desc="", units_total=None):
+        """units_total: the class is ALL dispatches of the kernel in the command, which together process that many units
+        (launches of different sizes: per-unit figures = sums over the dispatches / units_total)."""
         tr = [(i, r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, int(r["Grid_Size_X"]))
               for i, r in enumerate(trace_rows(os.path.join(o, "trace_" + cmd_tag)))]
-        sel = pick(tr, kernel, last)
+        sel = pick(tr, kernel, last, every=units_total is not None)
         if not sel:
+            return
+        if units_total is not None:
+            tot_ms = sum(x[2] for x in sel)
+            cls = {"kernel": sel[0][1][:120], "command": cmd_tag, "dispatches": len(sel), unit_name + "_total": units_total, "total_ms": tot_ms,
+                   "per_" + unit_name[:-1]: {}}
+            lines.append(f"== class {key}: {desc}")
+            lines.append(f"   kernel {cls['kernel']}")
+            lines.append(f"   rocprofv3 --kernel-trace: {len(sel)} dispatches (all sizes), {tot_ms:.3f} ms together for {units_total} {unit_name} -> {units_total / tot_ms / 1e3:.2f} M {unit_name}/s")
+            pm = pmc_rows(glob.glob(os.path.join(o, "pmc_" + cmd_tag + "_*")))
+            per = cls["per_" + unit_name[:-1]]
+            for c in sorted(pm):
+                sq = pick(pm[c], kernel, last, every=True)
+                if not sq:
+                    continue
+                tot = sum(x[2] for x in sq)
+                per[c] = tot / units_total
+                lines.append(f"   {c:24s} sum over {len(sq):5d} dispatches {tot:20.1f}   per {unit_name[:-1]} {tot / units_total:12.4f}")
+            if "FETCH_SIZE" in per:
+                per["hbm_bytes"] = 2.0 * per["FETCH_SIZE"] * 1024.0
+                gbs = per["hbm_bytes"] * units_total / (tot_ms * 1e-3) / 1e9
+                lines.append(f"   HBM traffic = 2 x FETCH_SIZE = {per['hbm_bytes']:.2f} B per {unit_name[:-1]} = {gbs:.0f} GB/s at the traced duration = {gbs / 8000:.3f} of the 8 TB/s peak")
+            classes[key] = cls
             return
         ms = [x[2] for x in sel]
         cls = {"kernel": sel[0][1][:120], "command": cmd_tag, "dispatches": len(sel), unit_name + "_per_dispatch": units_per_dispatch,
@@ -103,10 +130,10 @@ def main():
     add_class("sparse_scan_headline", "sparse_scan_kernel", "headline", "targets", a.targets, last=a.steps,
               desc=f"the {a.steps} timed 1-mask scans of the resident library (bench.py `value`)")
     add_class("dense_scan", "cds::scan_kernel", "headline", "targets", a.stage, desc="the dense-layout kernel over the verification windows")
-    add_class("sparse_multi", "sparse_multi_kernel", "full", "comparisons", None or 1, desc="aux.mask_batch (units filled in below)")
-    add_class("gradscore_list", "gradscore_list_kernel", "full", "pairs", a.pairs, desc="aux.gradient_scores")
-    if "sparse_multi" in classes:   # comparisons per dispatch = masks of the group x targets: not in the trace; report per dispatch
-        classes["sparse_multi"]["note"] = "per-dispatch figures; divide by (masks per group x targets) for per-comparison values"
+    add_class("sparse_multi", "sparse_multi_kernel", "full", "comparisons", None, units_total=a.multi_masks * a.targets + a.extra_multi,
+              desc=f"aux.mask_batch + the scans aux.gradient_scores' selection needs: every multi-mask launch of the command ({a.multi_masks} masks x {a.targets} targets)")
+    add_class("gradscore_list", "gradscore_list_kernel", "full", "pairs", None, units_total=a.pairs or (a.multi_masks * 500 + 1),
+              desc="aux.gradient_scores (one launch per window of targets) + the one fixture pair")
     for tagc in ("headline", "full"):
         for f in glob.glob(os.path.join(o, "trace_" + tagc, "**", "*kernel_stats.csv"), recursive=True):
             lines.append(f"== rocprofv3 --kernel-trace --stats (kernel_stats.csv), command `{tagc}` -- ALL dispatches of the run, mixed sizes")
