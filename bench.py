@@ -150,7 +150,7 @@ def main():
     stage_n = min(args.stage, n)
     dense = cds.Library(W, H, stage_n, context=ctx)             # dense staging slots (packed RGB rows)
     cap_px = (W * H + 4 * H) * n if args.kind == 1 else 24000 * n + 4_000_000
-    slib = cds.SparseLibrary(W, H, n, cap_px, context=ctx)      # the resident library
+    slib = cds.SparseLibrary(W, H, n, cap_px, context=ctx, density_limit=2.0 if args.kind == 1 else None)      # the resident library
     t0 = time.time()
     for first in range(0, n, stage_n):                          # this rank's shard: library indices rank*n + [0, n)
         c = min(stage_n, n - first)

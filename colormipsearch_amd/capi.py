@@ -90,6 +90,7 @@ SIGNATURES = {
     "cds_sparse_library_append": (_i, [_vp, _vp, _i64, _i64]),
     "cds_sparse_library_append_host": (_i, [_vp, _i64, _u8p]),
     "cds_sparse_library_layout": (_i, [_vp, _i32p, _i32p]),
+    "cds_sparse_library_set_density_limit": (_i, [_vp, ctypes.c_double]),
     "cds_sparse_library_size": (_i64, [_vp]),
     "cds_sparse_library_pixels": (_i64, [_vp]),
     "cds_sparse_library_clear": (_i, [_vp]),
@@ -110,6 +111,7 @@ SIGNATURES = {
     "cds_comm_uses_rccl": (_i32, [_vp]),
     "cds_search_sparse_sharded": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i64p, _i32p, _u8p]),
     "cds_shapeset_create": (_i, [_vp, _i32, _u8p, _i32, _i32, _i32, _i32, _u8p, _rp, _i32, ctypes.POINTER(_vp)]),
+    "cds_shapeset_create_bordered": (_i, [_vp, _i32, _u8p, _i32, _i32, _i32, _i32, _i32, _u8p, _rp, _i32, ctypes.POINTER(_vp)]),
     "cds_shapeset_destroy": (None, [_vp]),
     "cds_shapeset_mask_stats": (_i, [_vp, _i64p, _i64p]),
     "cds_gradscore": (_i, [_vp, _vp, _i64, _i32p, _i64p, _i64p, _i64p, _u8p]),

@@ -254,7 +254,9 @@ class SparseLibrary:
     """A resident shard of target MIPs kept as signal-pixel lists (cds_sparse_library): ~4 % of the dense bytes,
     for searches that need the pixel-match score only (`searchSparseLibrary*`)."""
 
-    def __init__(self, width, height, capacity_images, capacity_pixels, context=None):
+    def __init__(self, width, height, capacity_images, capacity_pixels, context=None, density_limit=None):
+        """density_limit: images averaging more signal pixels than this share of the frame are refused at append time (default
+        0.25: above it the dense layout's scan is faster); pass e.g. 2.0 to accept anything."""
         self.ctx = context or default_context()
         self._lib = capi.load()
         self.width, self.height = int(width), int(height)
@@ -266,6 +268,11 @@ class SparseLibrary:
         ns, sw = ctypes.c_int32(), ctypes.c_int32()
         capi.check(self._lib.cds_sparse_library_layout(self._h, ctypes.byref(ns), ctypes.byref(sw)))
         self.n_strips, self.strip_width = ns.value, sw.value
+        if density_limit is not None:
+            self.set_density_limit(density_limit)
+
+    def set_density_limit(self, max_signal_fraction):
+        capi.check(self._lib.cds_sparse_library_set_density_limit(self._h, float(max_signal_fraction)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -670,9 +677,11 @@ class PixelMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
 
 class Shape2DMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
     """API/cds/Shape2DMatchColorDepthSearchAlgorithm.java:23-247 for one mask (or a batch), prepared as
-    ColorDepthSearchAlgorithmProviderFactory.java:91-125 does (queryBorderSize 0 only)."""
+    ColorDepthSearchAlgorithmProviderFactory.java:91-125 does; `queryBorderSize` is the frame every fold over the query skips
+    (Factory:103, API/imageprocessing/LImage.java:89-113)."""
 
-    def __init__(self, queryImage, queryThreshold, mirrorQuery, roiMask=None, excludedRegions=None, context=None):
+    def __init__(self, queryImage, queryThreshold, mirrorQuery, roiMask=None, excludedRegions=None, context=None, queryBorderSize=0):
+        self.queryBorderSize = int(queryBorderSize or 0)
         self.ctx = context or default_context()
         self._lib = capi.load()
         self._masks = capi.rgb_images(queryImage)
@@ -692,8 +701,8 @@ class Shape2DMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
             self._roi = roi
             roi_p = capi.as_u8p(roi)
         h = ctypes.c_void_p()
-        capi.check(self._lib.cds_shapeset_create(self.ctx._h, n, capi.as_u8p(self._masks), W, H, self.queryThreshold,
-                                                 int(self.mirrorQuery), roi_p, r, nr, ctypes.byref(h)))
+        capi.check(self._lib.cds_shapeset_create_bordered(self.ctx._h, n, capi.as_u8p(self._masks), W, H, self.queryThreshold,
+                                                          self.queryBorderSize, int(self.mirrorQuery), roi_p, r, nr, ctypes.byref(h)))
         self._h = h
 
     def close(self):
@@ -716,15 +725,25 @@ class Shape2DMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
     def getQueryImage(self):
         return self._cleared()
 
+    def _inner_signal(self, mask_index=0):
+        """query pixels above the threshold that a fold visits: inside the border frame (LImage.java:89-113)"""
+        sig = self._cleared(mask_index).max(axis=2) > self.queryThreshold
+        b = self.queryBorderSize
+        if b > 0:
+            inner = np.zeros_like(sig)
+            inner[b:self.height - b, b:self.width - b] = True
+            sig &= inner
+        return sig
+
     def getQuerySize(self, mask_index=0):
-        return int((self._cleared(mask_index).max(axis=2) > self.queryThreshold).sum())
+        return int(self._inner_signal(mask_index).sum())
 
     def getQueryFirstPixelIndex(self):
-        nz = np.flatnonzero((self._cleared().max(axis=2) > self.queryThreshold).reshape(-1))
+        nz = np.flatnonzero(self._inner_signal().reshape(-1))
         return int(nz[0]) if len(nz) else -1
 
     def getQueryLastPixelIndex(self):
-        nz = np.flatnonzero((self._cleared().max(axis=2) > self.queryThreshold).reshape(-1))
+        nz = np.flatnonzero(self._inner_signal().reshape(-1))
         return int(nz[-1]) if len(nz) else -1
 
     def getRequiredTargetVariantTypes(self):
@@ -821,10 +840,8 @@ class _ShapeMatchProvider(ColorDepthSearchAlgorithmProvider):
         return self._defaults
 
     def createColorDepthSearchAlgorithm(self, queryImage, queryThreshold, queryBorderSize, cdsParams):
-        if queryBorderSize:
-            raise CdsError(capi.CDS_ERR_UNSUPPORTED, "queryBorderSize != 0 is not supported")
         return Shape2DMatchColorDepthSearchAlgorithm(queryImage, queryThreshold, cdsParams.getBoolParam("mirrorMask", self._m),
-                                                     self._roi, self._regions, context=self._ctx)
+                                                     self._roi, self._regions, context=self._ctx, queryBorderSize=queryBorderSize)
 
 
 class ColorDepthSearchAlgorithmProviderFactory:

@@ -684,6 +684,7 @@ struct PrepParams {
     const uint8_t *masks;  // [n][H][3W]
     const uint8_t *roi;    // [H][W] or NULL
     int W, H, wp, n, mirror, nrects;
+    int border;            // queryBorderSize: the frame every fold of the reference skips (LImage.java:89-113)
     cds_rect rects[CDS_MAX_RECTS];
     int k60, k20;
     const int *hw60, *hw20;
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(256) void prep_plane_kernel(PrepParams p) {
     const uint8_t *s = p.masks + ((size_t)m * p.H + y) * 3 * p.W + 3 * x;
     int r = s[0], g = s[1], b = s[2];
     if (dev_in_rects(p.rects, p.nrects, x, y)) r = g = b = 0;
-    const int qm = dev_gray_nogamma(r, g, b) > 2;                                   // Factory:108
+    const int qm0 = dev_gray_nogamma(r, g, b) > 2;                                  // Factory:108
     int qh = 0;
     if (bx1 > bx0 && x >= bx0 - p.k60 && x < bx1 + p.k60 && y >= by0 - p.k60 && y < by1 + p.k60) {
         const uint8_t *hd = p.hd + ((size_t)m * 7) * p.H * p.W + x;
@@ -782,7 +783,13 @@ __global__ __launch_bounds__(256) void prep_plane_kernel(PrepParams p) {
             qh = (got & 0x38) != 0 || __popc(got & 7) >= 2;
         }
     }
-    const int sq = (r | g | b) ? dev_slice(p.slice_lut, r, g, b, -1) : 0;
+    // queryBorderSize (Factory:103): the max filters above still SEE the frame's pixels (the lazy query image keeps them), but
+    // the reduce()d masks are 0 in the frame (toImageArray is a foldi over the inner rectangle) and the gap fold runs over
+    // the inner rectangle only (combine4 inherits the query image's borders): a frame cell contributes nothing
+    const bool frame = x < p.border || x >= p.W - p.border || y < p.border || y >= p.H - p.border;
+    const int qm = frame ? 0 : qm0;
+    if (frame) qh = 0;
+    const int sq = (!frame && (r | g | b)) ? dev_slice(p.slice_lut, r, g, b, -1) : 0;
     const uint16_t v = (uint16_t)(sq | (qm ? kPlaneQM : 0) | (qh ? kPlaneQH : 0));
     // sums over the whole frame, before the ROI (Shape2DMatch...Test.java:53-54 checks them on the un-mirrored, un-masked images)
     const unsigned long long bm = __ballot(qm), bh = __ballot(qh);
@@ -886,8 +893,15 @@ int cds_library_make_zgap_variants(cds_library *lib, int64_t first, int64_t coun
 int cds_shapeset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_rgb, int32_t W, int32_t H,
                         int32_t query_threshold, int32_t mirror, const uint8_t *roi, const cds_rect *excluded,
                         int32_t n_excluded, cds_shapeset **out) {
+    return cds_shapeset_create_bordered(ctx, n_masks, masks_rgb, W, H, query_threshold, 0, mirror, roi, excluded, n_excluded, out);
+}
+
+int cds_shapeset_create_bordered(cds_context *ctx, int32_t n_masks, const uint8_t *masks_rgb, int32_t W, int32_t H,
+                                 int32_t query_threshold, int32_t query_border_size, int32_t mirror, const uint8_t *roi,
+                                 const cds_rect *excluded, int32_t n_excluded, cds_shapeset **out) {
     if (!ctx || !out) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     *out = nullptr;
+    if (query_border_size < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "queryBorderSize is negative");
     if (n_masks <= 0 || !masks_rgb) return fail(CDS_ERR_INVALID_ARGUMENT, "no masks");
     if (W < 8 || H < 1 || W > kMaxW || H > kMaxH) return fail(CDS_ERR_UNSUPPORTED, "image size outside 8..2000 x 1..1000");
     if (n_excluded < 0 || n_excluded > CDS_MAX_RECTS || (n_excluded > 0 && !excluded)) return fail(CDS_ERR_INVALID_ARGUMENT, "bad excluded-region list");
@@ -950,6 +964,7 @@ int cds_shapeset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_
         SP_HIP(hipMemsetAsync(d_sums, 0, (size_t)nb * 2 * sizeof(unsigned long long), st));
         PrepParams p{};
         p.masks = d_masks; p.roi = d_roi; p.W = W; p.H = H; p.wp = wp; p.n = nb; p.mirror = mirror != 0; p.nrects = n_excluded;
+        p.border = query_border_size;
         for (int i = 0; i < n_excluded; i++) p.rects[i] = excluded[i];
         p.k60 = k60; p.k20 = k20; p.hw60 = d_hw; p.hw20 = d_hw + hw60.size();
         p.flags = d_flags; p.hd = d_hd; p.planes = ss->d_planes + (size_t)m0 * 2 * H * wp; p.acc = d_acc; p.rowflags = d_rfl; p.sums = d_sums;

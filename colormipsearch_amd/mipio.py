@@ -70,7 +70,7 @@ def read_mip(file_data, native=True):
         try:
             a = decode_image(_bytes(file_data))
             return a if a.ndim == 3 else np.ascontiguousarray(np.repeat(a.astype(np.uint8)[:, :, None], 3, axis=2))
-        except (CdsError, ImportError):
+        except (CdsError, ImportError, OSError):   # (OSError: the .so exists but its ROCm runtime does not load)
             pass
     with _pil().open(_open(file_data)) as im:
         return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
@@ -83,7 +83,7 @@ def read_gradient(file_data, native=True):
         from .capi import CdsError
         try:
             a = decode_image(_bytes(file_data))
-        except (CdsError, ImportError):
+        except (CdsError, ImportError, OSError):   # (OSError: the .so exists but its ROCm runtime does not load)
             a = None
     if a is None:
         with _pil().open(_open(file_data)) as im:

@@ -253,6 +253,26 @@ def normalizeTable(table: "MatchTable"):
     return table
 
 
+def resident_library_for(images, context=None, density_limit=0.25):
+    """Layout choice for a library of host images uint8[n,H,W,3]: a `cds.SparseLibrary` (signal-pixel records) unless the
+    images average more than `density_limit` of the frame in signal pixels -- the library itself refuses those
+    (cds_sparse_library_set_density_limit) because the dense layout's scan is the faster one there -- in which case a dense
+    `cds.Library` is returned.  Pass the result as `sparse_library=` or `library=` of GpuColorMIPSearchProcessor."""
+    imgs = np.ascontiguousarray(images, dtype=np.uint8)
+    n, H, W, _ = imgs.shape
+    signal = int((imgs.max(axis=3) > 0).sum())
+    try:
+        sl = cds.SparseLibrary(W, H, n, signal + 16 * H * n + 64, context=context, density_limit=density_limit)
+        sl.append(imgs)
+        return sl
+    except cds.CdsError as e:
+        if e.code != cds.capi.CDS_ERR_UNSUPPORTED:
+            raise
+    lib = cds.Library(W, H, n, context=context)
+    lib.upload(0, imgs)
+    return lib
+
+
 class GpuColorMIPSearchProcessor:
     """masks: uint8[n_masks,H,W,3]; the targets live in a `cds.Library` (+ `targets` metadata, one NeuronInfo per slot).
 
@@ -280,6 +300,10 @@ class GpuColorMIPSearchProcessor:
         if self._targets is None:
             self._targets = [NeuronInfo(str(i), f"line{i}", f"sample{i}") for i in range(self.count)]
         return self._targets
+
+    @targets.setter
+    def targets(self, value):
+        self._targets = value
 
     def _scan(self, alg):
         if self.sparse_library is not None:

@@ -154,6 +154,11 @@ int cds_sparse_library_append_host(cds_sparse_library *slib, int64_t count, cons
 /* Record layout: an image is stored in n_strips column strips of strip_width pixels (the last may be narrower), a strip
  * row by row, a row by ascending x; a (strip, row) cell without signal pixels holds one filler record. */
 int cds_sparse_library_layout(const cds_sparse_library *slib, int32_t *n_strips, int32_t *strip_width);
+/* Layout choice.  The sparse scan's cost grows with the records it visits; above about a quarter of the frame the dense
+ * layout (cds_library + cds_search) is the faster one.  An append / import whose images average more signal pixels than
+ * `max_signal_fraction` of the frame (default 0.25) fails with CDS_ERR_UNSUPPORTED and a message saying so -- nothing is
+ * added -- so that a dense library is never silently scanned the slow way; >= 1.1 accepts everything. */
+int cds_sparse_library_set_density_limit(cds_sparse_library *slib, double max_signal_fraction);
 int64_t cds_sparse_library_size(const cds_sparse_library *slib);   /* images held  */
 int64_t cds_sparse_library_pixels(const cds_sparse_library *slib); /* records held */
 int cds_sparse_library_clear(cds_sparse_library *slib);
@@ -168,8 +173,8 @@ int cds_sparse_library_image_offsets(const cds_sparse_library *slib, int64_t fir
  * Export images [first, first+count): image_offsets[count+1] (record offsets relative to the first exported image),
  * cell_offsets[count][n_strips][H+1] and the records themselves (any of the last two may be NULL; call once with NULLs to
  * size the buffers: the record count is image_offsets[count]).  Import appends `count` images given in that form; the
- * layout (n_strips, strip_width) must be this library's; the offset tables are validated (records are data: a wrong
- * record can only produce wrong scores for its own image). */
+ * layout (n_strips, strip_width) must be this library's; the offset tables are validated on the host and the records
+ * on the device (every cell non-empty, row flags, x order, classes, fillers): an inconsistent shard is refused. */
 int cds_sparse_library_export(const cds_sparse_library *slib, int64_t first, int64_t count, uint64_t *image_offsets,
                               uint32_t *cell_offsets, uint32_t *records, int64_t records_capacity);
 int cds_sparse_library_import(cds_sparse_library *slib, int64_t count, const uint64_t *image_offsets, const uint32_t *cell_offsets,
@@ -235,11 +240,17 @@ int cds_maskset_last_kernel_ms(const cds_maskset *ms, double *avg_ms, int32_t *l
 
 /* ---- GradientAreaGap scorer (kernel 2) ----------------------------------------------------------
  * cds_shapeset_create == n x createShapeMatchCDSAlgorithmProvider(...).createColorDepthSearchAlgorithm
- * (API/cds/ColorDepthSearchAlgorithmProviderFactory.java:76-127), queryBorderSize 0.
+ * (API/cds/ColorDepthSearchAlgorithmProviderFactory.java:76-127) with queryBorderSize 0.
  * roi: optional W*H byte plane (non-zero = inside), NULL for none. */
 int cds_shapeset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_rgb, int32_t W, int32_t H,
                         int32_t query_threshold, int32_t mirror, const uint8_t *roi, const cds_rect *excluded,
                         int32_t n_excluded, cds_shapeset **out);
+/* The same with queryBorderSize != 0 (Factory:103, fed by the CLI's --borderSize: tools cmd/AbstractColorDepthMatchArgs.java:25):
+ * a frame of that many pixels is skipped by every fold over the query (API/imageprocessing/LImage.java:89-113) -- the query
+ * mask and the high-expression mask are empty there and the gap sum leaves it out, while the max filters still see its pixels. */
+int cds_shapeset_create_bordered(cds_context *ctx, int32_t n_masks, const uint8_t *masks_rgb, int32_t W, int32_t H,
+                                 int32_t query_threshold, int32_t query_border_size, int32_t mirror, const uint8_t *roi,
+                                 const cds_rect *excluded, int32_t n_excluded, cds_shapeset **out);
 void cds_shapeset_destroy(cds_shapeset *ss);
 /* Sum of the query mask and of the high-expression mask per mask
  * (the values Shape2DMatch...Test.java:53-54 checks). */

@@ -502,6 +502,19 @@ void cdso_make_zgap(const uint8_t *target, int W, int H, int thr, double radius,
  *   QM = gray(Q) > 2;
  *   QH = maxfilter20(Q) black && gray(maxfilter60(Q)) > 0.
  * Outputs: Q (3*W*H), QM (W*H, 0/1), QH (W*H, 0/1). */
+void cdso_shape_prepare(const uint8_t *mask, int W, int H, const cdso_rect *rects, int nrects, uint8_t *Q, uint8_t *QM, uint8_t *QH);
+/* queryBorderSize (FAC:103: LImageUtils.create(queryImageArray, b, b, b, b)): the lazy query image keeps its pixels, but
+ * every fold (LImage.java:89-113) skips a frame of `border` pixels -- the reduce()d masks QM and QH (FAC:104-108, toImageArray
+ * is a foldi) are therefore 0 in the frame although the max filters still SEE the frame's pixels, and the gap sum
+ * (combine4 inherits the query image's borders, LImageUtils.java:44-49) runs over the inner rectangle only. */
+void cdso_shape_prepare_b(const uint8_t *mask, int W, int H, const cdso_rect *rects, int nrects, int border, uint8_t *Q,
+                          uint8_t *QM, uint8_t *QH) {
+    cdso_shape_prepare(mask, W, H, rects, nrects, Q, QM, QH);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++)
+            if (x < border || x >= W - border || y < border || y >= H - border) QM[(size_t)y * W + x] = QH[(size_t)y * W + x] = 0;
+}
+
 void cdso_shape_prepare(const uint8_t *mask, int W, int H, const cdso_rect *rects, int nrects, uint8_t *Q,
                         uint8_t *QM, uint8_t *QH) {
     size_t N = (size_t)W * H;
@@ -524,10 +537,11 @@ void cdso_shape_prepare(const uint8_t *mask, int W, int H, const cdso_rect *rect
  * (S2D:206-217).  zgap must already be masked by the threshold (S2D:161). */
 static void negative_scores(const uint8_t *Q, const uint8_t *QM, const uint8_t *QH, const uint8_t *roi,
                             const uint8_t *tclr, const uint16_t *grad, const uint8_t *zm, int W, int H, int thr,
-                            int mirrored, int64_t *gap_out, int64_t *high_out) {
+                            int mirrored, int border, int64_t *gap_out, int64_t *high_out) {
     int64_t gaps = 0, high = 0;
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
+            const int inner = x >= border && x < W - border && y >= border && y < H - border;  /* the gap fold's range */
             int xo = mirrored ? W - 1 - x : x;
             size_t i = (size_t)y * W + x, io = (size_t)y * W + xo;
             int inroi = roi ? roi[i] != 0 : 1;
@@ -542,7 +556,7 @@ static void negative_scores(const uint8_t *Q, const uint8_t *QM, const uint8_t *
             } else {
                 gap = qm * g;
             }
-            gaps += gap > 3 ? gap : 0;
+            if (inner) gaps += gap > 3 ? gap : 0;
             if (qh == 1) {
                 int r1 = tclr[3 * i], g1 = tclr[3 * i + 1], b1 = tclr[3 * i + 2];
                 if (r1 > thr || g1 > thr || b1 > thr) high++;
@@ -561,9 +575,18 @@ int64_t cdso_shape_score_value(int64_t gap, int64_t high) {
 /* calculateMatchingScore -- S2D:150-186.  target: RGB; grad: u16 (a GRAY8 gradient is widened by
  * the caller); zgap: RGB, NOT yet masked; either NULL => (-1,-1,false) (S2D:155-158).
  * out[0]=gradientAreaGap out[1]=highExpressionArea out[2]=mirrored(0/1). */
+void cdso_shape_score_b(const uint8_t *Q, const uint8_t *QM, const uint8_t *QH, const uint8_t *roi,
+                        const uint8_t *target, const uint16_t *grad, const uint8_t *zgap, int W, int H, int thr,
+                        int mirror, const cdso_rect *rects, int nrects, int border, int64_t *out);
 void cdso_shape_score(const uint8_t *Q, const uint8_t *QM, const uint8_t *QH, const uint8_t *roi,
                       const uint8_t *target, const uint16_t *grad, const uint8_t *zgap, int W, int H, int thr,
                       int mirror, const cdso_rect *rects, int nrects, int64_t *out) {
+    cdso_shape_score_b(Q, QM, QH, roi, target, grad, zgap, W, H, thr, mirror, rects, nrects, 0, out);
+}
+
+void cdso_shape_score_b(const uint8_t *Q, const uint8_t *QM, const uint8_t *QH, const uint8_t *roi,
+                        const uint8_t *target, const uint16_t *grad, const uint8_t *zgap, int W, int H, int thr,
+                        int mirror, const cdso_rect *rects, int nrects, int border, int64_t *out) {
     if (!grad || !zgap) {
         out[0] = -1; out[1] = -1; out[2] = 0;
         return;
@@ -573,11 +596,11 @@ void cdso_shape_score(const uint8_t *Q, const uint8_t *QM, const uint8_t *QH, co
     cdso_clear_regions(target, W, H, rects, nrects, tclr);
     cdso_mask_rgb(zgap, (long)N, thr, zm);
     int64_t g0, h0;
-    negative_scores(Q, QM, QH, roi, tclr, grad, zm, W, H, thr, 0, &g0, &h0);
+    negative_scores(Q, QM, QH, roi, tclr, grad, zm, W, H, thr, 0, border, &g0, &h0);
     out[0] = g0; out[1] = h0; out[2] = 0;
     if (mirror) {
         int64_t g1, h1;
-        negative_scores(Q, QM, QH, roi, tclr, grad, zm, W, H, thr, 1, &g1, &h1);
+        negative_scores(Q, QM, QH, roi, tclr, grad, zm, W, H, thr, 1, border, &g1, &h1);
         if ((int)cdso_shape_score_value(g1, h1) < (int)cdso_shape_score_value(g0, h0)) {
             out[0] = g1; out[1] = h1; out[2] = 1;
         }

@@ -81,6 +81,9 @@ def lib():
     L.cdso_clear_regions.argtypes = [u8p, ctypes.c_int, ctypes.c_int, rp, ctypes.c_int, u8p]
     L.cdso_make_zgap.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, rp, ctypes.c_int, u8p]
     L.cdso_shape_prepare.argtypes = [u8p, ctypes.c_int, ctypes.c_int, rp, ctypes.c_int, u8p, u8p, u8p]
+    L.cdso_shape_prepare_b.argtypes = [u8p, ctypes.c_int, ctypes.c_int, rp, ctypes.c_int, ctypes.c_int, u8p, u8p, u8p]
+    L.cdso_shape_score_b.argtypes = [u8p, u8p, u8p, u8p, u8p, u16p, u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, rp, ctypes.c_int, ctypes.c_int, i64p]
     L.cdso_shape_score_value.restype = ctypes.c_int64
     L.cdso_shape_score_value.argtypes = [ctypes.c_int64, ctypes.c_int64]
     L.cdso_shape_score.argtypes = [u8p, u8p, u8p, u8p, u8p, u16p, u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -205,15 +208,16 @@ def make_zgap(target, thr, radius=10, rects=None):
 class ShapeQuery:
     """One prepared mask == one Shape2DMatchColorDepthSearchAlgorithm instance of the reference."""
 
-    def __init__(self, mask, query_thr, mirror, rects=None, roi=None):
+    def __init__(self, mask, query_thr, mirror, rects=None, roi=None, border=0):
         mask = _img(mask)
         self.H, self.W, _ = mask.shape
         self.thr, self.mirror, self.rects = int(query_thr), bool(mirror), list(rects or [])
+        self.border = int(border)   # queryBorderSize (ColorDepthSearchAlgorithmProviderFactory.java:103)
         r, n = _rects(self.rects)
         self.Q = np.empty_like(mask)
         self.QM = np.empty((self.H, self.W), dtype=np.uint8)
         self.QH = np.empty((self.H, self.W), dtype=np.uint8)
-        lib().cdso_shape_prepare(_u8(mask), self.W, self.H, r, n, _u8(self.Q), _u8(self.QM), _u8(self.QH))
+        lib().cdso_shape_prepare_b(_u8(mask), self.W, self.H, r, n, self.border, _u8(self.Q), _u8(self.QM), _u8(self.QH))
         self.roi = None
         if roi is not None:
             roi = np.ascontiguousarray(roi, dtype=np.uint8).copy()
@@ -233,9 +237,9 @@ class ShapeQuery:
         if zgap is not None:
             zgap = _img(zgap)
             zp = _u8(zgap)
-        lib().cdso_shape_score(_u8(self.Q), _u8(self.QM), _u8(self.QH), _u8(self.roi) if self.roi is not None else None,
-                               _u8(target), gp, zp, self.W, self.H, self.thr, int(self.mirror), r, n,
-                               out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        lib().cdso_shape_score_b(_u8(self.Q), _u8(self.QM), _u8(self.QH), _u8(self.roi) if self.roi is not None else None,
+                                 _u8(target), gp, zp, self.W, self.H, self.thr, int(self.mirror), r, n, self.border,
+                                 out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
         gap, high, mir = int(out[0]), int(out[1]), bool(out[2])
         return gap, high, int(np.int32(lib().cdso_shape_score_value(gap, high))), mir
 

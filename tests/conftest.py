@@ -10,6 +10,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the parity tests feed the sparse library dense-uniform and random images on purpose (worst cases of the format); the
+# density policy itself (cds_sparse_library_set_density_limit) is tested where it is set explicitly
+os.environ.setdefault("CDS_SPARSE_DENSITY_LIMIT", "2")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # keep libcds_hip.so in step with its sources (a no-op when it is up to date; hipcc cross-compiles without a GPU)

@@ -241,3 +241,23 @@ def test_sparse_shard_round_trip(tmp_path, fixtures, oracle):
         sl2.import_arrays(offs, cells, rec, n_strips=2, strip_width=608)
     with pytest.raises(ValueError):
         mipio.open_shard(path)                            # (a sparse shard is not a dense shard)
+    # corrupt RECORDS behind consistent offset tables are refused too (validated on the device), and nothing is added
+    n_before, px_before = len(sl2), sl2.pixels
+    first_cell = int(cells[0, 1, 300])                     # some cell of the first exported image with signal pixels
+    sig = np.flatnonzero((rec[: int(offs[1])] & 0x7FFFFFFF) != 0)
+    k = int(sig[len(sig) // 2])                            # a signal record of image 0
+    for what, mutate in (("row flag on a later record", lambda r: r.__setitem__(k + (1 if (r[k] >> 31) else 0), r[k + (1 if (r[k] >> 31) else 0)] | np.uint32(1 << 31))),
+                         ("class 0", lambda r: r.__setitem__(k, r[k] & np.uint32(~(7 << 16) & 0xFFFFFFFF))),
+                         ("class 7", lambda r: r.__setitem__(k, r[k] | np.uint32(7 << 16))),
+                         ("maximum not above the second channel", lambda r: r.__setitem__(k, (r[k] & np.uint32(0xFFFF0000)) | np.uint32(0x5050))),
+                         ("x outside the image", lambda r: r.__setitem__(k, r[k] | np.uint32(2047 << 20))),
+                         ("filler inside a cell", lambda r: r.__setitem__(k, np.uint32(1 << 31) if not (r[k] >> 31) else r[k] & np.uint32(0x7FFFFFFF)))):
+        bad_rec = rec.copy()
+        mutate(bad_rec)
+        assert not np.array_equal(bad_rec, rec), what
+        with pytest.raises(ValueError, match="inconsistent"):
+            sl2.import_arrays(offs, cells, bad_rec)
+        assert (len(sl2), sl2.pixels) == (n_before, px_before), what
+    sl2.import_arrays(offs, cells, rec)                    # the untouched arrays still import
+    assert len(sl2) == n_before + 3
+    del first_cell

@@ -85,3 +85,23 @@ def test_pixel_gap_quirks(oracle):
     # adjacent classes may give a NEGATIVE gap (no abs), which passes <= zTol
     g = oracle.pixel_gap((50, 0, 255), (0, 50, 255))                  # BR 0.196 vs BG 0.196
     assert g < 0
+
+
+def test_oracle_query_border_restatement(fixtures, oracle):
+    """queryBorderSize in the oracle (no reference test exercises it: a restatement of LImage.fold's loop bounds,
+    LImage.java:89-113, and of which images inherit the borders, LImageUtils.java:27-49 / LImageImpl.java:76-104): border 0
+    is the pinned behaviour; with a border the masks are empty in the frame, unchanged inside, and a gap under the frame
+    no longer counts."""
+    mask = fixtures["em_12191"]
+    q0 = oracle.ShapeQuery(mask, 20, True, E.STD_RECTS)
+    qb = oracle.ShapeQuery(mask, 20, True, E.STD_RECTS, border=200)
+    assert np.array_equal(q0.Q, qb.Q)
+    inner = np.zeros(q0.QM.shape, dtype=bool)
+    inner[200:-200, 200:-200] = True
+    assert np.array_equal(qb.QM, q0.QM * inner) and np.array_equal(qb.QH, q0.QH * inner)
+    assert qb.QM.sum() < q0.QM.sum()
+    t, g = fixtures["lm_VT033614"], fixtures["grad_VT033614"]
+    z = oracle.make_zgap(t, 20, 10, E.STD_RECTS)
+    g0, h0, _, _ = q0.score(t, g, z)
+    gb, hb, _, _ = qb.score(t, g, z)
+    assert 0 <= gb < g0 and 0 <= hb <= h0

@@ -193,3 +193,48 @@ def test_normalized_scores_per_mask(cds, oracle):
     got = [cds.calculateNormalizedScore(int(p), int(s), int(pix.max()), int(shape.max())) for p, s in zip(pix, shape)]
     want = [oracle.normalized_score(int(p), int(s), int(pix.max()), int(shape.max())) for p, s in zip(pix, shape)]
     assert got == want
+
+
+@pytest.mark.parametrize("border", [10, 37])
+def test_query_border_size(cds, fixtures, oracle, border):
+    """queryBorderSize != 0 (ColorDepthSearchAlgorithmProviderFactory.java:103; the CLI's --borderSize): every fold over the
+    query skips a frame of that many pixels (LImage.java:89-113).  A mask with signal INSIDE the frame (it still feeds the max
+    filters), the scorer against the oracle for plain / mirrored winners and with an ROI; mask sums and getQuerySize too."""
+    rng = np.random.default_rng(border)
+    lut = oracle.depth_lut()
+    mask = fixtures["em_12191"].copy()
+    mask[120:200, 2:60] = lut[rng.integers(0, 256, size=(80, 58))]            # signal inside the left frame and next to it
+    mask[H - 30:H - 3, 500:700] = lut[rng.integers(0, 256, size=(27, 200))]   # ... and in the bottom frame
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createShapeMatchCDSAlgorithmProvider(True, None, cds.label_regions)
+    alg = provider.createColorDepthQuerySearchAlgorithmWithDefaultParams(mask, 20, border)
+    alg0 = provider.createColorDepthQuerySearchAlgorithmWithDefaultParams(mask, 20, 0)
+    q = oracle.ShapeQuery(mask, 20, True, E.STD_RECTS, border=border)
+    sm, sh = alg.maskStats()
+    assert (int(sm[0]), int(sh[0])) == (int(q.QM.sum()), int(q.QH.sum()))
+    assert sm[0] < alg0.maskStats()[0][0]                                     # the frame really held mask pixels
+    inner = np.zeros((H, W), dtype=bool)
+    inner[border:H - border, border:W - border] = True
+    cleared = mask.copy()
+    for (x0, y0, x1, y1) in E.STD_RECTS:
+        cleared[y0:y1, x0:x1] = 0
+    assert alg.getQuerySize() == int(((cleared.max(axis=2) > 20) & inner).sum())
+    differs = 0
+    for tk, gk in (("lm_VT033614", "grad_VT033614"), ("lm_BJD", "grad_BJD"), ("lm_VT016795", "grad_VT016795")):
+        t = fixtures[tk].copy()
+        t[100:220, 0:80] = lut[rng.integers(0, 256, size=(120, 80))]          # target signal under the frame as well
+        zg = oracle.make_zgap(t, 20, 10, E.STD_RECTS)
+        sup = {cds.ComputeFileType.GradientImage: (lambda g=fixtures[gk]: g), cds.ComputeFileType.ZGapImage: (lambda z=zg: z)}
+        s = alg.calculateMatchingScore(t, sup)
+        want = q.score(t, fixtures[gk], zg)
+        assert (s.getGradientAreaGap(), s.getHighExpressionArea(), s.getScore(), s.isMirrored()) == want, tk
+        s0 = alg0.calculateMatchingScore(t, sup)
+        differs += (s0.getGradientAreaGap(), s0.getHighExpressionArea()) != (want[0], want[1])
+    assert differs > 0                                                        # the border changes the result on these inputs
+    roi = np.zeros((H, W), dtype=np.uint8)
+    roi[60:400, 0:800] = 1
+    alg_r = cds.Shape2DMatchColorDepthSearchAlgorithm(mask, 20, True, roi, cds.label_regions, queryBorderSize=border)
+    q_r = oracle.ShapeQuery(mask, 20, True, E.STD_RECTS, roi=roi, border=border)
+    t = fixtures["lm_VT016795"]
+    zg = oracle.make_zgap(t, 20, 10, E.STD_RECTS)
+    s = alg_r.calculateMatchingScore(t, {cds.ComputeFileType.GradientImage: lambda: fixtures["grad_VT016795"], cds.ComputeFileType.ZGapImage: lambda: zg})
+    assert (s.getGradientAreaGap(), s.getHighExpressionArea(), s.getScore(), s.isMirrored()) == q_r.score(t, fixtures["grad_VT016795"], zg)

@@ -601,3 +601,34 @@ def test_device_match_list_equals_host_filter(cds, oracle, monkeypatch):
     rc = capi.load().cds_search_sparse_matches(alg._h, sl._h, 0, n_t, 0.0, buf.ctypes.data_as(ctypes.c_void_p), 1, ctypes.byref(n))
     n_all = sum(1 for mm in range(len(masks)) for tt in range(n_t) if sizes[mm] > 0 and scores[mm, tt] > 0)
     assert rc == capi.CDS_ERR_OUT_OF_MEMORY and n.value == n_all
+
+
+# ---- layout choice: a sparse library refuses images the dense layout scans faster ---------------------------------------
+def test_density_limit_refuses_dense_images(cds, oracle):
+    """Default policy (cds_sparse_library_set_density_limit, 0.25 of the frame): a batch of dense-uniform images is refused
+    with a message that names the dense layout, nothing is appended; sparse images pass; the limit can be lifted; and
+    processor.resident_library_for picks the layout accordingly."""
+    from colormipsearch_amd import processor as P
+    dense = cds.Library(W, H, 4)
+    dense.generate_synthetic(0xC0FFEE, 0, 0, 4, kind=1)
+    sl = cds.SparseLibrary(W, H, 8, 8 * (W * H + 4 * H), density_limit=0.25)
+    with pytest.raises(cds.CdsError, match="dense-layout scan"):
+        sl.append_from(dense, 0, 4)
+    assert len(sl) == 0 and sl.pixels == 0
+    imgs = dense.download(0, 2)
+    with pytest.raises(cds.CdsError, match="density limit"):
+        sl.append(imgs)
+    dense.generate_synthetic(0xC0FFEE, 0, 0, 4, kind=0)
+    sl.append_from(dense, 0, 4)                                   # 1-4 % signal: fine
+    assert len(sl) == 4
+    sl.set_density_limit(2.0)
+    sl.append(imgs)
+    assert len(sl) == 6
+    lib_s = P.resident_library_for(dense.download(0, 4))
+    lib_d = P.resident_library_for(imgs)
+    assert isinstance(lib_s, cds.SparseLibrary) and isinstance(lib_d, cds.Library)
+    mask = oracle.synth_image(0xBADC0DE, 0, 2)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, cds.label_regions(W))
+    s_d, _ = alg.searchLibrary(lib_d)
+    s_s, _ = alg.searchSparseLibrary(sl, 4, 2)
+    assert np.array_equal(s_d, s_s)

@@ -36,7 +36,7 @@ def main():
     n, st = args.targets, min(args.stage, args.targets)
     dense = cds.Library(W, H, st, context=ctx)
     per_img = 46000 if args.kind == 0 else W * H + H
-    sl = cds.SparseLibrary(W, H, n, per_img * n if args.kind else 24000 * n + 4_000_000, context=ctx)
+    sl = cds.SparseLibrary(W, H, n, per_img * n if args.kind else 24000 * n + 4_000_000, context=ctx, density_limit=2.0 if args.kind else None)
     t0 = time.time()
     tg = ta = 0.0
     for first in range(0, n, st):
