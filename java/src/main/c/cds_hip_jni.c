@@ -1,0 +1,276 @@
+/*
+ * cds_hip_jni.c -- JNI implementations of org.janelia.colormipsearch.cds.gpu.CdsHip (one function per native method),
+ * over the C ABI of libcds_hip.so (include/cds_hip.h).  Build: see ../../../Makefile (needs a JDK for jni.h; the image this
+ * repository is developed in has none, so this file has never been compiled -- it is reviewed against the header only).
+ *
+ * Error mapping: CDS_ERR_INVALID_ARGUMENT -> IllegalArgumentException (where the reference throws it),
+ * everything else -> IllegalStateException; the message is cds_last_error().
+ * Arrays are pinned with Get/ReleasePrimitiveArrayCritical around calls that do not call back into the JVM.
+ */
+#include <jni.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "cds_hip.h"
+
+#define CLS(name) Java_org_janelia_colormipsearch_cds_gpu_CdsHip_##name
+#define P(type, h) ((type *)(intptr_t)(h))
+
+static void throw_for(JNIEnv *env, int rc) {
+    const char *cls = rc == CDS_ERR_INVALID_ARGUMENT ? "java/lang/IllegalArgumentException" : "java/lang/IllegalStateException";
+    (*env)->ThrowNew(env, (*env)->FindClass(env, cls), cds_last_error());
+}
+
+/* x0,y0,x1,y1 per rectangle -> cds_rect[]; returns the count or -1 (exception pending) */
+static int get_rects(JNIEnv *env, jintArray rects, cds_rect *out) {
+    jsize n = rects ? (*env)->GetArrayLength(env, rects) / 4 : 0;
+    if (n > CDS_MAX_RECTS) {
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), "more than 8 excluded rectangles");
+        return -1;
+    }
+    if (n) (*env)->GetIntArrayRegion(env, rects, 0, 4 * n, (jint *)out);
+    return (int)n;
+}
+
+/* ---- context ---- */
+JNIEXPORT jlong JNICALL CLS(contextCreate)(JNIEnv *env, jclass c, jint device) {
+    cds_context *ctx = NULL;
+    int rc = cds_context_create(device, &ctx);
+    if (rc) { throw_for(env, rc); return 0; }
+    return (jlong)(intptr_t)ctx;
+}
+JNIEXPORT void JNICALL CLS(contextDestroy)(JNIEnv *env, jclass c, jlong ctx) { cds_context_destroy(P(cds_context, ctx)); }
+JNIEXPORT void JNICALL CLS(contextSynchronize)(JNIEnv *env, jclass c, jlong ctx) {
+    int rc = cds_context_synchronize(P(cds_context, ctx));
+    if (rc) throw_for(env, rc);
+}
+
+/* ---- pixel-match mask sets ---- */
+JNIEXPORT jlong JNICALL CLS(masksetCreate)(JNIEnv *env, jclass c, jlong ctx, jint nMasks, jbyteArray masksRgb, jint w, jint h, jint maskThr,
+                                           jint dataThr, jdouble zTol, jint xyShift, jboolean mirror, jintArray rects) {
+    cds_pixmatch_params p = {maskThr, dataThr, zTol, xyShift, mirror ? 1 : 0};
+    cds_rect r[CDS_MAX_RECTS];
+    int n = get_rects(env, rects, r);
+    if (n < 0) return 0;
+    if ((jlong)(*env)->GetArrayLength(env, masksRgb) < (jlong)nMasks * 3 * w * h) { throw_for(env, CDS_ERR_INVALID_ARGUMENT); return 0; }
+    jbyte *px = (*env)->GetPrimitiveArrayCritical(env, masksRgb, NULL);
+    cds_maskset *ms = NULL;
+    int rc = cds_maskset_create(P(cds_context, ctx), nMasks, (const uint8_t *)px, w, h, &p, r, n, &ms);
+    (*env)->ReleasePrimitiveArrayCritical(env, masksRgb, px, JNI_ABORT);
+    if (rc) { throw_for(env, rc); return 0; }
+    return (jlong)(intptr_t)ms;
+}
+JNIEXPORT void JNICALL CLS(masksetDestroy)(JNIEnv *env, jclass c, jlong ms) { cds_maskset_destroy(P(cds_maskset, ms)); }
+JNIEXPORT void JNICALL CLS(masksetQuerySizes)(JNIEnv *env, jclass c, jlong ms, jintArray sizes) {
+    jint *s = (*env)->GetIntArrayElements(env, sizes, NULL);
+    int rc = cds_maskset_query_sizes(P(cds_maskset, ms), (int32_t *)s);
+    (*env)->ReleaseIntArrayElements(env, sizes, s, 0);
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT jlong JNICALL CLS(scorePair)(JNIEnv *env, jclass c, jlong ms, jint maskIndex, jbyteArray targetRgb, jint w, jint h) {
+    int32_t score = 0;
+    uint8_t mirrored = 0;
+    jbyte *px = (*env)->GetPrimitiveArrayCritical(env, targetRgb, NULL);
+    int rc = cds_score_pair(P(cds_maskset, ms), maskIndex, (const uint8_t *)px, w, h, &score, &mirrored);
+    (*env)->ReleasePrimitiveArrayCritical(env, targetRgb, px, JNI_ABORT);
+    if (rc) { throw_for(env, rc); return 0; }
+    return ((jlong)mirrored << 32) | (uint32_t)score;
+}
+
+/* ---- dense resident library ---- */
+JNIEXPORT jlong JNICALL CLS(libraryCreate)(JNIEnv *env, jclass c, jlong ctx, jint w, jint h, jlong capacity) {
+    cds_library *lib = NULL;
+    int rc = cds_library_create(P(cds_context, ctx), w, h, capacity, &lib);
+    if (rc) { throw_for(env, rc); return 0; }
+    return (jlong)(intptr_t)lib;
+}
+JNIEXPORT void JNICALL CLS(libraryDestroy)(JNIEnv *env, jclass c, jlong lib) { cds_library_destroy(P(cds_library, lib)); }
+JNIEXPORT void JNICALL CLS(libraryUpload)(JNIEnv *env, jclass c, jlong lib, jlong first, jlong count, jobject directRgb) {
+    const uint8_t *px = (const uint8_t *)(*env)->GetDirectBufferAddress(env, directRgb);
+    int rc = px ? cds_library_upload(P(cds_library, lib), first, count, px) : CDS_ERR_INVALID_ARGUMENT;
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT void JNICALL CLS(libraryUploadVariants)(JNIEnv *env, jclass c, jlong lib, jlong first, jlong count, jobject directGrad, jobject directZgap) {
+    const uint16_t *g = directGrad ? (const uint16_t *)(*env)->GetDirectBufferAddress(env, directGrad) : NULL;
+    const uint8_t *z = directZgap ? (const uint8_t *)(*env)->GetDirectBufferAddress(env, directZgap) : NULL;
+    int rc = cds_library_upload_variants(P(cds_library, lib), first, count, g, z);
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT void JNICALL CLS(libraryMakeZgapVariants)(JNIEnv *env, jclass c, jlong lib, jlong first, jlong count, jint threshold, jdouble radius,
+                                                    jintArray rects) {
+    cds_rect r[CDS_MAX_RECTS];
+    int n = get_rects(env, rects, r);
+    if (n < 0) return;
+    int rc = cds_library_make_zgap_variants(P(cds_library, lib), first, count, threshold, radius, r, n);
+    if (rc) throw_for(env, rc);
+}
+static void search_common(JNIEnv *env, int sparse, jlong ms, jlong lib, jlong first, jlong count, jintArray scores, jbyteArray mirrored) {
+    jint *s = (*env)->GetIntArrayElements(env, scores, NULL);
+    jbyte *m = (*env)->GetByteArrayElements(env, mirrored, NULL);
+    int rc = sparse ? cds_search_sparse(P(cds_maskset, ms), P(cds_sparse_library, lib), first, count, (int32_t *)s, (uint8_t *)m)
+                    : cds_search(P(cds_maskset, ms), P(cds_library, lib), first, count, (int32_t *)s, (uint8_t *)m);
+    (*env)->ReleaseIntArrayElements(env, scores, s, 0);
+    (*env)->ReleaseByteArrayElements(env, mirrored, m, 0);
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT void JNICALL CLS(search)(JNIEnv *env, jclass c, jlong ms, jlong lib, jlong first, jlong count, jintArray scores, jbyteArray mirrored) {
+    search_common(env, 0, ms, lib, first, count, scores, mirrored);
+}
+
+/* ---- sparse resident library ---- */
+JNIEXPORT jlong JNICALL CLS(sparseLibraryCreate)(JNIEnv *env, jclass c, jlong ctx, jint w, jint h, jlong capImages, jlong capPixels) {
+    cds_sparse_library *sl = NULL;
+    int rc = cds_sparse_library_create(P(cds_context, ctx), w, h, capImages, capPixels, &sl);
+    if (rc) { throw_for(env, rc); return 0; }
+    return (jlong)(intptr_t)sl;
+}
+JNIEXPORT void JNICALL CLS(sparseLibraryDestroy)(JNIEnv *env, jclass c, jlong sl) { cds_sparse_library_destroy(P(cds_sparse_library, sl)); }
+JNIEXPORT void JNICALL CLS(sparseLibrarySetDensityLimit)(JNIEnv *env, jclass c, jlong sl, jdouble limit) {
+    int rc = cds_sparse_library_set_density_limit(P(cds_sparse_library, sl), limit);
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT void JNICALL CLS(sparseLibraryAppend)(JNIEnv *env, jclass c, jlong sl, jlong count, jobject directRgb) {
+    const uint8_t *px = (const uint8_t *)(*env)->GetDirectBufferAddress(env, directRgb);
+    int rc = px ? cds_sparse_library_append_host(P(cds_sparse_library, sl), count, px) : CDS_ERR_INVALID_ARGUMENT;
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT void JNICALL CLS(sparseLibraryAppendFiles)(JNIEnv *env, jclass c, jlong sl, jobjectArray paths, jint threads) {
+    jsize n = (*env)->GetArrayLength(env, paths);
+    const char **cp = (const char **)calloc((size_t)n + 1, sizeof(char *));
+    jstring *js = (jstring *)calloc((size_t)n + 1, sizeof(jstring));
+    for (jsize i = 0; i < n; i++) {
+        js[i] = (jstring)(*env)->GetObjectArrayElement(env, paths, i);
+        cp[i] = (*env)->GetStringUTFChars(env, js[i], NULL);
+    }
+    int rc = cds_sparse_library_append_files(P(cds_sparse_library, sl), cp, n, threads);
+    for (jsize i = 0; i < n; i++) (*env)->ReleaseStringUTFChars(env, js[i], cp[i]);
+    free(cp);
+    free(js);
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT jlong JNICALL CLS(sparseLibrarySize)(JNIEnv *env, jclass c, jlong sl) { return cds_sparse_library_size(P(cds_sparse_library, sl)); }
+JNIEXPORT jlong JNICALL CLS(sparseLibraryPixels)(JNIEnv *env, jclass c, jlong sl) { return cds_sparse_library_pixels(P(cds_sparse_library, sl)); }
+JNIEXPORT void JNICALL CLS(sparseLibraryClear)(JNIEnv *env, jclass c, jlong sl) {
+    int rc = cds_sparse_library_clear(P(cds_sparse_library, sl));
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT void JNICALL CLS(searchSparse)(JNIEnv *env, jclass c, jlong ms, jlong sl, jlong first, jlong count, jintArray scores, jbyteArray mirrored) {
+    search_common(env, 1, ms, sl, first, count, scores, mirrored);
+}
+JNIEXPORT jlong JNICALL CLS(searchSparseMatches)(JNIEnv *env, jclass c, jlong ms, jlong sl, jlong first, jlong count, jdouble pct, jintArray triples) {
+    jsize cap = (*env)->GetArrayLength(env, triples) / 3;
+    jint *t = (*env)->GetIntArrayElements(env, triples, NULL);   /* cds_match = 3 x int32: the array IS the match buffer */
+    int64_t n = 0;
+    int rc = cds_search_sparse_matches(P(cds_maskset, ms), P(cds_sparse_library, sl), first, count, pct, (cds_match *)t, cap, &n);
+    (*env)->ReleaseIntArrayElements(env, triples, t, 0);
+    if (rc == CDS_ERR_OUT_OF_MEMORY && n > cap) return (jlong)n;   /* too small: the caller repeats the call with n */
+    if (rc) { throw_for(env, rc); return 0; }
+    return (jlong)n;
+}
+
+/* ---- several GPUs of one node ---- */
+JNIEXPORT jlong JNICALL CLS(commCreate)(JNIEnv *env, jclass c, jlongArray contexts) {
+    jsize n = (*env)->GetArrayLength(env, contexts);
+    jlong *h = (*env)->GetLongArrayElements(env, contexts, NULL);
+    cds_context **ctxs = (cds_context **)calloc((size_t)n + 1, sizeof(*ctxs));
+    for (jsize i = 0; i < n; i++) ctxs[i] = P(cds_context, h[i]);
+    (*env)->ReleaseLongArrayElements(env, contexts, h, JNI_ABORT);
+    cds_comm *comm = NULL;
+    int rc = cds_comm_create(ctxs, n, &comm);
+    free(ctxs);
+    if (rc) { throw_for(env, rc); return 0; }
+    return (jlong)(intptr_t)comm;
+}
+JNIEXPORT void JNICALL CLS(commDestroy)(JNIEnv *env, jclass c, jlong comm) { cds_comm_destroy(P(cds_comm, comm)); }
+JNIEXPORT jlongArray JNICALL CLS(searchSparseSharded)(JNIEnv *env, jclass c, jlong comm, jlongArray masksets, jlongArray slibs, jintArray scores,
+                                                      jbyteArray mirrored) {
+    jsize n = (*env)->GetArrayLength(env, masksets);
+    jlong *mh = (*env)->GetLongArrayElements(env, masksets, NULL), *sh = (*env)->GetLongArrayElements(env, slibs, NULL);
+    const cds_maskset **ms = (const cds_maskset **)calloc((size_t)n + 1, sizeof(*ms));
+    const cds_sparse_library **sl = (const cds_sparse_library **)calloc((size_t)n + 1, sizeof(*sl));
+    for (jsize i = 0; i < n; i++) { ms[i] = P(cds_maskset, mh[i]); sl[i] = P(cds_sparse_library, sh[i]); }
+    (*env)->ReleaseLongArrayElements(env, masksets, mh, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, slibs, sh, JNI_ABORT);
+    int64_t *offs = (int64_t *)calloc((size_t)n + 1, sizeof(int64_t));
+    jint *s = (*env)->GetIntArrayElements(env, scores, NULL);
+    jbyte *m = (*env)->GetByteArrayElements(env, mirrored, NULL);
+    int rc = cds_search_sparse_sharded(P(cds_comm, comm), ms, sl, offs, (int32_t *)s, (uint8_t *)m);
+    (*env)->ReleaseIntArrayElements(env, scores, s, 0);
+    (*env)->ReleaseByteArrayElements(env, mirrored, m, 0);
+    jlongArray out = NULL;
+    if (rc) {
+        throw_for(env, rc);
+    } else {
+        out = (*env)->NewLongArray(env, n + 1);
+        (*env)->SetLongArrayRegion(env, out, 0, n + 1, (const jlong *)offs);
+    }
+    free(ms); free(sl); free(offs);
+    return out;
+}
+
+/* ---- GradientAreaGap scorer ---- */
+JNIEXPORT jlong JNICALL CLS(shapesetCreate)(JNIEnv *env, jclass c, jlong ctx, jint nMasks, jbyteArray masksRgb, jint w, jint h, jint queryThr,
+                                            jint border, jboolean mirror, jbyteArray roi, jintArray rects) {
+    cds_rect r[CDS_MAX_RECTS];
+    int n = get_rects(env, rects, r);
+    if (n < 0) return 0;
+    jbyte *px = (*env)->GetByteArrayElements(env, masksRgb, NULL);
+    jbyte *rp = roi ? (*env)->GetByteArrayElements(env, roi, NULL) : NULL;
+    cds_shapeset *ss = NULL;
+    int rc = cds_shapeset_create_bordered(P(cds_context, ctx), nMasks, (const uint8_t *)px, w, h, queryThr, border, mirror ? 1 : 0,
+                                          (const uint8_t *)rp, r, n, &ss);
+    (*env)->ReleaseByteArrayElements(env, masksRgb, px, JNI_ABORT);
+    if (rp) (*env)->ReleaseByteArrayElements(env, roi, rp, JNI_ABORT);
+    if (rc) { throw_for(env, rc); return 0; }
+    return (jlong)(intptr_t)ss;
+}
+JNIEXPORT void JNICALL CLS(shapesetDestroy)(JNIEnv *env, jclass c, jlong ss) { cds_shapeset_destroy(P(cds_shapeset, ss)); }
+JNIEXPORT void JNICALL CLS(shapesetMaskStats)(JNIEnv *env, jclass c, jlong ss, jlongArray maskSizes, jlongArray highSizes) {
+    jlong *a = (*env)->GetLongArrayElements(env, maskSizes, NULL), *b = (*env)->GetLongArrayElements(env, highSizes, NULL);
+    int rc = cds_shapeset_mask_stats(P(cds_shapeset, ss), (int64_t *)a, (int64_t *)b);
+    (*env)->ReleaseLongArrayElements(env, maskSizes, a, 0);
+    (*env)->ReleaseLongArrayElements(env, highSizes, b, 0);
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT void JNICALL CLS(shapeScorePair)(JNIEnv *env, jclass c, jlong ss, jint maskIndex, jbyteArray targetRgb, jshortArray grad, jbyteArray zgapRgb,
+                                           jint w, jint h, jlongArray out) {
+    jbyte *t = (*env)->GetByteArrayElements(env, targetRgb, NULL);
+    jshort *g = grad ? (*env)->GetShortArrayElements(env, grad, NULL) : NULL;
+    jbyte *z = zgapRgb ? (*env)->GetByteArrayElements(env, zgapRgb, NULL) : NULL;
+    int64_t gap = -1, high = -1;
+    uint8_t mirrored = 0;
+    int rc = cds_shape_score_pair(P(cds_shapeset, ss), maskIndex, (const uint8_t *)t, (const uint16_t *)g, (const uint8_t *)z, w, h, &gap, &high, &mirrored);
+    (*env)->ReleaseByteArrayElements(env, targetRgb, t, JNI_ABORT);
+    if (g) (*env)->ReleaseShortArrayElements(env, grad, g, JNI_ABORT);
+    if (z) (*env)->ReleaseByteArrayElements(env, zgapRgb, z, JNI_ABORT);
+    if (rc) { throw_for(env, rc); return; }
+    jlong v[3] = {gap, high, mirrored};
+    (*env)->SetLongArrayRegion(env, out, 0, 3, v);
+}
+JNIEXPORT void JNICALL CLS(gradscore)(JNIEnv *env, jclass c, jlong ss, jlong lib, jintArray pairMask, jlongArray pairSlot, jlongArray gap,
+                                      jlongArray high, jbyteArray mirrored) {
+    jsize n = (*env)->GetArrayLength(env, pairMask);
+    jint *pm = (*env)->GetIntArrayElements(env, pairMask, NULL);
+    jlong *ps = (*env)->GetLongArrayElements(env, pairSlot, NULL), *g = (*env)->GetLongArrayElements(env, gap, NULL),
+          *hi = (*env)->GetLongArrayElements(env, high, NULL);
+    jbyte *m = (*env)->GetByteArrayElements(env, mirrored, NULL);
+    int rc = cds_gradscore(P(cds_shapeset, ss), P(cds_library, lib), n, (const int32_t *)pm, (const int64_t *)ps, (int64_t *)g, (int64_t *)hi, (uint8_t *)m);
+    (*env)->ReleaseIntArrayElements(env, pairMask, pm, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, pairSlot, ps, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, gap, g, 0);
+    (*env)->ReleaseLongArrayElements(env, high, hi, 0);
+    (*env)->ReleaseByteArrayElements(env, mirrored, m, 0);
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT void JNICALL CLS(makeZgap)(JNIEnv *env, jclass c, jlong ctx, jbyteArray targetRgb, jint w, jint h, jint threshold, jdouble radius,
+                                     jintArray rects, jbyteArray zgapOut) {
+    cds_rect r[CDS_MAX_RECTS];
+    int n = get_rects(env, rects, r);
+    if (n < 0) return;
+    jbyte *t = (*env)->GetByteArrayElements(env, targetRgb, NULL), *z = (*env)->GetByteArrayElements(env, zgapOut, NULL);
+    int rc = cds_make_zgap(P(cds_context, ctx), (const uint8_t *)t, w, h, threshold, radius, r, n, (uint8_t *)z);
+    (*env)->ReleaseByteArrayElements(env, targetRgb, t, JNI_ABORT);
+    (*env)->ReleaseByteArrayElements(env, zgapOut, z, 0);
+    if (rc) throw_for(env, rc);
+}

@@ -1,0 +1,76 @@
+package org.janelia.colormipsearch.cds.gpu;
+
+import java.nio.ByteBuffer;
+
+/**
+ * The JNI surface of libcds_hip.so (include/cds_hip.h): one native method per C entry point the plugin uses; the
+ * implementations are in src/main/c/cds_hip_jni.c.  Handles are opaque pointers carried as long.  A failing call throws:
+ * CDS_ERR_INVALID_ARGUMENT becomes IllegalArgumentException (where the reference throws it too), everything else
+ * IllegalStateException with cds_last_error() as the message.  There is no CPU fallback behind any of these.
+ */
+final class CdsHip {
+    static {
+        System.loadLibrary("cds_hip_jni");   // links libcds_hip.so
+    }
+
+    private CdsHip() {
+    }
+
+    // ---- context ----
+    static native long contextCreate(int device);
+    static native void contextDestroy(long ctx);
+    static native void contextSynchronize(long ctx);
+
+    // ---- pixel-match mask sets (n x PixelMatchColorDepthSearchAlgorithm) ----
+    /** masksRgb: nMasks x 3*w*h bytes; rectsXYXY: x0,y0,x1,y1 per excluded rectangle (at most 8). */
+    static native long masksetCreate(long ctx, int nMasks, byte[] masksRgb, int w, int h, int maskThreshold, int dataThreshold,
+                                     double zTolerance, int xyShift, boolean mirror, int[] rectsXYXY);
+    static native void masksetDestroy(long maskset);
+    static native void masksetQuerySizes(long maskset, int[] sizes);
+    /** calculateMatchingScore of one host image: score | mirrored << 32. */
+    static native long scorePair(long maskset, int maskIndex, byte[] targetRgb, int w, int h);
+
+    // ---- dense resident library (targets + gradient / zgap variants; what the shape scorer reads) ----
+    static native long libraryCreate(long ctx, int w, int h, long capacity);
+    static native void libraryDestroy(long lib);
+    /** directRgb: count x 3*w*h bytes in a direct buffer. */
+    static native void libraryUpload(long lib, long first, long count, ByteBuffer directRgb);
+    /** directGrad (count x w*h unsigned shorts, native order) and directZgapRgb may each be null. */
+    static native void libraryUploadVariants(long lib, long first, long count, ByteBuffer directGrad, ByteBuffer directZgapRgb);
+    static native void libraryMakeZgapVariants(long lib, long first, long count, int threshold, double radius, int[] rectsXYXY);
+    static native void search(long maskset, long lib, long first, long count, int[] scores, byte[] mirrored);
+
+    // ---- sparse resident library (signal-pixel records: the pixel-match scan's layout) ----
+    static native long sparseLibraryCreate(long ctx, int w, int h, long capacityImages, long capacityPixels);
+    static native void sparseLibraryDestroy(long slib);
+    static native void sparseLibrarySetDensityLimit(long slib, double maxSignalFraction);
+    static native void sparseLibraryAppend(long slib, long count, ByteBuffer directRgb);
+    static native void sparseLibraryAppendFiles(long slib, String[] paths, int threads);
+    static native long sparseLibrarySize(long slib);
+    static native long sparseLibraryPixels(long slib);
+    static native void sparseLibraryClear(long slib);
+    static native void searchSparse(long maskset, long slib, long first, long count, int[] scores, byte[] mirrored);
+    /**
+     * Scan + ColorMIPSearch.isMatch + compaction on the device.  triples: capacity x (mask, target, score | mirrored << 31).
+     * Returns the number of matches; when it exceeds triples.length / 3 nothing was written and the call is to be repeated
+     * with a larger array.
+     */
+    static native long searchSparseMatches(long maskset, long slib, long first, long count, double pctPositivePixels, int[] triples);
+
+    // ---- several GPUs of one node ----
+    static native long commCreate(long[] contexts);
+    static native void commDestroy(long comm);
+    /** scores / mirrored: nMasks x (sum of the shards' sizes), library order; returns shard offsets (n + 1). */
+    static native long[] searchSparseSharded(long comm, long[] masksets, long[] slibs, int[] scores, byte[] mirrored);
+
+    // ---- GradientAreaGap scorer (n x Shape2DMatchColorDepthSearchAlgorithm) ----
+    static native long shapesetCreate(long ctx, int nMasks, byte[] masksRgb, int w, int h, int queryThreshold, int queryBorderSize,
+                                      boolean mirror, byte[] roiOrNull, int[] rectsXYXY);
+    static native void shapesetDestroy(long shapeset);
+    static native void shapesetMaskStats(long shapeset, long[] maskSizes, long[] highExpressionSizes);
+    /** out: gradientAreaGap, highExpressionArea, mirrored (0/1); grad / zgapRgb null -> (-1, -1, 0). */
+    static native void shapeScorePair(long shapeset, int maskIndex, byte[] targetRgb, short[] grad, byte[] zgapRgb, int w, int h, long[] out);
+    static native void gradscore(long shapeset, long lib, int[] pairMask, long[] pairSlot, long[] gradientAreaGap, long[] highExpressionArea,
+                                 byte[] mirrored);
+    static native void makeZgap(long ctx, byte[] targetRgb, int w, int h, int threshold, double radius, int[] rectsXYXY, byte[] zgapRgbOut);
+}

@@ -1,0 +1,71 @@
+package org.janelia.colormipsearch.cds.gpu;
+
+import java.nio.ByteBuffer;
+import java.util.ArrayList;
+import java.util.List;
+
+import org.janelia.colormipsearch.imageprocessing.ImageArray;
+import org.janelia.colormipsearch.imageprocessing.ImageArrayBytes;
+
+/**
+ * The resident target library of a colorDepthSearch run: a cds_sparse_library (signal-pixel records, ~4 % of the packed
+ * RGB bytes, so a million MIPs stay in one GPU's HBM) plus, per resident image, the caller's own key (the neuron entity).
+ * It replaces the host-side Guava cache of decoded MIPs (cmd/CachedMIPsUtils.java:60-100) for the pixel-match scan.
+ * Images are handed over in batches through one direct staging buffer.
+ */
+public final class GpuTargetLibrary<K> implements AutoCloseable {
+    private final long handle;
+    private final int width, height;
+    private final List<K> keys = new ArrayList<>();
+    private final ByteBuffer staging;
+    private final int stagingImages;
+    private final List<K> pendingKeys = new ArrayList<>();
+
+    public GpuTargetLibrary(long ctx, int width, int height, long capacityImages, long capacityRecords, int stagingImages) {
+        this.width = width;
+        this.height = height;
+        this.stagingImages = Math.max(1, stagingImages);
+        this.handle = CdsHip.sparseLibraryCreate(ctx, width, height, capacityImages, capacityRecords);
+        this.staging = ByteBuffer.allocateDirect(this.stagingImages * 3 * width * height);
+    }
+
+    long nativeHandle() {
+        return handle;
+    }
+
+    public int size() {
+        return keys.size();
+    }
+
+    public K key(int index) {
+        return keys.get(index);
+    }
+
+    /** queue one target; it becomes resident (and searchable) at the next flush(). */
+    public synchronized void add(K key, ImageArray<?> image) {
+        if (image.getWidth() != width || image.getHeight() != height) {
+            throw new IllegalArgumentException(String.format(
+                    "Invalid image size - target's image size (%d, %d) must match query's image size: (%d, %d)",
+                    image.getWidth(), image.getHeight(), width, height));
+        }
+        staging.put(ImageArrayBytes.rgb(image));
+        pendingKeys.add(key);
+        if (pendingKeys.size() == stagingImages) {
+            flush();
+        }
+    }
+
+    public synchronized void flush() {
+        if (!pendingKeys.isEmpty()) {
+            CdsHip.sparseLibraryAppend(handle, pendingKeys.size(), staging);
+            keys.addAll(pendingKeys);
+            pendingKeys.clear();
+            staging.clear();
+        }
+    }
+
+    @Override
+    public void close() {
+        CdsHip.sparseLibraryDestroy(handle);
+    }
+}

@@ -1,0 +1,126 @@
+package org.janelia.colormipsearch.cmd.cdsprocess;
+
+import java.util.ArrayList;
+import java.util.List;
+import java.util.Map;
+import java.util.Set;
+
+import org.janelia.colormipsearch.cds.ColorMIPSearch;
+import org.janelia.colormipsearch.cds.gpu.GpuBatchSearch;
+import org.janelia.colormipsearch.cmd.CachedMIPsUtils;
+import org.janelia.colormipsearch.imageprocessing.ImageArray;
+import org.janelia.colormipsearch.imageprocessing.ImageRegionDefinition;
+import org.janelia.colormipsearch.mips.NeuronMIP;
+import org.janelia.colormipsearch.mips.NeuronMIPUtils;
+import org.janelia.colormipsearch.model.AbstractNeuronEntity;
+import org.janelia.colormipsearch.model.CDMatchEntity;
+import org.janelia.colormipsearch.model.ComputeFileType;
+import org.janelia.colormipsearch.model.ProcessingType;
+import org.slf4j.Logger;
+import org.slf4j.LoggerFactory;
+
+/**
+ * ColorMIPSearchProcessor on MI355X: the counterpart of LocalColorMIPSearchProcessor (:55-116) at the granularity a GPU
+ * wants.  The reference makes one calculateMatchingScore call per (mask, target) pair from a thread pool; here
+ *   1. the target MIPs are decoded once (through the reference's own loader / cache) and made resident as a sparse
+ *      library on the GPU, partition by partition,
+ *   2. the masks are prepared in sets of up to 64 and every set scans the whole resident library in a few launches (groups of
+ *      masks share one pass over the records),
+ *   3. ColorMIPSearch.isMatch and the compaction run on the device: only the matches come back,
+ * and each match becomes the CDMatchEntity findPixelMatch would have produced (same fields, same tags, same "mask is empty /
+ * has no image: skip" rules).  The search parameters are read from ColorMIPSearch.getCDSParameters(), so the processor
+ * takes the same ColorMIPSearch object the local one does.
+ */
+public class GpuColorMIPSearchProcessor<M extends AbstractNeuronEntity, T extends AbstractNeuronEntity> extends AbstractColorMIPSearchProcessor<M, T> {
+
+    private static final Logger LOG = LoggerFactory.getLogger(GpuColorMIPSearchProcessor.class);
+    private static final int MASKS_PER_SET = 64;
+
+    private final ImageRegionDefinition excludedRegions;
+    private final int device;
+
+    public GpuColorMIPSearchProcessor(Number cdsRunId,
+                                      ColorMIPSearch colorMIPSearch,
+                                      int localProcessingPartitionSize,
+                                      ImageRegionDefinition excludedRegions,
+                                      int device,
+                                      Set<String> tags) {
+        super(cdsRunId, colorMIPSearch, localProcessingPartitionSize, tags);
+        this.excludedRegions = excludedRegions;
+        this.device = device;
+    }
+
+    @Override
+    public List<CDMatchEntity<M, T>> findAllColorDepthMatches(List<M> queryMIPs, List<T> targetMIPs) {
+        long startTime = System.currentTimeMillis();
+        LOG.info("Searching {} masks against {} targets on GPU {}", queryMIPs.size(), targetMIPs.size(), device);
+        Map<String, Object> params = colorMIPSearch.getCDSParameters();
+        List<CDMatchEntity<M, T>> results = new ArrayList<>();
+        try (GpuBatchSearch<T> search = new GpuBatchSearch<>(device, params, excludedRegions)) {
+            // 1. the targets, resident once for all masks; partitions bound the host memory held at a time
+            for (int p0 = 0; p0 < targetMIPs.size(); p0 += localProcessingPartitionSize) {
+                for (T targetMIP : targetMIPs.subList(p0, Math.min(targetMIPs.size(), p0 + localProcessingPartitionSize))) {
+                    NeuronMIP<T> targetImage = CachedMIPsUtils.loadMIP(targetMIP, ComputeFileType.InputColorDepthImage);
+                    if (NeuronMIPUtils.hasImageArray(targetImage)) {
+                        search.addTarget(targetMIP, NeuronMIPUtils.getImageArray(targetImage));
+                    }
+                }
+            }
+            search.targetsComplete();
+            LOG.info("{} of {} targets resident after {}s", search.targetCount(), targetMIPs.size(), (System.currentTimeMillis() - startTime) / 1000.);
+            // 2. the masks, a set at a time
+            List<M> setMIPs = new ArrayList<>();
+            List<ImageArray<?>> setImages = new ArrayList<>();
+            for (int qi = 0; qi <= queryMIPs.size(); qi++) {
+                if (qi < queryMIPs.size()) {
+                    M queryMIP = queryMIPs.get(qi);
+                    NeuronMIP<M> queryImage = NeuronMIPUtils.loadComputeFile(queryMIP, ComputeFileType.InputColorDepthImage);   // no caching for the mask
+                    if (queryImage == null || queryImage.hasNoImageArray()) {
+                        LOG.error("No input color depth image found for mask {}", queryMIP);
+                        continue;
+                    }
+                    setMIPs.add(queryMIP);
+                    setImages.add(queryImage.getImageArray());
+                }
+                if (setMIPs.size() == MASKS_PER_SET || (qi == queryMIPs.size() && !setMIPs.isEmpty())) {
+                    collectMatches(search, setMIPs, setImages, results);
+                    setMIPs.clear();
+                    setImages.clear();
+                }
+            }
+        }
+        LOG.info("Finished all color depth searches {} masks with {} targets in {}s: {} matches", queryMIPs.size(), targetMIPs.size(),
+                (System.currentTimeMillis() - startTime) / 1000., results.size());
+        return results;
+    }
+
+    @SuppressWarnings("unchecked")
+    private void collectMatches(GpuBatchSearch<T> search, List<M> maskMIPs, List<ImageArray<?>> maskImages, List<CDMatchEntity<M, T>> results) {
+        GpuBatchSearch.Matches found;
+        try {
+            found = search.findMatches(maskImages);     // masks whose query size is 0 yield nothing ("No computation created ... because it is empty")
+        } catch (IllegalArgumentException e) {            // e.g. a mask whose size differs from the library's: every pair of the set is in error
+            LOG.warn("Error comparing masks {} with the resident targets", maskMIPs, e);
+            return;
+        }
+        for (int i = 0; i < found.count; i++) {
+            M maskMIP = maskMIPs.get(found.mask[i]);
+            T targetMIP = search.target(found.target[i]);
+            CDMatchEntity<M, T> result = new CDMatchEntity<>();
+            result.setMaskImage((M) maskMIP.addProcessedTags(ProcessingType.ColorDepthSearch, tags));
+            result.setMatchedImage((T) targetMIP.addProcessedTags(ProcessingType.ColorDepthSearch, tags));
+            result.setSessionRefId(cdsRunId);
+            result.setMatchFound(true);
+            result.setMatchingPixels(found.score[i]);
+            result.setMatchingPixelsRatio((float) ((double) found.score[i] / (double) found.querySize[found.mask[i]]));
+            result.setMirrored(found.mirrored[i]);
+            result.addAllTags(tags);
+            results.add(result);
+        }
+    }
+
+    @Override
+    public void terminate() {
+        // nothing to do here: the native handles are released when findAllColorDepthMatches returns
+    }
+}
