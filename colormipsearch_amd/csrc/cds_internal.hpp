@@ -139,13 +139,19 @@ namespace cds {
 
 // ---- sparse library (cds_sparse.hip) ------------------------------------------------------------------------------
 // Record of one signal pixel (a pixel with a strict maximum channel -- every other pixel has no hue class and can never
-// match, AbstractColorDepthSearchAlgorithm.java:195-225): the hue class and the two channel values its ratio is made of.
-//   bit 31 first record of its image row | bits 30..20 x | bits 18..16 hue class 1..6 | bits 15..8 second channel | bits 7..0 max
-// An image is stored strip by strip (up to 4 column strips), a strip row by row, a row by ascending x.  A (strip, row) cell
-// without signal pixels holds one filler record (bit 31 only), so "row = rows started so far" holds everywhere.
+// match, AbstractColorDepthSearchAlgorithm.java:195-225): the two channel values its hue ratio is made of, its HUE BAND
+// (class * 5 + floor(5 * second / max) with the device's own arithmetic: 5..34; class = band / 5) -- what stage 1 of the scan
+// tests against the mask's band map, computed once when the image is converted instead of once per scan -- and its column
+// RELATIVE TO ITS STRIP (a run of records lies in one strip, whose first column is wave-uniform in the scan):
+//   bit 31 first record of its image row | bits 30..22 x - strip start (< 512) | bits 21..16 band | bits 15..8 second channel | bits 7..0 max
+// An image is stored strip by strip (up to 4 column strips of at most 512 pixels), a strip row by row, a row by ascending x.
+// A (strip, row) cell without signal pixels holds one filler record (bit 31 only), so "row = rows started so far" holds everywhere.
 constexpr uint32_t kRecRowFlag = 0x80000000u;
-constexpr int kRecXShift = 20;
-constexpr int kRecClsShift = 16;
+constexpr int kRecXShift = 22;
+constexpr uint32_t kRecXMask = 511u;
+constexpr int kRecBandShift = 16;
+constexpr uint32_t kRecBandMask = 63u;
+constexpr int kMaxStripW = 512;
 
 // One mask prepared for the sparse scan: the mask's bounding box cut into slabs of `slab_rows` mask rows; per slab one
 // ready-to-copy LDS image [plane u16 or u8 (slab_rows + 8) x pitch | band map u32 ceil((slab_rows + 4) / 4) x nwpr (one word per 4-row x 8-column cell)]:

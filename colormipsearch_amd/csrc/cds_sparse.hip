@@ -9,7 +9,7 @@
 // without a strict maximum channel (black, grey, two equal maxima) has no hue class and can never match anything.  The
 // dense scan streams 300 KB of mostly zeros per target to find the ~6 K pixels that matter; 1 M targets are 2 TB and do not
 // fit one GPU.  Here the library keeps, per image, its signal pixels only, as 4-byte records in row-major order
-// (x | hue class | second channel | max channel -- independent of every search parameter) plus one row-pointer array:
+// (strip-relative x | hue band | second channel | max channel -- independent of every search parameter) plus one row-pointer array:
 // ~80 KB per synthetic target instead of 2.06 MB, so a 1 M-target library (80 GB) is RESIDENT in one MI355X's 288 GB.
 //
 // The scan turns around accordingly (target-centric instead of the reference's mask-centric gather):
@@ -67,13 +67,17 @@ struct BuildParams {
     uint64_t *total;     // [1] records of the whole batch (read back by the host)
 };
 
-// hue class (AbstractColorDepthSearchAlgorithm.java:195-225; the nibble table of cds_scan.hip) and the two channels its
-// ratio is made of; 0 for a pixel without a strict maximum channel
+// hue class (AbstractColorDepthSearchAlgorithm.java:195-225; the nibble table of cds_scan.hip), the two channels its ratio is
+// made of and the hue band class * 5 + floor(5 * ratio) -- the ratio as the scan's evaluation computes it, second * v_rcp_f32(max),
+// so that the band of a record and the code the interval test sees come from the same float; 0 for a pixel without a strict
+// maximum channel
 __device__ __forceinline__ uint32_t px_record(uint32_t r, uint32_t g, uint32_t b) {
     const uint32_t mx = max(r, max(g, b)), mn = min(r, min(g, b)), md = r + g + b - mx - mn;
     const uint32_t idx = (r > g ? 4u : 0u) | (g > b ? 8u : 0u) | (b > r ? 16u : 0u);
     const uint32_t cls = (0x03125460u >> idx) & 7u;
-    return mx > md ? (cls << kRecClsShift) | (md << 8) | mx : 0u;
+    const float hf = (float)md * __builtin_amdgcn_rcpf((float)mx);
+    const uint32_t band = cls * 5u + (uint32_t)(hf * 5.0f);
+    return mx > md ? (band << kRecBandShift) | (md << 8) | mx : 0u;
 }
 
 // One wave per image row.  An image is stored strip by strip (column strips of strip_w pixels), a strip row by row, a row
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(BuildParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if (rec[j]) {
-                        dst[pos] = rec[j] | ((uint32_t)(4 * g + j) << kRecXShift) | (pos == 0 ? kRecRowFlag : 0u);
+                        dst[pos] = rec[j] | ((uint32_t)(4 * g + j - k * p.strip_w) << kRecXShift) | (pos == 0 ? kRecRowFlag : 0u);
                         pos++;
                     }
             }
@@ -206,8 +210,8 @@ __global__ __launch_bounds__(1024) void sparse_imgscan_kernel(BuildParams p) {
 
 // Consistency of imported records (a shard file is untrusted input).  One thread per (image, strip, row) cell: the cell
 // holds at least one record; its first record -- and no other -- carries the row flag; a cell is either ONE filler record
-// or signal records with class 1..6, maximum > second channel, bit 19 clear and x strictly ascending inside the strip (and the
-// image).  The scan derives rows from the flags and plane offsets from x: a record that breaks these rules would be read as
+// or signal records with maximum > second channel, the hue band that those two channels and a class 1..6 give on this device,
+// and x strictly ascending inside the strip (and the image).  The scan derives rows from the flags and plane offsets from x: a record that breaks these rules would be read as
 // another pixel, so such a shard is refused instead of giving silently wrong scores.
 struct ValidateParams {
     const uint32_t *px;
@@ -236,8 +240,10 @@ __global__ __launch_bounds__(256) void sparse_validate_kernel(ValidateParams p) 
             int prev = xlo - 1;
             for (uint32_t i = a; i < b && ok; i++) {
                 const uint32_t v = r[i];
-                const int x = (int)((v >> kRecXShift) & 2047u), cls = (int)((v >> kRecClsShift) & 7u);
-                ok = ((v >> 31) == (i == a ? 1u : 0u)) && cls >= 1 && cls <= 6 && (v & 255u) > ((v >> 8) & 255u) && !(v & (1u << 19)) &&
+                const int x = xlo + (int)((v >> kRecXShift) & kRecXMask);
+                const uint32_t band = (v >> kRecBandShift) & kRecBandMask, cls = (band * 13u) >> 6, mx = v & 255u, md = (v >> 8) & 255u;
+                const float hf = (float)md * __builtin_amdgcn_rcpf((float)mx);
+                ok = ((v >> 31) == (i == a ? 1u : 0u)) && band >= 5u && band <= 34u && mx > md && band == cls * 5u + (uint32_t)(hf * 5.0f) &&
                      x > prev && x < xhi;
                 prev = x;
             }
@@ -307,14 +313,12 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
         // The per-pixel constants live in VGPRs (uniform values, pinned by the asm so that hipcc does not move them back):
         // the kernel's scalar registers are needed for the 18 counters, the queue state and the loop state, and every
         // scalar spilled to a VGPR lane comes back as a v_readlane inside the 64-pixel loop.
-        uint32_t v_thr, v_cx0, v_cm0, v_wnear, v_nwpr, v_pitch, poff;
+        uint32_t v_thr, v_wnear, v_nwpr, v_pitch, poff;
 #if SP_BAND
         uint32_t near_lds;  // LDS address of the band map
         asm volatile("v_mov_b32 %0, %1" : "=v"(near_lds) : "s"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)nearb));
 #endif
         asm volatile("v_mov_b32 %0, %1" : "=v"(v_thr) : "s"(p.thr));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(v_cx0) : "s"(cx0));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(v_cm0) : "s"(cm0));
         asm volatile("v_mov_b32 %0, %1" : "=v"(v_wnear) : "s"(wnear));
 #if SP_BAND
         asm volatile("v_mov_b32 %0, %1" : "=v"(v_nwpr) : "s"(p.nwpr * 4));  // bytes per cell row of the band map
@@ -403,7 +407,8 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                     const uint32_t r = ent.x;
                     const int off = valid ? (int)ent.y : safe_off;
                     const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
-                    uint32_t code = (((r >> kRecClsShift) & 7u) << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
+                    const uint32_t cls = (((r >> kRecBandShift) & kRecBandMask) * 13u) >> 6;  // band / 5 for bands 5..34
+                    uint32_t code = (cls << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
                     code = valid ? code : 0u;  // 0 lies in no interval
                     const plane_t *c0 = plane + off - (XY2 ? 2 : 0);  // (column offsets 0, 2, 4 below)
                     uint32_t idx[NS];
@@ -448,6 +453,13 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
 
                 for (int r = 0; r < nruns; r++) {  // wave-uniform
                     int yrel = ra - 1 - ry0;  // (rows started before the current block) - 1, relative to the band map
+                    // a record's x is relative to its strip: the strip's first column goes into the two column origins of the run
+                    uint32_t v_cx0, v_cm0;
+                    {
+                        const uint32_t sbase = (uint32_t)(ks0 + kin) * (uint32_t)p.strip_w;
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(v_cx0) : "s"(cx0 - sbase));
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(v_cm0) : "s"(cm0 - sbase));
+                    }
                     for (uint32_t i = a; i < b; i += 64 * NB) {  // wave-uniform
                         const uint32_t rem = b - i;  // records of this run from block 0 of this iteration on
                         // the next NB blocks -- of this run, or the first ones of the grab's next run -- are in flight while
@@ -475,18 +487,17 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                             const unsigned long long fb = __ballot((int)rec[j] < 0);
                             const uint32_t ry = (uint32_t)(yrel + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0))) + (rec[j] >> 31);
                             yrel += __popcll(fb);
-                            const uint32_t x = (rec[j] >> kRecXShift) & 2047u;
+                            const uint32_t x = (rec[j] >> kRecXShift) & kRecXMask;  // (relative to the strip, see v_cx0 / v_cm0)
 #if !SP_BAND
                             passbit[j] = (rec[j] & 255u) > v_thr ? 1u : 0u;
 #endif
                             cxp[j] = min(x - v_cx0, v_wnear);
                             cxm[j] = MIRROR ? min(v_cm0 - x, v_wnear) : 0u;
 #if SP_BAND
-                            // hue band of the pixel = class * 5 + floor(5 * ratio), the ratio as the evaluation computes it (a filler
-                            // record gives NaN -> 0 and fails the threshold anyway); the map cell = 4 rows x 8 columns
-                            const float hf = (float)((rec[j] >> 8) & 255u) * __builtin_amdgcn_rcpf((float)(rec[j] & 255u));
-                            band[j] = __umul24((rec[j] >> kRecClsShift) & 7u, 5u) + (uint32_t)(hf * 5.0f);
-                            band[j] = (rec[j] & 255u) > v_thr ? band[j] : 3u;  // below the threshold: bit 3, which no band maps to
+                            // hue band of the pixel (class * 5 + floor(5 * ratio), 5..34: it comes with the record; v_bfe takes it mod 32);
+                            // the map cell = 4 rows x 8 columns
+                            band[j] = (rec[j] >> kRecBandShift) & kRecBandMask;
+                            band[j] = (rec[j] & 255u) > v_thr ? band[j] : 3u;  // below the threshold (a filler too): bit 3, which no band maps to
                             // LDS address of the cell's word = map + (ry / 4) * row bytes + (column / 8) * 4: one mad for the row, one
                             // shift-add per orientation (written as asm: hipcc turns (c >> 3) << 2 into shift, mask and a separate add)
                             typedef __attribute__((address_space(3))) const uint32_t lds_u32;
@@ -628,7 +639,7 @@ static size_t multi_lds_bytes(int threads, int n_iv, int umap_words) { return mu
 template <bool XY2, bool MIRROR, bool P8>
 __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams p) {
     extern __shared__ uint4 lds4[];
-    constexpr int NS = XY2 ? 9 : 1, NSX = XY2 ? 3 : 1;
+    constexpr int NS = XY2 ? 9 : 1;
     constexpr int HALO = XY2 ? 2 : 0;
     #ifndef SM_NB
 #define SM_NB 2
@@ -725,7 +736,8 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                 const uint32_t e = valid ? ent.y : safe_off;
                 const uint32_t off = e & 0xFFFFFu, bit = e >> 20, m = bit & 7u, o = bit >> 3;
                 const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
-                uint32_t code = (((r >> kRecClsShift) & 7u) << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
+                const uint32_t rcls = (((r >> kRecBandShift) & kRecBandMask) * 13u) >> 6;  // band / 5 for bands 5..34
+                uint32_t code = (rcls << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
                 code = valid ? code : 0u;  // 0 lies in no interval
                 // plane bytes of the entry's own mask: mask row = target row - dy, mask column = target column - dx
                 const uint4 *ivm = ivt + ivb[m];  // (requested before the plane reads: the asm below is a memory barrier to hipcc)
@@ -780,6 +792,8 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
 
             for (int r = 0; r < nruns; r++) {  // wave-uniform
                 int yrel = ra - 1 - ry0;  // (rows started before the current block) - 1, relative to the map's first row
+                const uint32_t sbase = (uint32_t)(ks0 + kin) * (uint32_t)p.strip_w;  // the run's strip: record columns are relative to it
+                const uint32_t cx0r = cx0 - sbase, cm0r = cm0 - sbase;
                 for (uint32_t i = a; i < b; i += 64 * NB) {  // wave-uniform
                     const uint32_t rem = b - i;
                     // stage 1 of all NB blocks first (row, columns, bin, the map bytes of both orientations: 2 NB L2 gathers in flight
@@ -791,13 +805,14 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                         const unsigned long long fb = __ballot((int)rec < 0);
                         const uint32_t ry = (uint32_t)(yrel + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0))) + (rec >> 31);
                         yrel += __popcll(fb);
-                        const uint32_t x = (rec >> kRecXShift) & 2047u;
-                        const uint32_t cxp = min(x - cx0, wnear);
-                        const uint32_t cxm = MIRROR ? min(cm0 - x, wnear) : 0u;
+                        const uint32_t x = (rec >> kRecXShift) & kRecXMask;  // relative to the strip: cx0r / cm0r carry its first column
+                        const uint32_t cxp = min(x - cx0r, wnear);
+                        const uint32_t cxm = MIRROR ? min(cm0r - x, wnear) : 0u;
                         // hue bin = class * 64 + floor(64 * ratio) (448 per cell; class 0 = bins no mask accepts, where a pixel below
                         // the data threshold is sent; a filler record gives NaN -> 0 and fails the threshold anyway)
                         const float hf = (float)((rec >> 8) & 255u) * __builtin_amdgcn_rcpf((float)(rec & 255u));
-                        uint32_t bin = (((rec >> kRecClsShift) & 7u) << kSparseGroupBinsLog2) + (uint32_t)(hf * (float)kSparseGroupBins);
+                        const uint32_t band = (rec >> kRecBandShift) & kRecBandMask;
+                        uint32_t bin = (((band * 13u) >> 6) << kSparseGroupBinsLog2) + (uint32_t)(hf * (float)kSparseGroupBins);
                         bin = (rec & 255u) > thr ? bin : 0u;
                         const uint32_t rowc = __umul24(ry >> 2, nwpr);
                         // the group's UNION band map (LDS, one word per cell, the single-mask kernel's 30 coarse bands) first: only a
@@ -806,10 +821,9 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                         const uint32_t cellp = rowc + (cxp >> 3), cellm = rowc + (cxm >> 3);
                         bool passp = true, passm = MIRROR;
                         if (prefilter) {
-                            uint32_t band = (__umul24((rec >> kRecClsShift) & 7u, 5u) + (uint32_t)(hf * 5.0f)) & 31u;
-                            band = (rec & 255u) > thr ? band : 3u;  // bit 3 is never set
-                            passp = __builtin_amdgcn_ubfe(umap[cellp], band, 1u) != 0;
-                            if (MIRROR) passm = __builtin_amdgcn_ubfe(umap[cellm], band, 1u) != 0;
+                            const uint32_t cband = (rec & 255u) > thr ? band : 3u;  // bit 3 is never set (v_bfe takes the band mod 32)
+                            passp = __builtin_amdgcn_ubfe(umap[cellp], cband, 1u) != 0;
+                            if (MIRROR) passm = __builtin_amdgcn_ubfe(umap[cellm], cband, 1u) != 0;
                         }
                         uint32_t w = 0;
                         if (passp) w = __builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)(__umul24(cellp, 7u * kSparseGroupBins) + bin), 0, 0);
@@ -833,8 +847,8 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                             if (w != 0) {
                                 const uint32_t bit = (uint32_t)__builtin_ctz(w);
                                 const int slot = (qt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0))) & (SM_QCAP - 1);
-                                const uint32_t x = (rec >> kRecXShift) & 2047u;
-                                const uint32_t cx = (MIRROR && bit >= 8u) ? min(cm0 - x, wnear) : min(x - cx0, wnear);
+                                const uint32_t x = (rec >> kRecXShift) & kRecXMask;
+                                const uint32_t cx = (MIRROR && bit >= 8u) ? min(cm0r - x, wnear) : min(x - cx0r, wnear);
                                 q[slot] = make_uint2(rec, (prow + cx) | (bit << 20));
                                 w &= w - 1u;
                             }
@@ -1613,9 +1627,9 @@ int cds_sparse_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t ca
     sl->strip_w = std::max(64, round_up((W + 3) / 4, 4));
     if (const char *e = getenv("CDS_SPARSE_STRIP_W")) sl->strip_w = std::max(4, round_up(atoi(e), 4));
     sl->nstrips = (W + sl->strip_w - 1) / sl->strip_w;
-    if (sl->nstrips > 16) {
+    if (sl->nstrips > 16 || sl->strip_w > kMaxStripW) {
         delete sl;
-        return fail(CDS_ERR_INVALID_ARGUMENT, "CDS_SPARSE_STRIP_W is too small for this image width");
+        return fail(CDS_ERR_INVALID_ARGUMENT, "CDS_SPARSE_STRIP_W must give at most 16 strips of at most 512 pixels (a record holds its column relative to its strip in 9 bits)");
     }
     hipError_t e = hipMalloc(&sl->d_px, (size_t)capacity_pixels * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&sl->d_img_off, (size_t)(capacity_images + 1) * sizeof(uint64_t));

@@ -126,7 +126,7 @@ def upload_shard(library, shard_pixels, first_slot=0, batch=256):
 
 
 # ---- sparse shards: a converted library on disk -------------------------------------------------------------
-SPARSE_MAGIC = "cds-sparse-shard-v1"
+SPARSE_MAGIC = "cds-sparse-shard-v2"   # v2: records carry the hue band and a strip-relative column (cds_internal.hpp); v1 files are refused
 
 
 def write_sparse_shard(path, sparse_library, first=0, count=None, meta=None):

@@ -136,7 +136,7 @@ int cds_is_match(int32_t score, int32_t query_size, double pct_positive_pixels);
 /* ---- sparse target library (pixel-match scan only) -------------------------------------------------
  * A color-depth MIP is a few percent signal on black, and a pixel without a strict maximum channel has no hue
  * class and matches nothing (API/cds/AbstractColorDepthSearchAlgorithm.java:195-225, 227-232).  A sparse library
- * keeps per image only its signal pixels (4 bytes each: x, hue class, second and maximum channel -- independent of
+ * keeps per image only its signal pixels (4 bytes each: x, hue band, second and maximum channel -- independent of
  * every search parameter) in row-major order: ~4 % of the dense bytes, so a 1 M-image library fits one GPU.
  * It replaces the same host-side MIP cache (tools cmd/CachedMIPsUtils.java:60-100) for searches that need the
  * pixel-match score only; the shape scorer keeps reading dense slots + variants.  Results of cds_search_sparse*
@@ -162,8 +162,9 @@ int cds_sparse_library_set_density_limit(cds_sparse_library *slib, double max_si
 int64_t cds_sparse_library_size(const cds_sparse_library *slib);   /* images held  */
 int64_t cds_sparse_library_pixels(const cds_sparse_library *slib); /* records held */
 int cds_sparse_library_clear(cds_sparse_library *slib);
-/* Diagnostic: the records of one image (bit 31 first of its cell | x << 20 | class << 16 | second << 8 | max) and
- * its n_strips x (H+1) cell offsets; either output may be NULL; *n_records is always set. */
+/* Diagnostic: the records of one image (bit 31 first of its cell | (x - strip start) << 22 | hue band << 16 | second << 8 | max,
+ * band = class * 5 + floor(5 * second / max) in the device's arithmetic, 5..34) and its n_strips x (H+1) cell offsets; either
+ * output may be NULL; *n_records is always set. */
 int cds_sparse_library_image_records(const cds_sparse_library *slib, int64_t index, uint32_t *records, int64_t capacity,
                                      int64_t *n_records, uint32_t *row_offsets);
 /* Diagnostic: offsets[count+1] = position of the first record of images first..first+count in the library's record

@@ -247,10 +247,11 @@ def test_sparse_shard_round_trip(tmp_path, fixtures, oracle):
     sig = np.flatnonzero((rec[: int(offs[1])] & 0x7FFFFFFF) != 0)
     k = int(sig[len(sig) // 2])                            # a signal record of image 0
     for what, mutate in (("row flag on a later record", lambda r: r.__setitem__(k + (1 if (r[k] >> 31) else 0), r[k + (1 if (r[k] >> 31) else 0)] | np.uint32(1 << 31))),
-                         ("class 0", lambda r: r.__setitem__(k, r[k] & np.uint32(~(7 << 16) & 0xFFFFFFFF))),
-                         ("class 7", lambda r: r.__setitem__(k, r[k] | np.uint32(7 << 16))),
+                         ("band 0", lambda r: r.__setitem__(k, r[k] & np.uint32(~(63 << 16) & 0xFFFFFFFF))),
+                         ("band that second / max do not give", lambda r: r.__setitem__(k, (r[k] & np.uint32(~(63 << 16) & 0xFFFFFFFF)) |
+                                                                              np.uint32((lambda b: b + 1 if b % 5 < 4 else b - 1)((int(r[k]) >> 16) & 63) << 16))),
                          ("maximum not above the second channel", lambda r: r.__setitem__(k, (r[k] & np.uint32(0xFFFF0000)) | np.uint32(0x5050))),
-                         ("x outside the image", lambda r: r.__setitem__(k, r[k] | np.uint32(2047 << 20))),
+                         ("x outside the strip", lambda r: r.__setitem__(k, r[k] | np.uint32(511 << 22))),
                          ("filler inside a cell", lambda r: r.__setitem__(k, np.uint32(1 << 31) if not (r[k] >> 31) else r[k] & np.uint32(0x7FFFFFFF)))):
         bad_rec = rec.copy()
         mutate(bad_rec)

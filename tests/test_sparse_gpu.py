@@ -31,10 +31,22 @@ def sparse_of(cds, images, w=None, h=None, slack=0):
     return sl
 
 
+_RCP = {}
+
+
+def device_rcp():
+    """v_rcp_f32(0..255) of the GPU under test (the band of a record is made with it)."""
+    if "t" not in _RCP:
+        from colormipsearch_amd import cds as m
+        _RCP["t"] = m.default_context().device_rcp_table()
+    return _RCP["t"]
+
+
 def records_model(img, n_strips=1, strip_w=None):
     """The specification of the record stream (include/cds_hip.h, cds_internal.hpp): strip by strip (column strips of
     strip_w pixels), row by row, x ascending, the pixels with a strict maximum channel as
-    x << 20 | class << 16 | second << 8 | max,  bit 31 on the first record of a (strip, row) cell; a cell without such a
+    (x - strip start) << 22 | band << 16 | second << 8 | max  with  band = class * 5 + floor(5 * fl32(second) * rcp[max])
+    (float32 arithmetic, the device's reciprocal),  bit 31 on the first record of a (strip, row) cell; a cell without such a
     pixel holds the single filler record 1 << 31."""
     img = img.astype(np.int64)
     strip_w = strip_w or img.shape[1]
@@ -57,7 +69,9 @@ def records_model(img, n_strips=1, strip_w=None):
             if len(xs) == 0:
                 rec = np.array([1 << 31], dtype=np.int64)
             else:
-                rec = (xs << 20) | (cls[y, xs] << 16) | (md[y, xs] << 8) | mx[y, xs]
+                hf = (md[y, xs].astype(np.float32) * device_rcp()[mx[y, xs]]).astype(np.float32)
+                band = cls[y, xs] * 5 + (hf * np.float32(5.0)).astype(np.int64)
+                rec = ((xs - k * strip_w) << 22) | (band << 16) | (md[y, xs] << 8) | mx[y, xs]
                 rec[0] |= 1 << 31
             out.append(rec)
             pos += len(rec)
