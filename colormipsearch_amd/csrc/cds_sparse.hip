@@ -1361,7 +1361,7 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
     hipStream_t st = ctx->stream;
     std::lock_guard<std::mutex> lk(ms->sp_mu);
     const int threads = sparse_threads();
-    int group = count >= 4096 ? 2 : 1;  // (grabs are cheap since the counters are partitioned; small grabs balance the tail)
+    int group = count >= 262144 ? 4 : count >= 4096 ? 2 : 1;  // (grabs are cheap since the counters are partitioned; small grabs balance the tail; 4 per grab at 1 M targets: +2.4 %)
     if (const char *e = getenv("CDS_SPARSE_GROUP")) group = std::max(1, atoi(e));
     group = std::min(group, 64 / sl->nstrips);  // a grab's run headers (targets x visited strips) live in the lanes of one wave
     int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(SP_MAX_PARTS, count / 2048));
@@ -1466,7 +1466,7 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
             for (int j = 0; j < kSparseGroupMasks; j++) p.iv_base[j] = gp.iv_base[j];
             p.xlo = gp.xlo; p.cols = gp.cols; p.ylo = gp.ylo; p.nrows = gp.nrows; p.pitch = gp.pitch; p.nwpr = gp.nwpr;
             p.thr = std::max(0, ms->params.data_threshold);
-            p.group = group; p.nparts = nparts;
+            p.group = std::min(group, 2); p.nparts = nparts;   // (a grab of the multi-mask kernel is 8 masks' worth of work already)
             p.psize = (uint32_t)((count + nparts - 1) / nparts);
             p.work = ms->d_sp_work;
             p.out = d_scores + (size_t)(gp.first_mask - m_begin) * count;
