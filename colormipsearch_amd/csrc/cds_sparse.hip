@@ -636,7 +636,7 @@ constexpr int SM_WAVE_BYTES = SM_QCAP * 8 + kSparseGroupMasks * CDS_N_TRANSFORMS
 static size_t multi_fixed_bytes(int n_iv, int umap_words) { return (size_t)round_up(n_iv, 4) * 16 + 64 + (size_t)round_up(umap_words, 4) * 4; }
 static size_t multi_lds_bytes(int threads, int n_iv, int umap_words) { return multi_fixed_bytes(n_iv, umap_words) + (size_t)(threads / 64) * SM_WAVE_BYTES; }
 
-template <bool XY2, bool MIRROR, bool P8>
+template <bool XY2, bool MIRROR, bool P8, bool PF>
 __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams p) {
     extern __shared__ uint4 lds4[];
     constexpr int NS = XY2 ? 9 : 1;
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
     int *cnt = reinterpret_cast<int *>(wb + SM_QCAP * 8);
     for (int i = threadIdx.x; i < p.n_iv; i += blockDim.x) ivt[i] = p.iv[i];
     for (int i = threadIdx.x; i < p.umap_words; i += blockDim.x) umap[i] = p.umap[i];
-    const bool prefilter = p.umap_words > 0;  // (a map too large for the LDS is left out: every record then asks the L2 map)
+    // (PF = false: a union map too large for the LDS is left out -- every record then asks the L2 map)
     if (threadIdx.x < K) ivb[threadIdx.x] = p.iv_base[threadIdx.x];
     for (int i = lane; i < K * CDS_N_TRANSFORMS; i += 64) cnt[i] = 0;
     __syncthreads();
@@ -796,9 +796,13 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                 const uint32_t cx0r = cx0 - sbase, cm0r = cm0 - sbase;
                 for (uint32_t i = a; i < b; i += 64 * NB) {  // wave-uniform
                     const uint32_t rem = b - i;
-                    // stage 1 of all NB blocks first (row, columns, bin, the map bytes of both orientations: 2 NB L2 gathers in flight
-                    // together, one wait), then the next NB record blocks are requested, then the set bits become queue entries
-                    uint32_t w4[NB], prow4[NB];
+                    // Stage 1 of the NB blocks in PHASES, so that no block waits alone: (A) row, columns, cells, and the two words of
+                    // the group's UNION band map (LDS, one word per cell, the single-mask kernel's 30 coarse bands) of every block;
+                    // (B) the hue bin and, only for the lanes some mask of the group can accept at all, the byte per orientation of
+                    // the fine map in L2 -- the gathers are what this kernel waits for, and their cost is the number of distinct
+                    // lines the ACTIVE lanes touch; (C), after the next record blocks have been requested, the set bits become
+                    // queue entries.  One LDS wait and one L2 wait per NB blocks.
+                    uint32_t wp4[NB], wm4[NB], prow4[NB], cellp4[NB], cellm4[NB], up4[NB], um4[NB];
 #pragma unroll
                     for (int j = 0; j < NB; j++) {
                         const uint32_t rec = cur[j];  // (lanes and whole blocks beyond the run were loaded as 0: no flag, below every threshold)
@@ -808,28 +812,44 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                         const uint32_t x = (rec >> kRecXShift) & kRecXMask;  // relative to the strip: cx0r / cm0r carry its first column
                         const uint32_t cxp = min(x - cx0r, wnear);
                         const uint32_t cxm = MIRROR ? min(cm0r - x, wnear) : 0u;
+                        const uint32_t rowc = __umul24(ry >> 2, nwpr);
+                        cellp4[j] = rowc + (cxp >> 3);
+                        cellm4[j] = rowc + (cxm >> 3);
+                        prow4[j] = __umul24(ry, pitch) + poff;  // plane offset of column cx0 in the record's row
+                        if (PF) {
+                            up4[j] = umap[cellp4[j]];
+                            um4[j] = MIRROR ? umap[cellm4[j]] : 0u;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < NB; j++) {
+                        const uint32_t rec = cur[j];
                         // hue bin = class * 64 + floor(64 * ratio) (448 per cell; class 0 = bins no mask accepts, where a pixel below
                         // the data threshold is sent; a filler record gives NaN -> 0 and fails the threshold anyway)
                         const float hf = (float)((rec >> 8) & 255u) * __builtin_amdgcn_rcpf((float)(rec & 255u));
                         const uint32_t band = (rec >> kRecBandShift) & kRecBandMask;
+                        const bool bright = (rec & 255u) > thr;
                         uint32_t bin = (((band * 13u) >> 6) << kSparseGroupBinsLog2) + (uint32_t)(hf * (float)kSparseGroupBins);
-                        bin = (rec & 255u) > thr ? bin : 0u;
-                        const uint32_t rowc = __umul24(ry >> 2, nwpr);
-                        // the group's UNION band map (LDS, one word per cell, the single-mask kernel's 30 coarse bands) first: only a
-                        // record that some mask of the group can accept at all asks the fine map in L2 -- the gathers are what this
-                        // kernel waits for, and their cost is the number of distinct lines the ACTIVE lanes touch
-                        const uint32_t cellp = rowc + (cxp >> 3), cellm = rowc + (cxm >> 3);
+                        bin = bright ? bin : 0u;
                         bool passp = true, passm = MIRROR;
-                        if (prefilter) {
-                            const uint32_t cband = (rec & 255u) > thr ? band : 3u;  // bit 3 is never set (v_bfe takes the band mod 32)
-                            passp = __builtin_amdgcn_ubfe(umap[cellp], cband, 1u) != 0;
-                            if (MIRROR) passm = __builtin_amdgcn_ubfe(umap[cellm], cband, 1u) != 0;
+                        if (PF) {
+                            const uint32_t cband = bright ? band : 3u;  // bit 3 is never set (v_bfe takes the band mod 32)
+                            passp = __builtin_amdgcn_ubfe(up4[j], cband, 1u) != 0;
+                            if (MIRROR) passm = __builtin_amdgcn_ubfe(um4[j], cband, 1u) != 0;
                         }
-                        uint32_t w = 0;
-                        if (passp) w = __builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)(__umul24(cellp, 7u * kSparseGroupBins) + bin), 0, 0);
-                        if (MIRROR && passm) w |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)(__umul24(cellm, 7u * kSparseGroupBins) + bin), 0, 0) << 8;
-                        w4[j] = w;
-                        prow4[j] = __umul24(ry, pitch) + poff;  // plane offset of column cx0 in the record's row
+                        wp4[j] = 0, wm4[j] = 0;
+#if defined(SM_EXP) && SM_EXP == 2   // (timing experiment: no map loads at all -- the floor of stage 1)
+                        wp4[j] = (cellp4[j] + cellm4[j] + bin + (passp ? 1u : 0u) + (passm ? 2u : 0u)) == 0xFFFFFFFFu ? 1u : 0u;
+#else
+                        // (unconditional loads: a lane that did not pass reads byte 0 of the map -- cell 0, class 0: never set -- together
+                        // with every other such lane, ONE line; a branch around the load would make hipcc wait for it at the join)
+                        const uint32_t offp = passp ? __umul24(cellp4[j], 7u * kSparseGroupBins) + bin : 0u;
+                        wp4[j] = __builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)offp, 0, 0);
+                        if (MIRROR) {
+                            const uint32_t offm = passm ? __umul24(cellm4[j], 7u * kSparseGroupBins) + bin : 0u;
+                            wm4[j] = __builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)offm, 0, 0);
+                        }
+#endif
                     }
                     {   // the next NB blocks -- of this run or the first of the grab's next run -- are in flight meanwhile
                         const uint32_t *Pq = P;
@@ -841,7 +861,11 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
 #pragma unroll
                     for (int j = 0; j < NB; j++) {
                         const uint32_t rec = cur[j], prow = prow4[j];
-                        uint32_t w = w4[j];
+                        uint32_t w = wp4[j] | (wm4[j] << 8);
+#if defined(SM_EXP) && SM_EXP == 1   // (timing experiment: the map bytes are loaded and not used -- no entries, no rounds; scores become 0)
+                        asm volatile("" ::"v"(w));
+                        w = 0;
+#endif
                         unsigned long long bal = __ballot(w != 0);
                         while (bal) {  // one turn per set bit of the busiest lane
                             if (w != 0) {
@@ -1315,10 +1339,11 @@ static int launch_sparse(cds_context *ctx, const SparseScanParams &p, size_t lds
 
 
 static int launch_sparse_multi(cds_context *ctx, const SparseMultiParams &p, int threads, bool xy2, bool mirror, bool plane8, hipStream_t st) {
-    auto kern = plane8 ? (xy2 ? (mirror ? sparse_multi_kernel<true, true, true> : sparse_multi_kernel<true, false, true>)
-                              : (mirror ? sparse_multi_kernel<false, true, true> : sparse_multi_kernel<false, false, true>))
-                       : (xy2 ? (mirror ? sparse_multi_kernel<true, true, false> : sparse_multi_kernel<true, false, false>)
-                              : (mirror ? sparse_multi_kernel<false, true, false> : sparse_multi_kernel<false, false, false>));
+    const bool pf = p.umap_words > 0;
+#define SM_PICK(P8V, PFV) (xy2 ? (mirror ? sparse_multi_kernel<true, true, P8V, PFV> : sparse_multi_kernel<true, false, P8V, PFV>) \
+                               : (mirror ? sparse_multi_kernel<false, true, P8V, PFV> : sparse_multi_kernel<false, false, P8V, PFV>))
+    auto kern = plane8 ? (pf ? SM_PICK(true, true) : SM_PICK(true, false)) : (pf ? SM_PICK(false, true) : SM_PICK(false, false));
+#undef SM_PICK
     const size_t lds_bytes = multi_lds_bytes(threads, p.n_iv, p.umap_words);
     CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int per_cu = (int)std::min<size_t>((size_t)(2048 / threads), ctx->lds_per_block / lds_bytes);
