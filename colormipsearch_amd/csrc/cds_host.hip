@@ -205,6 +205,67 @@ uint32_t host_hue_code(const float *rcp, int r, int g, int b, int thr) {
     return (cls << 29) | ratio_code(rcp, md, mx);
 }
 
+cds_context *clone_context_for_slot(cds_context *parent) {
+    hipSetDevice(parent->device);
+    cds_context *c = new cds_context();
+    c->device = parent->device;
+    c->n_cus = parent->n_cus;
+    c->lds_per_block = parent->lds_per_block;
+    memcpy(c->rcp, parent->rcp, sizeof c->rcp);
+    c->ratios = parent->ratios;
+    c->d_slice_lut = parent->d_slice_lut;
+    c->owns_lut = false;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return nullptr;
+    }
+    c->stream = c->own_stream;
+    return c;
+}
+
+PairSlot::~PairSlot() {
+    if (lib) cds_library_destroy(lib);
+    if (d_scores) hipFree(d_scores);
+    if (sub) cds_context_destroy(sub);
+}
+
+int PairSlotPool::acquire(cds_context *parent, int W, int H, size_t score_elems, PairSlot **out) {
+    int max_slots = 8;
+    if (const char *e = getenv("CDS_PAIR_SLOTS")) max_slots = std::max(1, std::min(64, atoi(e)));
+    for (;;) {
+        size_t n;
+        {
+            std::lock_guard<std::mutex> lk(grow_mu);
+            n = slots.size();
+            for (size_t i = 0; i < n; i++)
+                if (slots[i]->mu.try_lock()) {
+                    *out = slots[i].get();
+                    return CDS_OK;
+                }
+            if ((int)n < max_slots) {  // every slot is busy: one more
+                std::unique_ptr<PairSlot> s(new PairSlot());
+                s->sub = clone_context_for_slot(parent);
+                if (!s->sub) return fail(CDS_ERR_HIP, "hipStreamCreate (pair slot)");
+                int rc = cds_library_create(s->sub, W, H, 1, &s->lib);
+                if (rc) return rc;
+                if (score_elems) {
+                    hipError_t e = hipMalloc(&s->d_scores, score_elems * sizeof(int32_t));
+                    if (e != hipSuccess) return hip_fail(e, "hipMalloc(pair scores)");
+                }
+                s->mu.lock();
+                *out = s.get();
+                slots.push_back(std::move(s));
+                return CDS_OK;
+            }
+        }
+        // the pool is full and busy: wait for one slot (round robin over the callers)
+        PairSlot *s = slots[next.fetch_add(1) % n].get();
+        s->mu.lock();
+        *out = s;
+        return CDS_OK;
+    }
+}
+
 static bool in_rects(const cds_rect *r, int n, int x, int y) {
     for (int i = 0; i < n; i++)
         if (x >= r[i].x0 && x < r[i].x1 && y >= r[i].y0 && y < r[i].y1) return true;
@@ -260,7 +321,7 @@ int cds_context_create(int device_id, cds_context **out) {
 void cds_context_destroy(cds_context *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    if (ctx->d_slice_lut) hipFree(ctx->d_slice_lut);
+    if (ctx->d_slice_lut && ctx->owns_lut) hipFree(ctx->d_slice_lut);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -721,8 +782,7 @@ void cds_maskset_destroy(cds_maskset *ms) {
     if (ms->d_px_pos) hipFree(ms->d_px_pos);
     if (ms->d_px_iv) hipFree(ms->d_px_iv);
     free_sparse_plans(ms);
-    if (ms->pair_scores) hipFree(ms->pair_scores);
-    if (ms->pair_lib) cds_library_destroy(ms->pair_lib);
+    ms->pair_pool.slots.clear();
     delete ms;
 }
 
@@ -732,8 +792,10 @@ int cds_maskset_query_sizes(const cds_maskset *ms, int32_t *sizes) {
     return CDS_OK;
 }
 
+// `on_stream` (the pair-slot path): launch on that stream instead of the context's; the library then belongs to a slot
+// context (same device) and the context check is skipped
 static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t first, int64_t count, int32_t *d_scores,
-                       int32_t *d_counts, bool timed_sync) {
+                       int32_t *d_counts, bool timed_sync, hipStream_t on_stream = nullptr) {
     if (!ms || !lib) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     int rc = check_range(lib, first, count);
     if (rc) return rc;
@@ -743,11 +805,11 @@ static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t fi
                  ms->W, ms->H, lib->W, lib->H);  // PixelMatchColorDepthSearchAlgorithm.java:171-175
         return fail(CDS_ERR_INVALID_ARGUMENT, buf);
     }
-    if (lib->ctx != ms->ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "mask set and library belong to different contexts");
+    if (!on_stream && lib->ctx != ms->ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "mask set and library belong to different contexts");
     if (count == 0) return CDS_OK;
     cds_context *ctx = ms->ctx;
     CDS_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = on_stream ? on_stream : ctx->stream;
     if (ms->n_px == 0) {  // no mask pixel can match: all-zero result without a launch (the kernel writes every output otherwise)
         CDS_HIP(hipMemsetAsync(d_scores, 0, (size_t)ms->n_masks * count * sizeof(int32_t), st));
         if (d_counts) CDS_HIP(hipMemsetAsync(d_counts, 0, (size_t)ms->n_masks * count * CDS_N_TRANSFORMS * sizeof(int32_t), st));
@@ -925,30 +987,23 @@ int cds_score_pair(const cds_maskset *ms, int32_t mask_index, const uint8_t *tar
                  ms->W, ms->H, W, H);
         return fail(CDS_ERR_INVALID_ARGUMENT, buf);
     }
-    // the per-pair call of the reference's interface: one resident slot and one device score array are kept with the mask
-    // set (created on first use), so a call costs an upload, a one-workgroup launch and a 4-byte-per-mask read-back
-    std::lock_guard<std::mutex> lk(ms->pair_mu);
-    int rc = CDS_OK;
-    if (!ms->pair_lib || !ms->pair_scores) {  // (both or neither: a half-made pair of an earlier failed call is remade)
-        if (!ms->pair_lib) {
-            rc = cds_library_create(ms->ctx, W, H, 1, &ms->pair_lib);
-            if (rc) return rc;
-        }
-        hipError_t e = hipMalloc(&ms->pair_scores, (size_t)ms->n_masks * sizeof(int32_t));
-        if (e != hipSuccess) {
-            ms->pair_scores = nullptr;
-            return hip_fail(e, "hipMalloc(pair scores)");
-        }
-    }
-    rc = cds_library_upload(ms->pair_lib, 0, 1, target_rgb);
+    // the per-pair call of the reference's interface: a pool of resident slots (each with a device score array and its own
+    // stream) is kept with the mask set, so a call costs an upload, a one-workgroup launch and a 4-byte-per-mask read-back, and
+    // calls from different host threads overlap
+    PairSlot *slot = nullptr;
+    int rc = ms->pair_pool.acquire(ms->ctx, W, H, (size_t)ms->n_masks, &slot);
     if (rc) return rc;
-    rc = search_impl(ms, ms->pair_lib, 0, 1, ms->pair_scores, nullptr, false);
+    std::lock_guard<std::mutex> lk(slot->mu, std::adopt_lock);
+    rc = cds_library_upload(slot->lib, 0, 1, target_rgb);
     if (rc) return rc;
-    std::vector<int32_t> packed((size_t)ms->n_masks);
-    CDS_HIP(hipMemcpyAsync(packed.data(), ms->pair_scores, packed.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ms->ctx->stream));
-    CDS_HIP(hipStreamSynchronize(ms->ctx->stream));
-    *score = packed[(size_t)mask_index] & 0x7fffffff;
-    *mirrored = (uint8_t)((uint32_t)packed[(size_t)mask_index] >> 31);
+    hipStream_t st = slot->sub->stream;
+    rc = search_impl(ms, slot->lib, 0, 1, slot->d_scores, nullptr, false, st);
+    if (rc) return rc;
+    int32_t packed = 0;
+    CDS_HIP(hipMemcpyAsync(&packed, slot->d_scores + mask_index, sizeof packed, hipMemcpyDeviceToHost, st));
+    CDS_HIP(hipStreamSynchronize(st));
+    *score = packed & 0x7fffffff;
+    *mirrored = (uint8_t)((uint32_t)packed >> 31);
     return CDS_OK;
 }
 

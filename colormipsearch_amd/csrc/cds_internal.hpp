@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -63,6 +65,7 @@ struct cds_context {
     float rcp[256];                        // v_rcp_f32 of 0..255 as THIS device computes it
     std::vector<cds::RatioEntry> ratios;   // sorted by value, distinct
     uint8_t *d_slice_lut = nullptr;        // [6][256][256] slice number - 1 (shape scorer)
+    bool owns_lut = true;                  // false in a pair-slot context (clone_context_for_slot): the table is the parent's
     std::mutex mu;
 };
 
@@ -130,6 +133,26 @@ struct MaskPx {
     uint32_t lo1, len1, lo2, len2;
 };
 // cds_sparse.hip: build the sparse-scan plans of a mask set from its device pixels (called by cds_maskset_create)
+// The per-pair entry points of the reference's interface (cds_score_pair, cds_shape_score_pair) are called from many
+// host threads on ONE algorithm object (tools cmd/cdsprocess/LocalColorMIPSearchProcessor.java:88-105).  Each call needs a
+// resident slot for its target; a mask set keeps a small POOL of them, each with its own stream (a light copy of the
+// context: same device and tables, own stream), so that concurrent calls overlap their uploads, launches and read-backs
+// instead of queueing on one lock.
+struct PairSlot {
+    std::mutex mu;
+    cds_context *sub = nullptr;      // own stream
+    cds_library *lib = nullptr;      // one dense slot (+ variants for the shape scorer)
+    int32_t *d_scores = nullptr;     // [n_masks] (pixel-match only)
+    ~PairSlot();
+};
+struct PairSlotPool {
+    std::mutex grow_mu;
+    std::vector<std::unique_ptr<PairSlot>> slots;
+    std::atomic<unsigned> next{0};
+    // a locked slot (created on demand, at most `max_slots`); *out stays locked until the caller unlocks out->mu
+    int acquire(cds_context *parent, int W, int H, size_t score_elems, PairSlot **out);
+};
+cds_context *clone_context_for_slot(cds_context *parent);
 int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &per_mask);
 void free_sparse_plans(cds_maskset *ms);
 
@@ -284,10 +307,8 @@ struct cds_maskset {
     uint8_t *d_sg_planes = nullptr, *d_sg_tmap = nullptr;
     uint4 *d_sg_iv = nullptr;
     mutable std::mutex sp_mu;        // one sparse search at a time per mask set (the work counters are shared)
-    // cds_score_pair: one resident slot + device scores, created on first use
-    mutable std::mutex pair_mu;
-    mutable cds_library *pair_lib = nullptr;
-    mutable int32_t *pair_scores = nullptr;
+    // cds_score_pair: resident slots + device scores, created on first use
+    mutable cds::PairSlotPool pair_pool;
     // timing of the last search
     mutable std::mutex mu;
     mutable double last_ms = 0;

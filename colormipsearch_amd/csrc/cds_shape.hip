@@ -88,6 +88,7 @@ static int ensure_slice_lut(cds_context *ctx) {
     if (ctx->d_slice_lut) return CDS_OK;
     const std::vector<uint8_t> &t = host_slice_table();
     CDS_HIP(hipMalloc(&ctx->d_slice_lut, t.size()));
+    ctx->owns_lut = true;   // (also for a pair-slot context cloned before its parent had the table)
     CDS_HIP(hipMemcpy(ctx->d_slice_lut, t.data(), t.size(), hipMemcpyHostToDevice));
     return CDS_OK;
 }
@@ -828,8 +829,7 @@ struct cds_shapeset {
     mutable std::mutex mu;
     mutable double last_ms = 0;
     mutable int last_launches = 0;
-    mutable std::mutex pair_mu;           // cds_shape_score_pair: one resident slot, created on first use
-    mutable cds_library *pair_lib = nullptr;
+    mutable cds::PairSlotPool pair_pool;  // cds_shape_score_pair: resident slots (own streams), created on first use
 };
 
 extern "C" {
@@ -1051,7 +1051,7 @@ void cds_shapeset_destroy(cds_shapeset *ss) {
     if (ss->d_list_off) hipFree(ss->d_list_off);
     if (ss->d_gl_a) hipFree(ss->d_gl_a);
     if (ss->d_gl_b) hipFree(ss->d_gl_b);
-    if (ss->pair_lib) cds_library_destroy(ss->pair_lib);
+    ss->pair_pool.slots.clear();
     delete ss;
 }
 
@@ -1077,13 +1077,22 @@ double cds_normalized_score(int32_t pix, int64_t shape, int64_t max_pix, int64_t
     return np / bounded * 100;
 }
 
+static int gradscore_impl(const cds_shapeset *ss, const cds_library *lib, int64_t n_pairs, const int32_t *pair_mask, const int64_t *pair_slot,
+                          int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored, hipStream_t on_stream);
+
 int cds_gradscore(const cds_shapeset *ss, const cds_library *lib, int64_t n_pairs, const int32_t *pair_mask,
                   const int64_t *pair_slot, int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored) {
+    return gradscore_impl(ss, lib, n_pairs, pair_mask, pair_slot, gradient_area_gap, high_expression_area, mirrored, nullptr);
+}
+
+// `on_stream` (the pair-slot path): launch on that stream; the library then belongs to a slot context of the same device
+static int gradscore_impl(const cds_shapeset *ss, const cds_library *lib, int64_t n_pairs, const int32_t *pair_mask, const int64_t *pair_slot,
+                          int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored, hipStream_t on_stream) {
     if (!ss || !lib) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n_pairs < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "n_pairs < 0");
     if (n_pairs == 0) return CDS_OK;
     if (!pair_mask || !pair_slot || !gradient_area_gap || !high_expression_area || !mirrored) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (lib->ctx != ss->ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "shape set and library belong to different contexts");
+    if (!on_stream && lib->ctx != ss->ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "shape set and library belong to different contexts");
     if (lib->W != ss->W || lib->H != ss->H) return fail(CDS_ERR_INVALID_ARGUMENT, "target image size must match the query image size");
     std::vector<int64_t> slots((size_t)n_pairs);
     for (int64_t i = 0; i < n_pairs; i++) {
@@ -1094,7 +1103,7 @@ int cds_gradscore(const cds_shapeset *ss, const cds_library *lib, int64_t n_pair
     }
     cds_context *ctx = ss->ctx;
     CDS_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = on_stream ? on_stream : ctx->stream;
     int32_t *d_pm = nullptr;
     int64_t *d_ps = nullptr, *d_out = nullptr;
     auto cleanup = [&]() { if (d_pm) hipFree(d_pm); if (d_ps) hipFree(d_ps); if (d_out) hipFree(d_out); };
@@ -1165,17 +1174,16 @@ int cds_shape_score_pair(const cds_shapeset *ss, int32_t mask_index, const uint8
         return CDS_OK;
     }
     if (W != ss->W || H != ss->H) return fail(CDS_ERR_INVALID_ARGUMENT, "target image size must match the query image size");
-    // one resident slot (with its variant planes) is kept with the mask set for the per-pair call of the reference's interface
-    std::lock_guard<std::mutex> lk(ss->pair_mu);
-    int rc = CDS_OK;
-    if (!ss->pair_lib) {
-        rc = cds_library_create(ss->ctx, W, H, 1, &ss->pair_lib);
-        if (rc) return rc;
-    }
-    rc = cds_library_upload(ss->pair_lib, 0, 1, target_rgb);
-    if (rc == CDS_OK) rc = cds_library_upload_variants(ss->pair_lib, 0, 1, grad, zgap_rgb);
-    int64_t slot = 0;
-    if (rc == CDS_OK) rc = cds_gradscore(ss, ss->pair_lib, 1, &mask_index, &slot, gradient_area_gap, high_expression_area, mirrored);
+    // resident slots (with their variant planes, each on its own stream) are kept with the mask set for the per-pair call of the
+    // reference's interface: calls from different host threads overlap
+    PairSlot *slot = nullptr;
+    int rc = ss->pair_pool.acquire(ss->ctx, W, H, 0, &slot);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(slot->mu, std::adopt_lock);
+    rc = cds_library_upload(slot->lib, 0, 1, target_rgb);
+    if (rc == CDS_OK) rc = cds_library_upload_variants(slot->lib, 0, 1, grad, zgap_rgb);
+    int64_t s0 = 0;
+    if (rc == CDS_OK) rc = gradscore_impl(ss, slot->lib, 1, &mask_index, &s0, gradient_area_gap, high_expression_area, mirrored, slot->sub->stream);
     return rc;
 }
 

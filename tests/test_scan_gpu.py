@@ -495,3 +495,43 @@ def test_size_independent_properties_large(cds, oracle):
     for t in (0, 777, 2047):
         s, m, _ = q.score(oracle.synth_image(0xC0FFEE, t, 0))
         assert (int(s1[0, t]), bool(m1[0, t])) == (s, m)
+
+
+def test_per_pair_calls_from_many_threads(cds, oracle, fixtures):
+    """The reference shares ONE algorithm object between all worker threads (LocalColorMIPSearchProcessor.java:88-105): 12
+    threads call calculateMatchingScore of one pixel-match and one shape algorithm concurrently (each call takes a resident
+    slot of the mask set's pool, with its own stream); every result equals the single-threaded one and the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    from tests.golden import expected as E
+    mask = fixtures["em_12191"]
+    tkeys = ["lm_BJD", "lm_VT016795", "lm_VT033614", "lm_GMR"]
+    targets = [fixtures[k] for k in tkeys] + [oracle.synth_image(0xC0FFEE, 70 + i, 0) for i in range(4)]
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, E.STD_RECTS)
+    q = oracle.PixelMatchQuery(mask, 20, 20, 0.01, 2, True, E.STD_RECTS)
+    want = [q.score(t)[:2] for t in targets]
+    jobs = [i % len(targets) for i in range(96)]
+
+    def one(i):
+        s = alg.calculateMatchingScore(targets[i])
+        return (s.getScore(), s.isMirrored())
+
+    with ThreadPoolExecutor(max_workers=12) as pool:
+        got = list(pool.map(one, jobs))
+    assert got == [want[i] for i in jobs]
+    assert want[0] == (414, False) and want[1] == (426, True)
+    shp = cds.Shape2DMatchColorDepthSearchAlgorithm(mask, 20, True, None, E.STD_RECTS)
+    sq = oracle.ShapeQuery(mask, 20, True, E.STD_RECTS)
+    gkeys = {"lm_BJD": "grad_BJD", "lm_VT016795": "grad_VT016795", "lm_VT033614": "grad_VT033614"}
+    triples = []
+    for k in gkeys:
+        z = oracle.make_zgap(fixtures[k], 20, 10, E.STD_RECTS)
+        triples.append((fixtures[k], fixtures[gkeys[k]], z, sq.score(fixtures[k], fixtures[gkeys[k]], z)))
+
+    def one_shape(i):
+        t, g, z, _ = triples[i % 3]
+        s = shp.calculateMatchingScore(t, {cds.ComputeFileType.GradientImage: lambda: g, cds.ComputeFileType.ZGapImage: lambda: z})
+        return (s.getGradientAreaGap(), s.getHighExpressionArea(), s.getScore(), s.isMirrored())
+
+    with ThreadPoolExecutor(max_workers=12) as pool:
+        got_s = list(pool.map(one_shape, range(48)))
+    assert got_s == [triples[i % 3][3] for i in range(48)]

@@ -49,3 +49,16 @@ for _ in range(50):
 out2["search_4096_targets_call_ms"] = round((time.perf_counter() - t0) / 50 * 1e3, 3)
 out2["search_kernel_ms"] = round(alg.lastKernelMs()[0], 3)
 print(json.dumps(out2))
+
+# many host threads on ONE algorithm object (the reference's usage: LocalColorMIPSearchProcessor.java:88-105): the mask set's
+# slot pool lets their uploads / launches / read-backs overlap (ctypes releases the GIL during a call)
+from concurrent.futures import ThreadPoolExecutor
+targets = [lib2.download(i, 1)[0] for i in range(16)]
+out3 = {}
+for n_thr in (1, 4, 8, 16):
+    with ThreadPoolExecutor(max_workers=n_thr) as pool:
+        list(pool.map(lambda i: alg.calculateMatchingScore(targets[i % 16]), range(64)))
+        t0 = time.perf_counter()
+        list(pool.map(lambda i: alg.calculateMatchingScore(targets[i % 16]), range(2000)))
+        out3[f"pixel_match_pairs_per_s_{n_thr}_threads"] = round(2000 / (time.perf_counter() - t0))
+print(json.dumps(out3))
