@@ -396,6 +396,11 @@ def main():
     # ---- secondary measurements (not `value`) ----
     if rank == 0 and world == 1 and not args.no_aux:
         out["aux"] = aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores, n, stage_n, dense_bytes_per_target, failed)
+        ri = out["aux"].get("real_images", {}).get("masks")
+        if ri:   # next to the headline: the same kernel on the reference's own (dense, mask-overlapping) images is 5-20x slower
+            out["real_image_comparisons_per_s"] = {k: v["sparse_comparisons_per_s"] for k, v in ri.items()}
+            out["real_image_note"] = ("`value` is measured on BASELINE's synthetic library, whose targets' colours are unrelated to the mask's; on the reference's LM "
+                                      "test MIPs -- every one chosen because it overlaps these EM masks -- the same single-mask scan runs at the rates above")
     if rank == 0:
         if failed:
             out["value"] = None     # a wrong result is not a measurement

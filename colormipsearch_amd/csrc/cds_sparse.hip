@@ -438,8 +438,6 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                     qh += n;
                     ql = qh + 64;
                 };
-                // (no wave-uniform test of hb around this: hipcc already skips an all-false `if (hit)` with s_cbranch_execz, and the
-                // scalar unit -- one per CU, shared by the four SIMDs -- is the busier pipe of this kernel: tools/valubench)
                 auto append = [&](uint2 *q, int &qt, const unsigned long long hb, const bool hit, const uint32_t r, const uint32_t off) {
 #if SP_EXP == 2
                     c[0] += __popcll(hb); return;
@@ -526,8 +524,12 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
 #else
                                 const bool hit = ((wp[j] >> (cxp[j] & 31u)) & passbit[j]) != 0;  // (one value for the ballot and the branch)
 #endif
-                                append(q0, qt0, __ballot(hit), hit, rec[j], prow[j] + cxp[j]);
-                                if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
+                                const unsigned long long hb = __ballot(hit);
+                                if (hb) {  // (wave-uniform: a block without a hit -- a third of them on sparse targets -- costs one scalar
+                                           // branch instead of the exec-mask region, the tail update and the queue test)
+                                    append(q0, qt0, hb, hit, rec[j], prow[j] + cxp[j]);
+                                    if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
+                                }
                             }
                             if (MIRROR) {
 #if SP_BAND
@@ -535,8 +537,11 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
 #else
                                 const bool hit = ((wm[j] >> (cxm[j] & 31u)) & passbit[j]) != 0;
 #endif
-                                append(q1, qt1, __ballot(hit), hit, rec[j], prow[j] + cxm[j]);
-                                if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
+                                const unsigned long long hb = __ballot(hit);
+                                if (hb) {
+                                    append(q1, qt1, hb, hit, rec[j], prow[j] + cxm[j]);
+                                    if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
+                                }
                             }
                         };
                         if (WPE <= 4) {
