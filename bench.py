@@ -482,6 +482,31 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
             ws, wm = qm.scan(dense.download(0, 128), n_threads=usable_cores(), partition=8)
             hs = bview[mi, :128].cpu().numpy()
             ok_or &= bool(np.array_equal(ws, hs & 0x7FFFFFFF) and np.array_equal(wm.astype(np.int64), ((hs >> 31) & 1).astype(np.int64)))
+    # the same workload END TO END through the caller the reference would use (processor.findAllColorDepthMatchesTable): mask sets of
+    # 128 prepared on a second host thread while the previous set is scanned, ColorMIPSearch.isMatch (pctPositivePixels 1 %) and the
+    # compaction on the device, only the match list downloaded
+    from colormipsearch_amd import processor as PR0
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(MIRROR, DATA_THR, ZTOL * 100, XY_SHIFT, cds.label_regions, context=ctx)
+    proc0 = PR0.GpuColorMIPSearchProcessor(cds.ColorMIPSearch(1.0, MASK_THR, provider), None, None, first=0, count=n_t, sparse_library=slib)
+    torch.cuda.synchronize()
+    ctx.reset_stream()        # (the context's own non-blocking stream: the synchronous copies of the preparing thread must not wait for the scans)
+    t0 = time.perf_counter()
+    mtable = proc0.findAllColorDepthMatchesTable(masks[:n_m], mask_set_size=128)
+    e2e_s = time.perf_counter() - t0
+    ctx.set_stream(stream.cuda_stream)
+    hs = bview.cpu().numpy() if n_m * n_t <= (1 << 26) else None     # (small runs: the whole list against a host-side filter)
+    want_matches = None
+    if hs is not None:
+        sz = np.asarray(batch.getQuerySizes())
+        want_matches = int(sum(int(cds.ColorMIPSearch(1.0, MASK_THR, provider).isMatchArray(hs[m] & 0x7FFFFFFF, int(sz[m])).sum()) for m in range(n_m)))
+    sample_ok = True
+    for mi in sample_masks[:2]:                                        # sampled masks: the list's rows == isMatch over the mask's score row
+        row = (bview[mi] & 0x7FFFFFFF).cpu().numpy()
+        keep = cds.ColorMIPSearch(1.0, MASK_THR, provider).isMatchArray(row, int(batch.getQuerySize(mi)))
+        sel = mtable.maskIndex == mi
+        sample_ok &= bool(np.array_equal(mtable.targetIndex[sel], np.flatnonzero(keep)) and np.array_equal(mtable.matchingPixels[sel], row[keep]))
+    if not sample_ok or (want_matches is not None and want_matches != len(mtable)):
+        failed.append("device match list disagrees with the host-side isMatch filter")
     mcls = pmc.get("classes", {}).get("sparse_multi")
     mroof = None
     if mcls and {"SQ_INSTS_VALU", "hbm_bytes"} <= set(mcls.get("per_comparison", {})):
@@ -500,6 +525,11 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
                          "comparisons_per_s": n_m * n_t / (bms * 1e-3), "seconds_per_pass": bms * 1e-3, "mask_preparation_s": prep_s,
                          "kernel": "cds::sparse_multi_kernel (groups of up to 8 masks per launch)", "multi_mask_groups": batch.sparseGroups(),
                          "roofline": mroof,
+                         "end_to_end": {"what": "processor.findAllColorDepthMatchesTable: mask sets of 128 prepared on a second host thread during the previous "
+                                                "set's scan, isMatch (pctPositivePixels 1) + compaction on the device, match list downloaded",
+                                        "seconds": e2e_s, "comparisons_per_s": n_m * n_t / e2e_s, "matches": int(len(mtable)),
+                                        "match_list_bytes": int(len(mtable)) * 12, "score_matrix_bytes": int(n_m) * int(n_t) * 4,
+                                        "sampled_masks_equal_host_filter": bool(sample_ok)},
                          "mask0_scores_equal_single_mask_scan": same_b,
                          "sampled_masks": sample_masks, "sampled_masks_equal_dense_scan": same_b3,
                          "sampled_masks_equal_oracle_on_128_targets": bool(ok_or) if not args.no_cpu_baseline else None,

@@ -639,22 +639,19 @@ class PixelMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
         capi.check(self._lib.cds_search_sparse_device(self._h, sparse_library._h, int(first), int(count),
                                                       ctypes.c_void_p(int(d_scores_ptr))))
 
-    def searchSparseLibraryMatches(self, sparse_library, pctPositivePixels, first=0, count=None, capacity=None):
+    def searchSparseLibraryMatches(self, sparse_library, pctPositivePixels, first=0, count=None):
         """The (mask, target) pairs of the scan for which ColorMIPSearch.isMatch holds, filtered and compacted on the device:
         (mask int32[n], target int32[n], score int32[n], mirrored bool[n]), ordered by mask, then target."""
         count = len(sparse_library) - first if count is None else int(count)
-        cap = int(capacity) if capacity else max(1 << 16, min(1 << 24, self.n_masks * count // 64))
-        while True:
-            buf = np.zeros((cap, 3), dtype=np.int32)
-            n = ctypes.c_int64()
-            rc = self._lib.cds_search_sparse_matches(self._h, sparse_library._h, int(first), count, float(pctPositivePixels or 0.0),
-                                                     buf.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n))
-            if rc == capi.CDS_ERR_OUT_OF_MEMORY and n.value > cap:
-                cap = int(n.value)          # the list is longer than the guess: once more with the exact size
-                continue
-            capi.check(rc)
-            buf = buf[: n.value]
-            return buf[:, 0].copy(), buf[:, 1].copy(), (buf[:, 2] & 0x7FFFFFFF).astype(np.int32), (buf[:, 2] < 0)
+        h, n = ctypes.c_void_p(), ctypes.c_int64()
+        capi.check(self._lib.cds_search_sparse_match_list(self._h, sparse_library._h, int(first), count, float(pctPositivePixels or 0.0),
+                                                          ctypes.byref(h), ctypes.byref(n)))
+        try:
+            buf = np.empty((n.value, 3), dtype=np.int32)     # (the list is built on the device to its exact length: one scan)
+            capi.check(self._lib.cds_match_list_fetch(h, 0, n.value, buf.ctypes.data_as(ctypes.c_void_p)))
+        finally:
+            self._lib.cds_match_list_destroy(h)
+        return buf[:, 0].copy(), buf[:, 1].copy(), (buf[:, 2] & 0x7FFFFFFF).astype(np.int32), (buf[:, 2] < 0)
 
     def sparseLayout(self, mask_index=0):
         """How the mask is laid out for the sparse scan (diagnostic): dict of slabs, rows per slab, LDS bytes, ..."""

@@ -1988,18 +1988,31 @@ static int sparse_search_host(const cds_maskset *ms, const cds_sparse_library *s
     return rc;
 }
 
-int cds_search_sparse_matches(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, double pct_positive_pixels,
-                              cds_match *matches, int64_t capacity, int64_t *n_matches) {
-    if (!ms || !sl || !n_matches) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
-    *n_matches = 0;
-    if (capacity < 0 || (capacity > 0 && !matches)) return fail(CDS_ERR_INVALID_ARGUMENT, "bad match buffer");
+// The match list stays on the device until it is fetched: its length is not known before the scan, and a caller that guessed
+// too small a host buffer must not pay for a second scan.
+struct cds_match_list {
+    cds_context *ctx = nullptr;
+    cds_match *d = nullptr;
+    int64_t n = 0, cap = 0;
+};
+
+int cds_search_sparse_match_list(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, double pct_positive_pixels,
+                                 cds_match_list **out, int64_t *n_matches) {
+    if (!ms || !sl || !out) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    if (n_matches) *n_matches = 0;
     int rc = sparse_check_range(sl, first, count);
     if (rc) return rc;
-    if (count == 0) return CDS_OK;
     if (count >= ((int64_t)1 << 31)) return fail(CDS_ERR_UNSUPPORTED, "more than 2^31 targets in one call");
     cds_context *ctx = ms->ctx;
     CDS_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    cds_match_list *ml = new cds_match_list();
+    ml->ctx = ctx;
+    if (count == 0) {
+        *out = ml;
+        return CDS_OK;
+    }
     // smallest passing score per mask (isMatch is monotone in the score); an empty mask is skipped as the reference does
     // ("No computation created ... because it is empty", LocalColorMIPSearchProcessor.java:88-92)
     std::vector<int32_t> min_score((size_t)ms->n_masks, INT32_MAX);
@@ -2036,19 +2049,18 @@ int cds_search_sparse_matches(const cds_maskset *ms, const cds_sparse_library *s
     int32_t *d_scores = nullptr, *d_min = nullptr;
     uint32_t *d_blockcnt = nullptr;
     unsigned long long *d_total = nullptr;
-    cds_match *d_out = nullptr;
     auto cleanup = [&]() {
         if (d_scores) hipFree(d_scores);
         if (d_min) hipFree(d_min);
         if (d_blockcnt) hipFree(d_blockcnt);
         if (d_total) hipFree(d_total);
-        if (d_out) hipFree(d_out);
     };
 #define MT_HIP(call)                         \
     do {                                     \
         hipError_t _e = (call);              \
         if (_e != hipSuccess) {              \
             cleanup();                       \
+            cds_match_list_destroy(ml);      \
             return cds::hip_fail(_e, #call); \
         }                                    \
     } while (0)
@@ -2056,40 +2068,89 @@ int cds_search_sparse_matches(const cds_maskset *ms, const cds_sparse_library *s
     MT_HIP(hipMalloc(&d_min, (size_t)ms->n_masks * sizeof(int32_t)));
     MT_HIP(hipMalloc(&d_blockcnt, (size_t)widest * nblk * sizeof(uint32_t)));
     MT_HIP(hipMalloc(&d_total, 2 * sizeof(unsigned long long)));
-    if (capacity > 0) MT_HIP(hipMalloc(&d_out, (size_t)capacity * sizeof(cds_match)));
     MT_HIP(hipMemcpyAsync(d_min, min_score.data(), min_score.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     MT_HIP(hipMemsetAsync(d_total, 0, 2 * sizeof(unsigned long long), st));
     for (auto &c : chunks) {
         rc = sparse_search_impl(ms, sl, first, count, d_scores, nullptr, false, c.first, c.second);
         if (rc) {
             cleanup();
+            cds_match_list_destroy(ml);
             return rc;
         }
         MatchParams p{};
         p.scores = d_scores; p.min_score = d_min + c.first; p.n_masks = c.second - c.first; p.mask0 = c.first;
-        p.count = count; p.nblk = nblk; p.blockcnt = d_blockcnt; p.total = d_total; p.out = d_out; p.capacity = capacity;
+        p.count = count; p.nblk = nblk; p.blockcnt = d_blockcnt; p.total = d_total;
         const unsigned grid = (unsigned)((int64_t)p.n_masks * nblk);
         hipLaunchKernelGGL(match_count_kernel, dim3(grid), dim3(256), 0, st, p);
         hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, st, p);
+        MT_HIP(hipGetLastError());
+        unsigned long long total[2] = {0, 0};   // the chunk's length: the list grows to hold it before it is written
+        MT_HIP(hipMemcpyAsync(total, d_total, sizeof total, hipMemcpyDeviceToHost, st));
+        MT_HIP(hipStreamSynchronize(st));
+        const int64_t need = (int64_t)(total[0] + total[1]);
+        if (need > ml->cap) {
+            const int64_t cap = std::max<int64_t>(need, std::max<int64_t>(1 << 16, ml->cap * 2));
+            cds_match *nd = nullptr;
+            MT_HIP(hipMalloc(&nd, (size_t)cap * sizeof(cds_match)));
+            if (ml->n) MT_HIP(hipMemcpyAsync(nd, ml->d, (size_t)ml->n * sizeof(cds_match), hipMemcpyDeviceToDevice, st));
+            MT_HIP(hipStreamSynchronize(st));
+            if (ml->d) hipFree(ml->d);
+            ml->d = nd;
+            ml->cap = cap;
+        }
+        p.out = ml->d; p.capacity = ml->cap;
         hipLaunchKernelGGL(match_fill_kernel, dim3(grid), dim3(256), 0, st, p);
         hipLaunchKernelGGL(match_advance_kernel, dim3(1), dim3(1), 0, st, d_total);
         MT_HIP(hipGetLastError());
+        ml->n = need;
     }
-    unsigned long long total[2] = {0, 0};
-    MT_HIP(hipMemcpyAsync(total, d_total, sizeof total, hipMemcpyDeviceToHost, st));
     MT_HIP(hipStreamSynchronize(st));
-    *n_matches = (int64_t)total[0];
-    if ((int64_t)total[0] > capacity) {
-        cleanup();
-        char buf[160];
-        snprintf(buf, sizeof buf, "match buffer too small: %lld matches, capacity %lld (n_matches holds the count: call again)", (long long)total[0],
-                 (long long)capacity);
-        return fail(CDS_ERR_OUT_OF_MEMORY, buf);
-    }
-    if (total[0]) MT_HIP(hipMemcpy(matches, d_out, (size_t)total[0] * sizeof(cds_match), hipMemcpyDeviceToHost));
     cleanup();
 #undef MT_HIP
+    if (n_matches) *n_matches = ml->n;
+    *out = ml;
     return CDS_OK;
+}
+
+int64_t cds_match_list_size(const cds_match_list *ml) { return ml ? ml->n : 0; }
+
+int cds_match_list_fetch(const cds_match_list *ml, int64_t first, int64_t count, cds_match *matches) {
+    if (!ml) return fail(CDS_ERR_INVALID_ARGUMENT, "match list is NULL");
+    if (first < 0 || count < 0 || first + count > ml->n) return fail(CDS_ERR_INVALID_ARGUMENT, "range outside the match list");
+    if (count == 0) return CDS_OK;
+    if (!matches) return fail(CDS_ERR_INVALID_ARGUMENT, "matches is NULL");
+    CDS_HIP(hipSetDevice(ml->ctx->device));
+    CDS_HIP(hipMemcpy(matches, ml->d + first, (size_t)count * sizeof(cds_match), hipMemcpyDeviceToHost));
+    return CDS_OK;
+}
+
+void cds_match_list_destroy(cds_match_list *ml) {
+    if (!ml) return;
+    if (ml->d) {
+        hipSetDevice(ml->ctx->device);
+        hipFree(ml->d);
+    }
+    delete ml;
+}
+
+int cds_search_sparse_matches(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, double pct_positive_pixels,
+                              cds_match *matches, int64_t capacity, int64_t *n_matches) {
+    if (!n_matches) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *n_matches = 0;
+    if (capacity < 0 || (capacity > 0 && !matches)) return fail(CDS_ERR_INVALID_ARGUMENT, "bad match buffer");
+    cds_match_list *ml = nullptr;
+    int rc = cds_search_sparse_match_list(ms, sl, first, count, pct_positive_pixels, &ml, n_matches);
+    if (rc) return rc;
+    if (*n_matches > capacity) {
+        cds_match_list_destroy(ml);
+        char buf[200];
+        snprintf(buf, sizeof buf, "match buffer too small: %lld matches, capacity %lld (n_matches holds the count; cds_search_sparse_match_list avoids the second scan)",
+                 (long long)*n_matches, (long long)capacity);
+        return fail(CDS_ERR_OUT_OF_MEMORY, buf);
+    }
+    rc = cds_match_list_fetch(ml, 0, *n_matches, matches);
+    cds_match_list_destroy(ml);
+    return rc;
 }
 
 int cds_search_sparse(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, int32_t *scores,

@@ -323,6 +323,30 @@ class GpuColorMIPSearchProcessor:
         ratio = (sc.astype(np.float64) / np.maximum(sizes[m], 1.0)).astype(np.float32)
         return MatchTable(m.astype(np.int32), t.astype(np.int64), sc.astype(np.int32), ratio, mir.astype(bool))
 
+    def _pipelined_match_table(self, masks, mask_set_size) -> MatchTable:
+        """Many masks against a sparse library: mask sets of `mask_set_size` (a multiple of 8, the multi-mask kernel's group size);
+        the host-side preparation of set i + 1 (acceptance intervals, planes, maps: about as long as the scan of a set) runs on a
+        second thread while set i is scanned on the GPU (ctypes releases the GIL; the library's stream is non-blocking)."""
+        from concurrent.futures import ThreadPoolExecutor
+        masks = cds.capi.rgb_images(masks)
+        n = masks.shape[0]
+        make = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold
+        if n <= mask_set_size:
+            return self._device_match_table(make(masks))
+        parts = []
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            nxt = pool.submit(make, masks[:mask_set_size])
+            for m0 in range(0, n, mask_set_size):
+                alg = nxt.result()
+                if m0 + mask_set_size < n:
+                    nxt = pool.submit(make, masks[m0 + mask_set_size:m0 + 2 * mask_set_size])
+                t = self._device_match_table(alg)
+                t.maskIndex = t.maskIndex + np.int32(m0)
+                parts.append(t)
+                alg.close()
+        cat = lambda f: np.concatenate([getattr(t, f) for t in parts])
+        return MatchTable(cat("maskIndex"), cat("targetIndex"), cat("matchingPixels"), cat("matchingPixelsRatio"), cat("mirrored"))
+
     def findAllColorDepthMatches(self, masks) -> List[CDMatch]:
         alg = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold(masks)
         if self.sparse_library is not None:
@@ -339,8 +363,11 @@ class GpuColorMIPSearchProcessor:
                 out.append(CDMatch(m, int(t), int(scores[m, t]), float(ratio[t]), bool(mirrored[m, t])))
         return out
 
-    def findAllColorDepthMatchesTable(self, masks) -> MatchTable:
-        """findAllColorDepthMatches in columnar form (same rows, same order)."""
+    def findAllColorDepthMatchesTable(self, masks, mask_set_size=128) -> MatchTable:
+        """findAllColorDepthMatches in columnar form (same rows, same order).  Over a sparse library the masks go in sets of
+        `mask_set_size` whose preparation overlaps the previous set's scan."""
+        if self.sparse_library is not None:
+            return self._pipelined_match_table(masks, max(8, int(mask_set_size) // 8 * 8))
         alg = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold(masks)
         if self.sparse_library is not None:
             return self._device_match_table(alg)

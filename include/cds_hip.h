@@ -216,6 +216,14 @@ typedef struct cds_match {
 } cds_match;
 int cds_search_sparse_matches(const cds_maskset *ms, const cds_sparse_library *slib, int64_t first, int64_t count,
                               double pct_positive_pixels, cds_match *matches, int64_t capacity, int64_t *n_matches);
+/* The same in two steps, for callers that cannot guess the length: the list is built on the device (grown chunk by chunk to the
+ * exact length: one scan whatever it turns out to be), its size returned, and fetched -- whole or in pieces -- afterwards. */
+typedef struct cds_match_list cds_match_list;
+int cds_search_sparse_match_list(const cds_maskset *ms, const cds_sparse_library *slib, int64_t first, int64_t count,
+                                 double pct_positive_pixels, cds_match_list **out, int64_t *n_matches);
+int64_t cds_match_list_size(const cds_match_list *list);
+int cds_match_list_fetch(const cds_match_list *list, int64_t first, int64_t count, cds_match *matches);
+void cds_match_list_destroy(cds_match_list *list);
 
 /* ---- several GPUs of one node: the target-sharded search --------------------------------------------------------
  * The reference's only parallel strategy is data parallelism over target partitions (host threads:

@@ -186,15 +186,13 @@ public:
     }
     // scan + ColorMIPSearch.isMatch + compaction on the device: the pairs findAllColorDepthMatches keeps (mask, target, score | mirrored << 31)
     std::vector<cds_match> searchLibraryMatches(const SparseLibrary &lib, int64_t first, int64_t count, double pctPositivePixels) const {
-        std::vector<cds_match> out((size_t)std::max<int64_t>(1024, count / 64));
+        cds_match_list *list = nullptr;
         int64_t n = 0;
-        int rc = cds_search_sparse_matches(ms_, lib.handle(), first, count, pctPositivePixels, out.data(), (int64_t)out.size(), &n);
-        if (rc == CDS_ERR_OUT_OF_MEMORY && n > (int64_t)out.size()) {   // the list is longer than the guess: once more with the exact size
-            out.resize((size_t)n);
-            rc = cds_search_sparse_matches(ms_, lib.handle(), first, count, pctPositivePixels, out.data(), (int64_t)out.size(), &n);
-        }
+        check(cds_search_sparse_match_list(ms_, lib.handle(), first, count, pctPositivePixels, &list, &n));   // built on the device, exact length
+        std::vector<cds_match> out((size_t)n);
+        const int rc = cds_match_list_fetch(list, 0, n, out.data());
+        cds_match_list_destroy(list);
         check(rc);
-        out.resize((size_t)n);
         return out;
     }
 private:

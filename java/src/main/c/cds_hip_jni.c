@@ -158,16 +158,22 @@ JNIEXPORT void JNICALL CLS(sparseLibraryClear)(JNIEnv *env, jclass c, jlong sl) 
 JNIEXPORT void JNICALL CLS(searchSparse)(JNIEnv *env, jclass c, jlong ms, jlong sl, jlong first, jlong count, jintArray scores, jbyteArray mirrored) {
     search_common(env, 1, ms, sl, first, count, scores, mirrored);
 }
-JNIEXPORT jlong JNICALL CLS(searchSparseMatches)(JNIEnv *env, jclass c, jlong ms, jlong sl, jlong first, jlong count, jdouble pct, jintArray triples) {
-    jsize cap = (*env)->GetArrayLength(env, triples) / 3;
-    jint *t = (*env)->GetIntArrayElements(env, triples, NULL);   /* cds_match = 3 x int32: the array IS the match buffer */
+JNIEXPORT jlong JNICALL CLS(searchSparseMatchList)(JNIEnv *env, jclass c, jlong ms, jlong sl, jlong first, jlong count, jdouble pct) {
+    cds_match_list *list = NULL;
     int64_t n = 0;
-    int rc = cds_search_sparse_matches(P(cds_maskset, ms), P(cds_sparse_library, sl), first, count, pct, (cds_match *)t, cap, &n);
-    (*env)->ReleaseIntArrayElements(env, triples, t, 0);
-    if (rc == CDS_ERR_OUT_OF_MEMORY && n > cap) return (jlong)n;   /* too small: the caller repeats the call with n */
+    int rc = cds_search_sparse_match_list(P(cds_maskset, ms), P(cds_sparse_library, sl), first, count, pct, &list, &n);
     if (rc) { throw_for(env, rc); return 0; }
-    return (jlong)n;
+    return (jlong)(intptr_t)list;
 }
+JNIEXPORT jlong JNICALL CLS(matchListSize)(JNIEnv *env, jclass c, jlong list) { return cds_match_list_size(P(cds_match_list, list)); }
+JNIEXPORT void JNICALL CLS(matchListFetch)(JNIEnv *env, jclass c, jlong list, jlong first, jlong count, jintArray triples) {
+    if ((jlong)(*env)->GetArrayLength(env, triples) < 3 * count) { throw_for(env, CDS_ERR_INVALID_ARGUMENT); return; }
+    jint *t = (*env)->GetIntArrayElements(env, triples, NULL);   /* cds_match = 3 x int32: the array IS the match buffer */
+    int rc = cds_match_list_fetch(P(cds_match_list, list), first, count, (cds_match *)t);
+    (*env)->ReleaseIntArrayElements(env, triples, t, 0);
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT void JNICALL CLS(matchListDestroy)(JNIEnv *env, jclass c, jlong list) { cds_match_list_destroy(P(cds_match_list, list)); }
 
 /* ---- several GPUs of one node ---- */
 JNIEXPORT jlong JNICALL CLS(commCreate)(JNIEnv *env, jclass c, jlongArray contexts) {

@@ -51,11 +51,14 @@ final class CdsHip {
     static native void sparseLibraryClear(long slib);
     static native void searchSparse(long maskset, long slib, long first, long count, int[] scores, byte[] mirrored);
     /**
-     * Scan + ColorMIPSearch.isMatch + compaction on the device.  triples: capacity x (mask, target, score | mirrored << 31).
-     * Returns the number of matches; when it exceeds triples.length / 3 nothing was written and the call is to be repeated
-     * with a larger array.
+     * Scan + ColorMIPSearch.isMatch + compaction on the device: the match list is built there to its exact length (one scan);
+     * the call returns its handle, matchListSize its length, matchListFetch copies triples (mask, target, score | mirrored << 31)
+     * [first, first + count) into triples[0 .. 3 * count).
      */
-    static native long searchSparseMatches(long maskset, long slib, long first, long count, double pctPositivePixels, int[] triples);
+    static native long searchSparseMatchList(long maskset, long slib, long first, long count, double pctPositivePixels);
+    static native long matchListSize(long list);
+    static native void matchListFetch(long list, long first, long count, int[] triples);
+    static native void matchListDestroy(long list);
 
     // ---- several GPUs of one node ----
     static native long commCreate(long[] contexts);

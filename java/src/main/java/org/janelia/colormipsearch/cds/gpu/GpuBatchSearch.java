@@ -99,11 +99,15 @@ public final class GpuBatchSearch<K> implements AutoCloseable {
                 RegionRects.fromRegion(excludedRegions, maskImages.get(0)));
         try {
             CdsHip.masksetQuerySizes(maskset, out.querySize);
-            int[] triples = new int[3 * Math.max(1024, library.size() / 16)];
-            long found = CdsHip.searchSparseMatches(maskset, library.nativeHandle(), 0, library.size(), pctPositivePixels, triples);
-            if (found > triples.length / 3) {           // more matches than guessed: once more with the exact size
+            long list = CdsHip.searchSparseMatchList(maskset, library.nativeHandle(), 0, library.size(), pctPositivePixels);
+            long found;
+            int[] triples;
+            try {
+                found = CdsHip.matchListSize(list);      // (exact: the list was built on the device, one scan)
                 triples = new int[(int) (3 * found)];
-                found = CdsHip.searchSparseMatches(maskset, library.nativeHandle(), 0, library.size(), pctPositivePixels, triples);
+                CdsHip.matchListFetch(list, 0, found, triples);
+            } finally {
+                CdsHip.matchListDestroy(list);
             }
             out.count = (int) found;
             out.mask = new int[out.count];

@@ -163,6 +163,29 @@ def test_batched_gradient_scores_equal_the_resident_ones(oracle):
 
 
 @pytest.mark.gpu
+def test_mask_sets_prepared_while_the_previous_one_is_scanned(oracle):
+    """findAllColorDepthMatchesTable over a sparse library with 21 masks in sets of 8 (preparation of set i + 1 on a second
+    thread during the scan of set i) == one set of 21."""
+    from colormipsearch_amd import cds
+    n_masks, n_t = 21, 300
+    mlib = cds.Library(W, H, n_masks)
+    mlib.generate_synthetic(0xBADC0DE, 0, 0, n_masks, kind=2)
+    masks = mlib.download(0, n_masks)
+    lib = cds.Library(W, H, n_t)
+    lib.generate_synthetic(0xC0FFEE, 4000, 0, n_t, kind=0)
+    lib.upload(5, masks[[3, 17]])
+    slib = cds.SparseLibrary(W, H, n_t, 40000 * n_t)
+    slib.append_from(lib)
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(True, 20, 1, 2, cds.label_regions)
+    proc = P.GpuColorMIPSearchProcessor(cds.ColorMIPSearch(0.01, 20, provider), None, None, sparse_library=slib)
+    one = proc.findAllColorDepthMatchesTable(masks, mask_set_size=64)
+    piped = proc.findAllColorDepthMatchesTable(masks, mask_set_size=8)
+    for f in ("maskIndex", "targetIndex", "matchingPixels", "matchingPixelsRatio", "mirrored"):
+        assert np.array_equal(getattr(one, f), getattr(piped, f)), f
+    assert len(one) > 20 and set(one.maskIndex.tolist()) >= {3, 17}
+
+
+@pytest.mark.gpu
 def test_pipeline_equals_oracle_pipeline(oracle):
     from colormipsearch_amd import cds
     rects = cds.label_regions(W)
