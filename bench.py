@@ -555,14 +555,15 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
     n_gm, top = n_m, min(500, n_t)
     t0 = time.perf_counter()
     shp_masks = masks[:n_gm]
-    vals = bview & 0x7FFFFFFF
-    tv, ti = torch.topk(vals, top, dim=1)                       # (selection of the hits: harness work, torch on the device)
+    tk_t, tk_s, tk_m = batch.topKOfDeviceScores(bscores.data_ptr(), n_t, top)   # (per-mask top-k on the device: cds_scores_topk)
     pm = np.repeat(np.arange(n_gm, dtype=np.int32), top)
-    ps = ti.flatten().cpu().numpy().astype(np.int64)
-    pv = tv.flatten().cpu().numpy().astype(np.int32)
-    pmir = (torch.gather(bview, 1, ti) < 0).flatten().cpu().numpy()
-    del vals, tv, ti
+    ps = tk_t.reshape(-1).astype(np.int64)
+    pv = tk_s.reshape(-1).astype(np.int32)
+    pmir = tk_m.reshape(-1)
     sel_s = time.perf_counter() - t0
+    chk = (bview[n_gm // 2] & 0x7FFFFFFF).cpu().numpy().astype(np.int64)            # one mask's row against a stable host sort
+    if not np.array_equal(tk_t[n_gm // 2], np.lexsort((np.arange(n_t), -chk))[:top]):
+        failed.append("device top-k disagrees with the host-side selection")
     sizes = np.asarray(batch.getQuerySizes(), dtype=np.float64)
     table = PR.MatchTable(pm, ps, pv, (pv / np.maximum(sizes[pm], 1.0)).astype(np.float32), pmir)
     proc = PR.GpuColorMIPSearchProcessor(None, None, None, first=0, count=n_t, sparse_library=slib)

@@ -108,6 +108,8 @@ SIGNATURES = {
     "cds_match_list_size": (_i64, [_vp]),
     "cds_match_list_fetch": (_i, [_vp, _i64, _i64, _vp]),
     "cds_match_list_destroy": (None, [_vp]),
+    "cds_search_sparse_topk": (_i, [_vp, _vp, _i64, _i64, _i32, _i32p, _i32p]),
+    "cds_scores_topk": (_i, [_vp, _vp, _i64, _i32, _i32p, _i32p]),
     "cds_search_sparse_matches": (_i, [_vp, _vp, _i64, _i64, ctypes.c_double, _vp, _i64, _i64p]),
     "cds_comm_create": (_i, [ctypes.POINTER(_vp), _i32, ctypes.POINTER(_vp)]),
     "cds_comm_destroy": (None, [_vp]),

@@ -653,6 +653,22 @@ class PixelMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
             self._lib.cds_match_list_destroy(h)
         return buf[:, 0].copy(), buf[:, 1].copy(), (buf[:, 2] & 0x7FFFFFFF).astype(np.int32), (buf[:, 2] < 0)
 
+    def searchSparseLibraryTopK(self, sparse_library, k, first=0, count=None):
+        """Per mask the k best-scoring targets (score descending, equal scores by ascending target), selected on the device:
+        (targets int32[n_masks, k] with -1 behind the last one, scores int32[n_masks, k], mirrored bool[n_masks, k])."""
+        count = len(sparse_library) - first if count is None else int(count)
+        t = np.zeros((self.n_masks, int(k)), dtype=np.int32)
+        s = np.zeros((self.n_masks, int(k)), dtype=np.int32)
+        capi.check(self._lib.cds_search_sparse_topk(self._h, sparse_library._h, int(first), count, int(k), capi.as_i32p(t), capi.as_i32p(s)))
+        return t, (s & 0x7FFFFFFF).astype(np.int32), s < 0
+
+    def topKOfDeviceScores(self, d_scores_ptr, count, k):
+        """The same selection over a score matrix already on the device (int32[n_masks, count], as searchSparseLibraryDevice leaves it)."""
+        t = np.zeros((self.n_masks, int(k)), dtype=np.int32)
+        s = np.zeros((self.n_masks, int(k)), dtype=np.int32)
+        capi.check(self._lib.cds_scores_topk(self._h, ctypes.c_void_p(int(d_scores_ptr)), int(count), int(k), capi.as_i32p(t), capi.as_i32p(s)))
+        return t, (s & 0x7FFFFFFF).astype(np.int32), s < 0
+
     def sparseLayout(self, mask_index=0):
         """How the mask is laid out for the sparse scan (diagnostic): dict of slabs, rows per slab, LDS bytes, ..."""
         out = np.zeros(8, dtype=np.int32)

@@ -1630,6 +1630,124 @@ __global__ __launch_bounds__(256) void match_fill_kernel(MatchParams p) {
 
 __global__ void match_advance_kernel(unsigned long long *total) { total[0] += total[1]; }
 
+
+// =================================================================================================
+//            per-mask top-k on the device (the "top-500 hits per mask" of BASELINE configs[4])
+// =================================================================================================
+// One workgroup per mask: (1) histogram of the scores (4,096 bins of score >> shift; scores never exceed the query size) ->
+// the bin the k-th best score falls in, (2) histogram of that bin's low bits -> the exact threshold score T and how many
+// entries with score == T are still needed, (3) an ordered pass that writes the entries with score > T, and the first needed
+// ones with score == T, in target order, (4) a bitonic sort of the k entries by (score descending, target ascending).
+struct TopkParams {
+    const int32_t *scores;   // [n_masks][count] score | mirrored << 31
+    const int32_t *qsize;    // [n_masks] query sizes (upper bound of a mask's scores)
+    int64_t count;
+    int k, kp;               // kp = k rounded up to a power of two (<= 1024)
+    int32_t *out_target;     // [n_masks][k]  (-1 behind the last entry when count < k)
+    int32_t *out_score;      // [n_masks][k]  packed
+};
+
+__global__ __launch_bounds__(1024) void topk_kernel(TopkParams p) {
+    __shared__ uint32_t hist[4096];
+    __shared__ unsigned long long key[1024];
+    __shared__ uint32_t val[1024];
+    __shared__ uint32_t wsum[2][16];
+    __shared__ int sh_bin, sh_above, sh_T, sh_need, sh_baseA, sh_baseE;
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t *sc = p.scores + (size_t)m * p.count;
+    const int k = (int)min((int64_t)p.k, p.count);
+    int shift = 0;
+    while (((int64_t)p.qsize[m] >> shift) >= 4096) shift++;
+    // (1) coarse histogram
+    for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int64_t t = tid; t < p.count; t += 1024) atomicAdd(&hist[min((sc[t] & 0x7fffffff) >> shift, 4095)], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        int above = 0, b = 4095;
+        while (b > 0 && above + (int)hist[b] < k) above += (int)hist[b--];
+        sh_bin = b, sh_above = above;
+    }
+    __syncthreads();
+    const int tb = sh_bin;
+    // (2) exact threshold inside the bin
+    if (shift > 0) {
+        const int nfine = 1 << shift;
+        __syncthreads();
+        for (int i = tid; i < nfine; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for (int64_t t = tid; t < p.count; t += 1024) {
+            const int v = sc[t] & 0x7fffffff;
+            if ((v >> shift) == tb) atomicAdd(&hist[v & (nfine - 1)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int above = sh_above, f = nfine - 1;
+            while (f > 0 && above + (int)hist[f] < k) above += (int)hist[f--];
+            sh_T = (tb << shift) | f, sh_above = above;
+        }
+    } else if (tid == 0) {
+        sh_T = tb;
+    }
+    __syncthreads();
+    if (tid == 0) sh_need = k - sh_above, sh_baseA = 0, sh_baseE = 0;
+    for (int i = tid; i < 1024; i += 1024) key[i] = ~0ull, val[i] = 0;
+    __syncthreads();
+    const int T = sh_T, above = sh_above, need = sh_need;
+    // (3) ordered pass: entries above T to [0, above), the first `need` entries equal to T to [above, k)
+    for (int64_t base = 0; base < p.count; base += 1024) {
+        const int64_t t = base + tid;
+        const int32_t pk = t < p.count ? sc[t] : 0;
+        const int v = pk & 0x7fffffff;
+        const bool isA = t < p.count && v > T, isE = t < p.count && v == T;
+        const unsigned long long ba = __ballot(isA), be = __ballot(isE);
+        const int ra = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ba >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ba, 0));
+        const int re = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(be >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)be, 0));
+        if (lane == 0) wsum[0][wave] = (uint32_t)__popcll(ba), wsum[1][wave] = (uint32_t)__popcll(be);
+        __syncthreads();
+        int offA = sh_baseA, offE = sh_baseE;
+        for (int w = 0; w < wave; w++) offA += (int)wsum[0][w], offE += (int)wsum[1][w];
+        int pos = -1;
+        if (isA) pos = offA + ra;
+        else if (isE && offE + re < need) pos = above + offE + re;
+        if (pos >= 0 && pos < 1024) {
+            key[pos] = ((unsigned long long)(0x7fffffffu - (uint32_t)v) << 32) | (uint32_t)t;
+            val[pos] = (uint32_t)pk;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int a = 0, e = 0;
+            for (int w = 0; w < 16; w++) a += (int)wsum[0][w], e += (int)wsum[1][w];
+            sh_baseA += a, sh_baseE += e;
+        }
+        __syncthreads();
+        if (sh_baseA >= above && sh_baseE >= need) break;   // (uniform: everything is placed)
+    }
+    __syncthreads();
+    // (4) bitonic sort of the kp entries by (score descending, target ascending); the padding sorts to the end
+    for (int size = 2; size <= p.kp; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (tid < p.kp) {
+                const int partner = tid ^ stride;
+                if (partner > tid) {
+                    const bool up = (tid & size) == 0;
+                    const unsigned long long a = key[tid], b = key[partner];
+                    if ((a > b) == up) {
+                        key[tid] = b, key[partner] = a;
+                        const uint32_t va = val[tid];
+                        val[tid] = val[partner], val[partner] = va;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    if (tid < p.k) {
+        const bool have = tid < k;
+        p.out_target[(size_t)m * p.k + tid] = have ? (int32_t)(uint32_t)key[tid] : -1;
+        p.out_score[(size_t)m * p.k + tid] = have ? (int32_t)val[tid] : 0;
+    }
+}
+
 }  // namespace cds
 
 using namespace cds;
@@ -2151,6 +2269,118 @@ int cds_search_sparse_matches(const cds_maskset *ms, const cds_sparse_library *s
     rc = cds_match_list_fetch(ml, 0, *n_matches, matches);
     cds_match_list_destroy(ml);
     return rc;
+}
+
+int cds_scores_topk(const cds_maskset *ms, const int32_t *d_scores, int64_t count, int32_t k, int32_t *targets, int32_t *scores) {
+    if (!ms || !d_scores || !targets || !scores) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (k < 1 || k > 1024) return fail(CDS_ERR_INVALID_ARGUMENT, "k must be 1..1024");
+    if (count <= 0 || count >= ((int64_t)1 << 31)) return fail(CDS_ERR_INVALID_ARGUMENT, "count must be 1 .. 2^31 - 1");
+    cds_context *ctx = ms->ctx;
+    CDS_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t n_out = (size_t)ms->n_masks * (size_t)k;
+    int32_t *d_q = nullptr, *d_t = nullptr, *d_s = nullptr;
+    auto cleanup = [&]() {
+        for (void *q : {(void *)d_q, (void *)d_t, (void *)d_s})
+            if (q) hipFree(q);
+    };
+#define TK_HIP(call)                         \
+    do {                                     \
+        hipError_t _e = (call);              \
+        if (_e != hipSuccess) {              \
+            cleanup();                       \
+            return cds::hip_fail(_e, #call); \
+        }                                    \
+    } while (0)
+    TK_HIP(hipMalloc(&d_q, (size_t)ms->n_masks * sizeof(int32_t)));
+    TK_HIP(hipMalloc(&d_t, n_out * sizeof(int32_t)));
+    TK_HIP(hipMalloc(&d_s, n_out * sizeof(int32_t)));
+    TK_HIP(hipMemcpyAsync(d_q, ms->sizes.data(), (size_t)ms->n_masks * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    TopkParams p{};
+    p.scores = d_scores; p.qsize = d_q; p.count = count; p.k = k; p.kp = 1;
+    while (p.kp < k) p.kp <<= 1;
+    p.out_target = d_t; p.out_score = d_s;
+    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)ms->n_masks), dim3(1024), 0, st, p);
+    TK_HIP(hipGetLastError());
+    TK_HIP(hipMemcpyAsync(targets, d_t, n_out * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TK_HIP(hipMemcpyAsync(scores, d_s, n_out * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TK_HIP(hipStreamSynchronize(st));
+    cleanup();
+#undef TK_HIP
+    return CDS_OK;
+}
+
+int cds_search_sparse_topk(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, int32_t k, int32_t *targets,
+                           int32_t *scores) {
+    if (!ms || !sl || !targets || !scores) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (k < 1 || k > 1024) return fail(CDS_ERR_INVALID_ARGUMENT, "k must be 1..1024");
+    int rc = sparse_check_range(sl, first, count);
+    if (rc) return rc;
+    if (count >= ((int64_t)1 << 31)) return fail(CDS_ERR_UNSUPPORTED, "more than 2^31 targets in one call");
+    const size_t n_out = (size_t)ms->n_masks * (size_t)k;
+    if (count == 0) {
+        for (size_t i = 0; i < n_out; i++) targets[i] = -1, scores[i] = 0;
+        return CDS_OK;
+    }
+    cds_context *ctx = ms->ctx;
+    CDS_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int max_chunk = (int)std::max<int64_t>(1, std::min<int64_t>(128, (((int64_t)1 << 32) - 1) / count));
+    if (const char *e = getenv("CDS_MATCH_CHUNK_MASKS")) max_chunk = std::max(1, atoi(e));
+    std::vector<std::pair<int, int>> chunks;
+    if (ms->sg_plans.empty()) {
+        for (int m = 0; m < ms->n_masks; m += max_chunk) chunks.push_back({m, std::min(ms->n_masks, m + max_chunk)});
+    } else {
+        int b = 0, e = 0;
+        for (const SparseGroupPlan &gp : ms->sg_plans) {
+            if (e > b && gp.first_mask + gp.n_masks - b > max_chunk) {
+                chunks.push_back({b, e});
+                b = e;
+            }
+            e = gp.first_mask + gp.n_masks;
+        }
+        if (e > b) chunks.push_back({b, e});
+    }
+    int widest = 0;
+    for (auto &c : chunks) widest = std::max(widest, c.second - c.first);
+    int32_t *d_scores = nullptr, *d_q = nullptr, *d_t = nullptr, *d_s = nullptr;
+    auto cleanup = [&]() {
+        for (void *q : {(void *)d_scores, (void *)d_q, (void *)d_t, (void *)d_s})
+            if (q) hipFree(q);
+    };
+#define TK_HIP(call)                         \
+    do {                                     \
+        hipError_t _e = (call);              \
+        if (_e != hipSuccess) {              \
+            cleanup();                       \
+            return cds::hip_fail(_e, #call); \
+        }                                    \
+    } while (0)
+    TK_HIP(hipMalloc(&d_scores, (size_t)widest * count * sizeof(int32_t)));
+    TK_HIP(hipMalloc(&d_q, (size_t)ms->n_masks * sizeof(int32_t)));
+    TK_HIP(hipMalloc(&d_t, n_out * sizeof(int32_t)));
+    TK_HIP(hipMalloc(&d_s, n_out * sizeof(int32_t)));
+    TK_HIP(hipMemcpyAsync(d_q, ms->sizes.data(), (size_t)ms->n_masks * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    int kp = 1;
+    while (kp < k) kp <<= 1;
+    for (auto &c : chunks) {
+        rc = sparse_search_impl(ms, sl, first, count, d_scores, nullptr, false, c.first, c.second);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
+        TopkParams p{};
+        p.scores = d_scores; p.qsize = d_q + c.first; p.count = count; p.k = k; p.kp = kp;
+        p.out_target = d_t + (size_t)c.first * k; p.out_score = d_s + (size_t)c.first * k;
+        hipLaunchKernelGGL(topk_kernel, dim3((unsigned)(c.second - c.first)), dim3(1024), 0, st, p);
+        TK_HIP(hipGetLastError());
+    }
+    TK_HIP(hipMemcpyAsync(targets, d_t, n_out * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TK_HIP(hipMemcpyAsync(scores, d_s, n_out * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TK_HIP(hipStreamSynchronize(st));
+    cleanup();
+#undef TK_HIP
+    return CDS_OK;
 }
 
 int cds_search_sparse(const cds_maskset *ms, const cds_sparse_library *sl, int64_t first, int64_t count, int32_t *scores,

@@ -216,6 +216,14 @@ typedef struct cds_match {
 } cds_match;
 int cds_search_sparse_matches(const cds_maskset *ms, const cds_sparse_library *slib, int64_t first, int64_t count,
                               double pct_positive_pixels, cds_match *matches, int64_t capacity, int64_t *n_matches);
+/* Per mask the k (<= 1024) best-scoring targets of the scan, selected on the device (histogram threshold + ordered pass +
+ * sort: the "top-500 hits per mask" the gradient-score step starts from, cmd/CalculateGradientScoresCmd.java:323-379, before any
+ * grouping by line / sample): targets[m * k + i] (index relative to `first`; -1 behind the last one when count < k) and
+ * scores[m * k + i] = matching pixels | mirrored << 31, by score descending, equal scores by ascending target. */
+int cds_search_sparse_topk(const cds_maskset *ms, const cds_sparse_library *slib, int64_t first, int64_t count, int32_t k,
+                           int32_t *targets, int32_t *scores);
+/* The selection alone, over scores already on the device (d_scores[m * count + t], the layout cds_search_sparse_device leaves). */
+int cds_scores_topk(const cds_maskset *ms, const int32_t *d_scores, int64_t count, int32_t k, int32_t *targets, int32_t *scores);
 /* The same in two steps, for callers that cannot guess the length: the list is built on the device (grown chunk by chunk to the
  * exact length: one scan whatever it turns out to be), its size returned, and fetched -- whole or in pieces -- afterwards. */
 typedef struct cds_match_list cds_match_list;

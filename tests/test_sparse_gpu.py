@@ -646,3 +646,34 @@ def test_density_limit_refuses_dense_images(cds, oracle):
     s_d, _ = alg.searchLibrary(lib_d)
     s_s, _ = alg.searchSparseLibrary(sl, 4, 2)
     assert np.array_equal(s_d, s_s)
+
+
+def test_device_topk_equals_host_selection(cds, oracle):
+    """cds_search_sparse_topk == a stable host-side sort of the score rows (score descending, equal scores by ascending target),
+    for k = 1, 37, 500, 1024 and more than the library holds, with many tied scores (zeros) in every row and a mask whose
+    query size needs the two-level histogram (a whole-frame mask: scores up to hundreds of thousands)."""
+    rects = cds.label_regions(W)
+    masks = [oracle.synth_image(0xBADC0DE, i, 2) for i in range(9)]
+    big = oracle.depth_lut()[np.random.default_rng(8).integers(0, 256, size=(H, W))].astype(np.uint8)   # a whole-frame mask: query size ~ W * H
+    masks.append(big)
+    masks = np.stack(masks)
+    n_t = 2600
+    dense = cds.Library(W, H, n_t)
+    dense.generate_synthetic(0xC0FFEE, 52000, 0, n_t, kind=0)
+    dense.upload(11, np.stack([masks[4], np.fliplr(masks[7]).copy(), big]))
+    sl = cds.SparseLibrary(W, H, n_t, 30000 * n_t + 4 * H * n_t + W * H)
+    sl.append_from(dense)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    assert alg.getQuerySize(9) > 65536
+    scores, mir = alg.searchSparseLibrary(sl)
+    for k in (1, 37, 500, 1024):
+        t, s, m = alg.searchSparseLibraryTopK(sl, k)
+        for mi in range(len(masks)):
+            order = np.lexsort((np.arange(n_t), -scores[mi].astype(np.int64)))[:k]
+            assert np.array_equal(t[mi], order), (k, mi, t[mi][:8], order[:8])
+            assert np.array_equal(s[mi], scores[mi][order]) and np.array_equal(m[mi], mir[mi][order])
+    t, s, m = alg.searchSparseLibraryTopK(sl, 64, 10, 40)          # fewer targets than k: the tail is -1
+    for mi in (0, 4, 9):
+        order = np.lexsort((np.arange(40), -scores[mi, 10:50].astype(np.int64)))
+        assert np.array_equal(t[mi, :40], order) and (t[mi, 40:] == -1).all() and np.array_equal(s[mi, :40], scores[mi, 10:50][order])
+    assert scores[9, 13] > 65536 and scores[4, 11] > 0
