@@ -195,6 +195,12 @@ public:
         check(rc);
         return out;
     }
+    // the k best-scoring targets, selected on the device (score descending, equal scores by ascending target)
+    void searchLibraryTopK(const SparseLibrary &lib, int64_t first, int64_t count, int k, std::vector<int32_t> &targets, std::vector<int32_t> &packedScores) const {
+        targets.assign((size_t)k, -1);
+        packedScores.assign((size_t)k, 0);
+        check(cds_search_sparse_topk(ms_, lib.handle(), first, count, k, targets.data(), packedScores.data()));
+    }
 private:
     ImageArray query_;
     cds_maskset *ms_ = nullptr;

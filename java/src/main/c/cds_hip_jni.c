@@ -175,6 +175,15 @@ JNIEXPORT void JNICALL CLS(matchListFetch)(JNIEnv *env, jclass c, jlong list, jl
 }
 JNIEXPORT void JNICALL CLS(matchListDestroy)(JNIEnv *env, jclass c, jlong list) { cds_match_list_destroy(P(cds_match_list, list)); }
 
+JNIEXPORT void JNICALL CLS(searchSparseTopK)(JNIEnv *env, jclass c, jlong ms, jlong sl, jlong first, jlong count, jint k, jintArray targets,
+                                             jintArray scores) {
+    jint *t = (*env)->GetIntArrayElements(env, targets, NULL), *s = (*env)->GetIntArrayElements(env, scores, NULL);
+    int rc = cds_search_sparse_topk(P(cds_maskset, ms), P(cds_sparse_library, sl), first, count, k, (int32_t *)t, (int32_t *)s);
+    (*env)->ReleaseIntArrayElements(env, targets, t, 0);
+    (*env)->ReleaseIntArrayElements(env, scores, s, 0);
+    if (rc) throw_for(env, rc);
+}
+
 /* ---- several GPUs of one node ---- */
 JNIEXPORT jlong JNICALL CLS(commCreate)(JNIEnv *env, jclass c, jlongArray contexts) {
     jsize n = (*env)->GetArrayLength(env, contexts);

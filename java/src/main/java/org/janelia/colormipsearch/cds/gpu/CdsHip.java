@@ -59,6 +59,8 @@ final class CdsHip {
     static native long matchListSize(long list);
     static native void matchListFetch(long list, long first, long count, int[] triples);
     static native void matchListDestroy(long list);
+    /** per mask the k best-scoring targets, selected on the device: targets / scores are nMasks x k (score | mirrored << 31; -1 = no entry). */
+    static native void searchSparseTopK(long maskset, long slib, long first, long count, int k, int[] targets, int[] scores);
 
     // ---- several GPUs of one node ----
     static native long commCreate(long[] contexts);
