@@ -483,7 +483,7 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
             hs = bview[mi, :128].cpu().numpy()
             ok_or &= bool(np.array_equal(ws, hs & 0x7FFFFFFF) and np.array_equal(wm.astype(np.int64), ((hs >> 31) & 1).astype(np.int64)))
     # the same workload END TO END through the caller the reference would use (processor.findAllColorDepthMatchesTable): mask sets of
-    # 128 prepared on a second host thread while the previous set is scanned, ColorMIPSearch.isMatch (pctPositivePixels 1 %) and the
+    # 128 prepared on a second host thread while earlier sets are scanned (two search workers), ColorMIPSearch.isMatch (pctPositivePixels 1 %) and the
     # compaction on the device, only the match list downloaded
     from colormipsearch_amd import processor as PR0
     provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(MIRROR, DATA_THR, ZTOL * 100, XY_SHIFT, cds.label_regions, context=ctx)
@@ -525,8 +525,10 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
                          "comparisons_per_s": n_m * n_t / (bms * 1e-3), "seconds_per_pass": bms * 1e-3, "mask_preparation_s": prep_s,
                          "kernel": "cds::sparse_multi_kernel (groups of up to 8 masks per launch)", "multi_mask_groups": batch.sparseGroups(),
                          "roofline": mroof,
-                         "end_to_end": {"what": "processor.findAllColorDepthMatchesTable: mask sets of 128 prepared on a second host thread during the previous "
-                                                "set's scan, isMatch (pctPositivePixels 1) + compaction on the device, match list downloaded",
+                         "end_to_end": {"what": "processor.findAllColorDepthMatchesTable: mask sets of 128 through three overlapped stages (preparation on one host "
+                                                "thread; two search workers: scan + isMatch (pctPositivePixels 1) + compaction on the device, then the list "
+                                                "download and the host-side columns of a set while the next set is scanned)",
+                                        "pipeline_stage_seconds": getattr(proc0, "last_pipeline", None),
                                         "seconds": e2e_s, "comparisons_per_s": n_m * n_t / e2e_s, "matches": int(len(mtable)),
                                         "match_list_bytes": int(len(mtable)) * 12, "score_matrix_bytes": int(n_m) * int(n_t) * 4,
                                         "sampled_masks_equal_host_filter": bool(sample_ok)},

@@ -547,6 +547,8 @@ int cds_library_download_variants(cds_library *lib, int64_t first, int64_t count
 }
 
 // ---- pixel-match mask set -----------------------------------------------------------------------
+static int ensure_dense_layout(const cds_maskset *cms);   // (the dense kernel's records, laid out by the first dense search)
+
 int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_rgb, int32_t W, int32_t H,
                        const cds_pixmatch_params *params, const cds_rect *excluded, int32_t n_excluded,
                        cds_maskset **out) {
@@ -563,11 +565,8 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
     const bool mirror = params->mirror != 0;
     const size_t img_bytes = (size_t)3 * W * H;
 
-    struct Px {
-        int x, y;
-        Intervals iv;
-    };
-    std::vector<std::vector<Px>> per_mask((size_t)n_masks);
+    PrepTimer pt;
+    std::vector<std::vector<MaskPx>> per_mask((size_t)n_masks);
     std::vector<int32_t> sizes((size_t)n_masks, 0);
     int m0 = H, m1 = 0, xlo = W, xhi = 0;  // over all device pixels of all masks
     // the masks are independent: host threads take them in turn (each with its own interval cache)
@@ -581,7 +580,7 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
             int lm0 = H, lm1 = 0, lxlo = W, lxhi = 0;
             for (int m = next.fetch_add(1); m < n_masks; m = next.fetch_add(1)) {
                 const uint8_t *img = masks_rgb + (size_t)m * img_bytes;
-                std::vector<Px> &list = per_mask[(size_t)m];
+                std::vector<MaskPx> &list = per_mask[(size_t)m];
                 int32_t size = 0;
                 for (int y = 0; y < H; y++)
                     for (int x = 0; x < W; x++) {
@@ -605,7 +604,7 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
                             iv = it->second;
                         }
                         if (iv.len1 == 0 && iv.lo1 == 1 && iv.len2 == 0 && iv.lo2 == 1) continue;  // can never match
-                        list.push_back({x, y, iv});
+                        list.push_back({x, y, iv.lo1, iv.len1, iv.lo2, iv.len2});
                         lm0 = std::min(lm0, y); lm1 = std::max(lm1, y + 1);
                         lxlo = std::min(lxlo, x); lxhi = std::max(lxhi, x + 1);
                     }
@@ -619,45 +618,68 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
         worker();
         for (auto &th : pool) th.join();
     }
+    pt.lap("pixel lists + intervals");
     cds_maskset *ms = new cds_maskset();
     ms->ctx = ctx; ms->params = *params; ms->W = W; ms->H = H; ms->n_masks = n_masks; ms->sizes = sizes;
     size_t total = 0;
     for (auto &l : per_mask) total += l.size();
     ms->n_px = total;
-    {   // the same device pixels laid out for the sparse scan (cds_sparse.hip)
-        std::vector<std::vector<MaskPx>> spx((size_t)n_masks);
-        for (int m = 0; m < n_masks; m++) {
-            spx[(size_t)m].reserve(per_mask[(size_t)m].size());
-            for (const Px &q : per_mask[(size_t)m]) spx[(size_t)m].push_back({q.x, q.y, q.iv.lo1, q.iv.len1, q.iv.lo2, q.iv.len2});
-        }
-        int rc = build_sparse_plans(ms, spx);
+    {   // the device pixels laid out for the sparse scan (cds_sparse.hip)
+        int rc = build_sparse_plans(ms, per_mask);
         if (rc) {
             delete ms;
             return rc;
         }
     }
+    pt.lap("sparse plans (all)");
     if (total == 0) {  // nothing can ever match: the search returns zeros without a launch
         ms->m0 = ms->m1 = 0;
+        ms->dense_ready = true;
         *out = ms;
         return CDS_OK;
     }
-    // column window: plain probes touch [xlo-shift, xhi+shift), mirrored ones [W-xhi-shift, W-xlo+shift)
-    int clo = xlo - shift, chi = xhi + shift;
-    if (mirror) {
-        clo = std::min(clo, W - xhi - shift);
-        chi = std::max(chi, W - xlo + shift);
+    ms->m0 = m0; ms->m1 = m1; ms->px_xlo = xlo; ms->px_xhi = xhi;
+    // column window of the dense scan: plain probes touch [xlo-shift, xhi+shift), mirrored ones [W-xhi-shift, W-xlo+shift)
+    {
+        int clo = xlo - shift, chi = xhi + shift;
+        if (mirror) {
+            clo = std::min(clo, W - xhi - shift);
+            chi = std::max(chi, W - xlo + shift);
+        }
+        if (getenv("CDS_SCAN_FULLWINDOW")) {  // experiment: stage whole rows instead of the column window
+            clo = std::min(clo, 0);
+            chi = std::max(chi, W);
+        }
+        ms->cx0 = floor4(clo) & ~15;                       // floor to a multiple of 16 pixels (also for negatives)
+        ms->wc = std::max(32, ((ceil4(chi) - ms->cx0) + 15) & ~15);   // >= 2 items per row (32-bit magic division)
+        if (ms->wc > 2047) {
+            cds_maskset_destroy(ms);
+            return fail(CDS_ERR_UNSUPPORTED, "column window too wide");
+        }
     }
-    if (getenv("CDS_SCAN_FULLWINDOW")) {  // experiment: stage whole rows instead of the column window
-        clo = std::min(clo, 0);
-        chi = std::max(chi, W);
+    ms->lazy_px = std::move(per_mask);   // (the dense kernel's records are laid out by the first dense search)
+    if (getenv("CDS_MASKSET_EAGER_DENSE")) {
+        const int rc = ensure_dense_layout(ms);
+        if (rc) {
+            cds_maskset_destroy(ms);
+            return rc;
+        }
     }
-    ms->cx0 = floor4(clo) & ~15;                       // floor to a multiple of 16 pixels (also for negatives)
-    ms->wc = std::max(32, ((ceil4(chi) - ms->cx0) + 15) & ~15);   // >= 2 items per row (32-bit magic division)
-    ms->m0 = m0; ms->m1 = m1;
-    if (ms->wc > 2047) {
-        delete ms;
-        return fail(CDS_ERR_UNSUPPORTED, "column window too wide");
-    }
+    *out = ms;
+    return CDS_OK;
+}
+
+// The dense kernel's record layout of a mask set (see cds_scan.hip), built once, by the first search that needs it.
+static int build_dense_layout(cds_maskset *ms) {
+    PrepTimer pt;
+    cds_context *ctx = ms->ctx;
+    std::vector<std::vector<MaskPx>> &per_mask = ms->lazy_px;
+    const int n_masks = ms->n_masks, W = ms->W, H = ms->H;
+    const int shift = ms->params.xy_shift;
+    const bool mirror = ms->params.mirror != 0;
+    const int m0 = ms->m0, m1 = ms->m1;
+    size_t total = ms->n_px;
+    typedef MaskPx Px;
     const int nrows = m1 - m0;
     const int nbands = (nrows + kScanBandRows - 1) / kScanBandRows;
     ms->nbands = nbands;
@@ -704,6 +726,7 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
         for (const Px &p : per_mask[(size_t)m]) bands[(size_t)m][(size_t)((p.y - m0) / kScanBandRows)].push_back(p);
         std::vector<Px>().swap(per_mask[(size_t)m]);
     }
+    std::vector<std::vector<MaskPx>>().swap(per_mask);
     for (int q = 0; q < ngroups; q++) {
         for (int b = 0; b < nbands; b++) {
             bandptr[(size_t)q * (nbands + 1) + b] = (uint32_t)chunks.size();
@@ -727,8 +750,8 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
                             const uint32_t row0 = (uint32_t)((p.y - m0) & 15) * (uint32_t)ring_pitch(ms->wc);
                             pos.push_back((row0 + cpl - shift) | ((row0 + cmi - shift) << 16));
                         }
-                        ivs.push_back(make_uint4(p.iv.lo1, p.iv.len1, p.iv.lo2, p.iv.len2));
-                        two = two || !(p.iv.lo2 == kEmptyIv.lo2 && p.iv.len2 == kEmptyIv.len2);
+                        ivs.push_back(make_uint4(p.lo1, p.len1, p.lo2, p.len2));
+                        two = two || !(p.lo2 == kEmptyIv.lo2 && p.len2 == kEmptyIv.len2);
                     }
                     for (size_t i = s1; i < s0 + 64; i++) {  // pad the chunk: a pixel that can never match, at a valid position
                         pos.push_back(pos[pos.size() - (i - s0)]);
@@ -756,6 +779,7 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
         }
     }
     total = pos.size();
+    pt.lap("dense layout (host)");
     hipSetDevice(ctx->device);
     hipError_t e = hipMalloc(&ms->d_bandptr, bandptr.size() * 4);
     if (e == hipSuccess) e = hipMalloc(&ms->d_chunks, chunks.size() * sizeof(uint4));
@@ -766,11 +790,19 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
     if (e == hipSuccess) e = hipMemcpy(ms->d_chunks, chunks.data(), chunks.size() * sizeof(uint4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ms->d_px_pos, pos.data(), total * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ms->d_px_iv, ivs.data(), total * sizeof(uint4), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        cds_maskset_destroy(ms);
-        return hip_fail(e, "maskset upload");
-    }
-    *out = ms;
+    if (e != hipSuccess) return hip_fail(e, "maskset upload");
+    pt.lap("dense layout (upload)");
+    return CDS_OK;
+}
+
+static int ensure_dense_layout(const cds_maskset *cms) {
+    if (cms->dense_ready.load(std::memory_order_acquire)) return CDS_OK;
+    cds_maskset *ms = const_cast<cds_maskset *>(cms);
+    std::lock_guard<std::mutex> lk(ms->dense_mu);
+    if (ms->dense_ready.load(std::memory_order_relaxed)) return CDS_OK;
+    const int rc = build_dense_layout(ms);
+    if (rc) return rc;   // (a failed upload leaves the lists gone: the next call fails the same way on the empty arrays' NULL check)
+    ms->dense_ready.store(true, std::memory_order_release);
     return CDS_OK;
 }
 
@@ -809,6 +841,8 @@ static int search_impl(const cds_maskset *ms, const cds_library *lib, int64_t fi
     if (count == 0) return CDS_OK;
     cds_context *ctx = ms->ctx;
     CDS_HIP(hipSetDevice(ctx->device));
+    rc = ensure_dense_layout(ms);
+    if (rc) return rc;
     hipStream_t st = on_stream ? on_stream : ctx->stream;
     if (ms->n_px == 0) {  // no mask pixel can match: all-zero result without a launch (the kernel writes every output otherwise)
         CDS_HIP(hipMemsetAsync(d_scores, 0, (size_t)ms->n_masks * count * sizeof(int32_t), st));

@@ -5,6 +5,9 @@
 
 #include <atomic>
 #include <memory>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -153,6 +156,18 @@ struct PairSlotPool {
     int acquire(cds_context *parent, int W, int H, size_t score_elems, PairSlot **out);
 };
 cds_context *clone_context_for_slot(cds_context *parent);
+// phase timer of the mask-set preparation: CDS_TIME_PREP=1 prints one line per phase to stderr (diagnostic)
+struct PrepTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    PrepTimer() : on(getenv("CDS_TIME_PREP") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[cds prep] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &per_mask);
 void free_sparse_plans(cds_maskset *ms);
 
@@ -286,6 +301,7 @@ struct cds_sparse_library {
 struct cds_maskset {
     cds_context *ctx = nullptr;
     cds_pixmatch_params params{};
+
     int W = 0, H = 0, n_masks = 0;
     int group = 1;               // masks per launch; the chunk arrays are laid out per group (cds_maskset_create)
     bool batch = false;          // records are in the batch kernel's layout
@@ -298,6 +314,13 @@ struct cds_maskset {
     uint32_t *d_px_pos = nullptr;
     uint4 *d_px_iv = nullptr;
     size_t n_px = 0;
+    // The dense kernel's record layout (bands, chunks, d_px_*) is built by the first search over a dense library
+    // (cds_host.hip: ensure_dense_layout) from the pixel lists kept here until then: a mask set that only ever scans
+    // sparse libraries -- the processor's mask sets -- never pays for it (half of its preparation time).
+    mutable std::vector<std::vector<cds::MaskPx>> lazy_px;
+    int px_xlo = 0, px_xhi = 0;      // column range [xlo, xhi) of all device pixels of all masks
+    mutable std::mutex dense_mu;
+    mutable std::atomic<bool> dense_ready{false};
     // sparse scan (cds_sparse.hip): per mask a plan, slab images and interval tables
     std::vector<cds::SparseMaskPlan> sp_plans;
     uint8_t *d_sp_slabs = nullptr;

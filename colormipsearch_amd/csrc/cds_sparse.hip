@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void sparse_validate_kernel(ValidateParams p) 
 #define SP_BAND 1  // 1: stage 1 tests a (4 x 8-pixel cell) x (30 hue band) map; 0: the plain near bitmap (A/B builds)
 #endif
 #ifndef SP_EXP
-#define SP_EXP 0  // (timing experiments only: 1 = no evaluation rounds, 2 = nothing queued; scores become entry counts)
+#define SP_EXP 0  // (timing experiments only: 1 = no evaluation rounds, 2 = nothing queued, 3 = no interval reads, 4 = no plane reads,
+                  // 5 = interval reads on a quarter of the lanes; the scores are wrong in all of them)
 #endif
 template <bool XY2, bool MIRROR, bool IVLDS, bool P8, int WPE>
 __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams p) {
@@ -416,7 +417,13 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                     for (int iy = 0; iy < NSX; iy++) {
                         const plane_t *rowp = XY2 ? c0 + (1 - iy) * 2 * (int)pitch : c0;  // mask row = target row - dy
 #pragma unroll
-                        for (int ix = 0; ix < NSX; ix++) idx[ix * NSX + iy] = rowp[XY2 ? (2 - ix) * 2 : 0];  // mask column = target column - dx
+                        for (int ix = 0; ix < NSX; ix++) {
+#if SP_EXP == 4  // (timing only: no plane reads)
+                            idx[ix * NSX + iy] = (uint32_t)(off * 7 + (ix * NSX + iy) * 13) & 127u;
+#else
+                            idx[ix * NSX + iy] = rowp[XY2 ? (2 - ix) * 2 : 0];  // mask column = target column - dx
+#endif
+                        }
                         // (one unaligned ds_read_b64 per kernel row instead of three byte reads -- gfx950 serves it correctly,
                         // tools/valubench/ldsalign.hip -- was measured 1.5x SLOWER overall: 5.5 vs 3.6 ms per 524,288 targets)
                     }
@@ -425,7 +432,16 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                     for (int k0 = 0; k0 < NS; k0 += GS) {
                         uint4 iv[GS];
 #pragma unroll
-                        for (int k = 0; k < GS && k0 + k < NS; k++) iv[k] = IVLDS ? ivt[idx[k0 + k]] : p.iv[idx[k0 + k]];
+                        for (int k = 0; k < GS && k0 + k < NS; k++) {
+#if SP_EXP == 3  // (timing only: no interval reads)
+                            iv[k] = make_uint4(idx[k0 + k], idx[k0 + k], idx[k0 + k] * 3u, idx[k0 + k]);
+#elif SP_EXP == 5  // (timing only: a quarter of the lanes read their interval record)
+                            iv[k] = make_uint4(1u, 0u, 1u, 0u);
+                            if ((idx[k0 + k] & 3u) == 0u) iv[k] = ivt[idx[k0 + k]];
+#else
+                            iv[k] = IVLDS ? ivt[idx[k0 + k]] : p.iv[idx[k0 + k]];
+#endif
+                        }
 #pragma unroll
                         for (int k = 0; k < GS && k0 + k < NS; k++) {
                             // the OR is taken on the wave masks (s_or_b64), not on per-lane booleans.  (Counting in per-lane VGPR
@@ -1171,6 +1187,7 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
     if (const char *e = getenv("CDS_SPARSE_LDS_KB")) budget = (size_t)std::max(8, atoi(e)) << 10;
     budget = std::min(budget, ctx->lds_per_block);
     const size_t n_masks = per_mask.size();
+    PrepTimer pt;
     ms->sp_plans.assign(n_masks, SparseMaskPlan());
     std::vector<std::vector<uint8_t>> slab_of(n_masks);
     std::vector<std::vector<uint4>> iv_of(n_masks);
@@ -1282,6 +1299,7 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
         worker();
         for (auto &th : pool) th.join();
     }
+    pt.lap("  single-mask plans (host)");
     size_t slab_total = 0, iv_total = 0;
     for (size_t m = 0; m < n_masks; m++) {
         ms->sp_plans[m].slabs_off = slab_total;
@@ -1306,6 +1324,7 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
         free_sparse_plans(ms);
         return hip_fail(e, "sparse mask plans");
     }
+    pt.lap("  single-mask plans (upload)");
     if (slab_total > 0) {
         const int rc = build_group_plans(ms, per_mask);
         if (rc) {
@@ -1313,6 +1332,7 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
             return rc;
         }
     }
+    pt.lap("  group plans");
     return CDS_OK;
 }
 

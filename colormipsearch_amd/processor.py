@@ -18,6 +18,8 @@ records here; `colormipsearch_amd/results.py` turns them into the reference's JS
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
+import time
+
 import numpy as np
 
 from . import cds
@@ -321,31 +323,60 @@ class GpuColorMIPSearchProcessor:
         m, t, sc, mir = alg.searchSparseLibraryMatches(self.sparse_library, self.colorMIPSearch.pctPositivePixels, self.first, self.count)
         sizes = np.asarray(alg.getQuerySizes(), dtype=np.float64)
         ratio = (sc.astype(np.float64) / np.maximum(sizes[m], 1.0)).astype(np.float32)
-        return MatchTable(m.astype(np.int32), t.astype(np.int64), sc.astype(np.int32), ratio, mir.astype(bool))
+        return MatchTable(m.astype(np.int32, copy=False), t.astype(np.int64), sc.astype(np.int32, copy=False), ratio, mir.astype(bool, copy=False))
 
     def _pipelined_match_table(self, masks, mask_set_size) -> MatchTable:
-        """Many masks against a sparse library: mask sets of `mask_set_size` (a multiple of 8, the multi-mask kernel's group size);
-        the host-side preparation of set i + 1 (acceptance intervals, planes, maps: about as long as the scan of a set) runs on a
-        second thread while set i is scanned on the GPU (ctypes releases the GIL; the library's stream is non-blocking)."""
+        """Many masks against a sparse library: mask sets of `mask_set_size` (a multiple of 8, the multi-mask kernel's group size)
+        go through three overlapped stages -- the host-side preparation of a set (acceptance intervals, planes, maps: about as
+        long as its scan) on one thread, and two search workers taking the prepared sets in turn, so that the list download and the
+        host-side columns of set i are made while set i + 1 is scanned (ctypes releases the GIL; the mask sets are independent
+        objects and the context's stream orders their launches).  At most three prepared sets exist at a time."""
+        import threading
         from concurrent.futures import ThreadPoolExecutor
         masks = cds.capi.rgb_images(masks)
         n = masks.shape[0]
         make = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold
         if n <= mask_set_size:
             return self._device_match_table(make(masks))
-        parts = []
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            nxt = pool.submit(make, masks[:mask_set_size])
-            for m0 in range(0, n, mask_set_size):
-                alg = nxt.result()
-                if m0 + mask_set_size < n:
-                    nxt = pool.submit(make, masks[m0 + mask_set_size:m0 + 2 * mask_set_size])
+        ahead = threading.Semaphore(3)
+        self.last_pipeline = {"prepare_s": 0.0, "search_s": 0.0}
+
+        def prepare(m0):
+            ahead.acquire()
+            t0 = time.perf_counter()
+            try:
+                return make(masks[m0:m0 + mask_set_size])
+            except BaseException:
+                ahead.release()
+                raise
+            finally:
+                self.last_pipeline["prepare_s"] += time.perf_counter() - t0
+
+        def search(m0, prepared):
+            alg = prepared.result()
+            t0 = time.perf_counter()
+            try:
                 t = self._device_match_table(alg)
-                t.maskIndex = t.maskIndex + np.int32(m0)
-                parts.append(t)
+            finally:
                 alg.close()
-        cat = lambda f: np.concatenate([getattr(t, f) for t in parts])
-        return MatchTable(cat("maskIndex"), cat("targetIndex"), cat("matchingPixels"), cat("matchingPixelsRatio"), cat("mirrored"))
+                ahead.release()
+            t.maskIndex += np.int32(m0)
+            self.last_pipeline["search_s"] += time.perf_counter() - t0
+            return t
+
+        with ThreadPoolExecutor(max_workers=1) as prep_pool, ThreadPoolExecutor(max_workers=2) as search_pool:
+            prepared = [prep_pool.submit(prepare, m0) for m0 in range(0, n, mask_set_size)]
+            parts = [f.result() for f in [search_pool.submit(search, m0, pf) for m0, pf in zip(range(0, n, mask_set_size), prepared)]]
+        t0 = time.perf_counter()
+        rows = sum(len(t) for t in parts)
+        out = MatchTable(np.empty(rows, np.int32), np.empty(rows, np.int64), np.empty(rows, np.int32), np.empty(rows, np.float32), np.empty(rows, bool))
+        at = 0
+        for t in parts:
+            for f in ("maskIndex", "targetIndex", "matchingPixels", "matchingPixelsRatio", "mirrored"):
+                getattr(out, f)[at:at + len(t)] = getattr(t, f)
+            at += len(t)
+        self.last_pipeline["assemble_s"] = time.perf_counter() - t0
+        return out
 
     def findAllColorDepthMatches(self, masks) -> List[CDMatch]:
         alg = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold(masks)

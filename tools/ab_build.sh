@@ -1,0 +1,16 @@
+#!/bin/bash
+# A/B builds of the library: tools/ab_build.sh NAME "-DSP_EXP=3" -> build_ab/libcds_NAME.so (use with CDS_HIP_LIBRARY=...)
+set -e
+NAME=$1; shift
+R=$(cd "$(dirname "$0")/.." && pwd)
+D=$R/build_ab/$NAME
+mkdir -p $D
+cd $R/colormipsearch_amd/csrc
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-value -Wno-unused-result $*"
+for f in cds_host cds_scan cds_synth cds_shape cds_imageio cds_diag cds_multi; do
+    [ -f $R/build_ab/common_$f.o ] && [ $R/build_ab/common_$f.o -nt $f.hip ] || /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-value -Wno-unused-result -c $f.hip -o $R/build_ab/common_$f.o &
+done
+/opt/rocm/bin/hipcc $FLAGS -c cds_sparse.hip -o $D/cds_sparse.o &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_ab/libcds_$NAME.so $D/cds_sparse.o $R/build_ab/common_*.o -lz -ldl
+echo built $R/build_ab/libcds_$NAME.so

@@ -22,10 +22,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--copies", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--mask", default="", help="only this EM mask (e.g. em_12191)")
+    ap.add_argument("--sparse-only", action="store_true", help="time the sparse scan only (A/B builds: CDS_HIP_LIBRARY=...)")
     args = ap.parse_args()
     fx = np.load(os.path.join(ROOT, "tests", "golden", "cds_fixtures.npz"))
     lms = [k for k in fx.keys() if k.startswith("lm_")]
-    ems = [k for k in fx.keys() if k.startswith("em_")]
+    ems = [k for k in fx.keys() if k.startswith("em_") and (not args.mask or k == args.mask)]
     ctx = cds.Context(0)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
@@ -51,6 +53,8 @@ def main():
         out = {"mask": mk, "mask_pixels": int(alg.getQuerySize()) if hasattr(alg, "getQuerySize") else None, "layout": alg.sparseLayout(0)}
         for name, fn, buf in (("sparse", lambda b: alg.searchSparseLibraryDevice(sl, 0, n, b.data_ptr()), s_sp),
                               ("dense", lambda b: alg.searchLibraryDevice(dense, 0, n, b.data_ptr()), s_de)):
+            if args.sparse_only and name == "dense":
+                continue
             fn(buf)
             torch.cuda.synchronize()
             e0.record(stream)
@@ -67,6 +71,8 @@ def main():
         lay = out.pop("layout")
         out["interval_records"] = lay.get("interval_records") if isinstance(lay, dict) else None
         print(json.dumps(out), flush=True)
+    if args.sparse_only:
+        return
     # the three masks (and shifted / flipped variants of them: 8 masks = one group) in ONE mask set: the multi-mask scan
     # against one launch per mask
     em = [fx[k] for k in ems]
