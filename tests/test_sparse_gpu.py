@@ -576,6 +576,57 @@ def test_multi_mask_large_library_equals_dense_batch(cds, oracle):
     assert (s1 > 0).sum() > 100
 
 
+def test_multi_mask_random_geometry(cds, oracle, monkeypatch):
+    """Seeded random sweep for the multi-mask kernel: 9 .. 24 masks (full groups, a ragged last group, empty masks among them)
+    over random image sizes, thresholds, tolerances, shift / mirror settings, colour-rich masks (2-byte planes) and LUT masks:
+    scores and mirrored flags of every pair against the oracle and against one launch per mask."""
+    rng = np.random.default_rng(int(os.environ.get("CDS_TEST_SWEEP_SEED", "20261005")))
+    lut = oracle.depth_lut()
+
+    def blobs(w, h, n, rich):
+        img = np.zeros((h, w, 3), dtype=np.uint8)
+        for _ in range(n):
+            bw, bh = int(rng.integers(1, max(2, w // 3))), int(rng.integers(1, max(2, h // 3)))
+            x0, y0 = int(rng.integers(0, w - bw + 1)), int(rng.integers(0, h - bh + 1))
+            if rich:
+                img[y0:y0 + bh, x0:x0 + bw] = rng.integers(0, 256, size=(bh, bw, 3))
+            else:
+                z = rng.integers(0, 256, size=(bh, bw))
+                br = rng.uniform(0.3, 1.0, size=(bh, bw, 1))
+                img[y0:y0 + bh, x0:x0 + bw] = (lut[z] * br).astype(np.uint8)
+        return img
+
+    ran_multi = 0
+    for case in range(int(os.environ.get("CDS_TEST_MULTI_SWEEP_CASES", "10"))):
+        w, h = int(rng.integers(40, 520)), int(rng.integers(12, 160))
+        n_masks = int(rng.integers(9, 25))
+        masks = [blobs(w, h, int(rng.integers(1, 4)), bool(rng.integers(0, 4) == 0)) for _ in range(n_masks)]
+        masks[int(rng.integers(0, n_masks))] = np.zeros((h, w, 3), dtype=np.uint8)      # an empty mask inside a group
+        masks = np.stack(masks)
+        targets = [blobs(w, h, int(rng.integers(1, 8)), bool(rng.integers(0, 2))) for _ in range(5)]
+        targets += [masks[0], np.fliplr(masks[-1]), np.roll(masks[n_masks // 2], 2, axis=0), np.zeros_like(masks[0])]
+        targets = np.stack(targets)
+        mthr, dthr = int(rng.choice([0, 20, 60])), int(rng.choice([0, 20, 90]))
+        ztol = float(rng.choice([0.0, 0.01, 0.02, 0.1]))
+        xy, mirror = int(rng.choice([0, 2])), bool(rng.integers(0, 2))
+        rects = [(0, 0, w // 4, h // 5)] if rng.integers(0, 2) else []
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, mthr, mirror, None, 0, False, dthr, ztol, xy, rects)
+        sl = sparse_of(cds, targets)
+        monkeypatch.delenv("CDS_SPARSE_MULTI", raising=False)
+        ran_multi += alg.sparseGroups()[1]
+        scores, mir = alg.searchSparseLibrary(sl)
+        monkeypatch.setenv("CDS_SPARSE_MULTI", "0")
+        s_one, m_one = alg.searchSparseLibrary(sl)
+        monkeypatch.delenv("CDS_SPARSE_MULTI", raising=False)
+        info = (case, w, h, n_masks, mthr, dthr, ztol, xy, mirror)
+        assert np.array_equal(scores, s_one) and np.array_equal(mir, m_one), (info, np.argwhere(scores != s_one)[:5])
+        for m in range(n_masks):
+            q = oracle.PixelMatchQuery(masks[m], mthr, dthr, ztol, xy, mirror, rects)
+            ws, wm = q.scan(targets, n_threads=8)
+            assert np.array_equal(scores[m], ws) and np.array_equal(mir[m], wm.astype(bool)), (info, m)
+    assert ran_multi >= 10    # (the kernel under test really ran)
+
+
 # ---- match list: ColorMIPSearch.isMatch + compaction on the device ------------------------------------------------------
 def test_device_match_list_equals_host_filter(cds, oracle, monkeypatch):
     """cds_search_sparse_matches == scan + the host-side isMatch (oracle.is_match restates ColorMIPSearch.java:42-45) for several
