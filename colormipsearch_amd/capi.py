@@ -134,6 +134,7 @@ SIGNATURES = {
     "cds_debug_hue_code": (ctypes.c_uint32, [_f32p, _i32, _i32, _i32, _i32]),
     "cds_debug_device_rcp": (_i, [_vp, _f32p]),
     "cds_debug_valu_issue_ns": (_i, [_vp, ctypes.POINTER(ctypes.c_double)]),
+    "cds_debug_sparse_load_only": (_i, [ctypes.c_int32]),
     "cds_maskset_sparse_groups": (_i, [_vp, _i32p, _i32p, _i32p]),
     "cds_maskset_sparse_layout": (_i, [_vp, _i32, _i32p]),
 }

@@ -102,6 +102,10 @@ class Context:
         capi.check(self._lib.cds_debug_valu_issue_ns(self._h, ctypes.byref(v)))
         return v.value
 
+    def sparse_load_only(self, on):
+        """Diagnostic (bench.py): while on, single-mask sparse searches run the scan kernel's loads-only twin (process-wide)."""
+        capi.check(self._lib.cds_debug_sparse_load_only(int(bool(on))))
+
     def make_zgap(self, target, threshold, radius=10, excluded_regions=None):
         """clearRegion -> mask(threshold) -> unsafeMaxFilter(radius), on the GPU."""
         img = capi.rgb_images(target)[0]

@@ -265,16 +265,21 @@ __global__ __launch_bounds__(256) void sparse_validate_kernel(ValidateParams p) 
 #ifndef SP_BAND
 #define SP_BAND 1  // 1: stage 1 tests a (4 x 8-pixel cell) x (30 hue band) map; 0: the plain near bitmap (A/B builds)
 #endif
+#ifndef SP_NB
+#define SP_NB 4
+#endif
 #ifndef SP_EXP
 #define SP_EXP 0  // (timing experiments only: 1 = no evaluation rounds, 2 = nothing queued, 3 = no interval reads, 4 = no plane reads,
-                  // 5 = interval reads on a quarter of the lanes; the scores are wrong in all of them)
+                  // 5 = interval reads on a quarter of the lanes, 6 = record loads only; the scores are wrong in all of them)
 #endif
-template <bool XY2, bool MIRROR, bool IVLDS, bool P8, int WPE>
+// LO ("loads only", cds_debug_sparse_load_only): the kernel with its record loads, headers and work distribution and no examination
+// of the records -- the time the memory system needs for this access pattern, measured beside the real scan by bench.py.
+template <bool XY2, bool MIRROR, bool IVLDS, bool P8, int WPE, bool LO = false>
 __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams p) {
     extern __shared__ uint4 lds4[];
     constexpr int NS = XY2 ? 9 : 1, NSX = XY2 ? 3 : 1, NO = MIRROR ? 2 : 1, NC = NS * NO;
     constexpr int HALO = XY2 ? 2 : 0;
-    constexpr int NB = 4;  // record blocks (64 records each) in flight per wave.  (8 with the 128-VGPR budget: no faster, measured
+    constexpr int NB = SP_NB;  // record blocks (64 records each) in flight per wave (4).  (8 with the 128-VGPR budget: no faster, measured
                            // twice; requests two steps ahead need three statically named register sets, i.e. the loop body three
                            // times -- a rotation by copies makes hipcc wait for the loads it copies -- for the same <= 8 %.)
     typedef typename std::conditional<P8, uint8_t, uint16_t>::type plane_t;
@@ -380,9 +385,15 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                 // prefetch it has just issued.)
                 auto load_blocks = [&](const uint32_t *P, uint32_t i, uint32_t b, uint32_t (&r)[NB]) {
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(P), 0, (int)(b * 4u), 0x00020000);
+#if SP_EXP == 7  // (timing only, with SP_EXP 6's loop body: the same bytes as one 16-byte load per lane)
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((i + 4u * (uint32_t)lane) * 4u), 0, 0);
+                    r[0] = v.x, r[1] = v.y, r[2] = v.z, r[3] = v.w;
+#else
                     const uint32_t vo = (i + (uint32_t)lane) * 4u;
 #pragma unroll
                     for (int j = 0; j < NB; j++) r[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(vo + 256u * j), 0, 0);
+#endif
                 };
                 const uint32_t *P;
                 uint32_t a, b;
@@ -465,6 +476,38 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                     qt += __popcll(hb);
                 };
 
+                // end of a target: the rest of its queues, then its score (or this slab's per-transform counts)
+                auto finish_target = [&](const uint32_t t) {
+                    while (qt0 > qh0) round(q0, qh0, ql0, qt0, c);
+                    if (MIRROR)
+                        while (qt1 > qh1) round(q1, qh1, ql1, qt1, c + NS);
+                    if (p.partial) {  // per-transform counts of this slab: lane k holds transform k (the 18-entry layout of the ABI)
+                        int v = 0;
+#pragma unroll
+                        for (int k = 0; k < NS; k++) {
+                            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[k])), "n"(k));
+                            if (MIRROR) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[NS + k])), "n"(9 + k));
+                        }
+                        if (lane < CDS_N_TRANSFORMS) p.partial[((size_t)s * p.count + t) * CDS_N_TRANSFORMS + lane] = v;
+                    } else {
+                        int best = 0, bm = 0;
+#pragma unroll
+                        for (int k = 0; k < NS; k++) best = max(best, c[k]);
+                        if (MIRROR) {
+#pragma unroll
+                            for (int k = 0; k < NS; k++) bm = max(bm, c[NS + k]);
+                        }
+                        int32_t packed = best;
+                        if (MIRROR && bm > best) packed = (int32_t)((uint32_t)bm | 0x80000000u);
+                        if (lane == 0) p.out[t] = packed;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NC; k++) c[k] = 0;
+                    qh0 = qt0 = qh1 = qt1 = 0;
+                    ql0 = ql1 = 64;
+                };
+                // (Running a target's last rounds inside its last step, BEFORE that step waits for the blocks it has requested -- so that
+                // the rounds' chain of LDS round trips has a request of this wave in flight behind it -- was measured 3 % slower.)
                 for (int r = 0; r < nruns; r++) {  // wave-uniform
                     int yrel = ra - 1 - ry0;  // (rows started before the current block) - 1, relative to the band map
                     // a record's x is relative to its strip: the strip's first column goes into the two column origins of the run
@@ -560,6 +603,12 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                                 }
                             }
                         };
+                        if (LO || SP_EXP == 6 || SP_EXP == 7) {  // (timing only: the record loads and nothing else)
+                            uint32_t acc = 0;
+#pragma unroll
+                            for (int j = 0; j < NB; j++) acc ^= cur[j];
+                            c[0] += __popcll(__ballot(acc == 0x12345u));
+                        } else
                         if (WPE <= 4) {
 #pragma unroll
                             for (int j = 0; j < NB; j++) phase1(j);
@@ -580,34 +629,7 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                     if (r + 1 < nruns) header(r + 1, P, a, b);
                     if (++kin < nsv) continue;  // more strips of this target
                     kin = 0;
-                    const uint32_t t = t0 + (uint32_t)(r / nsv);
-                    while (qt0 > qh0) round(q0, qh0, ql0, qt0, c);
-                    if (MIRROR)
-                        while (qt1 > qh1) round(q1, qh1, ql1, qt1, c + NS);
-                    if (p.partial) {  // per-transform counts of this slab: lane k holds transform k (the 18-entry layout of the ABI)
-                        int v = 0;
-#pragma unroll
-                        for (int k = 0; k < NS; k++) {
-                            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[k])), "n"(k));
-                            if (MIRROR) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[NS + k])), "n"(9 + k));
-                        }
-                        if (lane < CDS_N_TRANSFORMS) p.partial[((size_t)s * p.count + t) * CDS_N_TRANSFORMS + lane] = v;
-                    } else {
-                        int best = 0, bm = 0;
-#pragma unroll
-                        for (int k = 0; k < NS; k++) best = max(best, c[k]);
-                        if (MIRROR) {
-#pragma unroll
-                            for (int k = 0; k < NS; k++) bm = max(bm, c[NS + k]);
-                        }
-                        int32_t packed = best;
-                        if (MIRROR && bm > best) packed = (int32_t)((uint32_t)bm | 0x80000000u);
-                        if (lane == 0) p.out[t] = packed;
-                    }
-#pragma unroll
-                    for (int k = 0; k < NC; k++) c[k] = 0;
-                    qh0 = qt0 = qh1 = qt1 = 0;
-                    ql0 = ql1 = 64;
+                    finish_target(t0 + (uint32_t)(r / nsv));
                 }
             }
         }
@@ -1336,6 +1358,8 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
     return CDS_OK;
 }
 
+static std::atomic<int> g_sparse_load_only{0};   // cds_debug_sparse_load_only
+
 template <bool XY2, bool MIRROR>
 static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t lds_bytes, int threads, hipStream_t st) {
     const bool wide = lds_bytes > ctx->lds_per_block / 2 && !getenv("CDS_SPARSE_WPE8");  // one workgroup per CU: 4 waves per SIMD, 128 VGPRs
@@ -1343,6 +1367,10 @@ static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t
                         : p.iv_in_lds ? sparse_scan_kernel<XY2, MIRROR, true, false, 4> : sparse_scan_kernel<XY2, MIRROR, false, false, 4>)
                      : (p.plane8 ? sparse_scan_kernel<XY2, MIRROR, true, true, 8>
                         : p.iv_in_lds ? sparse_scan_kernel<XY2, MIRROR, true, false, 8> : sparse_scan_kernel<XY2, MIRROR, false, false, 8>);
+    if (g_sparse_load_only.load()) {
+        if (!(wide && p.plane8)) return fail(CDS_ERR_UNSUPPORTED, "the load-only diagnostic exists for the one-workgroup-per-CU, one-byte-plane layout only");
+        kern = sparse_scan_kernel<XY2, MIRROR, true, true, 4, true>;
+    }
     CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     // persistent grid: as many workgroups as fit (LDS and the 2048 threads of a CU), every one visits every slab
     int per_cu = (int)std::min<size_t>((size_t)(2048 / threads), ctx->lds_per_block / std::max<size_t>(lds_bytes, 1));
@@ -2413,6 +2441,11 @@ int cds_search_sparse_counts(const cds_maskset *ms, const cds_sparse_library *sl
     return sparse_search_host(ms, sl, first, count, nullptr, nullptr, counts);
 }
 
+
+int cds_debug_sparse_load_only(int32_t on) {
+    g_sparse_load_only.store(on ? 1 : 0);
+    return CDS_OK;
+}
 
 #if SP_BAND
 // diagnostics of the stage-1 hue-band map (include/cds_hip_debug.h; host arithmetic identical to the kernel's)
