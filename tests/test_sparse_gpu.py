@@ -627,6 +627,31 @@ def test_multi_mask_random_geometry(cds, oracle, monkeypatch):
     assert ran_multi >= 10    # (the kernel under test really ran)
 
 
+def test_load_only_diagnostic_switches_on_and_off(cds, oracle):
+    """cds_debug_sparse_load_only (bench.py's memory-floor measurement): while on, the single-mask search launches the loads-only
+    twin (its scores are meaningless, the launch must complete); switched off, the scan is the real one again.  A layout without a
+    twin (two workgroups per CU) refuses instead of running something else."""
+    rects = cds.label_regions(W)
+    mask = oracle.synth_image(0xBADC0DE, 0, 2)
+    targets = np.stack([oracle.synth_image(0xC0FFEE, 900 + i, 0) for i in range(6)] + [mask])
+    sl = sparse_of(cds, targets)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    want, wm = alg.searchSparseLibrary(sl)
+    ctx = cds.default_context()
+    try:
+        ctx.sparse_load_only(True)
+        alg.searchSparseLibrary(sl)
+        small = np.zeros((H, W, 3), dtype=np.uint8)
+        small[300:310, 500:520] = oracle.depth_lut()[100]
+        alg_small = cds.PixelMatchColorDepthSearchAlgorithm(small, 20, True, None, 0, False, 20, 0.01, 2, rects)   # 80 KB layout: no twin
+        with pytest.raises(cds.CdsError):
+            alg_small.searchSparseLibrary(sl)
+    finally:
+        ctx.sparse_load_only(False)
+    got, gm = alg.searchSparseLibrary(sl)
+    assert np.array_equal(got, want) and np.array_equal(gm, wm) and got[0, -1] > 0
+
+
 # ---- match list: ColorMIPSearch.isMatch + compaction on the device ------------------------------------------------------
 def test_device_match_list_equals_host_filter(cds, oracle, monkeypatch):
     """cds_search_sparse_matches == scan + the host-side isMatch (oracle.is_match restates ColorMIPSearch.java:42-45) for several
