@@ -6,6 +6,7 @@ block (keyed by the SHA-256 of the kernel sources the counters were measured on)
 A launch class = the dispatches of one kernel in one profiled command whose work size is known:
   sparse_scan_headline  `bench.py --no-aux --no-cpu-baseline --verify-windows 3`: the LAST `--steps` dispatches of
                         cds::sparse_scan_kernel (the timed scans of TARGETS targets; the first `--warmup` ones are dropped)
+  sparse_scan_load_only same command: the 5 timed launches of the kernel's loads-only twin (template flag LO)
   dense_scan            same command: cds::scan_kernel dispatches of STAGE targets (the verification windows)
   sparse_multi          `bench.py --no-cpu-baseline --verify-windows 3`: cds::sparse_multi_kernel dispatches (aux.mask_batch:
                         one per mask group over TARGETS targets); per (mask, target) comparison
@@ -49,10 +50,14 @@ def pmc_rows(dirs):
     return out
 
 
+LOAD_ONLY = ", true>(cds::SparseScanParams)"   # the loads-only twin of the scan kernel (template flag LO): a class of its own
+
+
 def pick(seq, name, last=None, every=False):
     """dispatches of kernel `name` with the class's (= the largest) grid -- or every one of them --, optionally only the
-    last `last`"""
-    sel = [x for x in seq if name in x[1]]
+    last `last`; `name` = "A&B" asks for both substrings, the loads-only twin is only picked when asked for by LOAD_ONLY"""
+    parts = name.split("&")
+    sel = [x for x in seq if all(q in x[1] for q in parts) and (LOAD_ONLY in parts or LOAD_ONLY not in x[1])]
     if sel and not every:
         g = max(x[3] for x in sel)
         sel = [x for x in sel if x[3] == g]
@@ -129,6 +134,8 @@ def main():
 
     add_class("sparse_scan_headline", "sparse_scan_kernel", "headline", "targets", a.targets, last=a.steps,
               desc=f"the {a.steps} timed 1-mask scans of the resident library (bench.py `value`)")
+    add_class("sparse_scan_load_only", "sparse_scan_kernel&" + LOAD_ONLY, "headline", "targets", a.targets, last=5,
+              desc="the loads-only twin of the scan kernel (bench.py roofline.load_only): same grabs, headers, record loads, no examination")
     add_class("dense_scan", "cds::scan_kernel", "headline", "targets", a.stage, desc="the dense-layout kernel over the verification windows")
     add_class("sparse_multi", "sparse_multi_kernel", "full", "comparisons", None, units_total=a.multi_masks * a.targets + a.extra_multi,
               desc=f"aux.mask_batch + the scans aux.gradient_scores' selection needs: every multi-mask launch of the command ({a.multi_masks} masks x {a.targets} targets)")
