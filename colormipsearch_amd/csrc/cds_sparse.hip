@@ -772,6 +772,10 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
             // evaluate up to 64 queued (record, mask, orientation) entries: every lane busy, lanes of different masks
             auto round = [&]() {
                 const int n = min(qt - qh, 64);
+#if defined(SM_EXP) && SM_EXP == 3   // (timing experiment: entries are queued, rounds do nothing)
+                qh += n;
+                return;
+#endif
                 __builtin_amdgcn_wave_barrier();
                 const bool valid = lane < n;
                 const uint2 ent = q[(qh + lane) & (SM_QCAP - 1)];
@@ -786,7 +790,13 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                 const uint4 *ivm = ivt + ivb[m];  // (requested before the plane reads: the asm below is a memory barrier to hipcc)
                 const uint32_t top = (m * pcells + off + (XY2 ? 2u * pitch - 2u : 0u)) * ES;  // byte offset of cell (row + 2, column - 2) of mask m's plane
                 uint32_t idx[NS];
-                if (XY2) {
+#if defined(SM_EXP) && SM_EXP == 4   // (timing experiment: no plane gathers)
+                for (int k = 0; k < NS; k++) idx[k] = (top + 13u * k) & 127u;
+                if (false)
+#else
+                if (XY2)
+#endif
+                {
                     // The three cells of a plane row (columns -2, 0, +2 around the pixel = 5 consecutive cells) come with ONE
                     // unaligned load per row -- 12 bytes of u16 cells, 8 bytes of u8 cells -- instead of three narrow ones: a gather
                     // costs the texture addresser the same whatever its width, and the gathers are this kernel's tightest pipe.
@@ -1068,11 +1078,13 @@ static int build_group_plans(cds_maskset *ms, const std::vector<std::vector<Mask
     constexpr int K = kSparseGroupMasks;
     // consecutive masks, at most K, whose interval tables fit the LDS table together (sp_plans[m].n_iv = records of mask m,
     // the empty record included; a mask without device pixels has none and joins any group)
+    int kmax = K;
+    if (const char *e = getenv("CDS_SPARSE_GROUP_MASKS")) kmax = std::max(1, std::min(K, atoi(e)));   // (experiments: smaller groups)
     for (size_t m = 0; m < n_masks;) {
         SparseGroupPlan gp;
         gp.first_mask = (int)m;
         int sum = 0;
-        while (m < n_masks && gp.n_masks < K) {
+        while (m < n_masks && gp.n_masks < kmax) {
             const int niv = std::max(1, ms->sp_plans[m].n_iv);
             if (gp.n_masks > 0 && sum + niv > kSparseGroupIv) break;
             sum += niv;
