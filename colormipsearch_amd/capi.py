@@ -91,6 +91,8 @@ SIGNATURES = {
     "cds_sparse_library_append_host": (_i, [_vp, _i64, _u8p]),
     "cds_sparse_library_layout": (_i, [_vp, _i32p, _i32p]),
     "cds_sparse_library_set_density_limit": (_i, [_vp, ctypes.c_double]),
+    "cds_sparse_library_set_min_threshold": (_i, [_vp, ctypes.c_int32]),
+    "cds_sparse_library_min_threshold": (_i, [_vp, ctypes.POINTER(ctypes.c_int32)]),
     "cds_sparse_library_size": (_i64, [_vp]),
     "cds_sparse_library_pixels": (_i64, [_vp]),
     "cds_sparse_library_clear": (_i, [_vp]),

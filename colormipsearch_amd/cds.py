@@ -258,9 +258,11 @@ class SparseLibrary:
     """A resident shard of target MIPs kept as signal-pixel lists (cds_sparse_library): ~4 % of the dense bytes,
     for searches that need the pixel-match score only (`searchSparseLibrary*`)."""
 
-    def __init__(self, width, height, capacity_images, capacity_pixels, context=None, density_limit=None):
+    def __init__(self, width, height, capacity_images, capacity_pixels, context=None, density_limit=None, min_threshold=None):
         """density_limit: images averaging more signal pixels than this share of the frame are refused at append time (default
-        0.25: above it the dense layout's scan is faster); pass e.g. 2.0 to accept anything."""
+        0.25: above it the dense layout's scan is faster); pass e.g. 2.0 to accept anything.
+        min_threshold: pixels whose brightest channel is <= this are not stored (default 0: every signal pixel); searches with a
+        smaller data threshold are refused -- results never change, the library is smaller and its scan visits fewer records."""
         self.ctx = context or default_context()
         self._lib = capi.load()
         self.width, self.height = int(width), int(height)
@@ -274,6 +276,17 @@ class SparseLibrary:
         self.n_strips, self.strip_width = ns.value, sw.value
         if density_limit is not None:
             self.set_density_limit(density_limit)
+        if min_threshold is not None:
+            self.set_min_threshold(min_threshold)
+
+    def set_min_threshold(self, min_data_threshold):
+        capi.check(self._lib.cds_sparse_library_set_min_threshold(self._h, int(min_data_threshold)))
+
+    @property
+    def min_threshold(self):
+        v = ctypes.c_int32()
+        capi.check(self._lib.cds_sparse_library_min_threshold(self._h, ctypes.byref(v)))
+        return v.value
 
     def set_density_limit(self, max_signal_fraction):
         capi.check(self._lib.cds_sparse_library_set_density_limit(self._h, float(max_signal_fraction)))

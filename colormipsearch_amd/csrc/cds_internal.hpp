@@ -288,6 +288,7 @@ struct cds_sparse_library {
     int nstrips = 1, strip_w = 0;   // an image is stored strip by strip (column strips), a strip row by row
     int64_t cap_images = 0, cap_px = 0;
     int64_t n_images = 0, n_px = 0;
+    int min_threshold = 0;          // pixels whose maximum channel is <= this are not stored; searches below it are refused
     double density_limit = 0.25;    // appends / imports whose images average more signal pixels than this share of the frame are refused
     uint32_t *d_px = nullptr;
     uint64_t *d_img_off = nullptr;  // [cap_images + 1]

@@ -65,19 +65,20 @@ struct BuildParams {
     uint32_t *rowptr;
     uint32_t *tmp;       // [count] records per image
     uint64_t *total;     // [1] records of the whole batch (read back by the host)
+    uint32_t min_thr;    // pixels whose maximum channel is <= this are not stored (cds_sparse_library_set_min_threshold; 0: every signal pixel)
 };
 
 // hue class (AbstractColorDepthSearchAlgorithm.java:195-225; the nibble table of cds_scan.hip), the two channels its ratio is
 // made of and the hue band class * 5 + floor(5 * ratio) -- the ratio as the scan's evaluation computes it, second * v_rcp_f32(max),
 // so that the band of a record and the code the interval test sees come from the same float; 0 for a pixel without a strict
 // maximum channel
-__device__ __forceinline__ uint32_t px_record(uint32_t r, uint32_t g, uint32_t b) {
+__device__ __forceinline__ uint32_t px_record(uint32_t r, uint32_t g, uint32_t b, uint32_t min_thr) {
     const uint32_t mx = max(r, max(g, b)), mn = min(r, min(g, b)), md = r + g + b - mx - mn;
     const uint32_t idx = (r > g ? 4u : 0u) | (g > b ? 8u : 0u) | (b > r ? 16u : 0u);
     const uint32_t cls = (0x03125460u >> idx) & 7u;
     const float hf = (float)md * __builtin_amdgcn_rcpf((float)mx);
     const uint32_t band = cls * 5u + (uint32_t)(hf * 5.0f);
-    return mx > md ? (band << kRecBandShift) | (md << 8) | mx : 0u;
+    return (mx > md && mx > min_thr) ? (band << kRecBandShift) | (md << 8) | mx : 0u;
 }
 
 // One wave per image row.  An image is stored strip by strip (column strips of strip_w pixels), a strip row by row, a row
@@ -107,10 +108,10 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(BuildParams p) {
                 a = q[0], b = q[1], c = q[2];
             }
             uint32_t rec[4];
-            rec[0] = px_record(a & 255, (a >> 8) & 255, (a >> 16) & 255);
-            rec[1] = px_record(a >> 24, b & 255, (b >> 8) & 255);
-            rec[2] = px_record((b >> 16) & 255, b >> 24, c & 255);
-            rec[3] = px_record((c >> 8) & 255, (c >> 16) & 255, c >> 24);
+            rec[0] = px_record(a & 255, (a >> 8) & 255, (a >> 16) & 255, p.min_thr);
+            rec[1] = px_record(a >> 24, b & 255, (b >> 8) & 255, p.min_thr);
+            rec[2] = px_record((b >> 16) & 255, b >> 24, c & 255, p.min_thr);
+            rec[3] = px_record((c >> 8) & 255, (c >> 16) & 255, c >> 24, p.min_thr);
             int below = 0, all = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1441,6 +1442,12 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
                  ms->W, ms->H, sl->W, sl->H);  // PixelMatchColorDepthSearchAlgorithm.java:171-175
         return fail(CDS_ERR_INVALID_ARGUMENT, buf);
     }
+    if (ms->params.data_threshold < sl->min_threshold) {
+        char buf[240];
+        snprintf(buf, sizeof buf, "the sparse library holds no pixel at or below its minimum data threshold %d; a search with data threshold %d "
+                 "would miss the pixels in between (cds_sparse_library_set_min_threshold)", sl->min_threshold, ms->params.data_threshold);
+        return fail(CDS_ERR_INVALID_ARGUMENT, buf);
+    }
     if (sl->ctx != ms->ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "mask set and library belong to different contexts");
     if (count == 0) return CDS_OK;
     if (count >= ((int64_t)1 << 31)) return fail(CDS_ERR_UNSUPPORTED, "more than 2^31 targets in one call");
@@ -1882,6 +1889,22 @@ int cds_sparse_library_set_density_limit(cds_sparse_library *sl, double max_sign
     return CDS_OK;
 }
 
+int cds_sparse_library_set_min_threshold(cds_sparse_library *sl, int32_t min_data_threshold) {
+    if (!sl) return fail(CDS_ERR_INVALID_ARGUMENT, "sparse library is NULL");
+    if (min_data_threshold < 0 || min_data_threshold > 254) return fail(CDS_ERR_INVALID_ARGUMENT, "the minimum data threshold must be in 0..254");
+    std::lock_guard<std::mutex> lk(sl->mu);
+    if (sl->n_images > 0 && min_data_threshold < sl->min_threshold)
+        return fail(CDS_ERR_INVALID_ARGUMENT, "the minimum data threshold of a library that holds images can only be raised (its records below the old one are gone)");
+    sl->min_threshold = min_data_threshold;
+    return CDS_OK;
+}
+
+int cds_sparse_library_min_threshold(const cds_sparse_library *sl, int32_t *min_data_threshold) {
+    if (!sl || !min_data_threshold) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *min_data_threshold = sl->min_threshold;
+    return CDS_OK;
+}
+
 int64_t cds_sparse_library_size(const cds_sparse_library *sl) { return sl ? sl->n_images : 0; }
 int64_t cds_sparse_library_pixels(const cds_sparse_library *sl) { return sl ? sl->n_px : 0; }
 
@@ -1928,6 +1951,7 @@ static int sparse_append_locked(cds_sparse_library *sl, const cds_library *src, 
         p.px = sl->d_px; p.img_off = sl->d_img_off; p.rowptr = sl->d_rowptr;
         p.tmp = sl->d_tmp;
         p.total = reinterpret_cast<uint64_t *>(sl->d_tmp + sl->tmp_images);
+        p.min_thr = (uint32_t)sl->min_threshold;
         const unsigned row_blocks = (unsigned)((n * sl->H + 3) / 4);
         hipLaunchKernelGGL(sparse_rows_kernel<false>, dim3(row_blocks), dim3(256), 0, st, p);
         CDS_HIP(hipGetLastError());

@@ -134,7 +134,8 @@ def write_sparse_shard(path, sparse_library, first=0, count=None, meta=None):
     offsets (u32) and records (u32), each 64-byte aligned -- ~82 KB per synthetic target instead of 2 MB of pixels."""
     offs, cells, rec = sparse_library.export(first, count)
     hd = {"magic": SPARSE_MAGIC, "n": len(offs) - 1, "width": sparse_library.width, "height": sparse_library.height,
-          "n_strips": sparse_library.n_strips, "strip_width": sparse_library.strip_width, "records": int(rec.size), "meta": meta or []}
+          "n_strips": sparse_library.n_strips, "strip_width": sparse_library.strip_width, "records": int(rec.size),
+          "min_threshold": sparse_library.min_threshold, "meta": meta or []}
     header = json.dumps(hd).encode()
     header += b" " * (-(len(header) + 1) % 64) + b"\n"
     with open(path, "wb") as f:
@@ -167,6 +168,9 @@ def load_sparse_shard(sparse_library, path, batch=65536):
     hd, offs, co, rec = open_sparse_shard(path)
     if (hd["width"], hd["height"]) != (sparse_library.width, sparse_library.height):
         raise ValueError("image size of the shard differs from the library's")
+    if int(hd.get("min_threshold", 0)) > sparse_library.min_threshold:    # (the file does not hold the pixels in between)
+        raise ValueError(f"the shard was written with minimum data threshold {hd['min_threshold']}, the library's is "
+                         f"{sparse_library.min_threshold}: raise it first (SparseLibrary.set_min_threshold)")
     for a in range(0, hd["n"], batch):
         b = min(hd["n"], a + batch)
         o = np.asarray(offs[a:b + 1])

@@ -255,16 +255,17 @@ def normalizeTable(table: "MatchTable"):
     return table
 
 
-def resident_library_for(images, context=None, density_limit=0.25):
+def resident_library_for(images, context=None, density_limit=0.25, min_threshold=0):
     """Layout choice for a library of host images uint8[n,H,W,3]: a `cds.SparseLibrary` (signal-pixel records) unless the
     images average more than `density_limit` of the frame in signal pixels -- the library itself refuses those
     (cds_sparse_library_set_density_limit) because the dense layout's scan is the faster one there -- in which case a dense
-    `cds.Library` is returned.  Pass the result as `sparse_library=` or `library=` of GpuColorMIPSearchProcessor."""
+    `cds.Library` is returned.  Pass the result as `sparse_library=` or `library=` of GpuColorMIPSearchProcessor.
+    `min_threshold`: the smallest data threshold the library's searches will use (pixels at or below it are not kept)."""
     imgs = np.ascontiguousarray(images, dtype=np.uint8)
     n, H, W, _ = imgs.shape
     signal = int((imgs.max(axis=3) > 0).sum())
     try:
-        sl = cds.SparseLibrary(W, H, n, signal + 16 * H * n + 64, context=context, density_limit=density_limit)
+        sl = cds.SparseLibrary(W, H, n, signal + 16 * H * n + 64, context=context, density_limit=density_limit, min_threshold=min_threshold)
         sl.append(imgs)
         return sl
     except cds.CdsError as e:

@@ -159,6 +159,13 @@ int cds_sparse_library_layout(const cds_sparse_library *slib, int32_t *n_strips,
  * `max_signal_fraction` of the frame (default 0.25) fails with CDS_ERR_UNSUPPORTED and a message saying so -- nothing is
  * added -- so that a dense library is never silently scanned the slow way; >= 1.1 accepts everything. */
 int cds_sparse_library_set_density_limit(cds_sparse_library *slib, double max_signal_fraction);
+/* Minimum data threshold of the library (default 0).  The reference only looks at a target pixel whose brightest channel exceeds
+ * the search's data threshold (PixelMatchColorDepthSearchAlgorithm.java:247-251), so a library whose searches never go below T need
+ * not keep the pixels at or below T: images appended afterwards store signal pixels with max(r, g, b) > T only (on the reference's
+ * LM test MIPs T = 20 drops 3 % of the records, T = 50 19 %, T = 100 39 %), and a search whose data_threshold is below the library's is refused with
+ * CDS_ERR_INVALID_ARGUMENT -- results never change.  Can be raised, not lowered, once the library holds images. */
+int cds_sparse_library_set_min_threshold(cds_sparse_library *slib, int32_t min_data_threshold);
+int cds_sparse_library_min_threshold(const cds_sparse_library *slib, int32_t *min_data_threshold);
 int64_t cds_sparse_library_size(const cds_sparse_library *slib);   /* images held  */
 int64_t cds_sparse_library_pixels(const cds_sparse_library *slib); /* records held */
 int cds_sparse_library_clear(cds_sparse_library *slib);

@@ -104,6 +104,8 @@ public:
     void appendFrom(const Library &dense, int64_t first, int64_t count) { check(cds_sparse_library_append(lib_, dense.handle(), first, count)); }
     void append(int64_t count, const uint8_t *rgb) { check(cds_sparse_library_append_host(lib_, count, rgb)); }
     void clear() { check(cds_sparse_library_clear(lib_)); }
+    // pixels at or below the searches' data threshold need not be resident (searches below it are refused)
+    void setMinDataThreshold(int targetThreshold) { check(cds_sparse_library_set_min_threshold(lib_, targetThreshold)); }
 private:
     cds_sparse_library *lib_ = nullptr;
 };

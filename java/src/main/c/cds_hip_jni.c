@@ -130,6 +130,10 @@ JNIEXPORT void JNICALL CLS(sparseLibrarySetDensityLimit)(JNIEnv *env, jclass c, 
     int rc = cds_sparse_library_set_density_limit(P(cds_sparse_library, sl), limit);
     if (rc) throw_for(env, rc);
 }
+JNIEXPORT void JNICALL CLS(sparseLibrarySetMinThreshold)(JNIEnv *env, jclass c, jlong sl, jint minDataThreshold) {
+    int rc = cds_sparse_library_set_min_threshold(P(cds_sparse_library, sl), minDataThreshold);
+    if (rc) throw_for(env, rc);
+}
 JNIEXPORT void JNICALL CLS(sparseLibraryAppend)(JNIEnv *env, jclass c, jlong sl, jlong count, jobject directRgb) {
     const uint8_t *px = (const uint8_t *)(*env)->GetDirectBufferAddress(env, directRgb);
     int rc = px ? cds_sparse_library_append_host(P(cds_sparse_library, sl), count, px) : CDS_ERR_INVALID_ARGUMENT;

@@ -44,6 +44,7 @@ final class CdsHip {
     static native long sparseLibraryCreate(long ctx, int w, int h, long capacityImages, long capacityPixels);
     static native void sparseLibraryDestroy(long slib);
     static native void sparseLibrarySetDensityLimit(long slib, double maxSignalFraction);
+    static native void sparseLibrarySetMinThreshold(long slib, int minDataThreshold);
     static native void sparseLibraryAppend(long slib, long count, ByteBuffer directRgb);
     static native void sparseLibraryAppendFiles(long slib, String[] paths, int threads);
     static native long sparseLibrarySize(long slib);

@@ -58,6 +58,7 @@ public final class GpuBatchSearch<K> implements AutoCloseable {
             long images = Long.getLong("cds.gpu.library.images", 1L << 20);
             long records = Long.getLong("cds.gpu.library.records", 40_000L * images);
             library = new GpuTargetLibrary<>(ctx, image.getWidth(), image.getHeight(), images, records, 64);
+            library.setMinDataThreshold(dataThreshold);   // the library lives for this run's searches: pixels the scan never looks at stay out
         }
         library.add(key, image);
     }

@@ -33,6 +33,15 @@ public final class GpuTargetLibrary<K> implements AutoCloseable {
         return handle;
     }
 
+    /**
+     * Pixels whose brightest channel is at or below the run's target threshold are never looked at by the scan
+     * (PixelMatchColorDepthSearchAlgorithm: "if (red2 > targetThreshold || ...)"): a library built for one --dataThreshold need not
+     * hold them.  Call before the first add(); a search with a smaller threshold is then refused by the native library.
+     */
+    public void setMinDataThreshold(int targetThreshold) {
+        CdsHip.sparseLibrarySetMinThreshold(handle, targetThreshold);
+    }
+
     public int size() {
         return keys.size();
     }

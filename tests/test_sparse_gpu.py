@@ -652,6 +652,64 @@ def test_load_only_diagnostic_switches_on_and_off(cds, oracle):
     assert np.array_equal(got, want) and np.array_equal(gm, wm) and got[0, -1] > 0
 
 
+def test_library_minimum_data_threshold(cds, oracle, fixtures, tmp_path):
+    """cds_sparse_library_set_min_threshold: pixels at or below the library's minimum data threshold are not stored -- the record
+    stream of an image equals that of the image with those pixels blacked, the scores of every search at or above the threshold equal
+    those over a library that keeps everything (and the oracle's), a search below it is refused, the threshold can be raised but not
+    lowered once images are held, and a shard file carries it."""
+    from colormipsearch_amd import mipio
+    rects = cds.label_regions(W)
+    rng = np.random.default_rng(5)
+    lut = oracle.depth_lut()
+    dim = np.zeros((H, W, 3), dtype=np.uint8)                      # strokes of every brightness, many of them dim
+    for k in range(40):
+        y0, x0 = int(rng.integers(150, 340)), int(rng.integers(330, 860))
+        br = rng.uniform(0.02, 1.0)
+        dim[y0:y0 + 6, x0:x0 + 40] = (lut[rng.integers(0, 256, size=(6, 40))] * br).astype(np.uint8)
+    targets = np.stack([dim, fixtures["lm_VT016795"], fixtures["lm_BJD"], oracle.synth_image(0xC0FFEE, 77, 0), fixtures["em_12191"]])
+    T = 40
+    full = sparse_of(cds, targets)
+    lean = cds.SparseLibrary(W, H, len(targets), int((targets.max(axis=3) > 0).sum()) + 8 * H * len(targets) + 64, min_threshold=T)
+    assert lean.min_threshold == T and full.min_threshold == 0
+    lean.append(targets)
+    assert lean.pixels < 0.9 * full.pixels
+    blacked = targets.copy()
+    blacked[targets.max(axis=3) <= T] = 0
+    ref = sparse_of(cds, blacked)
+    for i in range(len(targets)):
+        a, ra = lean.image_records(i)
+        b, rb = ref.image_records(i)
+        assert np.array_equal(a, b) and np.array_equal(ra, rb), i
+    masks = np.stack([fixtures["em_12191"], oracle.synth_image(0xBADC0DE, 0, 2), dim])
+    for dthr in (T, T + 25, 200):
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, dthr, 0.01, 2, rects)
+        s1, m1 = alg.searchSparseLibrary(lean)
+        s0, m0 = alg.searchSparseLibrary(full)
+        assert np.array_equal(s1, s0) and np.array_equal(m1, m0), dthr
+        q = oracle.PixelMatchQuery(masks[0], 20, dthr, 0.01, 2, True, rects)
+        ws, wm = q.scan(targets, n_threads=8)
+        assert np.array_equal(s1[0], ws) and np.array_equal(m1[0], wm.astype(bool)), dthr
+        one = cds.PixelMatchColorDepthSearchAlgorithm(masks[2], 20, True, None, 0, False, dthr, 0.01, 2, rects)
+        assert np.array_equal(one.searchSparseLibrary(lean)[0], one.searchSparseLibrary(full)[0])
+    assert s1[0, 4] > 0
+    below = cds.PixelMatchColorDepthSearchAlgorithm(masks[0], 20, True, None, 0, False, T - 1, 0.01, 2, rects)
+    with pytest.raises(cds.CdsInvalidArgument, match="minimum data threshold"):
+        below.searchSparseLibrary(lean)
+    with pytest.raises(cds.CdsInvalidArgument):
+        lean.set_min_threshold(T - 10)              # its records between T - 10 and T are gone
+    lean.set_min_threshold(T + 5)                   # raising is fine (the library then merely holds a few pixels it need not)
+    assert lean.min_threshold == T + 5
+    path = str(tmp_path / "lean.cdss")
+    hd = mipio.write_sparse_shard(path, lean)
+    assert hd["min_threshold"] == T + 5
+    with pytest.raises(ValueError, match="minimum data threshold"):
+        mipio.load_sparse_shard(cds.SparseLibrary(W, H, 8, lean.pixels + 4096), path)
+    back = cds.SparseLibrary(W, H, 8, lean.pixels + 4096, min_threshold=T + 5)
+    assert mipio.load_sparse_shard(back, path) == len(targets)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 60, 0.01, 2, rects)
+    assert np.array_equal(alg.searchSparseLibrary(back)[0], alg.searchSparseLibrary(full)[0])
+
+
 # ---- match list: ColorMIPSearch.isMatch + compaction on the device ------------------------------------------------------
 def test_device_match_list_equals_host_filter(cds, oracle, monkeypatch):
     """cds_search_sparse_matches == scan + the host-side isMatch (oracle.is_match restates ColorMIPSearch.java:42-45) for several

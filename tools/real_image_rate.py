@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--copies", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--min-threshold", type=int, default=0, help="minimum data threshold of the sparse library (pixels at or below it are not stored)")
     ap.add_argument("--mask", default="", help="only this EM mask (e.g. em_12191)")
     ap.add_argument("--sparse-only", action="store_true", help="time the sparse scan only (A/B builds: CDS_HIP_LIBRARY=...)")
     args = ap.parse_args()
@@ -39,7 +40,7 @@ def main():
     for c in range(args.copies):
         dense.upload(c * len(lms), imgs)
     sig = [(int((fx[k].max(axis=2) > 0).sum())) for k in lms]
-    sl = cds.SparseLibrary(W, H, n, int(sum(sig) * args.copies * 1.05) + 8 * n * H, context=ctx)
+    sl = cds.SparseLibrary(W, H, n, int(sum(sig) * args.copies * 1.05) + 8 * n * H, context=ctx, min_threshold=args.min_threshold)
     for first in range(0, n, 4096):
         sl.append_from(dense, first, min(4096, n - first))
     rects = cds.label_regions(W)
