@@ -213,7 +213,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # the scan of one step (one kernel launch), on the launch stream
+    step_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = float(np.mean(step_ms))   # the scan of one step (one kernel launch), on the launch stream
     rank_kern_ms = [kern_ms]
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -318,7 +319,8 @@ def main():
         simds = 4 * n_cus
         roof = {"bound": "issue", "kernel": "cds::sparse_scan_kernel<xy2,mirror>", "achieved": None, "peak": simds / issue_ns,
                 "unit": "G wave64-VALU-instructions/s", "frac": None, "traffic": None,
-                "kernel_ms_per_launch": kern_ms, "targets_per_launch": n, "valu_issue_ns_per_simd": issue_ns, "simds": simds,
+                "kernel_ms_per_launch": kern_ms, "kernel_ms_min_median_max": [float(np.min(step_ms)), float(np.median(step_ms)), float(np.max(step_ms))],
+                "targets_per_launch": n, "valu_issue_ns_per_simd": issue_ns, "simds": simds,
                 "hbm": {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                         "measured_copy_rate": HBM_COPY_GBS, "frac_of_measured_copy_rate": None},
                 "load_only": None if load_only_ms is None else {
