@@ -634,6 +634,10 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
                                           "regenerated with their variants", "kernel": "cds::gradscore_list_kernel",
                               "pairs_per_s": n_pairs / (gms * 1e-3), "kernel_ms_total": gms, "launches": gs["launches"],
                               "end_to_end_s": wall_s, "end_to_end_pairs_per_s": n_pairs / wall_s, "top_hit_selection_s": sel_s,
+                              "product_seconds (mask preparation + scoring calls + selection)": (gs.get("mask_preparation_s") or 0) + (gs.get("score_calls_s") or 0) + sel_s,
+                              "end_to_end_breakdown_s": {"shape_mask_preparation": gs.get("mask_preparation_s"),
+                                                         "regeneration_of_the_synthetic_windows_with_variants (benchmark scaffolding: a real library ingests files)": gs.get("load_range_s"),
+                                                         "scoring_calls (pair upload + kernel + read-back)": gs.get("score_calls_s")},
                               "end_to_end_note": "includes the shape-mask preparation of all masks, the regeneration of every window of the synthetic library "
                                                  "with gradient and zgap variants, the host-side pair bookkeeping and normalisation",
                               "distinct_targets": int(len(np.unique(ps))), "normalized_scores_positive": int((table.normalizedScore > 0).sum()),

@@ -469,16 +469,19 @@ class GpuColorMIPSearchProcessor:
         library: `lambda lib, f, c: lib.generate_synthetic(seed, f, 0, c, kind=0, with_variants=True)`; ingested from a shard
         or from files otherwise), one `cds_gradscore` launch per window, per-mask normalisation on the host
         (CalculateGradientScoresCmd.java:541-586, 616-645).  The kernel time of the launches is left in
-        `self.last_gradscore = {kernel_ms, launches, pairs}`."""
+        `self.last_gradscore = {kernel_ms, launches, pairs, mask_preparation_s, load_range_s, score_calls_s}` (host seconds of the
+        shape-mask preparation, of the `load_range` callbacks and of the scoring calls)."""
         n = len(table)
         table.gradientAreaGap = np.full(n, -1, dtype=np.int64)
         table.highExpressionArea = np.full(n, -1, dtype=np.int64)
         table.normalizedScore = np.zeros(n, dtype=np.float32)
-        self.last_gradscore = {"kernel_ms": 0.0, "launches": 0, "pairs": 0}
+        self.last_gradscore = {"kernel_ms": 0.0, "launches": 0, "pairs": 0, "mask_preparation_s": 0.0, "load_range_s": 0.0, "score_calls_s": 0.0}
         if n == 0:
             return table
         ctx = library.ctx if library is not None else (self.library.ctx if self.library is not None else self.sparse_library.ctx)
+        t0 = time.perf_counter()
         alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, queryThreshold, mirrorMask, roiMask, excludedRegions, context=ctx)
+        self.last_gradscore["mask_preparation_s"] = time.perf_counter() - t0
         lib = library if library is not None else cds.Library(alg.width, alg.height, int(batch), context=ctx)
         batch = min(int(batch), lib.capacity)
         order = np.argsort(table.targetIndex, kind="stable")
@@ -489,8 +492,13 @@ class GpuColorMIPSearchProcessor:
             lo, hi = np.searchsorted(tsorted, w0), np.searchsorted(tsorted, w0 + batch)
             if hi > lo:
                 rows = order[lo:hi]
+                t0 = time.perf_counter()
                 load_range(lib, w0, min(batch, limit - w0))
+                ctx.synchronize()
+                t1 = time.perf_counter()
                 gap, high, _ = alg.scoreLibraryPairs(lib, table.maskIndex[rows].astype(np.int32), table.targetIndex[rows] - w0)
+                self.last_gradscore["load_range_s"] += t1 - t0
+                self.last_gradscore["score_calls_s"] += time.perf_counter() - t1
                 table.gradientAreaGap[rows] = gap
                 table.highExpressionArea[rows] = high
                 ms, launches = alg.lastKernelMs()
