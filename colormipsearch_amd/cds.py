@@ -164,6 +164,30 @@ class Comm:
         capi.check(self._lib.cds_search_sparse_sharded(self._h, ms, sl, capi.as_i64p(offs), capi.as_i32p(scores), capi.as_u8p(mirrored)))
         return scores, mirrored.astype(bool), offs
 
+    def searchSparseLibraryShardedMatches(self, algorithms, sparse_libraries, pctPositivePixels):
+        """The (mask, target) pairs for which ColorMIPSearch.isMatch holds, filtered and compacted on every GPU at once and handed to
+        the host by each GPU directly: (mask int32[n], target int32[n] in library order, score int32[n], mirrored bool[n],
+        shard_offsets int64[n + 1]), ordered by mask, then target -- the list searchSparseLibraryMatches gives over one library."""
+        n = len(self.contexts)
+        if len(algorithms) != n or len(sparse_libraries) != n:
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "one mask set and one shard per context")
+        ms = (ctypes.c_void_p * n)(*[a._h for a in algorithms])
+        sl = (ctypes.c_void_p * n)(*[s._h for s in sparse_libraries])
+        offs = np.zeros(n + 1, dtype=np.int64)
+        cnt = ctypes.c_int64()
+        cap = 1 << 16
+        while True:
+            buf = np.empty((cap, 3), dtype=np.int32)
+            rc = self._lib.cds_search_sparse_sharded_matches(self._h, ms, sl, float(pctPositivePixels or 0.0), capi.as_i64p(offs),
+                                                             buf.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(cnt))
+            if rc == capi.CDS_ERR_OUT_OF_MEMORY and cnt.value > cap:     # (the list is longer than the first guess: once more, exactly sized)
+                cap = cnt.value
+                continue
+            capi.check(rc)
+            break
+        buf = buf[:cnt.value]
+        return buf[:, 0].copy(), buf[:, 1].copy(), (buf[:, 2] & 0x7FFFFFFF).astype(np.int32), (buf[:, 2] < 0), offs
+
 
 _default_ctx = {}
 _ctx_lock = threading.Lock()

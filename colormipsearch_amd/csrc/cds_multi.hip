@@ -15,6 +15,7 @@
 
 #include <cstring>
 #include <set>
+#include <thread>
 
 #include "cds_internal.hpp"
 
@@ -227,6 +228,83 @@ int cds_search_sparse_sharded(cds_comm *c, const cds_maskset *const *masksets, c
             }
         }
     }
+    return CDS_OK;
+}
+
+// The match lists of the shards (cds_search_sparse_match_list per GPU: scan + isMatch + compaction on the device) in library order.
+// No collective: a list's length is only known to its own GPU, and n PCIe links move n lists faster than one link moves their
+// concatenation -- every GPU's list goes to the host directly; the host interleaves them by mask.  One host thread per shard, because
+// building a list reads its length back between its kernels.
+int cds_search_sparse_sharded_matches(cds_comm *c, const cds_maskset *const *masksets, const cds_sparse_library *const *slibs,
+                                      double pct_positive_pixels, int64_t *shard_offsets, cds_match *matches, int64_t capacity,
+                                      int64_t *n_matches) {
+    if (!c || !masksets || !slibs || !n_matches) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    *n_matches = 0;
+    if (capacity < 0 || (capacity > 0 && !matches)) return fail(CDS_ERR_INVALID_ARGUMENT, "bad match buffer");
+    const int n = (int)c->ctxs.size();
+    int n_masks = -1;
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    for (int r = 0; r < n; r++) {
+        if (!masksets[r] || !slibs[r]) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL shard");
+        if (masksets[r]->ctx != c->ctxs[(size_t)r] || slibs[r]->ctx != c->ctxs[(size_t)r])
+            return fail(CDS_ERR_INVALID_ARGUMENT, "shard r must have been created through context r of the communicator");
+        if (n_masks < 0) n_masks = masksets[r]->n_masks;
+        if (masksets[r]->n_masks != n_masks) return fail(CDS_ERR_INVALID_ARGUMENT, "the shards' mask sets differ in size (the mask set is replicated)");
+        off[(size_t)r + 1] = off[(size_t)r] + cds_sparse_library_size(slibs[r]);
+    }
+    if (shard_offsets) memcpy(shard_offsets, off.data(), off.size() * sizeof(int64_t));
+    if (off[(size_t)n] >= ((int64_t)1 << 31)) return fail(CDS_ERR_UNSUPPORTED, "more than 2^31 targets over the shards (a match holds its target in 32 bits)");
+    std::lock_guard<std::mutex> lk(c->mu);
+    std::vector<std::vector<cds_match>> part((size_t)n);
+    std::vector<int> rcs((size_t)n, CDS_OK);
+    std::vector<std::string> errs((size_t)n);
+    auto work = [&](int r) {
+        const int64_t nl = off[(size_t)r + 1] - off[(size_t)r];
+        if (nl == 0) return;
+        cds_match_list *ml = nullptr;
+        int64_t cnt = 0;
+        int rc = cds_search_sparse_match_list(masksets[r], slibs[r], 0, nl, pct_positive_pixels, &ml, &cnt);
+        if (rc == CDS_OK) {
+            try {
+                part[(size_t)r].resize((size_t)cnt);
+                if (cnt > 0) rc = cds_match_list_fetch(ml, 0, cnt, part[(size_t)r].data());
+            } catch (const std::bad_alloc &) {
+                rc = fail(CDS_ERR_OUT_OF_MEMORY, "out of host memory for a shard's match list");
+            }
+        }
+        if (ml) cds_match_list_destroy(ml);
+        rcs[(size_t)r] = rc;
+        if (rc) errs[(size_t)r] = cds_last_error();   // (the message lives in this thread)
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int r = 1; r < n; r++) pool.emplace_back(work, r);
+        work(0);
+        for (auto &t : pool) t.join();
+    }
+    for (int r = 0; r < n; r++)
+        if (rcs[(size_t)r]) return fail(rcs[(size_t)r], "shard " + std::to_string(r) + ": " + errs[(size_t)r]);
+    int64_t total = 0;
+    for (auto &v : part) total += (int64_t)v.size();
+    *n_matches = total;
+    if (total > capacity) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "match buffer too small: %lld matches, capacity %lld (n_matches holds the count)", (long long)total, (long long)capacity);
+        return fail(CDS_ERR_OUT_OF_MEMORY, buf);
+    }
+    // every shard's list is ordered by mask, then target: interleave by mask, shard after shard (= by mask, then library index)
+    std::vector<size_t> at((size_t)n, 0);
+    int64_t o = 0;
+    for (int m = 0; m < n_masks; m++)
+        for (int r = 0; r < n; r++) {
+            const std::vector<cds_match> &v = part[(size_t)r];
+            size_t &i = at[(size_t)r];
+            for (; i < v.size() && v[i].mask == m; i++) {
+                matches[o] = v[i];
+                matches[o].target += (int32_t)off[(size_t)r];
+                o++;
+            }
+        }
     return CDS_OK;
 }
 

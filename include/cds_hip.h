@@ -257,6 +257,14 @@ int32_t cds_comm_size(const cds_comm *comm);
 int32_t cds_comm_uses_rccl(const cds_comm *comm);
 int cds_search_sparse_sharded(cds_comm *comm, const cds_maskset *const *masksets, const cds_sparse_library *const *slibs,
                               int64_t *shard_offsets, int32_t *scores, uint8_t *mirrored);
+/* The same search with ColorMIPSearch.isMatch and the compaction on every GPU (cds_search_sparse_match_list per shard, all GPUs at
+ * once): the matches of all shards ordered by mask, then by library index (target = shard_offsets[r] + image of shard r), exactly the
+ * list cds_search_sparse_matches gives over one library holding all shards -- what SparkColorMIPSearchProcessor.java:50-73 collect()s.
+ * No collective on this path: list lengths differ per GPU and every GPU hands its list to the host over its own PCIe link.
+ * CDS_ERR_OUT_OF_MEMORY when the list is longer than `capacity` (*n_matches then holds the length needed). */
+int cds_search_sparse_sharded_matches(cds_comm *comm, const cds_maskset *const *masksets, const cds_sparse_library *const *slibs,
+                                      double pct_positive_pixels, int64_t *shard_offsets, cds_match *matches, int64_t capacity,
+                                      int64_t *n_matches);
 
 /* Average device time (ms) of the scan kernel launches of the last cds_search*_ call on this mask
  * set, measured with hipEvents on the launch stream, and the number of launches. */

@@ -203,6 +203,7 @@ public:
         packedScores.assign((size_t)k, 0);
         check(cds_search_sparse_topk(ms_, lib.handle(), first, count, k, targets.data(), packedScores.data()));
     }
+    const cds_maskset *handle() const { return ms_; }   // (for ShardedSearch: one mask set per context)
 private:
     ImageArray query_;
     cds_maskset *ms_ = nullptr;
@@ -227,6 +228,24 @@ public:
         scores.assign((size_t)nMasks * (size_t)total, 0);
         mirrored.assign((size_t)nMasks * (size_t)total, 0);
         check(cds_search_sparse_sharded(comm_, masksets.data(), shards.data(), offsets.data(), scores.data(), mirrored.data()));
+    }
+    // isMatch + compaction on every GPU: the matches of all shards by mask, then library index (cds_match.target = offsets[r] + t)
+    std::vector<cds_match> searchMatches(const std::vector<const cds_maskset *> &masksets, const std::vector<const cds_sparse_library *> &shards,
+                                         double pctPositivePixels, std::vector<int64_t> &offsets) const {
+        offsets.assign(shards.size() + 1, 0);
+        std::vector<cds_match> out((size_t)1 << 16);
+        for (;;) {
+            int64_t n = 0;
+            const int rc = cds_search_sparse_sharded_matches(comm_, masksets.data(), shards.data(), pctPositivePixels, offsets.data(), out.data(),
+                                                             (int64_t)out.size(), &n);
+            if (rc == CDS_ERR_OUT_OF_MEMORY && n > (int64_t)out.size()) {   // (longer than the first guess: once more, exactly sized)
+                out.resize((size_t)n);
+                continue;
+            }
+            check(rc);
+            out.resize((size_t)n);
+            return out;
+        }
     }
 private:
     cds_comm *comm_ = nullptr;

@@ -202,6 +202,33 @@ JNIEXPORT jlong JNICALL CLS(commCreate)(JNIEnv *env, jclass c, jlongArray contex
     return (jlong)(intptr_t)comm;
 }
 JNIEXPORT void JNICALL CLS(commDestroy)(JNIEnv *env, jclass c, jlong comm) { cds_comm_destroy(P(cds_comm, comm)); }
+JNIEXPORT jintArray JNICALL CLS(searchSparseShardedMatches)(JNIEnv *env, jclass c, jlong comm, jlongArray masksets, jlongArray slibs, jdouble pct) {
+    jsize n = (*env)->GetArrayLength(env, masksets);
+    jlong *mh = (*env)->GetLongArrayElements(env, masksets, NULL), *sh = (*env)->GetLongArrayElements(env, slibs, NULL);
+    const cds_maskset **ms = (const cds_maskset **)calloc((size_t)n + 1, sizeof(*ms));
+    const cds_sparse_library **sl = (const cds_sparse_library **)calloc((size_t)n + 1, sizeof(*sl));
+    for (jsize i = 0; i < n; i++) { ms[i] = P(cds_maskset, mh[i]); sl[i] = P(cds_sparse_library, sh[i]); }
+    (*env)->ReleaseLongArrayElements(env, masksets, mh, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, slibs, sh, JNI_ABORT);
+    int64_t cap = 1 << 16, cnt = 0;
+    cds_match *buf = (cds_match *)malloc((size_t)cap * sizeof(cds_match));
+    int rc = buf ? cds_search_sparse_sharded_matches(P(cds_comm, comm), ms, sl, pct, NULL, buf, cap, &cnt) : CDS_ERR_OUT_OF_MEMORY;
+    if (buf && rc == CDS_ERR_OUT_OF_MEMORY && cnt > cap) {   /* longer than the first guess: once more, exactly sized */
+        free(buf);
+        cap = cnt;
+        buf = (cds_match *)malloc((size_t)cap * sizeof(cds_match));
+        rc = buf ? cds_search_sparse_sharded_matches(P(cds_comm, comm), ms, sl, pct, NULL, buf, cap, &cnt) : CDS_ERR_OUT_OF_MEMORY;
+    }
+    jintArray out = NULL;
+    if (rc) {
+        throw_for(env, rc);
+    } else {
+        out = (*env)->NewIntArray(env, (jsize)(3 * cnt));
+        if (out) (*env)->SetIntArrayRegion(env, out, 0, (jsize)(3 * cnt), (const jint *)buf);   /* a cds_match IS three int32 */
+    }
+    free(buf); free(ms); free(sl);
+    return out;
+}
 JNIEXPORT jlongArray JNICALL CLS(searchSparseSharded)(JNIEnv *env, jclass c, jlong comm, jlongArray masksets, jlongArray slibs, jintArray scores,
                                                       jbyteArray mirrored) {
     jsize n = (*env)->GetArrayLength(env, masksets);

@@ -68,6 +68,8 @@ final class CdsHip {
     static native void commDestroy(long comm);
     /** scores / mirrored: nMasks x (sum of the shards' sizes), library order; returns shard offsets (n + 1). */
     static native long[] searchSparseSharded(long comm, long[] masksets, long[] slibs, int[] scores, byte[] mirrored);
+    /** The shards' match lists (isMatch + compaction on every GPU) as mask, target, score | mirrored << 31 triples, by mask, then library index. */
+    static native int[] searchSparseShardedMatches(long comm, long[] masksets, long[] slibs, double pctPositivePixels);
 
     // ---- GradientAreaGap scorer (n x Shape2DMatchColorDepthSearchAlgorithm) ----
     static native long shapesetCreate(long ctx, int nMasks, byte[] masksRgb, int w, int h, int queryThreshold, int queryBorderSize,

@@ -44,6 +44,32 @@ int main() {
         pm->searchLibrary(slib, 0, 4, s2, m2);
         if (slib.size() != 4 || s2 != scores || m2 != mirrored) return 7;
 
+        // match list and top-k on the device: the two targets that match (the mask itself and its mirror image)
+        std::vector<cds_match> ml = pm->searchLibraryMatches(slib, 0, 4, 1.0);
+        if (ml.size() != 2 || ml[0].target != 0 || ml[1].target != 3 || ml[0].score != scores[0] || ml[1].score != (int32_t)((uint32_t)scores[3] | 0x80000000u)) return 8;
+        std::vector<int32_t> tk, sk;
+        pm->searchLibraryTopK(slib, 0, 4, 2, tk, sk);
+        if (tk[0] != 0 || tk[1] != 3 || (sk[0] & 0x7fffffff) != scores[0]) return 9;
+
+        // the same library cut into two shards over two contexts (of the one GPU: the rehearsal path of cds_comm)
+        {
+            cds::Context ctx2(0);
+            auto provider2 = cds::ColorDepthSearchAlgorithmProviderFactory::createPixMatchCDSAlgorithmProvider(ctx2, true, 20, 1.0, 2, cds::labelRegions(W));
+            auto alg2 = provider2->createColorDepthQuerySearchAlgorithmWithDefaultParams(mask, 20, 0);
+            auto *pm2 = dynamic_cast<cds::PixelMatchColorDepthSearchAlgorithm *>(alg2.get());
+            cds::SparseLibrary sa(ctx, W, H, 4, (int64_t)4 * W * H), sb(ctx2, W, H, 4, (int64_t)4 * W * H);
+            sa.appendFrom(lib, 0, 3);
+            sb.append(1, flipped.rgb.data());
+            cds::ShardedSearch sharded({ctx.handle(), ctx2.handle()});
+            std::vector<int64_t> offs;
+            std::vector<int32_t> s3;
+            std::vector<uint8_t> m3;
+            sharded.search({pm->handle(), pm2->handle()}, {sa.handle(), sb.handle()}, 1, offs, s3, m3);
+            if (offs != std::vector<int64_t>({0, 3, 4}) || s3 != scores || m3 != mirrored) return 10;
+            std::vector<cds_match> sm = sharded.searchMatches({pm->handle(), pm2->handle()}, {sa.handle(), sb.handle()}, 1.0, offs);
+            if (sm.size() != ml.size() || sm[0].target != 0 || sm[1].target != 3 || sm[1].score != ml[1].score) return 11;
+        }
+
         cds::ColorMIPSearch search(1.0, 20, std::move(provider));
         if (!search.isMatch(self)) return 5;
 

@@ -68,6 +68,8 @@ def test_native_sharded_search_through_the_c_abi(oracle):
         ws, wm = oracle.PixelMatchQuery(masks[m], 20, 20, 0.01, 2, True, rects).scan(targets, n_threads=8)
         want_s.append(ws), want_m.append(wm.astype(bool))
     want_s, want_m = np.stack(want_s), np.stack(want_m)
+    sizes = cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects).getQuerySizes()
+    cms = lambda pct: cds.ColorMIPSearch(pct, 20, None)
     for bounds in ([0, n], [0, 17, 17, n], [0, 5, 30, n]):      # 1 shard (RCCL); 3 shards, one of them empty; 3 uneven shards
         k = len(bounds) - 1
         ctxs = [cds.Context(0) for _ in range(k)]
@@ -80,5 +82,15 @@ def test_native_sharded_search_through_the_c_abi(oracle):
         assert np.array_equal(s, want_s) and np.array_equal(mir, want_m), bounds
         s2, _, _ = comm.searchSparseLibrarySharded(algs, libs)   # (the buffers are reused)
         assert np.array_equal(s2, want_s)
+        # the match lists of the shards (isMatch + compaction on every GPU, one host thread per shard) == the host-side filter over
+        # the whole score matrix, ordered by mask, then library index
+        for pct in (0.0, 1.0):
+            mm, tt, sc, mr, offs2 = comm.searchSparseLibraryShardedMatches(algs, libs, pct)
+            assert offs2.tolist() == bounds
+            rows = []
+            for m in range(3):
+                keep = cms(pct).isMatchArray(want_s[m], int(sizes[m]))
+                rows += [(m, int(t), int(want_s[m, t]), bool(want_m[m, t])) for t in np.flatnonzero(keep)]
+            assert list(zip(mm.tolist(), tt.tolist(), sc.tolist(), mr.tolist())) == rows, (bounds, pct)
         comm.close()
-    assert want_s.max() > 0
+    assert want_s.max() > 0 and len(rows) > 0
