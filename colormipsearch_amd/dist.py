@@ -5,7 +5,8 @@ The reference's only parallel strategy is data parallelism over target partition
 targets, results `collect()`-ed).  Here every (mask, target) score depends on that pair alone, so the library is cut
 into `world` contiguous index ranges, each resident in one GPU's HBM; a search is a local scan per rank followed by
 ONE gather of the per-target score arrays (int32, score | mirrored << 31) to rank 0 -- the only collective on the path
-(4 MB per GPU per million targets: latency-, not bandwidth-bound on xGMI; no reduction, no ring).  The mask set is tiny
+(4 MB per GPU per million targets: latency-, not bandwidth-bound on xGMI; no reduction, no ring).  For mask sets the
+match lists are gathered instead of the score matrix (`gather_match_lists`: isMatch + compaction on every GPU).  The mask set is tiny
 and replicated by the host.
 
 torch is plumbing here (process group + device buffers); the scan itself is the HIP kernel behind the C ABI.
@@ -65,6 +66,38 @@ def sharded_search(local_scan, n_masks, n_total, device, group=None, dst=0):
     out = torch.empty((n_masks, e - b), dtype=torch.int32, device=device)
     local_scan(out)
     return gather_scores(out, n_total, group=group, dst=dst)
+
+
+def gather_match_lists(local_matches, begin, group=None, dst=0):
+    """local_matches: int32 tensor [k, 3] of THIS rank's match list -- (mask, target relative to the shard, score | mirrored << 31),
+    ordered by mask, then target, as the device compaction leaves it -- on the group's device type; `begin` = the shard's first
+    library index.  Returns on rank `dst` the int32 tensor [K, 3] of all shards' matches with library indices, ordered by mask,
+    then target (the list one library holding every shard would give); None elsewhere.  Two collectives: the lengths (they are
+    known only to their ranks), then one gather of the padded lists -- for a mask set this replaces the gather of the
+    n_masks x n_total score matrix."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = local_matches.device
+    k = torch.tensor([local_matches.shape[0]], dtype=torch.int64, device=dev)
+    ks = [torch.zeros_like(k) for _ in range(world)]
+    dist.all_gather(ks, k, group=group)
+    ks = [int(x.item()) for x in ks]
+    pad = max(1, max(ks))
+    send = torch.zeros((pad, 3), dtype=torch.int32, device=dev)
+    if ks[rank]:
+        send[: ks[rank]] = local_matches
+        send[: ks[rank], 1] += int(begin)
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    parts = [recv[r][: ks[r]] for r in range(world)]
+    cat = torch.cat(parts, dim=0)
+    if cat.shape[0] == 0:
+        return cat
+    # every part is ordered by mask and the parts come in shard (= library) order: a stable sort by mask alone interleaves them
+    order = torch.sort(cat[:, 0], stable=True).indices
+    return cat[order]
 
 
 class ShardedLibrary:
@@ -128,6 +161,20 @@ class ShardedLibrary:
                 algorithm.searchLibraryDevice(self.library, 0, self.n_local, out.data_ptr())
 
         return sharded_search(local_scan, algorithm.n_masks, self.n_total, self.device, group=self.group, dst=dst)
+
+    def search_matches(self, algorithm, pctPositivePixels, dst=0):
+        """All masks x the whole sharded sparse library with ColorMIPSearch.isMatch and the compaction on every GPU: the gathered
+        match list on rank dst (int32 [K, 3]: mask, library index, score | mirrored << 31; by mask, then index), None elsewhere."""
+        if not self.sparse:
+            raise ValueError("search_matches needs a sparse shard (the device match list is built over signal-pixel records)")
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        if self.n_local:
+            m, t, sc, mir = algorithm.searchSparseLibraryMatches(self.sparse_library, pctPositivePixels, 0, self.n_local)
+            packed = (sc.astype(np.int64) | (mir.astype(np.int64) << 31)).astype(np.uint32).view(np.int32)
+            local = torch.from_numpy(np.stack([m, t, packed], axis=1).astype(np.int32)).to(self.device)
+        else:
+            local = torch.zeros((0, 3), dtype=torch.int32, device=self.device)
+        return gather_match_lists(local, self.begin, group=self.group, dst=dst)
 
 
 def sharded_pair_scores(local_score, pair_mask, pair_target, n_total, device, group=None, dst=0):

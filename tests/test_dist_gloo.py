@@ -48,9 +48,20 @@ def _worker(rank, world, port, ret):
             return torch.tensor([[int(mi) * 1000 + int(sl) + b, int(sl) + b, int(mi) & 1] for mi, sl in zip(mask_idx, slots)], dtype=torch.int64)
 
         pairs = cdist.sharded_pair_scores(local_score, pm, pt, N_TOTAL, torch.device("cpu"))
+        # match lists: every rank filters ITS scores (score > 0 stands in for isMatch) into (mask, local target, packed) triples
+        # ordered by mask, then target -- what the device compaction leaves -- and the lists are gathered instead of the matrix
+        trip = []
+        for m, q in enumerate(queries):
+            if e > b:
+                s, mir = q.scan(shard, n_threads=2)
+                packed = (s.astype(np.int64) | (mir.astype(np.int64) << 31)).astype(np.uint32).view(np.int32)
+                trip += [(m, int(t), int(packed[t])) for t in np.flatnonzero(s > 0)]
+        local = torch.tensor(trip, dtype=torch.int32).reshape(-1, 3)
+        lists = cdist.gather_match_lists(local, b)
         if rank == 0:
             ret["scores"] = got.numpy().copy()
             ret["pairs"] = pairs.numpy().copy()
+            ret["matches"] = lists.numpy().copy()
     finally:
         dist.destroy_process_group()
 
@@ -77,6 +88,9 @@ def test_sharded_search_equals_single_process(world, oracle):
     pm = np.array([0, 1, 1, 0, 0, 1])
     pt = np.array([10, 0, 5, 3, 7, 10])
     assert np.array_equal(ret["pairs"], np.stack([pm * 1000 + pt, pt, pm & 1], axis=1))
+    # the gathered match lists == the filter over the gathered score matrix, by mask, then library index
+    want = [(m, int(t), int(ret["scores"][m, t])) for m in range(len(masks)) for t in np.flatnonzero(scores[m] > 0)]
+    assert [tuple(int(v) for v in row) for row in ret["matches"]] == want and len(want) >= 2
 
 
 def test_shard_ranges_partition_the_library():

@@ -42,6 +42,14 @@ def test_sharded_library_search_single_rank(oracle):
         packed2 = sshard.search(alg)
         torch.cuda.synchronize()
         assert torch.equal(packed2, packed)
+        # mask sets gather match lists instead of the score matrix: isMatch + compaction on the GPU, two small collectives
+        lists = sshard.search_matches(alg, 1.0).cpu().numpy()
+        sizes = alg.getQuerySizes()
+        want = []
+        for m in range(2):
+            keep = cds.ColorMIPSearch(1.0, 20, None).isMatchArray(scores[m], int(sizes[m]))
+            want += [(m, int(t), int(packed[m, t].item())) for t in np.flatnonzero(keep)]
+        assert [tuple(int(v) for v in r) for r in lists] == want and len(want) > 0
     finally:
         shard.ctx.reset_stream()
         dist.destroy_process_group()
