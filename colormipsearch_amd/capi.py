@@ -118,6 +118,7 @@ SIGNATURES = {
     "cds_comm_size": (_i32, [_vp]),
     "cds_comm_uses_rccl": (_i32, [_vp]),
     "cds_search_sparse_sharded": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i64p, _i32p, _u8p]),
+    "cds_search_sparse_sharded_topk": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int32, _i64p, _i32p, _i32p]),
     "cds_search_sparse_sharded_matches": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_double, _i64p, _vp, _i64, _i64p]),
     "cds_shapeset_create": (_i, [_vp, _i32, _u8p, _i32, _i32, _i32, _i32, _u8p, _rp, _i32, ctypes.POINTER(_vp)]),
     "cds_shapeset_create_bordered": (_i, [_vp, _i32, _u8p, _i32, _i32, _i32, _i32, _i32, _u8p, _rp, _i32, ctypes.POINTER(_vp)]),

@@ -164,6 +164,22 @@ class Comm:
         capi.check(self._lib.cds_search_sparse_sharded(self._h, ms, sl, capi.as_i64p(offs), capi.as_i32p(scores), capi.as_u8p(mirrored)))
         return scores, mirrored.astype(bool), offs
 
+    def searchSparseLibraryShardedTopK(self, algorithms, sparse_libraries, k):
+        """Per mask the k best-scoring targets over all shards (selected on every GPU at once, merged on the host):
+        (targets int32[n_masks, k] as library indices with -1 behind the last one, scores int32[n_masks, k], mirrored bool[n_masks, k],
+        shard_offsets int64[n + 1]); score descending, equal scores by ascending library index."""
+        n = len(self.contexts)
+        if len(algorithms) != n or len(sparse_libraries) != n:
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "one mask set and one shard per context")
+        ms = (ctypes.c_void_p * n)(*[a._h for a in algorithms])
+        sl = (ctypes.c_void_p * n)(*[s._h for s in sparse_libraries])
+        n_masks = algorithms[0].n_masks
+        t = np.zeros((n_masks, int(k)), dtype=np.int32)
+        s = np.zeros((n_masks, int(k)), dtype=np.int32)
+        offs = np.zeros(n + 1, dtype=np.int64)
+        capi.check(self._lib.cds_search_sparse_sharded_topk(self._h, ms, sl, int(k), capi.as_i64p(offs), capi.as_i32p(t), capi.as_i32p(s)))
+        return t, (s & 0x7FFFFFFF).astype(np.int32), s < 0, offs
+
     def searchSparseLibraryShardedMatches(self, algorithms, sparse_libraries, pctPositivePixels):
         """The (mask, target) pairs for which ColorMIPSearch.isMatch holds, filtered and compacted on every GPU at once and handed to
         the host by each GPU directly: (mask int32[n], target int32[n] in library order, score int32[n], mirrored bool[n],

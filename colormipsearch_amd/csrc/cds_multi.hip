@@ -13,6 +13,7 @@
 // refuses duplicate devices) moves the shards' scores with device-to-device copies instead -- same layout, same result.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstring>
 #include <set>
 #include <thread>
@@ -305,6 +306,70 @@ int cds_search_sparse_sharded_matches(cds_comm *c, const cds_maskset *const *mas
                 o++;
             }
         }
+    return CDS_OK;
+}
+
+// Per mask the k best-scoring targets over all shards: every GPU selects its own k (cds_search_sparse_topk, all GPUs at once), the host
+// merges the n * k candidates per mask (score descending, equal scores by ascending library index -- the order one library would give).
+int cds_search_sparse_sharded_topk(cds_comm *c, const cds_maskset *const *masksets, const cds_sparse_library *const *slibs, int32_t k,
+                                   int64_t *shard_offsets, int32_t *targets, int32_t *scores) {
+    if (!c || !masksets || !slibs || !targets || !scores) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (k < 1 || k > 1024) return fail(CDS_ERR_INVALID_ARGUMENT, "k must be 1..1024");
+    const int n = (int)c->ctxs.size();
+    int n_masks = -1;
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    for (int r = 0; r < n; r++) {
+        if (!masksets[r] || !slibs[r]) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL shard");
+        if (masksets[r]->ctx != c->ctxs[(size_t)r] || slibs[r]->ctx != c->ctxs[(size_t)r])
+            return fail(CDS_ERR_INVALID_ARGUMENT, "shard r must have been created through context r of the communicator");
+        if (n_masks < 0) n_masks = masksets[r]->n_masks;
+        if (masksets[r]->n_masks != n_masks) return fail(CDS_ERR_INVALID_ARGUMENT, "the shards' mask sets differ in size (the mask set is replicated)");
+        off[(size_t)r + 1] = off[(size_t)r] + cds_sparse_library_size(slibs[r]);
+    }
+    if (shard_offsets) memcpy(shard_offsets, off.data(), off.size() * sizeof(int64_t));
+    if (off[(size_t)n] >= ((int64_t)1 << 31)) return fail(CDS_ERR_UNSUPPORTED, "more than 2^31 targets over the shards");
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t per = (size_t)n_masks * (size_t)k;
+    std::vector<std::vector<int32_t>> tg((size_t)n), sc((size_t)n);
+    std::vector<int> rcs((size_t)n, CDS_OK);
+    std::vector<std::string> errs((size_t)n);
+    auto work = [&](int r) {
+        const int64_t nl = off[(size_t)r + 1] - off[(size_t)r];
+        tg[(size_t)r].assign(per, -1);
+        sc[(size_t)r].assign(per, 0);
+        if (nl == 0) return;
+        const int rc = cds_search_sparse_topk(masksets[r], slibs[r], 0, nl, k, tg[(size_t)r].data(), sc[(size_t)r].data());
+        rcs[(size_t)r] = rc;
+        if (rc) errs[(size_t)r] = cds_last_error();
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int r = 1; r < n; r++) pool.emplace_back(work, r);
+        work(0);
+        for (auto &t : pool) t.join();
+    }
+    for (int r = 0; r < n; r++)
+        if (rcs[(size_t)r]) return fail(rcs[(size_t)r], "shard " + std::to_string(r) + ": " + errs[(size_t)r]);
+    struct Cand {
+        int32_t score, target, packed;
+    };
+    std::vector<Cand> cand;
+    for (int m = 0; m < n_masks; m++) {
+        cand.clear();
+        for (int r = 0; r < n; r++)
+            for (int i = 0; i < k; i++) {
+                const int32_t t = tg[(size_t)r][(size_t)m * k + i];
+                if (t < 0) break;   // (behind a shard's last candidate)
+                const int32_t p = sc[(size_t)r][(size_t)m * k + i];
+                cand.push_back({p & 0x7fffffff, (int32_t)(t + off[(size_t)r]), p});
+            }
+        std::sort(cand.begin(), cand.end(), [](const Cand &a, const Cand &b) { return a.score > b.score || (a.score == b.score && a.target < b.target); });
+        for (int i = 0; i < k; i++) {
+            const bool have = (size_t)i < cand.size();
+            targets[(size_t)m * k + i] = have ? cand[(size_t)i].target : -1;
+            scores[(size_t)m * k + i] = have ? cand[(size_t)i].packed : 0;
+        }
+    }
     return CDS_OK;
 }
 

@@ -265,6 +265,11 @@ int cds_search_sparse_sharded(cds_comm *comm, const cds_maskset *const *masksets
 int cds_search_sparse_sharded_matches(cds_comm *comm, const cds_maskset *const *masksets, const cds_sparse_library *const *slibs,
                                       double pct_positive_pixels, int64_t *shard_offsets, cds_match *matches, int64_t capacity,
                                       int64_t *n_matches);
+/* Per mask the k (<= 1024) best-scoring targets over all shards (cds_search_sparse_topk on every GPU at once, the n * k candidates of a
+ * mask merged on the host): targets[m * k + i] = library index (-1 behind the last one), scores[m * k + i] = matching pixels |
+ * mirrored << 31, by score descending, equal scores by ascending library index. */
+int cds_search_sparse_sharded_topk(cds_comm *comm, const cds_maskset *const *masksets, const cds_sparse_library *const *slibs, int32_t k,
+                                   int64_t *shard_offsets, int32_t *targets, int32_t *scores);
 
 /* Average device time (ms) of the scan kernel launches of the last cds_search*_ call on this mask
  * set, measured with hipEvents on the launch stream, and the number of launches. */

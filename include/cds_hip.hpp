@@ -229,6 +229,14 @@ public:
         mirrored.assign((size_t)nMasks * (size_t)total, 0);
         check(cds_search_sparse_sharded(comm_, masksets.data(), shards.data(), offsets.data(), scores.data(), mirrored.data()));
     }
+    // the k best-scoring targets of every mask over all shards: targets[m * k + i] (library index, -1 behind the last), packedScores likewise
+    void searchTopK(const std::vector<const cds_maskset *> &masksets, const std::vector<const cds_sparse_library *> &shards, int nMasks, int k,
+                    std::vector<int64_t> &offsets, std::vector<int32_t> &targets, std::vector<int32_t> &packedScores) const {
+        offsets.assign(shards.size() + 1, 0);
+        targets.assign((size_t)nMasks * (size_t)k, -1);
+        packedScores.assign((size_t)nMasks * (size_t)k, 0);
+        check(cds_search_sparse_sharded_topk(comm_, masksets.data(), shards.data(), k, offsets.data(), targets.data(), packedScores.data()));
+    }
     // isMatch + compaction on every GPU: the matches of all shards by mask, then library index (cds_match.target = offsets[r] + t)
     std::vector<cds_match> searchMatches(const std::vector<const cds_maskset *> &masksets, const std::vector<const cds_sparse_library *> &shards,
                                          double pctPositivePixels, std::vector<int64_t> &offsets) const {

@@ -202,6 +202,22 @@ JNIEXPORT jlong JNICALL CLS(commCreate)(JNIEnv *env, jclass c, jlongArray contex
     return (jlong)(intptr_t)comm;
 }
 JNIEXPORT void JNICALL CLS(commDestroy)(JNIEnv *env, jclass c, jlong comm) { cds_comm_destroy(P(cds_comm, comm)); }
+JNIEXPORT void JNICALL CLS(searchSparseShardedTopK)(JNIEnv *env, jclass c, jlong comm, jlongArray masksets, jlongArray slibs, jint k, jintArray targets,
+                                                    jintArray scores) {
+    jsize n = (*env)->GetArrayLength(env, masksets);
+    jlong *mh = (*env)->GetLongArrayElements(env, masksets, NULL), *sh = (*env)->GetLongArrayElements(env, slibs, NULL);
+    const cds_maskset **ms = (const cds_maskset **)calloc((size_t)n + 1, sizeof(*ms));
+    const cds_sparse_library **sl = (const cds_sparse_library **)calloc((size_t)n + 1, sizeof(*sl));
+    for (jsize i = 0; i < n; i++) { ms[i] = P(cds_maskset, mh[i]); sl[i] = P(cds_sparse_library, sh[i]); }
+    (*env)->ReleaseLongArrayElements(env, masksets, mh, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, slibs, sh, JNI_ABORT);
+    jint *t = (*env)->GetIntArrayElements(env, targets, NULL), *s = (*env)->GetIntArrayElements(env, scores, NULL);
+    int rc = cds_search_sparse_sharded_topk(P(cds_comm, comm), ms, sl, k, NULL, (int32_t *)t, (int32_t *)s);
+    (*env)->ReleaseIntArrayElements(env, targets, t, 0);
+    (*env)->ReleaseIntArrayElements(env, scores, s, 0);
+    free(ms); free(sl);
+    if (rc) throw_for(env, rc);
+}
 JNIEXPORT jintArray JNICALL CLS(searchSparseShardedMatches)(JNIEnv *env, jclass c, jlong comm, jlongArray masksets, jlongArray slibs, jdouble pct) {
     jsize n = (*env)->GetArrayLength(env, masksets);
     jlong *mh = (*env)->GetLongArrayElements(env, masksets, NULL), *sh = (*env)->GetLongArrayElements(env, slibs, NULL);

@@ -70,6 +70,8 @@ final class CdsHip {
     static native long[] searchSparseSharded(long comm, long[] masksets, long[] slibs, int[] scores, byte[] mirrored);
     /** The shards' match lists (isMatch + compaction on every GPU) as mask, target, score | mirrored << 31 triples, by mask, then library index. */
     static native int[] searchSparseShardedMatches(long comm, long[] masksets, long[] slibs, double pctPositivePixels);
+    /** Per mask the k best targets over all shards: targets[m * k + i] (library index, -1 behind the last), scores likewise (| mirrored << 31). */
+    static native void searchSparseShardedTopK(long comm, long[] masksets, long[] slibs, int k, int[] targets, int[] scores);
 
     // ---- GradientAreaGap scorer (n x Shape2DMatchColorDepthSearchAlgorithm) ----
     static native long shapesetCreate(long ctx, int nMasks, byte[] masksRgb, int w, int h, int queryThreshold, int queryBorderSize,

@@ -100,5 +100,13 @@ def test_native_sharded_search_through_the_c_abi(oracle):
                 keep = cms(pct).isMatchArray(want_s[m], int(sizes[m]))
                 rows += [(m, int(t), int(want_s[m, t]), bool(want_m[m, t])) for t in np.flatnonzero(keep)]
             assert list(zip(mm.tolist(), tt.tolist(), sc.tolist(), mr.tolist())) == rows, (bounds, pct)
+        # top-k over the shards == a stable host selection over the whole score matrix (score descending, ties by library index)
+        for k in (1, 5, n + 3):
+            tk, sk, mk, _ = comm.searchSparseLibraryShardedTopK(algs, libs, k)
+            for m in range(3):
+                order = np.lexsort((np.arange(n), -want_s[m].astype(np.int64)))[:k]
+                kk = len(order)
+                assert np.array_equal(tk[m, :kk], order) and np.array_equal(sk[m, :kk], want_s[m][order]) and np.array_equal(mk[m, :kk], want_m[m][order]), (bounds, k, m)
+                assert (tk[m, kk:] == -1).all()
         comm.close()
     assert want_s.max() > 0 and len(rows) > 0
