@@ -1,5 +1,6 @@
 package org.janelia.colormipsearch.cds.gpu;
 
+import java.util.ArrayList;
 import java.util.List;
 import java.util.Map;
 
@@ -11,6 +12,11 @@ import org.janelia.colormipsearch.imageprocessing.ImageRegionDefinition;
  * Batch-level search: a resident target library + mask sets scanned against all of it, the match list filtered and compacted
  * on the device (cds_search_sparse_matches).  Parameters come from ColorMIPSearch.getCDSParameters() (cds/ColorMIPSearch.java:26-31:
  * mirrorMask, dataThreshold, pixColorFluctuation, xyShift, pctPositivePixels, defaultMaskThreshold).
+ *
+ * With several devices the library is cut into one shard per GPU (targets dealt round-robin; library index = the shard's offset +
+ * the index inside the shard), the mask set is replicated, every GPU filters and compacts its own matches and the lists come back
+ * merged by mask and library index (cds_search_sparse_sharded_matches) -- the counterpart of the reference's partitions of targets
+ * whose results are collect()-ed (cdsprocess/SparkColorMIPSearchProcessor.java:50-73).
  */
 public final class GpuBatchSearch<K> implements AutoCloseable {
 
@@ -22,15 +28,29 @@ public final class GpuBatchSearch<K> implements AutoCloseable {
         public int[] querySize;      // per mask of the set
     }
 
-    private final long ctx;
+    private final long[] ctxs;       // one context per device
+    private final long comm;         // 0 with one device
     private final boolean mirrorMask;
     private final int dataThreshold, xyShift, maskThreshold;
     private final double zTolerance, pctPositivePixels;
     private final ImageRegionDefinition excludedRegions;
-    private GpuTargetLibrary<K> library;
+    private final List<GpuTargetLibrary<K>> shards = new ArrayList<>();
+    private long[] offsets = new long[]{0};   // library index of every shard's first target (set by targetsComplete)
+    private int dealt;
 
     public GpuBatchSearch(int device, Map<String, Object> cdsParameters, ImageRegionDefinition excludedRegions) {
-        this.ctx = GpuContext.get(device);
+        this(new int[]{device}, cdsParameters, excludedRegions);
+    }
+
+    public GpuBatchSearch(int[] devices, Map<String, Object> cdsParameters, ImageRegionDefinition excludedRegions) {
+        if (devices.length == 0) {
+            throw new IllegalArgumentException("no GPU device given");
+        }
+        this.ctxs = new long[devices.length];
+        for (int i = 0; i < devices.length; i++) {
+            ctxs[i] = GpuContext.get(devices[i]);
+        }
+        this.comm = devices.length > 1 ? CdsHip.commCreate(ctxs) : 0;
         this.mirrorMask = Boolean.parseBoolean(String.valueOf(cdsParameters.getOrDefault("mirrorMask", "false")));
         this.dataThreshold = intParam(cdsParameters, "dataThreshold", 0);
         this.xyShift = intParam(cdsParameters, "xyShift", 0);
@@ -54,27 +74,37 @@ public final class GpuBatchSearch<K> implements AutoCloseable {
     }
 
     public synchronized void addTarget(K key, ImageArray<?> image) {
-        if (library == null) {   // sized for a million 1210 x 566 MIPs of a few percent signal; -Dcds.gpu.library.* override
-            long images = Long.getLong("cds.gpu.library.images", 1L << 20);
+        if (shards.isEmpty()) {   // sized for a million 1210 x 566 MIPs of a few percent signal; -Dcds.gpu.library.* override
+            long images = Long.getLong("cds.gpu.library.images", 1L << 20) / ctxs.length + 1;
             long records = Long.getLong("cds.gpu.library.records", 40_000L * images);
-            library = new GpuTargetLibrary<>(ctx, image.getWidth(), image.getHeight(), images, records, 64);
-            library.setMinDataThreshold(dataThreshold);   // the library lives for this run's searches: pixels the scan never looks at stay out
+            for (long ctx : ctxs) {
+                GpuTargetLibrary<K> shard = new GpuTargetLibrary<>(ctx, image.getWidth(), image.getHeight(), images, records, 64);
+                shard.setMinDataThreshold(dataThreshold);   // the library lives for this run's searches: pixels the scan never looks at stay out
+                shards.add(shard);
+            }
         }
-        library.add(key, image);
+        shards.get(dealt++ % shards.size()).add(key, image);
     }
 
-    public void targetsComplete() {
-        if (library != null) {
-            library.flush();
+    public synchronized void targetsComplete() {
+        offsets = new long[shards.size() + 1];
+        for (int r = 0; r < shards.size(); r++) {
+            shards.get(r).flush();
+            offsets[r + 1] = offsets[r] + shards.get(r).size();
         }
     }
 
     public int targetCount() {
-        return library == null ? 0 : library.size();
+        return (int) offsets[offsets.length - 1];
     }
 
+    /** the target behind a library index of a match (shard offset + index inside the shard). */
     public K target(int index) {
-        return library.key(index);
+        int r = 0;
+        while (r + 1 < shards.size() && index >= offsets[r + 1]) {
+            r++;
+        }
+        return shards.get(r).key((int) (index - offsets[r]));
     }
 
     /** one mask set (all images of the library's size) against every resident target. */
@@ -82,7 +112,7 @@ public final class GpuBatchSearch<K> implements AutoCloseable {
         Matches out = new Matches();
         int n = maskImages.size();
         out.querySize = new int[n];
-        if (n == 0 || library == null || library.size() == 0) {
+        if (n == 0 || targetCount() == 0) {
             out.mask = out.target = out.score = new int[0];
             out.mirrored = new boolean[0];
             return out;
@@ -96,19 +126,31 @@ public final class GpuBatchSearch<K> implements AutoCloseable {
             }
             System.arraycopy(ImageArrayBytes.rgb(m), 0, masks, i * 3 * w * h, 3 * w * h);
         }
-        long maskset = CdsHip.masksetCreate(ctx, n, masks, w, h, maskThreshold, dataThreshold, zTolerance, xyShift, mirrorMask,
-                RegionRects.fromRegion(excludedRegions, maskImages.get(0)));
+        long[] masksets = new long[ctxs.length];
         try {
-            CdsHip.masksetQuerySizes(maskset, out.querySize);
-            long list = CdsHip.searchSparseMatchList(maskset, library.nativeHandle(), 0, library.size(), pctPositivePixels);
+            int[] regions = RegionRects.fromRegion(excludedRegions, maskImages.get(0));
+            for (int r = 0; r < ctxs.length; r++) {   // the mask set is tiny: one replica per GPU
+                masksets[r] = CdsHip.masksetCreate(ctxs[r], n, masks, w, h, maskThreshold, dataThreshold, zTolerance, xyShift, mirrorMask, regions);
+            }
+            CdsHip.masksetQuerySizes(masksets[0], out.querySize);
             long found;
             int[] triples;
-            try {
-                found = CdsHip.matchListSize(list);      // (exact: the list was built on the device, one scan)
-                triples = new int[(int) (3 * found)];
-                CdsHip.matchListFetch(list, 0, found, triples);
-            } finally {
-                CdsHip.matchListDestroy(list);
+            if (ctxs.length == 1) {
+                long list = CdsHip.searchSparseMatchList(masksets[0], shards.get(0).nativeHandle(), 0, shards.get(0).size(), pctPositivePixels);
+                try {
+                    found = CdsHip.matchListSize(list);      // (exact: the list was built on the device, one scan)
+                    triples = new int[(int) (3 * found)];
+                    CdsHip.matchListFetch(list, 0, found, triples);
+                } finally {
+                    CdsHip.matchListDestroy(list);
+                }
+            } else {   // every GPU scans, filters and compacts its shard; the lists come back merged by mask and library index
+                long[] slibs = new long[ctxs.length];
+                for (int r = 0; r < ctxs.length; r++) {
+                    slibs[r] = shards.get(r).nativeHandle();
+                }
+                triples = CdsHip.searchSparseShardedMatches(comm, masksets, slibs, pctPositivePixels);
+                found = triples.length / 3;
             }
             out.count = (int) found;
             out.mask = new int[out.count];
@@ -122,16 +164,23 @@ public final class GpuBatchSearch<K> implements AutoCloseable {
                 out.mirrored[i] = triples[3 * i + 2] < 0;
             }
         } finally {
-            CdsHip.masksetDestroy(maskset);
+            for (long ms : masksets) {
+                if (ms != 0) {
+                    CdsHip.masksetDestroy(ms);
+                }
+            }
         }
         return out;
     }
 
     @Override
     public void close() {
-        if (library != null) {
-            library.close();
-            library = null;
+        for (GpuTargetLibrary<K> shard : shards) {
+            shard.close();
+        }
+        shards.clear();
+        if (comm != 0) {
+            CdsHip.commDestroy(comm);
         }
     }
 }

@@ -37,7 +37,7 @@ public class GpuColorMIPSearchProcessor<M extends AbstractNeuronEntity, T extend
     private static final int MASKS_PER_SET = 64;
 
     private final ImageRegionDefinition excludedRegions;
-    private final int device;
+    private final int[] devices;
 
     public GpuColorMIPSearchProcessor(Number cdsRunId,
                                       ColorMIPSearch colorMIPSearch,
@@ -45,18 +45,32 @@ public class GpuColorMIPSearchProcessor<M extends AbstractNeuronEntity, T extend
                                       ImageRegionDefinition excludedRegions,
                                       int device,
                                       Set<String> tags) {
+        this(cdsRunId, colorMIPSearch, localProcessingPartitionSize, excludedRegions, new int[]{device}, tags);
+    }
+
+    /**
+     * Several GPUs of the node: the targets are cut into one resident shard per device, every mask set is scanned by all of them at
+     * once and the match lists come back merged (the reference's counterpart: partitions of targets on Spark executors,
+     * SparkColorMIPSearchProcessor.java:50-73).
+     */
+    public GpuColorMIPSearchProcessor(Number cdsRunId,
+                                      ColorMIPSearch colorMIPSearch,
+                                      int localProcessingPartitionSize,
+                                      ImageRegionDefinition excludedRegions,
+                                      int[] devices,
+                                      Set<String> tags) {
         super(cdsRunId, colorMIPSearch, localProcessingPartitionSize, tags);
         this.excludedRegions = excludedRegions;
-        this.device = device;
+        this.devices = devices.clone();
     }
 
     @Override
     public List<CDMatchEntity<M, T>> findAllColorDepthMatches(List<M> queryMIPs, List<T> targetMIPs) {
         long startTime = System.currentTimeMillis();
-        LOG.info("Searching {} masks against {} targets on GPU {}", queryMIPs.size(), targetMIPs.size(), device);
+        LOG.info("Searching {} masks against {} targets on GPU(s) {}", queryMIPs.size(), targetMIPs.size(), java.util.Arrays.toString(devices));
         Map<String, Object> params = colorMIPSearch.getCDSParameters();
         List<CDMatchEntity<M, T>> results = new ArrayList<>();
-        try (GpuBatchSearch<T> search = new GpuBatchSearch<>(device, params, excludedRegions)) {
+        try (GpuBatchSearch<T> search = new GpuBatchSearch<>(devices, params, excludedRegions)) {
             // 1. the targets, resident once for all masks; partitions bound the host memory held at a time
             for (int p0 = 0; p0 < targetMIPs.size(); p0 += localProcessingPartitionSize) {
                 for (T targetMIP : targetMIPs.subList(p0, Math.min(targetMIPs.size(), p0 + localProcessingPartitionSize))) {
