@@ -890,6 +890,10 @@ class _PixMatchProvider(ColorDepthSearchAlgorithmProvider):
     def getDefaultCDSParams(self):
         return self._defaults
 
+    def forContext(self, context):
+        """The same provider bound to another GPU's context (a replicated mask set per shard of a target-sharded library)."""
+        return _PixMatchProvider(self._m, self._t, self._f, self._s, self._regions, context)
+
     def createColorDepthSearchAlgorithm(self, queryImage, queryThreshold, queryBorderSize, cdsParams):
         fl = cdsParams.getDoubleParam("pixColorFluctuation", self._f)
         zTolerance = 0.0 if fl is None else fl / 100      # Factory:55-56

@@ -276,6 +276,39 @@ def resident_library_for(images, context=None, density_limit=0.25, min_threshold
     return lib
 
 
+class ShardedGpuColorMIPSearchProcessor:
+    """colorDepthSearch over a target-sharded library in ONE process with several GPUs (`cds.Comm`): `shards[r]` is the
+    `cds.SparseLibrary` of context r of the communicator (library index = shard offset + index inside the shard), the mask set is
+    replicated, every GPU scans, filters (`ColorMIPSearch.isMatch`) and compacts its own shard, and the match lists come back merged
+    by mask and library index (`cds_search_sparse_sharded_matches`) -- the reference's partitions of targets with their results
+    collect()-ed (SparkColorMIPSearchProcessor.java:50-73).  `colorMIPSearch`'s provider must be a pixel-match provider of this
+    package (it is re-bound to every context)."""
+
+    def __init__(self, colorMIPSearch: cds.ColorMIPSearch, comm: cds.Comm, shards):
+        assert len(shards) == len(comm.contexts)
+        self.colorMIPSearch, self.comm, self.shards = colorMIPSearch, comm, list(shards)
+        self.count = sum(len(s) for s in self.shards)
+
+    def findAllColorDepthMatchesTable(self, masks, mask_set_size=128) -> MatchTable:
+        """The rows of GpuColorMIPSearchProcessor.findAllColorDepthMatchesTable over one library holding all shards, same order."""
+        masks = cds.capi.rgb_images(masks)
+        thr = 0 if self.colorMIPSearch.defaultQueryThreshold is None else self.colorMIPSearch.defaultQueryThreshold
+        providers = [self.colorMIPSearch.cdsAlgorithmProvider.forContext(c) for c in self.comm.contexts]
+        parts = []
+        for m0 in range(0, masks.shape[0], int(mask_set_size)):
+            algs = [p.createColorDepthQuerySearchAlgorithmWithDefaultParams(masks[m0:m0 + int(mask_set_size)], thr, 0) for p in providers]
+            try:
+                m, t, sc, mir, _ = self.comm.searchSparseLibraryShardedMatches(algs, self.shards, self.colorMIPSearch.pctPositivePixels)
+                sizes = np.asarray(algs[0].getQuerySizes(), dtype=np.float64)
+            finally:
+                for a in algs:
+                    a.close()
+            ratio = (sc.astype(np.float64) / np.maximum(sizes[m], 1.0)).astype(np.float32)
+            parts.append(MatchTable(m.astype(np.int32) + np.int32(m0), t.astype(np.int64), sc.astype(np.int32), ratio, mir.astype(bool)))
+        cat = lambda f: np.concatenate([getattr(p, f) for p in parts]) if parts else np.zeros(0)
+        return MatchTable(cat("maskIndex"), cat("targetIndex"), cat("matchingPixels"), cat("matchingPixelsRatio"), cat("mirrored"))
+
+
 class GpuColorMIPSearchProcessor:
     """masks: uint8[n_masks,H,W,3]; the targets live in a `cds.Library` (+ `targets` metadata, one NeuronInfo per slot).
 

@@ -186,6 +186,40 @@ def test_mask_sets_prepared_while_the_previous_one_is_scanned(oracle):
 
 
 @pytest.mark.gpu
+def test_sharded_processor_equals_single_library(oracle):
+    """ShardedGpuColorMIPSearchProcessor (one process, cds.Comm over three contexts of the one GPU: uneven shards) == the processor
+    over one sparse library holding all targets: same match rows, same order."""
+    from colormipsearch_amd import cds
+    n_masks, n_t = 11, 120
+    mlib = cds.Library(W, H, n_masks)
+    mlib.generate_synthetic(0xBADC0DE, 0, 0, n_masks, kind=2)
+    masks = mlib.download(0, n_masks)
+    lib = cds.Library(W, H, n_t)
+    lib.generate_synthetic(0xC0FFEE, 9000, 0, n_t, kind=0)
+    lib.upload(7, masks[[2, 9]])
+    lib.upload(100, np.fliplr(masks[5])[None].copy())
+    targets = lib.download(0, n_t)
+    whole = cds.SparseLibrary(W, H, n_t, 40000 * n_t)
+    whole.append(targets)
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(True, 20, 1, 2, cds.label_regions)
+    search = cds.ColorMIPSearch(0.01, 20, provider)
+    want = P.GpuColorMIPSearchProcessor(search, None, None, sparse_library=whole).findAllColorDepthMatchesTable(masks, mask_set_size=64)
+    bounds = [0, 50, 57, n_t]
+    ctxs = [cds.Context(0) for _ in range(3)]
+    comm = cds.Comm(ctxs)
+    shards = []
+    for r in range(3):
+        s = cds.SparseLibrary(W, H, max(1, bounds[r + 1] - bounds[r]), 40000 * (bounds[r + 1] - bounds[r]) + 64, context=ctxs[r])
+        s.append(targets[bounds[r]:bounds[r + 1]])
+        shards.append(s)
+    got = P.ShardedGpuColorMIPSearchProcessor(search, comm, shards).findAllColorDepthMatchesTable(masks, mask_set_size=8)
+    for f in ("maskIndex", "targetIndex", "matchingPixels", "matchingPixelsRatio", "mirrored"):
+        assert np.array_equal(getattr(want, f), getattr(got, f)), f
+    assert len(want) > 10 and {2, 5, 9} <= set(want.maskIndex.tolist())
+    comm.close()
+
+
+@pytest.mark.gpu
 def test_pipeline_equals_oracle_pipeline(oracle):
     from colormipsearch_amd import cds
     rects = cds.label_regions(W)
