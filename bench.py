@@ -249,6 +249,11 @@ def main():
         finally:
             ctx.sparse_load_only(False)
         del scratch
+    stream_gbs = None
+    try:
+        stream_gbs, _ = slib.stream_read_gbs()     # a plain streaming read of the whole record arena on THIS device (fastest of three)
+    except cds.CdsError:
+        pass
     native_comm = None
     if use_dist and rank == 0:
         # the same gather behind the C ABI (cds_comm over this rank's context: ncclCommInitAll + ncclGather through libcds_hip.so,
@@ -322,17 +327,20 @@ def main():
                 "kernel_ms_per_launch": kern_ms, "kernel_ms_min_median_max": [float(np.min(step_ms)), float(np.median(step_ms)), float(np.max(step_ms))],
                 "targets_per_launch": n, "valu_issue_ns_per_simd": issue_ns, "simds": simds,
                 "hbm": {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                        "measured_copy_rate": HBM_COPY_GBS, "frac_of_measured_copy_rate": None},
+                        "measured_copy_rate": HBM_COPY_GBS, "frac_of_measured_copy_rate": None,
+                        "stream_read_of_the_record_arena_in_this_run": stream_gbs, "frac_of_stream_read_in_this_run": None},
                 "load_only": None if load_only_ms is None else {
                     "what": "the same launch with the scan kernel's loads-only twin (cds_debug_sparse_load_only: same grabs, run headers, record "
                             "loads and prefetch distance, no examination of the records), mean of 5 launches in this run: what the memory "
                             "system delivers for this access pattern",
-                    "kernel_ms_per_launch": load_only_ms, "scan_time_over_load_only_time": kern_ms / load_only_ms, "hbm_gbs": None},
+                    "kernel_ms_per_launch": load_only_ms, "scan_time_over_load_only_time": kern_ms / load_only_ms, "hbm_gbs": None,
+                    "frac_of_stream_read_in_this_run": None},
                 "dense_layout_bytes_per_target": dense_bytes_per_target,
                 "note": "The sparse library removed the bytes a dense scan streams (dense_layout_bytes_per_target).  frac = VALU wave-instructions "
                         "per launch (PMC, counters.source) x the issue time of one wave64 VALU instruction per SIMD measured in this run / "
                         "(SIMDs x kernel time of this run).  hbm = measured HBM traffic (2 x FETCH_SIZE) / kernel time against the 8 TB/s spec "
-                        "(and against the 6.29 TB/s the guide measures for a float4 copy).  load_only = the memory floor of the access pattern "
+                        "(and against the 6.29 TB/s the guide measures for a float4 copy, and against a plain streaming read of the whole record arena "
+                        "measured in this run: 16 bytes per lane, four loads in flight).  load_only = the memory floor of the access pattern "
                         "(runs of ~7 KB behind two dependent header loads), measured in this run: the scan takes scan_time_over_load_only_time x "
                         "as long as issuing its loads alone.  The HBM-streaming variant of the scan is aux.dense_layout."}
         cls = (pmc or {}).get("classes", {}).get("sparse_scan_headline") if args.kind == 0 else None
@@ -345,8 +353,12 @@ def main():
             roof["hbm"]["achieved"] = roof["traffic"] / (kern_ms * 1e-3) / 1e9
             roof["hbm"]["frac"] = roof["hbm"]["achieved"] / HBM_PEAK_GBS
             roof["hbm"]["frac_of_measured_copy_rate"] = roof["hbm"]["achieved"] / HBM_COPY_GBS
+            if stream_gbs:
+                roof["hbm"]["frac_of_stream_read_in_this_run"] = roof["hbm"]["achieved"] / stream_gbs
             if roof["load_only"]:
                 roof["load_only"]["hbm_gbs"] = roof["traffic"] / (load_only_ms * 1e-3) / 1e9
+                if stream_gbs:
+                    roof["load_only"]["frac_of_stream_read_in_this_run"] = roof["load_only"]["hbm_gbs"] / stream_gbs
             roof["counters"] = {"source": f"profiles/scan_pmc.json (tag {pmc.get('tag')}): separate rocprofv3 --pmc passes of "
                                           f"`{pmc.get('command')}`, mean of {cls.get('dispatches')} launches of {cls.get('targets_per_dispatch')} targets",
                                 "measured_in_this_run": False, "stale_sources": pmc["stale_sources"],

@@ -139,6 +139,7 @@ SIGNATURES = {
     "cds_debug_device_rcp": (_i, [_vp, _f32p]),
     "cds_debug_valu_issue_ns": (_i, [_vp, ctypes.POINTER(ctypes.c_double)]),
     "cds_debug_sparse_load_only": (_i, [ctypes.c_int32]),
+    "cds_debug_sparse_stream_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "cds_maskset_sparse_groups": (_i, [_vp, _i32p, _i32p, _i32p]),
     "cds_maskset_sparse_layout": (_i, [_vp, _i32, _i32p]),
 }

@@ -328,6 +328,12 @@ class SparseLibrary:
         capi.check(self._lib.cds_sparse_library_min_threshold(self._h, ctypes.byref(v)))
         return v.value
 
+    def stream_read_gbs(self):
+        """Diagnostic (bench.py): GB/s of a plain streaming read of the whole record arena on this device, and the bytes read."""
+        g, b = ctypes.c_double(), ctypes.c_double()
+        capi.check(self._lib.cds_debug_sparse_stream_read(self._h, ctypes.byref(g), ctypes.byref(b)))
+        return g.value, b.value
+
     def set_density_limit(self, max_signal_fraction):
         capi.check(self._lib.cds_sparse_library_set_density_limit(self._h, float(max_signal_fraction)))
 

@@ -39,6 +39,9 @@ int cds_debug_valu_issue_ns(cds_context *ctx, double *ns_per_wave_instruction_pe
  * examination of the records; the scores it writes are meaningless.  Only for the one-workgroup-per-CU layout with one-byte
  * planes (CDS_ERR_UNSUPPORTED otherwise).  Process-wide: not for use beside real searches. */
 int cds_debug_sparse_load_only(int32_t on);
+/* Reference point of the same measurement: a plain streaming read of the library's whole record arena (16 bytes per lane, four loads in
+ * flight, fastest of three launches) -- the rate THIS device's HBM delivers for the simplest pattern over the same memory. */
+int cds_debug_sparse_stream_read(const cds_sparse_library *slib, double *gb_per_s, double *bytes_read);
 #ifdef __cplusplus
 }
 #endif
