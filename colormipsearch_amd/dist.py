@@ -105,7 +105,8 @@ class ShardedLibrary:
     memory) or, with sparse=True, a cds.SparseLibrary (signal-pixel records; pixel-match scan only) filled through
     `stage` dense staging slots."""
 
-    def __init__(self, width, height, n_total, context=None, group=None, sparse=False, records_per_target=24000, stage=1024, density_limit=None):
+    def __init__(self, width, height, n_total, context=None, group=None, sparse=False, records_per_target=24000, stage=1024, density_limit=None,
+                 min_threshold=None):
         from . import cds
         self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
@@ -121,7 +122,7 @@ class ShardedLibrary:
         self.sparse_library = None
         if self.sparse:
             self.sparse_library = cds.SparseLibrary(width, height, n_local, int(records_per_target) * n_local + 4 * height * n_local,
-                                                    context=self.ctx, density_limit=density_limit)
+                                                    context=self.ctx, density_limit=density_limit, min_threshold=min_threshold)
 
     @property
     def n_local(self):

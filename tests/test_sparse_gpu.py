@@ -627,6 +627,21 @@ def test_multi_mask_random_geometry(cds, oracle, monkeypatch):
     assert ran_multi >= 10    # (the kernel under test really ran)
 
 
+def test_stream_read_diagnostic(cds, oracle):
+    """cds_debug_sparse_stream_read (bench.py's reference point): a plain read of the record arena reports a plausible rate and
+    refuses a library too small to measure."""
+    n = 512
+    dense = cds.Library(W, H, n)
+    dense.generate_synthetic(0xC0FFEE, 0, 0, n, kind=0)
+    sl = cds.SparseLibrary(W, H, n, 24000 * n + 4 * H * n)
+    sl.append_from(dense)
+    gbs, nbytes = sl.stream_read_gbs()
+    assert nbytes >= 16 << 20 and 50.0 < gbs < 9000.0, (gbs, nbytes)
+    tiny = sparse_of(cds, oracle.synth_image(0xC0FFEE, 1, 0))
+    with pytest.raises(cds.CdsInvalidArgument):
+        tiny.stream_read_gbs()
+
+
 def test_load_only_diagnostic_switches_on_and_off(cds, oracle):
     """cds_debug_sparse_load_only (bench.py's memory-floor measurement): while on, the single-mask search launches the loads-only
     twin (its scores are meaningless, the launch must complete); switched off, the scan is the real one again.  A layout without a
