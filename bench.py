@@ -720,6 +720,32 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
             ok_r &= same_r
             real["masks"][mk] = {"sparse_comparisons_per_s": n_r / (rms * 1e-3), "dense_comparisons_per_s": n_rd / (dms * 1e-3),
                                  "scores_equal": same_r}
+        # (e) the same images at the reference CLI's DEFAULT parameters (AbstractColorDepthMatchArgs.java:18-31: thresholds 100 / 100,
+        # pixColorFluctuation 2, xyShift 0, no mirror) over the library above and over one built with minimum data threshold 100
+        # (pixels the scan never looks at are not stored): same scores, fewer records
+        rs100 = cds.SparseLibrary(W, H, n_r, rs.pixels + 64, context=ctx, min_threshold=100)
+        for _ in range(reps):
+            for first in range(0, n_rd, 4096):
+                rs100.append_from(dense, first, min(4096, n_rd - first))
+        cli = {"parameters": "maskThreshold 100, dataThreshold 100, pixColorFluctuation 2, xyShift 0, mirror off (the reference CLI's defaults)",
+               "records_per_target": rs.pixels / n_r, "records_per_target_with_minimum_data_threshold_100": rs100.pixels / n_r, "masks": {}}
+        for mk in sorted(k for k in fx if k.startswith("em_")):
+            a = cds.PixelMatchColorDepthSearchAlgorithm(fx[mk], 100, False, None, 0, False, 100, 0.02, 0, E.STD_RECTS, context=ctx)
+            r0 = torch.empty(n_r, dtype=torch.int32, device=dev)
+            r1 = torch.empty(n_r, dtype=torch.int32, device=dev)
+            rde = torch.empty(n_rd, dtype=torch.int32, device=dev)
+            a.searchSparseLibraryDevice(rs, 0, n_r, r0.data_ptr())
+            ms0 = timed(stream, lambda: a.searchSparseLibraryDevice(rs, 0, n_r, r0.data_ptr()), 3)
+            a.searchSparseLibraryDevice(rs100, 0, n_r, r1.data_ptr())
+            ms1 = timed(stream, lambda: a.searchSparseLibraryDevice(rs100, 0, n_r, r1.data_ptr()), 3)
+            a.searchLibraryDevice(dense, 0, n_rd, rde.data_ptr())
+            torch.cuda.synchronize()
+            same_c = bool(torch.equal(r0, r1) and torch.equal(r0.view(reps, n_rd), rde.view(1, n_rd).expand(reps, n_rd)))
+            ok_r &= same_c
+            cli["masks"][mk] = {"sparse_comparisons_per_s": n_r / (ms0 * 1e-3), "sparse_comparisons_per_s_with_minimum_data_threshold_100": n_r / (ms1 * 1e-3),
+                                "scores_equal (both libraries, dense scan)": same_c}
+        real["reference_cli_defaults"] = cli
+        del rs100
         aux["real_images"] = real
         if not ok_r:
             failed.append("sparse and dense scans disagree on the reference's images")

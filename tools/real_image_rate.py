@@ -22,6 +22,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--copies", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--mask-thr", type=int, default=20)
+    ap.add_argument("--data-thr", type=int, default=20)
+    ap.add_argument("--ztol", type=float, default=0.01)
+    ap.add_argument("--xy", type=int, default=2)
+    ap.add_argument("--no-mirror", action="store_true")
     ap.add_argument("--min-threshold", type=int, default=0, help="minimum data threshold of the sparse library (pixels at or below it are not stored)")
     ap.add_argument("--mask", default="", help="only this EM mask (e.g. em_12191)")
     ap.add_argument("--sparse-only", action="store_true", help="time the sparse scan only (A/B builds: CDS_HIP_LIBRARY=...)")
@@ -48,7 +53,7 @@ def main():
     print(json.dumps({"targets": n, "images": lms, "nonblack_pixels": dict(zip(lms, sig)), "records_per_target": sl.pixels / n,
                       "sparse_bytes_per_target": 4 * sl.pixels / n}))
     for mk in ems:
-        alg = cds.PixelMatchColorDepthSearchAlgorithm(fx[mk], 20, True, None, 0, False, 20, 0.01, 2, rects, context=ctx)
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(fx[mk], args.mask_thr, not args.no_mirror, None, 0, False, args.data_thr, args.ztol, args.xy, rects, context=ctx)
         s_sp = torch.empty(n, dtype=torch.int32, device="cuda")
         s_de = torch.empty(n, dtype=torch.int32, device="cuda")
         out = {"mask": mk, "mask_pixels": int(alg.getQuerySize()) if hasattr(alg, "getQuerySize") else None, "layout": alg.sparseLayout(0)}
