@@ -120,6 +120,7 @@ SIGNATURES = {
     "cds_search_sparse_sharded": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i64p, _i32p, _u8p]),
     "cds_search_sparse_sharded_topk": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int32, _i64p, _i32p, _i32p]),
     "cds_search_sparse_sharded_matches": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_double, _i64p, _vp, _i64, _i64p]),
+    "cds_gradscore_sharded": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i64p, _i64, _i32p, _i64p, _i64p, _i64p, _i64p, _u8p]),
     "cds_shapeset_create": (_i, [_vp, _i32, _u8p, _i32, _i32, _i32, _i32, _u8p, _rp, _i32, ctypes.POINTER(_vp)]),
     "cds_shapeset_create_bordered": (_i, [_vp, _i32, _u8p, _i32, _i32, _i32, _i32, _i32, _u8p, _rp, _i32, ctypes.POINTER(_vp)]),
     "cds_shapeset_destroy": (None, [_vp]),
@@ -138,7 +139,8 @@ SIGNATURES = {
     "cds_debug_hue_code": (ctypes.c_uint32, [_f32p, _i32, _i32, _i32, _i32]),
     "cds_debug_device_rcp": (_i, [_vp, _f32p]),
     "cds_debug_valu_issue_ns": (_i, [_vp, ctypes.POINTER(ctypes.c_double)]),
-    "cds_debug_sparse_load_only": (_i, [ctypes.c_int32]),
+    "cds_debug_sparse_load_only": (_i, [_vp, ctypes.c_int32]),
+    "cds_debug_sparse_load_only_state": (ctypes.c_int32, [_vp]),
     "cds_debug_sparse_stream_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "cds_maskset_sparse_groups": (_i, [_vp, _i32p, _i32p, _i32p]),
     "cds_maskset_sparse_layout": (_i, [_vp, _i32, _i32p]),

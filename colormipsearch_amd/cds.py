@@ -103,8 +103,12 @@ class Context:
         return v.value
 
     def sparse_load_only(self, on):
-        """Diagnostic (bench.py): while on, single-mask sparse searches run the scan kernel's loads-only twin (process-wide)."""
-        capi.check(self._lib.cds_debug_sparse_load_only(int(bool(on))))
+        """Diagnostic (bench.py): while on, single-mask sparse searches made through THIS context run the scan kernel's loads-only
+        twin; other contexts are not affected (the flag lives in the context)."""
+        capi.check(self._lib.cds_debug_sparse_load_only(self._h, int(bool(on))))
+
+    def sparse_load_only_state(self):
+        return bool(self._lib.cds_debug_sparse_load_only_state(self._h))
 
     def make_zgap(self, target, threshold, radius=10, excluded_regions=None):
         """clearRegion -> mask(threshold) -> unsafeMaxFilter(radius), on the GPU."""
@@ -203,6 +207,31 @@ class Comm:
             break
         buf = buf[:cnt.value]
         return buf[:, 0].copy(), buf[:, 1].copy(), (buf[:, 2] & 0x7FFFFFFF).astype(np.int32), (buf[:, 2] < 0), offs
+
+    def scoreLibraryPairsSharded(self, shape_algorithms, libraries, pair_mask, pair_target, shard_sizes=None):
+        """GradientAreaGap of (mask index, LIBRARY index) pairs over dense shards (cds_gradscore_sharded): shape_algorithms[r] /
+        libraries[r] = the replicated shape set and the dense shard (targets + gradient / zgap variants in slots 0 .. size_r - 1) of
+        context r; every pair is scored on the GPU that owns its target, all GPUs at once.  Returns (gradientAreaGap int64[n],
+        highExpressionArea int64[n], mirrored bool[n], shard_offsets int64[len + 1]) in pair order -- what
+        Shape2DMatchColorDepthSearchAlgorithm.scoreLibraryPairs gives over one library holding all shards."""
+        n = len(self.contexts)
+        if len(shape_algorithms) != n or len(libraries) != n:
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "one shape set and one shard per context")
+        ss = (ctypes.c_void_p * n)(*[a._h for a in shape_algorithms])
+        lb = (ctypes.c_void_p * n)(*[l._h for l in libraries])
+        pm = np.ascontiguousarray(pair_mask, dtype=np.int32)
+        pt = np.ascontiguousarray(pair_target, dtype=np.int64)
+        if pm.shape != pt.shape or pm.ndim != 1:
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "pair_mask and pair_target must be 1-D arrays of one length")
+        sizes = None if shard_sizes is None else np.ascontiguousarray(shard_sizes, dtype=np.int64)
+        if sizes is not None and len(sizes) != n:
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "one shard size per context")
+        k = len(pm)
+        gap, high, mir = np.zeros(k, dtype=np.int64), np.zeros(k, dtype=np.int64), np.zeros(k, dtype=np.uint8)
+        offs = np.zeros(n + 1, dtype=np.int64)
+        capi.check(self._lib.cds_gradscore_sharded(self._h, ss, lb, capi.as_i64p(sizes) if sizes is not None else None, k, capi.as_i32p(pm),
+                                                   capi.as_i64p(pt), capi.as_i64p(offs), capi.as_i64p(gap), capi.as_i64p(high), capi.as_u8p(mir)))
+        return gap, high, mir.astype(bool), offs
 
 
 _default_ctx = {}

@@ -69,6 +69,7 @@ struct cds_context {
     std::vector<cds::RatioEntry> ratios;   // sorted by value, distinct
     uint8_t *d_slice_lut = nullptr;        // [6][256][256] slice number - 1 (shape scorer)
     bool owns_lut = true;                  // false in a pair-slot context (clone_context_for_slot): the table is the parent's
+    std::atomic<int> sparse_load_only{0};  // cds_debug_sparse_load_only: THIS context's single-mask sparse searches launch the loads-only twin
     std::mutex mu;
 };
 
@@ -168,6 +169,13 @@ struct PrepTimer {
         t = n;
     }
 };
+// cds_shape.hip: a GradientAreaGap scoring call in two halves (asynchronous begin, blocking end) for cds_gradscore_sharded
+struct GradscoreJob;
+int gradscore_begin(const cds_shapeset *ss, const cds_library *lib, int64_t n_pairs, const int32_t *pair_mask, const int64_t *pair_slot,
+                    hipStream_t on_stream, GradscoreJob **out);
+int gradscore_end(GradscoreJob *job, int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored);  // NULL outputs: wait and free
+cds_context *shapeset_context(const cds_shapeset *ss);
+int shapeset_n_masks(const cds_shapeset *ss);
 int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &per_mask);
 void free_sparse_plans(cds_maskset *ms);
 

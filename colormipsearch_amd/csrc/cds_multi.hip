@@ -183,13 +183,33 @@ int cds_search_sparse_sharded(cds_comm *c, const cds_maskset *const *masksets, c
         CDS_HIP(hipMalloc(&c->d_recv, elems * (size_t)n * sizeof(int32_t)));
         c->recv_elems = elems * (size_t)n;
     }
+    // Once a scan has been launched, no error path may return while kernels on other GPUs still write into the communicator's
+    // buffers (the caller may destroy them next): every failure below first waits for all the shards' streams.
+    auto quiesce = [&]() {
+        for (int r = 0; r < n; r++) {
+            hipSetDevice(c->ctxs[(size_t)r]->device);
+            hipStreamSynchronize(c->ctxs[(size_t)r]->stream);
+        }
+    };
+#define MG_HIP(call)                                 \
+    do {                                             \
+        hipError_t _e = (call);                      \
+        if (_e != hipSuccess) {                      \
+            quiesce();                               \
+            return cds::hip_fail(_e, #call);         \
+        }                                            \
+    } while (0)
     // 1. every GPU scans its own shard: asynchronous launches, all devices busy at once.  Shard r writes mask m's scores
     //    at d_send[r] + m * n_local (its own row pitch); the padding is never read back
     for (int r = 0; r < n; r++) {
         const int64_t nl = off[(size_t)r + 1] - off[(size_t)r];
         if (nl == 0) continue;
         const int rc = cds_search_sparse_device(masksets[r], slibs[r], 0, nl, c->d_send[(size_t)r]);
-        if (rc) return rc;
+        if (rc) {
+            const std::string msg = "shard " + std::to_string(r) + ": " + cds_last_error();
+            quiesce();
+            return fail(rc, msg);
+        }
     }
     // 2. ONE gather to the first GPU: RCCL over xGMI (each peer -> root transfer rides its own link), stream-ordered after
     //    the scans; contexts sharing a device (rehearsal) copy device-to-device instead
@@ -201,23 +221,27 @@ int cds_search_sparse_sharded(cds_comm *c, const cds_maskset *const *masksets, c
         }
         const int rc2 = c->api->GroupEnd();
         if (rc == 0) rc = rc2;
-        if (rc != 0) return fail(CDS_ERR_HIP, std::string("ncclGather: ") + c->api->GetErrorString(rc));
+        if (rc != 0) {
+            quiesce();
+            return fail(CDS_ERR_HIP, std::string("ncclGather: ") + c->api->GetErrorString(rc));
+        }
     } else {
         for (int r = 0; r < n; r++) {
-            CDS_HIP(hipSetDevice(c->ctxs[(size_t)r]->device));
-            CDS_HIP(hipStreamSynchronize(c->ctxs[(size_t)r]->stream));
-            CDS_HIP(hipMemcpyAsync(c->d_recv + (size_t)r * elems, c->d_send[(size_t)r], elems * sizeof(int32_t), hipMemcpyDeviceToDevice, c->ctxs[0]->stream));
+            MG_HIP(hipSetDevice(c->ctxs[(size_t)r]->device));
+            MG_HIP(hipStreamSynchronize(c->ctxs[(size_t)r]->stream));
+            MG_HIP(hipMemcpyAsync(c->d_recv + (size_t)r * elems, c->d_send[(size_t)r], elems * sizeof(int32_t), hipMemcpyDeviceToDevice, c->ctxs[0]->stream));
         }
     }
     // 3. root -> host, then into library order: scores[m * n_total + offset_r + t]
-    CDS_HIP(hipSetDevice(c->ctxs[0]->device));
+    MG_HIP(hipSetDevice(c->ctxs[0]->device));
     std::vector<int32_t> packed(elems * (size_t)n);
-    CDS_HIP(hipMemcpyAsync(packed.data(), c->d_recv, packed.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->ctxs[0]->stream));
-    CDS_HIP(hipStreamSynchronize(c->ctxs[0]->stream));
+    MG_HIP(hipMemcpyAsync(packed.data(), c->d_recv, packed.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->ctxs[0]->stream));
+    MG_HIP(hipStreamSynchronize(c->ctxs[0]->stream));
     for (int r = 1; r < n; r++) {  // (the peers' streams: their send buffers are free again)
-        CDS_HIP(hipSetDevice(c->ctxs[(size_t)r]->device));
-        CDS_HIP(hipStreamSynchronize(c->ctxs[(size_t)r]->stream));
+        MG_HIP(hipSetDevice(c->ctxs[(size_t)r]->device));
+        MG_HIP(hipStreamSynchronize(c->ctxs[(size_t)r]->stream));
     }
+#undef MG_HIP
     for (int r = 0; r < n; r++) {
         const int64_t nl = off[(size_t)r + 1] - off[(size_t)r];
         for (int m = 0; m < n_masks; m++) {
@@ -370,6 +394,84 @@ int cds_search_sparse_sharded_topk(cds_comm *c, const cds_maskset *const *maskse
             scores[(size_t)m * k + i] = have ? cand[(size_t)i].packed : 0;
         }
     }
+    return CDS_OK;
+}
+
+// GradientAreaGap over the shards (kernel 2, BASELINE configs[4] on several GPUs).  The reference scores every selected (mask, target)
+// pair on whichever worker holds the target's partition (Spark: SparkColorMIPSearchProcessor.java:50-73; per pair
+// CalculateGradientScoresCmd.java:541-586 -> Shape2DMatchColorDepthSearchAlgorithm.calculateMatchingScore).  Here shard r keeps library
+// indices [shard_offsets[r], shard_offsets[r + 1]) in slots 0 .. size_r - 1 of its dense library (targets + gradient / zgap variants),
+// the shape set is replicated (one per GPU), and a pair goes to the GPU that owns its target: ONE host thread sorts the pairs by owner,
+// starts every GPU's scoring call (pair upload, kernel, read-back: all asynchronous on that GPU's stream), then collects them in shard
+// order and puts the results back in pair order.  No collective: a result is 17 bytes and every GPU hands its own to the host.
+int cds_gradscore_sharded(cds_comm *c, const cds_shapeset *const *shapesets, const cds_library *const *libs, const int64_t *shard_sizes,
+                          int64_t n_pairs, const int32_t *pair_mask, const int64_t *pair_target, int64_t *shard_offsets,
+                          int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored) {
+    if (!c || !shapesets || !libs) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_pairs < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "n_pairs < 0");
+    const int n = (int)c->ctxs.size();
+    int n_masks = -1;
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    for (int r = 0; r < n; r++) {
+        if (!shapesets[r] || !libs[r]) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL shard");
+        if (shapeset_context(shapesets[r]) != c->ctxs[(size_t)r] || libs[r]->ctx != c->ctxs[(size_t)r])
+            return fail(CDS_ERR_INVALID_ARGUMENT, "shard r must have been created through context r of the communicator");
+        if (n_masks < 0) n_masks = shapeset_n_masks(shapesets[r]);
+        if (shapeset_n_masks(shapesets[r]) != n_masks) return fail(CDS_ERR_INVALID_ARGUMENT, "the shards' shape sets differ in size (the mask set is replicated)");
+        const int64_t nl = shard_sizes ? shard_sizes[r] : libs[r]->capacity;
+        if (nl < 0 || nl > libs[r]->capacity) return fail(CDS_ERR_INVALID_ARGUMENT, "a shard size exceeds its library's capacity");
+        off[(size_t)r + 1] = off[(size_t)r] + nl;
+    }
+    if (shard_offsets) memcpy(shard_offsets, off.data(), off.size() * sizeof(int64_t));
+    if (n_pairs == 0) return CDS_OK;
+    if (!pair_mask || !pair_target || !gradient_area_gap || !high_expression_area || !mirrored) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    // 1. route: pair i -> the shard whose index range holds its target (empty shards own nothing)
+    std::vector<std::vector<int32_t>> pm((size_t)n);
+    std::vector<std::vector<int64_t>> ps((size_t)n), at((size_t)n);
+    for (int64_t i = 0; i < n_pairs; i++) {
+        const int64_t t = pair_target[i];
+        if (t < 0 || t >= off[(size_t)n]) return fail(CDS_ERR_INVALID_ARGUMENT, "pair target outside the sharded library");
+        if (pair_mask[i] < 0 || pair_mask[i] >= n_masks) return fail(CDS_ERR_INVALID_ARGUMENT, "pair mask index out of range");
+        const int r = (int)(std::upper_bound(off.begin() + 1, off.end(), t) - (off.begin() + 1));
+        pm[(size_t)r].push_back(pair_mask[i]);
+        ps[(size_t)r].push_back(t - off[(size_t)r]);
+        at[(size_t)r].push_back(i);
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    // 2. every GPU scores its own pairs: all calls are started before the first one is waited for
+    std::vector<GradscoreJob *> jobs((size_t)n, nullptr);
+    int rc = CDS_OK;
+    std::string err;
+    for (int r = 0; r < n && rc == CDS_OK; r++) {
+        if (pm[(size_t)r].empty()) continue;
+        rc = gradscore_begin(shapesets[r], libs[r], (int64_t)pm[(size_t)r].size(), pm[(size_t)r].data(), ps[(size_t)r].data(), nullptr, &jobs[(size_t)r]);
+        if (rc) err = "shard " + std::to_string(r) + ": " + cds_last_error();
+    }
+    // 3. collect in shard order, results back into pair order.  After a failure the other GPUs' calls are still waited for (their
+    //    kernels write into buffers the jobs own), only their results are dropped.
+    std::vector<int64_t> g, h;
+    std::vector<uint8_t> mr;
+    for (int r = 0; r < n; r++) {
+        GradscoreJob *j = jobs[(size_t)r];
+        if (!j) continue;
+        const size_t k = pm[(size_t)r].size();
+        if (rc != CDS_OK) {
+            gradscore_end(j, nullptr, nullptr, nullptr);
+            continue;
+        }
+        g.resize(k), h.resize(k), mr.resize(k);
+        const int rc2 = gradscore_end(j, g.data(), h.data(), mr.data());
+        if (rc2) {
+            rc = rc2;
+            err = "shard " + std::to_string(r) + ": " + cds_last_error();
+            continue;
+        }
+        for (size_t q = 0; q < k; q++) {
+            const int64_t i = at[(size_t)r][q];
+            gradient_area_gap[i] = g[q], high_expression_area[i] = h[q], mirrored[i] = mr[q];
+        }
+    }
+    if (rc) return fail(rc, err);
     return CDS_OK;
 }
 

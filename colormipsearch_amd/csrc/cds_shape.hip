@@ -1077,43 +1077,70 @@ double cds_normalized_score(int32_t pix, int64_t shape, int64_t max_pix, int64_t
     return np / bounded * 100;
 }
 
-static int gradscore_impl(const cds_shapeset *ss, const cds_library *lib, int64_t n_pairs, const int32_t *pair_mask, const int64_t *pair_slot,
-                          int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored, hipStream_t on_stream);
+// A scoring call in two halves, so that one host thread can keep several GPUs busy (cds_gradscore_sharded, cds_multi.hip):
+// gradscore_begin uploads the pair list, launches the kernel and requests the read-back -- all asynchronous on the stream --,
+// gradscore_end waits for that stream and turns the four sums per pair into the reference's (gap, high, mirrored).
+}  // extern "C"
+namespace cds {
+struct GradscoreJob {
+    const cds_shapeset *ss = nullptr;
+    hipStream_t st = nullptr;
+    int64_t n_pairs = 0;
+    std::vector<int64_t> slots;      // < 0: the pair has no variants (-1, -1)
+    int32_t *d_pm = nullptr;
+    int64_t *d_ps = nullptr, *d_out = nullptr;
+    int64_t *h_res = nullptr;        // pinned: [n_pairs][4]
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void release() {
+        if (d_pm) hipFree(d_pm);
+        if (d_ps) hipFree(d_ps);
+        if (d_out) hipFree(d_out);
+        if (h_res) hipHostFree(h_res);
+        if (ev0) hipEventDestroy(ev0);
+        if (ev1) hipEventDestroy(ev1);
+        d_pm = nullptr; d_ps = d_out = h_res = nullptr; ev0 = ev1 = nullptr;
+    }
+};
 
-int cds_gradscore(const cds_shapeset *ss, const cds_library *lib, int64_t n_pairs, const int32_t *pair_mask,
-                  const int64_t *pair_slot, int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored) {
-    return gradscore_impl(ss, lib, n_pairs, pair_mask, pair_slot, gradient_area_gap, high_expression_area, mirrored, nullptr);
-}
+cds_context *shapeset_context(const cds_shapeset *ss) { return ss ? ss->ctx : nullptr; }
+int shapeset_n_masks(const cds_shapeset *ss) { return ss ? ss->n_masks : 0; }
 
 // `on_stream` (the pair-slot path): launch on that stream; the library then belongs to a slot context of the same device
-static int gradscore_impl(const cds_shapeset *ss, const cds_library *lib, int64_t n_pairs, const int32_t *pair_mask, const int64_t *pair_slot,
-                          int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored, hipStream_t on_stream) {
+int gradscore_begin(const cds_shapeset *ss, const cds_library *lib, int64_t n_pairs, const int32_t *pair_mask, const int64_t *pair_slot,
+                    hipStream_t on_stream, GradscoreJob **out) {
+    *out = nullptr;
     if (!ss || !lib) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n_pairs < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "n_pairs < 0");
     if (n_pairs == 0) return CDS_OK;
-    if (!pair_mask || !pair_slot || !gradient_area_gap || !high_expression_area || !mirrored) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!pair_mask || !pair_slot) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!on_stream && lib->ctx != ss->ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "shape set and library belong to different contexts");
     if (lib->W != ss->W || lib->H != ss->H) return fail(CDS_ERR_INVALID_ARGUMENT, "target image size must match the query image size");
-    std::vector<int64_t> slots((size_t)n_pairs);
+    std::unique_ptr<GradscoreJob> job(new GradscoreJob());
+    job->ss = ss;
+    job->n_pairs = n_pairs;
+    job->slots.resize((size_t)n_pairs);
     for (int64_t i = 0; i < n_pairs; i++) {
         if (pair_mask[i] < 0 || pair_mask[i] >= ss->n_masks) return fail(CDS_ERR_INVALID_ARGUMENT, "pair mask index out of range");
         if (pair_slot[i] < 0 || pair_slot[i] >= lib->capacity) return fail(CDS_ERR_INVALID_ARGUMENT, "pair slot out of range");
         const bool ok = lib->d_grad && lib->d_zgap && lib->has_grad[(size_t)pair_slot[i]] && lib->has_zgap[(size_t)pair_slot[i]];
-        slots[(size_t)i] = ok ? pair_slot[i] : -1;  // Shape2DMatch...Algorithm.java:155-158
+        job->slots[(size_t)i] = ok ? pair_slot[i] : -1;  // Shape2DMatch...Algorithm.java:155-158
     }
     cds_context *ctx = ss->ctx;
     CDS_HIP(hipSetDevice(ctx->device));
     hipStream_t st = on_stream ? on_stream : ctx->stream;
-    int32_t *d_pm = nullptr;
-    int64_t *d_ps = nullptr, *d_out = nullptr;
-    auto cleanup = [&]() { if (d_pm) hipFree(d_pm); if (d_ps) hipFree(d_ps); if (d_out) hipFree(d_out); };
-#define GS_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); return hip_fail(_e, #call); } } while (0)
-    GS_HIP(hipMalloc(&d_pm, (size_t)n_pairs * 4));
-    GS_HIP(hipMalloc(&d_ps, (size_t)n_pairs * 8));
-    GS_HIP(hipMalloc(&d_out, (size_t)n_pairs * 32));
-    GS_HIP(hipMemcpyAsync(d_pm, pair_mask, (size_t)n_pairs * 4, hipMemcpyHostToDevice, st));
-    GS_HIP(hipMemcpyAsync(d_ps, slots.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, st));
-    GS_HIP(hipMemsetAsync(d_out, 0, (size_t)n_pairs * 32, st));
+    job->st = st;
+    GradscoreJob *j = job.get();
+#define GS_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { hipStreamSynchronize(st); j->release(); return hip_fail(_e, #call); } } while (0)
+    GS_HIP(hipMalloc(&j->d_pm, (size_t)n_pairs * 4));
+    GS_HIP(hipMalloc(&j->d_ps, (size_t)n_pairs * 8));
+    GS_HIP(hipMalloc(&j->d_out, (size_t)n_pairs * 32));
+    GS_HIP(hipHostMalloc((void **)&j->h_res, (size_t)n_pairs * 32));
+    // (pair_mask is the caller's and may be gone before the copy runs when begin / end are apart: the slots are the job's own copy,
+    // the mask indices go through the pinned result buffer's first quarter, which the read-back overwrites later)
+    memcpy(j->h_res, pair_mask, (size_t)n_pairs * 4);
+    GS_HIP(hipMemcpyAsync(j->d_pm, j->h_res, (size_t)n_pairs * 4, hipMemcpyHostToDevice, st));
+    GS_HIP(hipMemcpyAsync(j->d_ps, j->slots.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, st));
+    GS_HIP(hipMemsetAsync(j->d_out, 0, (size_t)n_pairs * 32, st));
     ShapeParams p{};
     p.rgb = lib->d_rgb; p.zslice = lib->d_zslice; p.grad = lib->d_grad;
     p.img_stride = lib->img_stride; p.grad_stride = lib->grad_stride;
@@ -1121,47 +1148,73 @@ static int gradscore_impl(const cds_shapeset *ss, const cds_library *lib, int64_
     p.planes = ss->d_planes; p.boxes = ss->d_boxes; p.rowflags = ss->d_rowflags;
     p.thr = ss->thr; p.mirror = ss->mirror; p.nrects = ss->nrects;
     for (int i = 0; i < ss->nrects; i++) p.rects[i] = ss->rects[i];
-    p.pair_mask = d_pm; p.pair_slot = d_ps; p.n_pairs = n_pairs; p.out = d_out;
+    p.pair_mask = j->d_pm; p.pair_slot = j->d_ps; p.n_pairs = n_pairs; p.out = j->d_out;
     int per_cu = 32;
     if (const char *e = getenv("CDS_SHAPE_WGS_PER_CU")) per_cu = atoi(e);
     int64_t g64 = (int64_t)ctx->n_cus * per_cu;
     int grid = (int)std::min<int64_t>(n_pairs, g64);
-    hipEvent_t ev0, ev1;
-    GS_HIP(hipEventCreate(&ev0));
-    GS_HIP(hipEventCreate(&ev1));
-    GS_HIP(hipEventRecord(ev0, st));
+    GS_HIP(hipEventCreate(&j->ev0));
+    GS_HIP(hipEventCreate(&j->ev1));
+    GS_HIP(hipEventRecord(j->ev0, st));
     p.glist = ss->d_glist; p.hlist = ss->d_hlist; p.list_off = ss->d_list_off; p.gl_a = ss->d_gl_a; p.gl_b = ss->d_gl_b;
     if (getenv("CDS_SHAPE_SCAN_KERNEL")) hipLaunchKernelGGL(gradscore_kernel, dim3(grid), dim3(256), 0, st, p);   // (the plane-window scan, for A/B runs)
     else hipLaunchKernelGGL(gradscore_list_kernel, dim3(grid), dim3(256), 0, st, p);
     GS_HIP(hipGetLastError());
-    GS_HIP(hipEventRecord(ev1, st));
-    std::vector<int64_t> res((size_t)n_pairs * 4);
-    GS_HIP(hipMemcpyAsync(res.data(), d_out, (size_t)n_pairs * 32, hipMemcpyDeviceToHost, st));
-    GS_HIP(hipStreamSynchronize(st));
-    float t = 0;
-    hipEventElapsedTime(&t, ev0, ev1);
-    hipEventDestroy(ev0);
-    hipEventDestroy(ev1);
+    GS_HIP(hipEventRecord(j->ev1, st));
+    GS_HIP(hipMemcpyAsync(j->h_res, j->d_out, (size_t)n_pairs * 32, hipMemcpyDeviceToHost, st));
 #undef GS_HIP
-    cleanup();
-    {
-        std::lock_guard<std::mutex> lk(ss->mu);
-        ss->last_ms = t;
-        ss->last_launches = 1;
-    }
-    for (int64_t i = 0; i < n_pairs; i++) {
-        if (slots[(size_t)i] < 0) {
-            gradient_area_gap[i] = -1; high_expression_area[i] = -1; mirrored[i] = 0;
-            continue;
-        }
-        const int64_t *r = &res[(size_t)i * 4];
-        gradient_area_gap[i] = r[0]; high_expression_area[i] = r[1]; mirrored[i] = 0;
-        // keep the mirrored orientation iff its int-cast score is lower (Shape2DMatch...Algorithm.java:181-183)
-        if (ss->mirror && (int)cds_shape_score_value(r[2], r[3]) < (int)cds_shape_score_value(r[0], r[1])) {
-            gradient_area_gap[i] = r[2]; high_expression_area[i] = r[3]; mirrored[i] = 1;
-        }
-    }
+    *out = job.release();
     return CDS_OK;
+}
+
+// waits for the job's stream; outputs may be NULL (abandon: wait and free only).  The job is gone afterwards.
+int gradscore_end(GradscoreJob *j, int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored) {
+    if (!j) return CDS_OK;
+    const cds_shapeset *ss = j->ss;
+    hipSetDevice(ss->ctx->device);
+    const hipError_t e = hipStreamSynchronize(j->st);
+    int rc = CDS_OK;
+    if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize (gradscore)");
+    if (rc == CDS_OK && gradient_area_gap) {
+        float t = 0;
+        hipEventElapsedTime(&t, j->ev0, j->ev1);
+        {
+            std::lock_guard<std::mutex> lk(ss->mu);
+            ss->last_ms = t;
+            ss->last_launches = 1;
+        }
+        for (int64_t i = 0; i < j->n_pairs; i++) {
+            if (j->slots[(size_t)i] < 0) {
+                gradient_area_gap[i] = -1; high_expression_area[i] = -1; mirrored[i] = 0;
+                continue;
+            }
+            const int64_t *r = &j->h_res[(size_t)i * 4];
+            gradient_area_gap[i] = r[0]; high_expression_area[i] = r[1]; mirrored[i] = 0;
+            // keep the mirrored orientation iff its int-cast score is lower (Shape2DMatch...Algorithm.java:181-183)
+            if (ss->mirror && (int)cds_shape_score_value(r[2], r[3]) < (int)cds_shape_score_value(r[0], r[1])) {
+                gradient_area_gap[i] = r[2]; high_expression_area[i] = r[3]; mirrored[i] = 1;
+            }
+        }
+    }
+    j->release();
+    delete j;
+    return rc;
+}
+}  // namespace cds
+extern "C" {
+
+static int gradscore_impl(const cds_shapeset *ss, const cds_library *lib, int64_t n_pairs, const int32_t *pair_mask, const int64_t *pair_slot,
+                          int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored, hipStream_t on_stream) {
+    if (n_pairs > 0 && (!gradient_area_gap || !high_expression_area || !mirrored)) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    GradscoreJob *job = nullptr;
+    const int rc = gradscore_begin(ss, lib, n_pairs, pair_mask, pair_slot, on_stream, &job);
+    if (rc || !job) return rc;
+    return gradscore_end(job, gradient_area_gap, high_expression_area, mirrored);
+}
+
+int cds_gradscore(const cds_shapeset *ss, const cds_library *lib, int64_t n_pairs, const int32_t *pair_mask,
+                  const int64_t *pair_slot, int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored) {
+    return gradscore_impl(ss, lib, n_pairs, pair_mask, pair_slot, gradient_area_gap, high_expression_area, mirrored, nullptr);
 }
 
 int cds_shape_score_pair(const cds_shapeset *ss, int32_t mask_index, const uint8_t *target_rgb, const uint16_t *grad,

@@ -1371,8 +1371,6 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
     return CDS_OK;
 }
 
-static std::atomic<int> g_sparse_load_only{0};   // cds_debug_sparse_load_only
-
 template <bool XY2, bool MIRROR>
 static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t lds_bytes, int threads, hipStream_t st) {
     const bool wide = lds_bytes > ctx->lds_per_block / 2 && !getenv("CDS_SPARSE_WPE8");  // one workgroup per CU: 4 waves per SIMD, 128 VGPRs
@@ -1380,7 +1378,7 @@ static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t
                         : p.iv_in_lds ? sparse_scan_kernel<XY2, MIRROR, true, false, 4> : sparse_scan_kernel<XY2, MIRROR, false, false, 4>)
                      : (p.plane8 ? sparse_scan_kernel<XY2, MIRROR, true, true, 8>
                         : p.iv_in_lds ? sparse_scan_kernel<XY2, MIRROR, true, false, 8> : sparse_scan_kernel<XY2, MIRROR, false, false, 8>);
-    if (g_sparse_load_only.load()) {
+    if (ctx->sparse_load_only.load()) {   // (a diagnostic of THIS context only: cds_debug_sparse_load_only)
         if (!(wide && p.plane8)) return fail(CDS_ERR_UNSUPPORTED, "the load-only diagnostic exists for the one-workgroup-per-CU, one-byte-plane layout only");
         kern = sparse_scan_kernel<XY2, MIRROR, true, true, 4, true>;
     }
@@ -2478,10 +2476,13 @@ int cds_search_sparse_counts(const cds_maskset *ms, const cds_sparse_library *sl
 }
 
 
-int cds_debug_sparse_load_only(int32_t on) {
-    g_sparse_load_only.store(on ? 1 : 0);
+// per CONTEXT: another context's searches (another thread's, another GPU's) are never affected
+int cds_debug_sparse_load_only(cds_context *ctx, int32_t on) {
+    if (!ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL context");
+    ctx->sparse_load_only.store(on ? 1 : 0);
     return CDS_OK;
 }
+int32_t cds_debug_sparse_load_only_state(const cds_context *ctx) { return ctx ? ctx->sparse_load_only.load() : 0; }
 
 #if SP_BAND
 // diagnostics of the stage-1 hue-band map (include/cds_hip_debug.h; host arithmetic identical to the kernel's)

@@ -204,3 +204,14 @@ def sharded_pair_scores(local_score, pair_mask, pair_target, n_total, device, gr
         if len(idx):
             out[torch.as_tensor(idx, device=device)] = recv[r][: len(idx)]
     return out
+
+
+def gradscore_scorer(shape_algorithm, library):
+    """The `local_score` of sharded_pair_scores backed by the HIP kernel: (mask indices, slots of THIS rank's dense shard) ->
+    int64 tensor [k, 3] = gradientAreaGap, highExpressionArea, mirrored (cds_gradscore: one launch for the rank's pairs)."""
+
+    def local_score(mask_idx, slots):
+        gap, high, mir = shape_algorithm.scoreLibraryPairs(library, mask_idx, slots)
+        return torch.from_numpy(np.stack([gap, high, mir.astype(np.int64)], axis=1))
+
+    return local_score

@@ -270,6 +270,17 @@ int cds_search_sparse_sharded_matches(cds_comm *comm, const cds_maskset *const *
  * mirrored << 31, by score descending, equal scores by ascending library index. */
 int cds_search_sparse_sharded_topk(cds_comm *comm, const cds_maskset *const *masksets, const cds_sparse_library *const *slibs, int32_t k,
                                    int64_t *shard_offsets, int32_t *targets, int32_t *scores);
+/* Kernel 2 over the shards (declared here with the communicator; the scorer itself is further down): the GradientAreaGap scores of
+ * n_pairs (mask index, LIBRARY index) pairs when the library's targets -- with their gradient / zgap variants -- are spread over
+ * the GPUs as dense shards: shard r keeps library indices [shard_offsets[r], shard_offsets[r] + shard_sizes[r]) in slots
+ * 0 .. shard_sizes[r] - 1 of libs[r] (shard_sizes NULL: every library's capacity); the shape set is replicated (shapesets[r] made
+ * through context r from the same masks).  Every pair is scored on the GPU that owns its target -- the data parallelism over target
+ * partitions of the reference (tools cmd/cdsprocess/SparkColorMIPSearchProcessor.java:50-73; the per-pair call is
+ * cmd/CalculateGradientScoresCmd.java:541-586) --, all GPUs at once from one host thread, and the results come back in pair order
+ * with the meaning of cds_gradscore (a slot without variants gives -1, -1).  No collective on this path. */
+int cds_gradscore_sharded(cds_comm *comm, const cds_shapeset *const *shapesets, const cds_library *const *libs,
+                          const int64_t *shard_sizes, int64_t n_pairs, const int32_t *pair_mask, const int64_t *pair_target,
+                          int64_t *shard_offsets, int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored);
 
 /* Average device time (ms) of the scan kernel launches of the last cds_search*_ call on this mask
  * set, measured with hipEvents on the launch stream, and the number of launches. */

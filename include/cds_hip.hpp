@@ -255,6 +255,19 @@ public:
             return out;
         }
     }
+    // kernel 2 over dense shards: GradientAreaGap of (mask index, LIBRARY index) pairs, every pair scored on the GPU owning its target
+    // (shapesets[r] / libs[r] made through contexts[r]; shard r = library indices [offsets[r], offsets[r] + shardSizes[r]) in its slots 0..)
+    void gradScores(const std::vector<const cds_shapeset *> &shapesets, const std::vector<const cds_library *> &libs,
+                    const std::vector<int64_t> &shardSizes, const std::vector<int32_t> &pairMask, const std::vector<int64_t> &pairTarget,
+                    std::vector<int64_t> &offsets, std::vector<int64_t> &gradientAreaGap, std::vector<int64_t> &highExpressionArea,
+                    std::vector<uint8_t> &mirrored) const {
+        offsets.assign(libs.size() + 1, 0);
+        gradientAreaGap.assign(pairMask.size(), 0);
+        highExpressionArea.assign(pairMask.size(), 0);
+        mirrored.assign(pairMask.size(), 0);
+        check(cds_gradscore_sharded(comm_, shapesets.data(), libs.data(), shardSizes.empty() ? nullptr : shardSizes.data(), (int64_t)pairMask.size(),
+                                    pairMask.data(), pairTarget.data(), offsets.data(), gradientAreaGap.data(), highExpressionArea.data(), mirrored.data()));
+    }
 private:
     cds_comm *comm_ = nullptr;
 };
@@ -286,6 +299,7 @@ public:
         return ShapeMatchScore(gap, high, -1, m != 0);
     }
     void maskStats(int64_t &maskSize, int64_t &highExpressionSize) const { check(cds_shapeset_mask_stats(ss_, &maskSize, &highExpressionSize)); }
+    const cds_shapeset *handle() const { return ss_; }   // (for ShardedSearch::gradScores: one shape set per context)
 private:
     ImageArray query_;
     int thr_;

@@ -34,11 +34,13 @@ int32_t cds_debug_band_of(const float *rcp_table, int32_t cls, int32_t second, i
 /* Calibration of the instruction-issue roofline (bench.py): ns one SIMD needs per wave64 integer VALU instruction with 8
  * waves resident, measured on this device with independent v_add / v_xor chains (tools/valubench/valubench.hip, mode 0). */
 int cds_debug_valu_issue_ns(cds_context *ctx, double *ns_per_wave_instruction_per_simd);
-/* Measurement of the sparse scan's memory floor (bench.py): while `on` is non-zero, single-mask sparse searches of this process
- * launch the scan kernel's LOADS-ONLY twin -- same work distribution, run headers, record loads and prefetch distance, no
+/* Measurement of the sparse scan's memory floor (bench.py): while `on` is non-zero, single-mask sparse searches made through THIS
+ * CONTEXT launch the scan kernel's LOADS-ONLY twin -- same work distribution, run headers, record loads and prefetch distance, no
  * examination of the records; the scores it writes are meaningless.  Only for the one-workgroup-per-CU layout with one-byte
- * planes (CDS_ERR_UNSUPPORTED otherwise).  Process-wide: not for use beside real searches. */
-int cds_debug_sparse_load_only(int32_t on);
+ * planes (CDS_ERR_UNSUPPORTED otherwise).  The flag lives in the context: searches through any other context (another thread's,
+ * another GPU's, a mask set's pair slots) are never affected.  cds_debug_sparse_load_only_state reads it back. */
+int cds_debug_sparse_load_only(cds_context *ctx, int32_t on);
+int32_t cds_debug_sparse_load_only_state(const cds_context *ctx);
 /* Reference point of the same measurement: a plain streaming read of the library's whole record arena (16 bytes per lane, four loads in
  * flight, fastest of three launches) -- the rate THIS device's HBM delivers for the simplest pattern over the same memory. */
 int cds_debug_sparse_stream_read(const cds_sparse_library *slib, double *gb_per_s, double *bytes_read);

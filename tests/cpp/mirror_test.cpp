@@ -68,6 +68,21 @@ int main() {
             if (offs != std::vector<int64_t>({0, 3, 4}) || s3 != scores || m3 != mirrored) return 10;
             std::vector<cds_match> sm = sharded.searchMatches({pm->handle(), pm2->handle()}, {sa.handle(), sb.handle()}, 1.0, offs);
             if (sm.size() != ml.size() || sm[0].target != 0 || sm[1].target != 3 || sm[1].score != ml[1].score) return 11;
+
+            // kernel 2 over the same two contexts (cds_gradscore_sharded): library indices 0..4 as dense shards of 3 + 2 targets with
+            // their gradient / zgap variants; every pair goes to the context owning its target == cds_gradscore over one library
+            cds::Library whole(ctx, W, H, 5), la(ctx, W, H, 3), lb(ctx2, W, H, 2);
+            whole.generateSynthetic(0xC0FFEEull, 100, 0, 5, 0, true);
+            la.generateSynthetic(0xC0FFEEull, 100, 0, 3, 0, true);
+            lb.generateSynthetic(0xC0FFEEull, 103, 0, 2, 0, true);
+            cds::Shape2DMatchColorDepthSearchAlgorithm sh1(ctx, mask, 20, true, nullptr, cds::labelRegions(W)), sh2(ctx2, mask, 20, true, nullptr, cds::labelRegions(W));
+            const std::vector<int32_t> pmask = {0, 0, 0, 0, 0, 0};
+            const std::vector<int64_t> ptarget = {4, 0, 3, 1, 2, 4};
+            std::vector<int64_t> wg(6), wh(6), gg, gh;
+            std::vector<uint8_t> wm(6), gm;
+            cds::check(cds_gradscore(sh1.handle(), whole.handle(), 6, pmask.data(), ptarget.data(), wg.data(), wh.data(), wm.data()));
+            sharded.gradScores({sh1.handle(), sh2.handle()}, {la.handle(), lb.handle()}, {}, pmask, ptarget, offs, gg, gh, gm);
+            if (offs != std::vector<int64_t>({0, 3, 5}) || gg != wg || gh != wh || gm != wm || wg[0] <= 0) return 12;
         }
 
         cds::ColorMIPSearch search(1.0, 20, std::move(provider));

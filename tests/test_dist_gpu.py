@@ -110,3 +110,101 @@ def test_native_sharded_search_through_the_c_abi(oracle):
                 assert (tk[m, kk:] == -1).all()
         comm.close()
     assert want_s.max() > 0 and len(rows) > 0
+
+
+def _variant_shard(cds, ctx, seed, first, count):
+    lib = cds.Library(W, H, max(1, count), context=ctx)
+    if count:
+        lib.generate_synthetic(seed, first, 0, count, kind=0, with_variants=True)
+    return lib
+
+
+def test_native_sharded_gradient_scores_through_the_c_abi(oracle):
+    """cds_gradscore_sharded (kernel 2 over dense shards, one process): every (mask, library index) pair is scored on the context
+    owning its target.  (a) one context = the communicator RCCL initialises, (b) three contexts on the one GPU with uneven and
+    empty shards; results in pair order equal cds_gradscore over ONE library holding every target, and the CPU oracle on a sample.
+    A slot without variants gives (-1, -1) on whichever shard it lives."""
+    from colormipsearch_amd import cds
+    rects = cds.label_regions(W)
+    n, seed, base = 13, 0xC0FFEE, 500
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(3)])
+    ctx0 = cds.default_context()
+    whole = _variant_shard(cds, ctx0, seed, base, n)
+    sh0 = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, 20, True, None, rects, context=ctx0)
+    rng = np.random.default_rng(11)
+    pm = rng.integers(0, 3, size=40).astype(np.int32)
+    pt = rng.integers(0, n, size=40).astype(np.int64)
+    want = sh0.scoreLibraryPairs(whole, pm, pt)
+    assert (want[0] > 0).any() and want[2].any() and (~want[2]).any()       # (both orientations win somewhere)
+    # the CPU oracle on a few of the pairs
+    for i in (0, 7, 23):
+        sq = oracle.ShapeQuery(masks[pm[i]], 20, True, rects)
+        zg, gr = oracle.synth_variants(seed, base + int(pt[i]))
+        og, oh, _, om = sq.score(oracle.synth_image(seed, base + int(pt[i]), 0), gr, zg)
+        assert (int(want[0][i]), int(want[1][i]), bool(want[2][i])) == (og, oh, bool(om))
+    for bounds in ([0, n], [0, 6, 6, n], [0, 2, 9, n]):
+        k = len(bounds) - 1
+        ctxs = [cds.Context(0) for _ in range(k)]
+        comm = cds.Comm(ctxs)
+        assert comm.uses_rccl == (k == 1)
+        shapes = [cds.Shape2DMatchColorDepthSearchAlgorithm(masks, 20, True, None, rects, context=c) for c in ctxs]
+        libs = [_variant_shard(cds, ctxs[r], seed, base + bounds[r], bounds[r + 1] - bounds[r]) for r in range(k)]
+        sizes = [bounds[r + 1] - bounds[r] for r in range(k)]
+        gap, high, mir, offs = comm.scoreLibraryPairsSharded(shapes, libs, pm, pt, shard_sizes=sizes)
+        assert offs.tolist() == bounds
+        assert np.array_equal(gap, want[0]) and np.array_equal(high, want[1]) and np.array_equal(mir, want[2]), bounds
+        # no pairs at all, and pairs that all live on the last shard
+        g0, _, _, _ = comm.scoreLibraryPairsSharded(shapes, libs, np.zeros(0, np.int32), np.zeros(0, np.int64), shard_sizes=sizes)
+        assert len(g0) == 0
+        last = np.flatnonzero(pt >= bounds[-2])
+        g1, h1, m1, _ = comm.scoreLibraryPairsSharded(shapes, libs, pm[last], pt[last], shard_sizes=sizes)
+        assert np.array_equal(g1, want[0][last]) and np.array_equal(h1, want[1][last]) and np.array_equal(m1, want[2][last])
+        # errors: a target outside the library, a mask outside the set, a shard larger than its library
+        for bad_m, bad_t, bad_sizes in (([0], [n], sizes), ([3], [0], sizes), ([0], [0], [s + 64 for s in sizes])):
+            with pytest.raises(cds.CdsInvalidArgument):
+                comm.scoreLibraryPairsSharded(shapes, libs, np.array(bad_m, np.int32), np.array(bad_t, np.int64), shard_sizes=bad_sizes)
+        comm.close()
+    # a shard whose slots have no variants: (-1, -1, False) for its pairs, the other shard's pairs unchanged
+    ctxs = [cds.Context(0) for _ in range(2)]
+    comm = cds.Comm(ctxs)
+    shapes = [cds.Shape2DMatchColorDepthSearchAlgorithm(masks, 20, True, None, rects, context=c) for c in ctxs]
+    bare = cds.Library(W, H, 6, context=ctxs[0])
+    bare.generate_synthetic(seed, base, 0, 6, kind=0)
+    libs = [bare, _variant_shard(cds, ctxs[1], seed, base + 6, n - 6)]
+    gap, high, mir, _ = comm.scoreLibraryPairsSharded(shapes, libs, pm, pt, shard_sizes=[6, n - 6])
+    lo = pt < 6
+    assert (gap[lo] == -1).all() and (high[lo] == -1).all() and not mir[lo].any()
+    assert np.array_equal(gap[~lo], want[0][~lo]) and np.array_equal(high[~lo], want[1][~lo]) and np.array_equal(mir[~lo], want[2][~lo])
+    comm.close()
+
+
+def test_sharded_pair_scores_with_the_real_kernel(oracle):
+    """dist.sharded_pair_scores (one process per GPU, torch.distributed) driven by cds_gradscore: nccl with one rank on the one-GPU
+    box -- the routing, padding, gather and reordering are the multi-rank code; the scorer is the HIP kernel, not a stand-in."""
+    import torch
+    import torch.distributed as dist
+    from colormipsearch_amd import cds
+    from colormipsearch_amd import dist as cdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29613"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rects = cds.label_regions(W)
+        n, seed, base = 9, 0xC0FFEE, 700
+        ctx = cds.default_context()
+        masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(2)])
+        lib = _variant_shard(cds, ctx, seed, base, n)
+        shape = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, 20, True, None, rects, context=ctx)
+        pm = np.array([0, 1, 1, 0, 0, 1, 0], dtype=np.int32)
+        pt = np.array([8, 0, 5, 3, 7, 8, 0], dtype=np.int64)
+        scorer = cdist.gradscore_scorer(shape, lib)
+        got = cdist.sharded_pair_scores(scorer, pm, pt, n, torch.device("cuda", 0)).cpu().numpy()
+        want = shape.scoreLibraryPairs(lib, pm, pt)
+        assert np.array_equal(got[:, 0], want[0]) and np.array_equal(got[:, 1], want[1]) and np.array_equal(got[:, 2].astype(bool), want[2])
+        sq = oracle.ShapeQuery(masks[1], 20, True, rects)
+        zg, gr = oracle.synth_variants(seed, base + 5)
+        og, oh, _, om = sq.score(oracle.synth_image(seed, base + 5, 0), gr, zg)
+        assert (int(got[2, 0]), int(got[2, 1]), bool(got[2, 2])) == (og, oh, bool(om))
+    finally:
+        dist.destroy_process_group()

@@ -156,3 +156,15 @@ def test_band_map_bits_cover_every_code_of_an_interval(oracle, ztol):
         inside = (((codes - np.uint32(iv[0])) & 0xFFFFFFFF) <= iv[1]) | (((codes - np.uint32(iv[2])) & 0xFFFFFFFF) <= iv[3])
         missed = inside & (((bits >> band_all) & 1) == 0)
         assert not missed.any(), (m.tolist(), ztol, cols[missed][:5].tolist())
+
+
+def test_load_only_diagnostic_is_not_process_wide():
+    """cds_debug_sparse_load_only takes a context (round 3 had a process-global switch that turned every search of the process into
+    the loads-only twin): without a context there is nothing to switch, and the call says so instead of flipping a global."""
+    lib = capi.load()
+    assert lib.cds_debug_sparse_load_only(None, 1) == -1      # CDS_ERR_INVALID_ARGUMENT
+    assert lib.cds_debug_sparse_load_only_state(None) == 0
+    hdr = open(os.path.join(ROOT, "include", "cds_hip_debug.h")).read()
+    assert re.search(r"int cds_debug_sparse_load_only\(cds_context \*ctx, int32_t on\);", hdr)
+    src = open(os.path.join(ROOT, "colormipsearch_amd", "csrc", "cds_sparse.hip")).read()
+    assert not re.search(r"\bg_sparse_load_only\b", src) and "static std::atomic<int> g_" not in src

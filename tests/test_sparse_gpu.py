@@ -653,9 +653,17 @@ def test_load_only_diagnostic_switches_on_and_off(cds, oracle):
     alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
     want, wm = alg.searchSparseLibrary(sl)
     ctx = cds.default_context()
+    # the flag lives in the context: a second context on the same GPU keeps searching for real while the first one's flag is on
+    ctx2 = cds.Context(0)
+    sl2 = cds.SparseLibrary(W, H, len(targets), int((targets.max(axis=3) > 0).sum()) + 4 * H * len(targets) + 64, context=ctx2)
+    sl2.append(targets)
+    alg2 = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects, context=ctx2)
     try:
         ctx.sparse_load_only(True)
+        assert ctx.sparse_load_only_state() and not ctx2.sparse_load_only_state()
         alg.searchSparseLibrary(sl)
+        got2, gm2 = alg2.searchSparseLibrary(sl2)
+        assert np.array_equal(got2, want) and np.array_equal(gm2, wm)
         small = np.zeros((H, W, 3), dtype=np.uint8)
         small[300:310, 500:520] = oracle.depth_lut()[100]
         alg_small = cds.PixelMatchColorDepthSearchAlgorithm(small, 20, True, None, 0, False, 20, 0.01, 2, rects)   # 80 KB layout: no twin
