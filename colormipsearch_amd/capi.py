@@ -99,7 +99,7 @@ SIGNATURES = {
     "cds_sparse_library_image_records": (_i, [_vp, _i64, _u32p, _i64, _i64p, _u32p]),
     "cds_sparse_library_image_offsets": (_i, [_vp, _i64, _i64, ctypes.POINTER(ctypes.c_uint64)]),
     "cds_sparse_library_export": (_i, [_vp, _i64, _i64, ctypes.POINTER(ctypes.c_uint64), _u32p, _u32p, _i64]),
-    "cds_sparse_library_import": (_i, [_vp, _i64, ctypes.POINTER(ctypes.c_uint64), _u32p, _u32p, _i32, _i32]),
+    "cds_sparse_library_import": (_i, [_vp, _i64, ctypes.POINTER(ctypes.c_uint64), _u32p, _u32p, _i32, _i32, _i32]),
     "cds_image_probe": (_i, [_u8p, ctypes.c_size_t, ctypes.POINTER(ImageInfo)]),
     "cds_image_decode": (_i, [_u8p, ctypes.c_size_t, _vp, ctypes.c_size_t]),
     "cds_sparse_library_append_files": (_i, [_vp, ctypes.POINTER(ctypes.c_char_p), _i64, _i32]),
@@ -120,6 +120,10 @@ SIGNATURES = {
     "cds_search_sparse_sharded": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i64p, _i32p, _u8p]),
     "cds_search_sparse_sharded_topk": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int32, _i64p, _i32p, _i32p]),
     "cds_search_sparse_sharded_matches": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_double, _i64p, _vp, _i64, _i64p]),
+    "cds_maskset_size": (ctypes.c_int32, [_vp]),
+    "cds_shapeset_size": (ctypes.c_int32, [_vp]),
+    "cds_library_dims": (_i, [_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _i64p]),
+    "cds_sparse_library_dims": (_i, [_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "cds_gradscore_sharded": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i64p, _i64, _i32p, _i64p, _i64p, _i64p, _i64p, _u8p]),
     "cds_shapeset_create": (_i, [_vp, _i32, _u8p, _i32, _i32, _i32, _i32, _u8p, _rp, _i32, ctypes.POINTER(_vp)]),
     "cds_shapeset_create_bordered": (_i, [_vp, _i32, _u8p, _i32, _i32, _i32, _i32, _i32, _u8p, _rp, _i32, ctypes.POINTER(_vp)]),

@@ -419,7 +419,7 @@ class SparseLibrary:
                                                        rec.ctypes.data_as(u32p), rec.size))
         return offs, cells, rec
 
-    def import_arrays(self, image_offsets, cell_offsets, records, n_strips=None, strip_width=None):
+    def import_arrays(self, image_offsets, cell_offsets, records, n_strips=None, strip_width=None, min_data_threshold=0):
         """Append images given as exported arrays (possibly memory-mapped)."""
         offs = np.ascontiguousarray(image_offsets, dtype=np.uint64)
         cells = np.ascontiguousarray(cell_offsets, dtype=np.uint32)
@@ -430,7 +430,7 @@ class SparseLibrary:
         u64p, u32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)
         capi.check(self._lib.cds_sparse_library_import(self._h, count, offs.ctypes.data_as(u64p), cells.ctypes.data_as(u32p), rec.ctypes.data_as(u32p),
                                                        self.n_strips if n_strips is None else int(n_strips),
-                                                       self.strip_width if strip_width is None else int(strip_width)))
+                                                       self.strip_width if strip_width is None else int(strip_width), int(min_data_threshold or 0)))
 
     def image_offsets(self, first=0, count=None):
         """uint64[count + 1]: absolute position of the first record of images first..first+count in the record arena."""

@@ -399,6 +399,14 @@ int cds_library_wrap(cds_context *ctx, int32_t W, int32_t H, int64_t capacity, v
     return CDS_OK;
 }
 
+int cds_library_dims(const cds_library *lib, int32_t *W, int32_t *H, int64_t *capacity) {
+    if (!lib) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (W) *W = lib->W;
+    if (H) *H = lib->H;
+    if (capacity) *capacity = lib->capacity;
+    return CDS_OK;
+}
+
 void cds_library_destroy(cds_library *lib) {
     if (!lib) return;
     hipSetDevice(lib->ctx->device);
@@ -724,9 +732,9 @@ static int build_dense_layout(cds_maskset *ms) {
     for (int m = 0; m < n_masks; m++) {
         bands[(size_t)m].resize((size_t)nbands);
         for (const Px &p : per_mask[(size_t)m]) bands[(size_t)m][(size_t)((p.y - m0) / kScanBandRows)].push_back(p);
-        std::vector<Px>().swap(per_mask[(size_t)m]);
     }
-    std::vector<std::vector<MaskPx>>().swap(per_mask);
+    // (the pixel lists stay with the mask set until the upload below has succeeded: a failed build -- out of device memory with
+    // several host threads in the per-pair path -- must leave the set as it was, so that the next dense search can try again)
     for (int q = 0; q < ngroups; q++) {
         for (int b = 0; b < nbands; b++) {
             bandptr[(size_t)q * (nbands + 1) + b] = (uint32_t)chunks.size();
@@ -790,7 +798,16 @@ static int build_dense_layout(cds_maskset *ms) {
     if (e == hipSuccess) e = hipMemcpy(ms->d_chunks, chunks.data(), chunks.size() * sizeof(uint4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ms->d_px_pos, pos.data(), total * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ms->d_px_iv, ivs.data(), total * sizeof(uint4), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return hip_fail(e, "maskset upload");
+    if (e != hipSuccess) {   // nothing half-built stays behind: the next call starts from the pixel lists again
+        if (ms->d_bandptr) hipFree(ms->d_bandptr);
+        if (ms->d_chunks) hipFree(ms->d_chunks);
+        if (ms->d_px_pos) hipFree(ms->d_px_pos);
+        if (ms->d_px_iv) hipFree(ms->d_px_iv);
+        ms->d_bandptr = nullptr; ms->d_chunks = nullptr; ms->d_px_pos = nullptr; ms->d_px_iv = nullptr;
+        ms->h_bandptr.clear();
+        return hip_fail(e, "maskset upload");
+    }
+    std::vector<std::vector<MaskPx>>().swap(ms->lazy_px);   // the layout is on the device: the lists have served their purpose
     pt.lap("dense layout (upload)");
     return CDS_OK;
 }
@@ -801,7 +818,7 @@ static int ensure_dense_layout(const cds_maskset *cms) {
     std::lock_guard<std::mutex> lk(ms->dense_mu);
     if (ms->dense_ready.load(std::memory_order_relaxed)) return CDS_OK;
     const int rc = build_dense_layout(ms);
-    if (rc) return rc;   // (a failed upload leaves the lists gone: the next call fails the same way on the empty arrays' NULL check)
+    if (rc) return rc;   // (a failed build frees what it allocated and keeps the pixel lists: the next dense search builds again)
     ms->dense_ready.store(true, std::memory_order_release);
     return CDS_OK;
 }
@@ -817,6 +834,8 @@ void cds_maskset_destroy(cds_maskset *ms) {
     ms->pair_pool.slots.clear();
     delete ms;
 }
+
+int32_t cds_maskset_size(const cds_maskset *ms) { return ms ? ms->n_masks : 0; }
 
 int cds_maskset_query_sizes(const cds_maskset *ms, int32_t *sizes) {
     if (!ms || !sizes) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");

@@ -459,7 +459,14 @@ static int append_files_impl(cds_sparse_library *sl, const char *const *paths, i
 
 int cds_sparse_library_append_files(cds_sparse_library *sl, const char *const *paths, int64_t count, int32_t threads) {
     CDS_NOEXCEPT_BEGIN
-    return append_files_impl(sl, paths, count, threads);
+    const int64_t n_images0 = sl ? sl->n_images : 0, n_px0 = sl ? sl->n_px : 0;
+    const int rc = append_files_impl(sl, paths, count, threads);
+    if (rc == CDS_ERR_UNSUPPORTED) {   // a density refusal leaves nothing of the call behind (the message survives: same thread)
+        const std::string msg = cds_last_error();
+        cds::sparse_library_rollback(sl, n_images0, n_px0);
+        return fail(rc, msg);
+    }
+    return rc;
     CDS_NOEXCEPT_END
 }
 

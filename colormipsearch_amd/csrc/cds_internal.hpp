@@ -176,6 +176,7 @@ int gradscore_begin(const cds_shapeset *ss, const cds_library *lib, int64_t n_pa
 int gradscore_end(GradscoreJob *job, int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored);  // NULL outputs: wait and free
 cds_context *shapeset_context(const cds_shapeset *ss);
 int shapeset_n_masks(const cds_shapeset *ss);
+int sparse_library_rollback(cds_sparse_library *sl, int64_t n_images, int64_t n_px);   // cds_sparse.hip (for cds_sparse_library_append_files)
 int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &per_mask);
 void free_sparse_plans(cds_maskset *ms);
 

@@ -1040,6 +1040,8 @@ int cds_shapeset_create_bordered(cds_context *ctx, int32_t n_masks, const uint8_
     return CDS_OK;
 }
 
+int32_t cds_shapeset_size(const cds_shapeset *ss) { return ss ? ss->n_masks : 0; }
+
 void cds_shapeset_destroy(cds_shapeset *ss) {
     if (!ss) return;
     hipSetDevice(ss->ctx->device);

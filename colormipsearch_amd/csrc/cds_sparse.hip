@@ -1860,6 +1860,13 @@ int cds_sparse_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t ca
     return CDS_OK;
 }
 
+int cds_sparse_library_dims(const cds_sparse_library *sl, int32_t *W, int32_t *H) {
+    if (!sl) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (W) *W = sl->W;
+    if (H) *H = sl->H;
+    return CDS_OK;
+}
+
 void cds_sparse_library_destroy(cds_sparse_library *sl) {
     if (!sl) return;
     hipSetDevice(sl->ctx->device);
@@ -1926,7 +1933,35 @@ static int density_refused(double density, double limit) {
     return fail(CDS_ERR_UNSUPPORTED, buf);
 }
 
-static int sparse_append_locked(cds_sparse_library *sl, const cds_library *src, int64_t first, int64_t count) {
+// One APPEND CALL is a transaction: the density limit is tested on the call's average (AppendTally sums its sub-batches; a
+// sub-batch is refused early only when the records seen so far already put the whole call above the limit), and a call that fails
+// -- density, capacity, a HIP error -- puts n_images / n_px back to their values at entry (the records written behind the
+// logical end are simply overwritten by the next append), so "nothing is added" holds for the call, not per sub-batch.
+struct AppendTally {
+    int64_t images_total = 0;   // images of the whole call
+    int64_t images = 0;         // ... converted so far
+    double records = 0;         // ... and their records
+    int64_t n_images0 = 0, n_px0 = 0;   // the library at entry
+};
+static void append_begin(const cds_sparse_library *sl, int64_t images_total, AppendTally &t) {
+    t = AppendTally();
+    t.images_total = images_total;
+    t.n_images0 = sl->n_images;
+    t.n_px0 = sl->n_px;
+}
+static int append_end(cds_sparse_library *sl, const AppendTally &t, int rc) {
+    if (rc == CDS_OK && t.images > 0) {
+        const double density = t.records / ((double)t.images * sl->W * sl->H);
+        if (density > sl->density_limit) rc = density_refused(density, sl->density_limit);
+    }
+    if (rc != CDS_OK) {
+        sl->n_images = t.n_images0;
+        sl->n_px = t.n_px0;
+    }
+    return rc;
+}
+
+static int sparse_append_locked(cds_sparse_library *sl, const cds_library *src, int64_t first, int64_t count, AppendTally &tally) {
     cds_context *ctx = sl->ctx;
     hipStream_t st = ctx->stream;
     // one launch covers at most 2^32 / 64 image rows (one wave each)
@@ -1960,7 +1995,12 @@ static int sparse_append_locked(cds_sparse_library *sl, const cds_library *src, 
         uint64_t total = 0;
         CDS_HIP(hipMemcpyAsync(&total, p.total, sizeof total, hipMemcpyDeviceToHost, st));
         CDS_HIP(hipStreamSynchronize(st));
-        if ((double)total / ((double)n * sl->W * sl->H) > sl->density_limit) return density_refused((double)total / ((double)n * sl->W * sl->H), sl->density_limit);
+        tally.images += n;
+        tally.records += (double)total;
+        {   // already certain: even if every remaining image were black, the call's average would be above the limit
+            const double floor_density = tally.records / ((double)std::max(tally.images_total, tally.images) * sl->W * sl->H);
+            if (floor_density > sl->density_limit) return density_refused(tally.records / ((double)tally.images * sl->W * sl->H), sl->density_limit);
+        }
         if (sl->n_px + (int64_t)total > sl->cap_px) {
             char buf[200];
             snprintf(buf, sizeof buf, "sparse library is full: %lld records held, %lld more needed, capacity %lld", (long long)sl->n_px,
@@ -1986,7 +2026,9 @@ int cds_sparse_library_append(cds_sparse_library *sl, const cds_library *src, in
     std::lock_guard<std::mutex> lk(sl->mu);
     if (sl->n_images + count > sl->cap_images) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (images)");
     CDS_HIP(hipSetDevice(sl->ctx->device));
-    return sparse_append_locked(sl, src, first, count);
+    AppendTally tally;
+    append_begin(sl, count, tally);
+    return append_end(sl, tally, sparse_append_locked(sl, src, first, count, tally));
 }
 
 int cds_sparse_library_append_host(cds_sparse_library *sl, int64_t count, const uint8_t *rgb) {
@@ -2003,15 +2045,30 @@ int cds_sparse_library_append_host(cds_sparse_library *sl, int64_t count, const 
         if (rc) return rc;
     }
     const size_t img_bytes = (size_t)3 * sl->W * sl->H;
-    for (int64_t done = 0; done < count; done += stage_n) {
+    AppendTally tally;
+    append_begin(sl, count, tally);
+    int rc = CDS_OK;
+    for (int64_t done = 0; done < count && rc == CDS_OK; done += stage_n) {
         const int64_t n = std::min(stage_n, count - done);
-        int rc = cds_library_upload(sl->stage, 0, n, rgb + (size_t)done * img_bytes);
-        if (rc) return rc;
-        rc = sparse_append_locked(sl, sl->stage, 0, n);
-        if (rc) return rc;
+        rc = cds_library_upload(sl->stage, 0, n, rgb + (size_t)done * img_bytes);
+        if (rc == CDS_OK) rc = sparse_append_locked(sl, sl->stage, 0, n, tally);
+    }
+    return append_end(sl, tally, rc);
+}
+
+// cds_sparse_library_append_files commits batch by batch (a file that cannot be read leaves the earlier batches in place, as
+// documented); a density refusal, however, must leave nothing of the call behind: cds_imageio.hip rolls back with this.
+}  // extern "C"
+int cds::sparse_library_rollback(cds_sparse_library *sl, int64_t n_images, int64_t n_px) {
+    if (!sl) return CDS_OK;
+    std::lock_guard<std::mutex> lk(sl->mu);
+    if (n_images <= sl->n_images && n_px <= sl->n_px) {
+        sl->n_images = n_images;
+        sl->n_px = n_px;
     }
     return CDS_OK;
 }
+extern "C" {
 
 int cds_sparse_library_image_records(const cds_sparse_library *sl, int64_t index, uint32_t *records, int64_t capacity,
                                      int64_t *n_records, uint32_t *row_offsets) {
@@ -2086,9 +2143,16 @@ int cds_sparse_library_export(const cds_sparse_library *sl, int64_t first, int64
 }
 
 int cds_sparse_library_import(cds_sparse_library *sl, int64_t count, const uint64_t *image_offsets, const uint32_t *cell_offsets,
-                              const uint32_t *records, int32_t n_strips, int32_t strip_width) {
+                              const uint32_t *records, int32_t n_strips, int32_t strip_width, int32_t min_data_threshold) {
     if (!sl) return fail(CDS_ERR_INVALID_ARGUMENT, "sparse library is NULL");
     if (count < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "count is negative");
+    if (min_data_threshold < 0 || min_data_threshold > 255) return fail(CDS_ERR_INVALID_ARGUMENT, "minimum data threshold must be 0..255");
+    if (count > 0 && min_data_threshold > sl->min_threshold) {
+        char buf[260];
+        snprintf(buf, sizeof buf, "the records were made with minimum data threshold %d (pixels at or below it are missing), this library promises searches "
+                 "down to data threshold %d: raise it first (cds_sparse_library_set_min_threshold) or convert the images again", min_data_threshold, sl->min_threshold);
+        return fail(CDS_ERR_INVALID_ARGUMENT, buf);
+    }
     if (count == 0) return CDS_OK;
     if (!image_offsets || !cell_offsets || !records) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n_strips != sl->nstrips || strip_width != sl->strip_w) return fail(CDS_ERR_INVALID_ARGUMENT, "record layout (strips) differs from this library's");

@@ -174,7 +174,8 @@ def load_sparse_shard(sparse_library, path, batch=65536):
     for a in range(0, hd["n"], batch):
         b = min(hd["n"], a + batch)
         o = np.asarray(offs[a:b + 1])
-        sparse_library.import_arrays(o - o[0], co[a:b], rec[int(o[0]):int(o[-1])], hd["n_strips"], hd["strip_width"])
+        sparse_library.import_arrays(o - o[0], co[a:b], rec[int(o[0]):int(o[-1])], hd["n_strips"], hd["strip_width"],
+                                     min_data_threshold=int(hd.get("min_threshold", 0)))   # (the C ABI checks it too: any caller's import is covered)
     return hd["n"]
 
 

@@ -264,12 +264,15 @@ def resident_library_for(images, context=None, density_limit=0.25, min_threshold
     imgs = np.ascontiguousarray(images, dtype=np.uint8)
     n, H, W, _ = imgs.shape
     signal = int((imgs.max(axis=3) > 0).sum())
+    sl = None
     try:
         sl = cds.SparseLibrary(W, H, n, signal + 16 * H * n + 64, context=context, density_limit=density_limit, min_threshold=min_threshold)
         sl.append(imgs)
         return sl
     except cds.CdsError as e:
-        if e.code != cds.capi.CDS_ERR_UNSUPPORTED:
+        if sl is not None:
+            sl.close()          # (the refused library's record arena and staging slots go before the dense slots are allocated:
+        if e.code != cds.capi.CDS_ERR_UNSUPPORTED:   # dense images are exactly where GPU memory is tightest)
             raise
     lib = cds.Library(W, H, n, context=context)
     lib.upload(0, imgs)
@@ -434,8 +437,6 @@ class GpuColorMIPSearchProcessor:
         if self.sparse_library is not None:
             return self._pipelined_match_table(masks, max(8, int(mask_set_size) // 8 * 8))
         alg = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold(masks)
-        if self.sparse_library is not None:
-            return self._device_match_table(alg)
         scores, mirrored = self._scan(alg)
         sizes = np.asarray(alg.getQuerySizes())
         mi, ti, sc, ra, mr = [], [], [], [], []
@@ -497,8 +498,9 @@ class GpuColorMIPSearchProcessor:
                                             excludedRegions=cds.label_regions, batch=8192, library=None) -> MatchTable:
         """calculateGradientScoresTable for a library far larger than the dense slots the shape scorer reads (BASELINE configs[4]:
         1,024 masks x top-500 of a 1 M-target library resident as signal-pixel records): the table's pairs are visited in windows
-        of `batch` consecutive target indices; `load_range(lib, first_target, count)` makes targets first_target..+count-1
-        resident WITH their gradient / zgap variants in slots 0..count-1 of `lib` (regenerated on the device for a synthetic
+        of `batch` consecutive target indices (the table's targetIndex is relative to `self.first`, like every table this class
+        makes); `load_range(lib, first_target, count)` makes LIBRARY targets first_target..+count-1 (absolute: self.first is
+        added here) resident WITH their gradient / zgap variants in slots 0..count-1 of `lib` (regenerated on the device for a synthetic
         library: `lambda lib, f, c: lib.generate_synthetic(seed, f, 0, c, kind=0, with_variants=True)`; ingested from a shard
         or from files otherwise), one `cds_gradscore` launch per window, per-mask normalisation on the host
         (CalculateGradientScoresCmd.java:541-586, 616-645).  The kernel time of the launches is left in
@@ -519,14 +521,14 @@ class GpuColorMIPSearchProcessor:
         batch = min(int(batch), lib.capacity)
         order = np.argsort(table.targetIndex, kind="stable")
         tsorted = table.targetIndex[order]
-        limit = self.first + self.count
+        limit = self.count                      # (relative, like targetIndex and the windows below)
         w0 = (int(tsorted[0]) // batch) * batch
         while w0 <= int(tsorted[-1]):
             lo, hi = np.searchsorted(tsorted, w0), np.searchsorted(tsorted, w0 + batch)
             if hi > lo:
                 rows = order[lo:hi]
                 t0 = time.perf_counter()
-                load_range(lib, w0, min(batch, limit - w0))
+                load_range(lib, self.first + w0, min(batch, limit - w0))
                 ctx.synchronize()
                 t1 = time.perf_counter()
                 gap, high, _ = alg.scoreLibraryPairs(lib, table.maskIndex[rows].astype(np.int32), table.targetIndex[rows] - w0)

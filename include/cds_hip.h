@@ -86,6 +86,8 @@ int cds_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t capacity,
 int cds_library_wrap(cds_context *ctx, int32_t W, int32_t H, int64_t capacity, void *device_ptr,
                      size_t device_bytes, cds_library **out);
 void cds_library_destroy(cds_library *lib);
+/* Image size and slot count of a library (any output may be NULL): what a binding checks its buffers against. */
+int cds_library_dims(const cds_library *lib, int32_t *W, int32_t *H, int64_t *capacity);
 /* Host -> device: `count` images, packed RGB pitch 3*W, into slots [first, first+count). */
 int cds_library_upload(cds_library *lib, int64_t first, int64_t count, const uint8_t *rgb);
 int cds_library_download(cds_library *lib, int64_t first, int64_t count, uint8_t *rgb);
@@ -108,6 +110,8 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
                        const cds_pixmatch_params *params, const cds_rect *excluded, int32_t n_excluded,
                        cds_maskset **out);
 void cds_maskset_destroy(cds_maskset *ms);
+/* Masks in the set (bindings size their score arrays with it). */
+int32_t cds_maskset_size(const cds_maskset *ms);
 /* getQuerySize() per mask (API/cds/ColorDepthSearchAlgorithm.java:27). */
 int cds_maskset_query_sizes(const cds_maskset *ms, int32_t *sizes);
 /* Scan slots [first, first+count) of the library with every mask of the set ==
@@ -145,9 +149,10 @@ int cds_is_match(int32_t score, int32_t query_size, double pct_positive_pixels);
 int cds_sparse_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t capacity_images, int64_t capacity_pixels,
                               cds_sparse_library **out);
 void cds_sparse_library_destroy(cds_sparse_library *slib);
+int cds_sparse_library_dims(const cds_sparse_library *slib, int32_t *W, int32_t *H);
 /* Append slots [first, first+count) of a resident dense library (device -> device); the images get the next
- * indices size() .. size()+count-1.  CDS_ERR_OUT_OF_MEMORY when a capacity would be exceeded (nothing is added
- * from the failing batch on). */
+ * indices size() .. size()+count-1.  An append call is a transaction: when it fails -- CDS_ERR_OUT_OF_MEMORY (a capacity
+ * would be exceeded), CDS_ERR_UNSUPPORTED (density limit, below), a HIP error -- the library is as it was before the call. */
 int cds_sparse_library_append(cds_sparse_library *slib, const cds_library *src, int64_t first, int64_t count);
 /* Append `count` host images (packed RGB, pitch 3*W) through internal dense staging slots. */
 int cds_sparse_library_append_host(cds_sparse_library *slib, int64_t count, const uint8_t *rgb);
@@ -155,9 +160,10 @@ int cds_sparse_library_append_host(cds_sparse_library *slib, int64_t count, cons
  * row by row, a row by ascending x; a (strip, row) cell without signal pixels holds one filler record. */
 int cds_sparse_library_layout(const cds_sparse_library *slib, int32_t *n_strips, int32_t *strip_width);
 /* Layout choice.  The sparse scan's cost grows with the records it visits; above about a quarter of the frame the dense
- * layout (cds_library + cds_search) is the faster one.  An append / import whose images average more signal pixels than
- * `max_signal_fraction` of the frame (default 0.25) fails with CDS_ERR_UNSUPPORTED and a message saying so -- nothing is
- * added -- so that a dense library is never silently scanned the slow way; >= 1.1 accepts everything. */
+ * layout (cds_library + cds_search) is the faster one.  An append / import CALL whose images average more signal pixels than
+ * `max_signal_fraction` of the frame (default 0.25) fails with CDS_ERR_UNSUPPORTED and a message saying so -- nothing of the
+ * call is added, however it is cut into batches internally -- so that a dense library is never silently scanned the slow way;
+ * >= 1.1 accepts everything. */
 int cds_sparse_library_set_density_limit(cds_sparse_library *slib, double max_signal_fraction);
 /* Minimum data threshold of the library (default 0).  The reference only looks at a target pixel whose brightest channel exceeds
  * the search's data threshold (PixelMatchColorDepthSearchAlgorithm.java:247-251), so a library whose searches never go below T need
@@ -182,11 +188,14 @@ int cds_sparse_library_image_offsets(const cds_sparse_library *slib, int64_t fir
  * cell_offsets[count][n_strips][H+1] and the records themselves (any of the last two may be NULL; call once with NULLs to
  * size the buffers: the record count is image_offsets[count]).  Import appends `count` images given in that form; the
  * layout (n_strips, strip_width) must be this library's; the offset tables are validated on the host and the records
- * on the device (every cell non-empty, row flags, x order, classes, fillers): an inconsistent shard is refused. */
+ * on the device (every cell non-empty, row flags, x order, classes, fillers): an inconsistent shard is refused.
+ * min_data_threshold = cds_sparse_library_min_threshold of the library the records were exported from (their pixels at or below it
+ * are missing): an import into a library whose own minimum data threshold is LOWER is refused with CDS_ERR_INVALID_ARGUMENT --
+ * its searches between the two thresholds would silently miss pixels. */
 int cds_sparse_library_export(const cds_sparse_library *slib, int64_t first, int64_t count, uint64_t *image_offsets,
                               uint32_t *cell_offsets, uint32_t *records, int64_t records_capacity);
 int cds_sparse_library_import(cds_sparse_library *slib, int64_t count, const uint64_t *image_offsets, const uint32_t *cell_offsets,
-                              const uint32_t *records, int32_t n_strips, int32_t strip_width);
+                              const uint32_t *records, int32_t n_strips, int32_t strip_width, int32_t min_data_threshold);
 
 /* ---- MIP files (host side) ------------------------------------------------------------------------
  * Decoding of the files the reference's pipeline reads -- replaces ImageArrayUtils.readImageArray
@@ -201,7 +210,8 @@ int cds_image_probe(const uint8_t *data, size_t size, cds_image_info *info);
 int cds_image_decode(const uint8_t *data, size_t size, void *out, size_t out_bytes);
 /* Append `count` image files (8-bit RGB, the library's size) to a sparse library: decoded on `threads` host threads
  * (<= 0: all cores) while the previous batch of 64 is uploaded and converted on the GPU.  Fails at the first file that
- * cannot be read / decoded (its path is in cds_last_error()); batches appended before it stay. */
+ * cannot be read / decoded (its path is in cds_last_error()); batches appended before it stay.  A density refusal
+ * (CDS_ERR_UNSUPPORTED, tested per batch of 64 files) removes everything the call had appended. */
 int cds_sparse_library_append_files(cds_sparse_library *slib, const char *const *paths, int64_t count, int32_t threads);
 
 /* The scan over images [first, first+count) of a sparse library: same outputs as cds_search / cds_search_device /
@@ -300,6 +310,7 @@ int cds_shapeset_create_bordered(cds_context *ctx, int32_t n_masks, const uint8_
                                  int32_t query_threshold, int32_t query_border_size, int32_t mirror, const uint8_t *roi,
                                  const cds_rect *excluded, int32_t n_excluded, cds_shapeset **out);
 void cds_shapeset_destroy(cds_shapeset *ss);
+int32_t cds_shapeset_size(const cds_shapeset *ss); /* masks in the set */
 /* Sum of the query mask and of the high-expression mask per mask
  * (the values Shape2DMatch...Test.java:53-54 checks). */
 int cds_shapeset_mask_stats(const cds_shapeset *ss, int64_t *mask_size, int64_t *high_expression_size);

@@ -82,5 +82,12 @@ final class CdsHip {
     static native void shapeScorePair(long shapeset, int maskIndex, byte[] targetRgb, short[] grad, byte[] zgapRgb, int w, int h, long[] out);
     static native void gradscore(long shapeset, long lib, int[] pairMask, long[] pairSlot, long[] gradientAreaGap, long[] highExpressionArea,
                                  byte[] mirrored);
+    /**
+     * The same over dense shards (one library with variants and one replicated shape set per context of the communicator): pairTarget holds
+     * LIBRARY indices, shard r owning [offsets[r], offsets[r] + shardSizes[r]) in its slots 0.. (shardSizesOrNull == null: the libraries'
+     * capacities); every pair is scored on the GPU that owns its target, all GPUs at once; results in pair order; returns the offsets (n + 1).
+     */
+    static native long[] gradscoreSharded(long comm, long[] shapesets, long[] libs, long[] shardSizesOrNull, int[] pairMask, long[] pairTarget,
+                                          long[] gradientAreaGap, long[] highExpressionArea, byte[] mirrored);
     static native void makeZgap(long ctx, byte[] targetRgb, int w, int h, int threshold, double radius, int[] rectsXYXY, byte[] zgapRgbOut);
 }

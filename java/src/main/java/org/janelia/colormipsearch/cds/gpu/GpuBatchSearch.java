@@ -173,6 +173,29 @@ public final class GpuBatchSearch<K> implements AutoCloseable {
         return out;
     }
 
+    /**
+     * GradientAreaGap scores of (mask index, library index) pairs when the selected targets and their gradient / zgap variants are
+     * resident as one dense shard per GPU (cds_gradscore_sharded): every pair is scored on the GPU that owns its target, all GPUs at
+     * once -- the gradient-score step (cmd/CalculateGradientScoresCmd.java:541-586) over the target partitions of
+     * cdsprocess/SparkColorMIPSearchProcessor.java:50-73.  shapesets[r] / denseShards[r] belong to device r of this search;
+     * returns {gradientAreaGap, highExpressionArea, mirrored (0 / 1)} in pair order.
+     */
+    public long[][] gradientScoresSharded(long[] shapesets, long[] denseShards, long[] shardSizes, int[] pairMask, long[] pairTarget) {
+        int n = pairMask.length;
+        long[] gap = new long[n], high = new long[n];
+        byte[] mirrored = new byte[n];
+        if (comm == 0) {   // one device: the plain call (slot = library index)
+            CdsHip.gradscore(shapesets[0], denseShards[0], pairMask, pairTarget, gap, high, mirrored);
+        } else {
+            CdsHip.gradscoreSharded(comm, shapesets, denseShards, shardSizes, pairMask, pairTarget, gap, high, mirrored);
+        }
+        long[] mir = new long[n];
+        for (int i = 0; i < n; i++) {
+            mir[i] = mirrored[i];
+        }
+        return new long[][]{gap, high, mir};
+    }
+
     @Override
     public void close() {
         for (GpuTargetLibrary<K> shard : shards) {

@@ -32,6 +32,7 @@ public class GpuPixelMatchColorDepthSearchAlgorithm implements ColorDepthSearchA
     private final int[] excludedRects;
     private transient long handle;
     private transient int querySize = -1;
+    private transient int[] strip;
 
     public GpuPixelMatchColorDepthSearchAlgorithm(ImageArray<?> queryImage, int queryThreshold, boolean mirrorQuery,
                                                   int targetThreshold, double zTolerance, int xyShift, int[] excludedRectsXYXY) {
@@ -72,30 +73,70 @@ public class GpuPixelMatchColorDepthSearchAlgorithm implements ColorDepthSearchA
 
     @Override
     public int getQueryFirstPixelIndex() {
-        return scanQuery(true);
+        return stripBounds()[0];
     }
 
     @Override
     public int getQueryLastPixelIndex() {
-        return scanQuery(false);
+        return stripBounds()[1];
     }
 
-    /** first / last query position above the threshold outside the excluded rectangles (row-major index), -1 if none. */
-    private int scanQuery(boolean first) {
+    /**
+     * The two values the reference returns, quirks included (the accessors are informational: nothing in the reference reads them):
+     * the base class MULTIPLIES row, width and column of the query's bounding box -- miny * width * minx and maxy * width * maxx
+     * with maxx / maxy one past the last pixel (cds/AbstractColorDepthSearchAlgorithm.java:76-84, :96-126) -- and the pixel-match
+     * class lowers / raises those by the FIRST / LAST entry of every shifted (and mirrored) position list, an entry shifted
+     * out of the image being -1 (cds/PixelMatchColorDepthSearchAlgorithm.java:59-100, :113-158).  Same result as
+     * colormipsearch_amd/cds.py (PixelMatchColorDepthSearchAlgorithm._strip).
+     */
+    private synchronized int[] stripBounds() {
+        if (strip != null) {
+            return strip;
+        }
         byte[] px = ImageArrayBytes.rgb(queryImage);
-        int w = queryImage.getWidth(), n = queryImage.getPixelCount();
-        for (int k = 0; k < n; k++) {
-            int i = first ? k : n - 1 - k;
+        int w = queryImage.getWidth(), h = queryImage.getHeight(), n = queryImage.getPixelCount();
+        int minx = w, miny = h, maxx = 0, maxy = 0, firstPos = -1, lastPos = -1;
+        for (int i = 0; i < n; i++) {
             int x = i % w, y = i / w;
             boolean excluded = false;
             for (int r = 0; r + 3 < excludedRects.length && !excluded; r += 4) {
                 excluded = x >= excludedRects[r] && x < excludedRects[r + 2] && y >= excludedRects[r + 1] && y < excludedRects[r + 3];
             }
-            if (!excluded && ((px[3 * i] & 0xFF) > queryThreshold || (px[3 * i + 1] & 0xFF) > queryThreshold || (px[3 * i + 2] & 0xFF) > queryThreshold)) {
-                return i;
+            if (excluded || !((px[3 * i] & 0xFF) > queryThreshold || (px[3 * i + 1] & 0xFF) > queryThreshold || (px[3 * i + 2] & 0xFF) > queryThreshold)) {
+                continue;
+            }
+            if (firstPos < 0) {
+                firstPos = i;
+            }
+            lastPos = i;
+            minx = Math.min(minx, x);
+            maxx = Math.max(maxx, x + 1);
+            miny = Math.min(miny, y);
+            maxy = Math.max(maxy, y + 1);
+        }
+        int first = miny * w * minx, last = maxy * w * maxx;
+        if (firstPos >= 0) {
+            // every position list keeps the order of the query positions, so its first / last entry is the shifted (mirrored)
+            // first / last query position, or -1 when the shift leaves the image
+            for (int dx = -xyShift; dx <= xyShift; dx += Math.max(xyShift, 1)) {
+                for (int dy = -xyShift; dy <= xyShift; dy += Math.max(xyShift, 1)) {
+                    int a = shifted(firstPos, dx, dy, w, h), b = shifted(lastPos, dx, dy, w, h);
+                    first = Math.min(first, a);
+                    last = Math.max(last, b);
+                    if (mirrorQuery) {
+                        first = Math.min(first, a == -1 ? -1 : a + (w - 1) - 2 * (a % w));
+                        last = Math.max(last, b == -1 ? -1 : b + (w - 1) - 2 * (b % w));
+                    }
+                }
             }
         }
-        return -1;
+        strip = new int[]{first, last};
+        return strip;
+    }
+
+    private static int shifted(int pos, int dx, int dy, int w, int h) {
+        int x = pos % w + dx, y = pos / w + dy;
+        return x >= 0 && x < w && y >= 0 && y < h ? y * w + x : -1;
     }
 
     @Override

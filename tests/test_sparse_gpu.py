@@ -805,6 +805,62 @@ def test_density_limit_refuses_dense_images(cds, oracle):
     assert np.array_equal(s_d, s_s)
 
 
+def test_an_append_call_is_a_transaction(cds, oracle):
+    """the density limit used to be tested per internal sub-batch (64 staged images), so a call mixing sparse and
+    dense images failed midway and left a partially appended library.  Now the call's AVERAGE decides and a failing call leaves the
+    library as it was -- whatever the reason (density, record capacity) and however the call is cut into batches."""
+    sparse_imgs = np.stack([oracle.synth_image(0xC0FFEE, 300 + i, 0) for i in range(64)])
+    dense_imgs = np.stack([oracle.synth_image(0xC0FFEE, i, 1) for i in range(3)])
+    n_rec = int((sparse_imgs.max(axis=3) > 0).sum())
+    sl = cds.SparseLibrary(W, H, 200, 3 * (W * H + 4 * H) + 4 * n_rec + 4 * H * 200, density_limit=0.05)
+    sl.append(sparse_imgs[:5])
+    before = (len(sl), sl.pixels)
+    # 64 sparse images fill the first staging batch and pass on their own; the 3 dense ones that follow push the CALL's average
+    # (3 x 100 % + 64 x ~3 % over 67 images = ~7 %) above the 5 % limit: nothing of the call stays
+    with pytest.raises(cds.CdsError, match="density limit"):
+        sl.append(np.concatenate([sparse_imgs, dense_imgs]))
+    assert (len(sl), sl.pixels) == before
+    # the other order (dense images first): refused as soon as it is certain, same outcome
+    with pytest.raises(cds.CdsError, match="density limit"):
+        sl.append(np.concatenate([dense_imgs, dense_imgs, dense_imgs, sparse_imgs]))
+    assert (len(sl), sl.pixels) == before
+    # a call whose average stays below the limit passes although one of its images is dense
+    sl.set_density_limit(0.10)
+    sl.append(np.concatenate([sparse_imgs, dense_imgs[:1]]))
+    assert len(sl) == before[0] + 65
+    # record capacity exceeded in the SECOND staging batch: the first batch's images do not stay either
+    small = cds.SparseLibrary(W, H, 200, n_rec + 4 * H * 64 + (W * H) // 2, density_limit=2.0)
+    with pytest.raises(cds.CdsError, match="full"):
+        small.append(np.concatenate([sparse_imgs, dense_imgs[:1]]))
+    assert (len(small), small.pixels) == (0, 0)
+    # and the library is still usable: the same images score as they do in a fresh library
+    small.append(sparse_imgs[:8])
+    mask = oracle.synth_image(0xBADC0DE, 0, 2)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, cds.label_regions(W))
+    got, _ = alg.searchSparseLibrary(small)
+    want, _ = alg.searchSparseLibrary(sparse_of(cds, sparse_imgs[:8]))
+    assert np.array_equal(got, want)
+
+
+def test_import_checks_the_shards_minimum_data_threshold_in_the_c_abi(cds, oracle):
+    """only mipio.py compared a shard's minimum data threshold with the library's; a C or Java caller could import
+    records that lack the pixels <= T into a library that promises searches down to 0.  cds_sparse_library_import now takes the
+    threshold the records were made with and refuses when it exceeds the library's own."""
+    imgs = np.stack([oracle.synth_image(0xC0FFEE, 40 + i, 0) for i in range(3)])
+    src = cds.SparseLibrary(W, H, 3, int((imgs.max(axis=3) > 0).sum()) + 4 * H * 3 + 64, min_threshold=60)
+    src.append(imgs)
+    offs, cells, rec = src.export()
+    dst = cds.SparseLibrary(W, H, 3, len(rec) + 64)                       # promises searches down to data threshold 0
+    with pytest.raises(cds.CdsInvalidArgument, match="minimum data threshold 60"):
+        dst.import_arrays(offs, cells, rec, min_data_threshold=60)
+    assert len(dst) == 0
+    dst.set_min_threshold(60)
+    dst.import_arrays(offs, cells, rec, min_data_threshold=60)
+    assert len(dst) == 3 and dst.pixels == src.pixels
+    with pytest.raises(cds.CdsInvalidArgument):
+        dst.import_arrays(offs, cells, rec, min_data_threshold=300)
+
+
 def test_device_topk_equals_host_selection(cds, oracle):
     """cds_search_sparse_topk == a stable host-side sort of the score rows (score descending, equal scores by ascending target),
     for k = 1, 37, 500, 1024 and more than the library holds, with many tied scores (zeros) in every row and a mask whose
