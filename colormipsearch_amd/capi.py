@@ -120,6 +120,7 @@ SIGNATURES = {
     "cds_search_sparse_sharded": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i64p, _i32p, _u8p]),
     "cds_search_sparse_sharded_topk": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int32, _i64p, _i32p, _i32p]),
     "cds_search_sparse_sharded_matches": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_double, _i64p, _vp, _i64, _i64p]),
+    "cds_shapeset_last_call_info": (_i, [_vp, ctypes.POINTER(ctypes.c_int32), _i64p, ctypes.POINTER(ctypes.c_double)]),
     "cds_maskset_size": (ctypes.c_int32, [_vp]),
     "cds_shapeset_size": (ctypes.c_int32, [_vp]),
     "cds_library_dims": (_i, [_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _i64p]),

@@ -894,6 +894,13 @@ class Shape2DMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
                                            capi.as_i64p(high), capi.as_u8p(mir)))
         return gap, high, mir.astype(bool)
 
+    def lastCallInfo(self):
+        """(used the converted zslice plane?, zgap images converted by the last call, device ms of that conversion)"""
+        mode, ms = ctypes.c_int32(), ctypes.c_double()
+        n = np.zeros(1, dtype=np.int64)
+        capi.check(self._lib.cds_shapeset_last_call_info(self._h, ctypes.byref(mode), capi.as_i64p(n), ctypes.byref(ms)))
+        return bool(mode.value), int(n[0]), ms.value
+
     def lastKernelMs(self):
         ms, n = ctypes.c_double(), ctypes.c_int32()
         capi.check(self._lib.cds_shapeset_last_kernel_ms(self._h, ctypes.byref(ms), ctypes.byref(n)))

@@ -363,6 +363,7 @@ static int library_init(cds_context *ctx, int W, int H, int64_t capacity, cds_li
     lib->grad_stride = (size_t)H * lib->gpitch;
     lib->has_grad.assign((size_t)capacity, 0);
     lib->has_zgap.assign((size_t)capacity, 0);
+    lib->zslice_ok.assign((size_t)capacity, 0);
     *out = lib;
     return CDS_OK;
 }
@@ -501,11 +502,7 @@ int cds_library_ensure_variants(cds_library *lib) {
         CDS_HIP(hipMalloc(&lib->d_zgap, bytes));
         CDS_HIP(hipMemsetAsync(lib->d_zgap, 0, bytes, lib->ctx->stream));
     }
-    if (!lib->d_zslice) {
-        size_t bytes = (size_t)lib->capacity * lib->grad_stride;
-        CDS_HIP(hipMalloc(&lib->d_zslice, bytes));
-        CDS_HIP(hipMemsetAsync(lib->d_zslice, 0, bytes, lib->ctx->stream));
-    }
+    // (the derived zslice plane is allocated by the first scoring call that wants it: cds_shape.hip, ensure_zslice)
     return CDS_OK;
 }
 
@@ -526,9 +523,7 @@ int cds_library_upload_variants(cds_library *lib, int64_t first, int64_t count, 
         rc = rows_h2d(lib, lib->d_zgap + (size_t)first * lib->img_stride, lib->pitch, zgap_rgb, (size_t)3 * lib->W,
                       (size_t)lib->H * count);
         if (rc) return rc;
-        for (int64_t i = 0; i < count; i++) lib->has_zgap[(size_t)(first + i)] = 1;
-        rc = refresh_zslice(lib, first, count);
-        if (rc) return rc;
+        zgap_written(lib, first, count);
     }
     CDS_HIP(hipStreamSynchronize(lib->ctx->stream));
     return CDS_OK;

@@ -85,8 +85,10 @@ struct cds_library {
     bool owns_rgb = false;
     uint16_t *d_grad = nullptr;  // lazily allocated
     uint8_t *d_zgap = nullptr;   // lazily allocated, same layout as d_rgb
-    uint16_t *d_zslice = nullptr;  // derived from d_zgap, gradient layout: (slice number - 1) | max channel << 8
+    uint16_t *d_zslice = nullptr;  // derived from d_zgap, gradient layout: (slice number - 1) | max channel << 8; allocated and filled
+                                   // LAZILY, per slot, by the first scoring call that prefers the converted plane (cds_shape.hip)
     std::vector<uint8_t> has_grad, has_zgap;  // per slot
+    std::vector<uint8_t> zslice_ok;           // per slot: d_zslice holds the conversion of the slot's current zgap
     uint8_t *d_stage = nullptr;  // contiguous staging buffer of the host <-> pitched-rows transfers
     size_t stage_bytes = 0;
     std::mutex stage_mu;
@@ -130,7 +132,7 @@ struct ScanParams {
 
 int launch_scan(cds_context *ctx, const ScanParams &p, bool xy2, bool mirror, hipStream_t stream);
 size_t scan_lds_bytes(int wc, int n_masks, bool batch, bool xy2, bool mirror);  // dynamic LDS of one workgroup
-int refresh_zslice(cds_library *lib, int64_t first, int64_t count);  // cds_shape.hip: zgap RGB -> zslice plane
+void zgap_written(cds_library *lib, int64_t first, int64_t count);  // cds_shape.hip: slots got a new zgap image (their zslice entries are stale)
 int init_rcp_table(cds_context *ctx);
 struct MaskPx {
     int x, y;

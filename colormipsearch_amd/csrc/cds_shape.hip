@@ -234,6 +234,8 @@ constexpr int kPlaneS = 511, kPlaneQM = 1 << 9, kPlaneQH = 1 << 10;
 struct ShapeParams {
     const uint8_t *rgb;
     const uint16_t *grad, *zslice;  // zslice: (slice number - 1) | max channel << 8 per zgap pixel (gradient layout)
+    const uint8_t *zgap;            // the zgap images themselves (RGB layout) and the slice-number table: read instead of zslice by the
+    const uint8_t *slice_lut;       // ZRGB variant of the list kernel (no conversion pass; a target that serves few pairs)
     size_t img_stride, grad_stride;
     int pitch, gpitch, W, H, wp;  // wp: plane row length (u16 elements), multiple of 4
     const uint16_t *planes;       // [n_masks][2][H][wp]
@@ -271,11 +273,12 @@ __device__ __forceinline__ int gap_of(int pl, int sz, int g) {
 // zgap RGB -> zslice plane, once per uploaded / generated variant image: the colour-LUT search of
 // GradientAreaGapUtils.calculateSliceGap becomes one table gather here and a byte compare in the scorer.
 struct ZsliceParams {
-    const uint8_t *zgap;
+    const uint8_t *zgap;        // slot 0 of the library
     uint16_t *zslice;
     const uint8_t *slice_lut;
     size_t img_stride, grad_stride;
     int pitch, gpitch, H, gpr;  // gpr: 4-pixel groups per row (covers the padded row)
+    const int32_t *slots;       // the `count` slots to convert
     int64_t count;
 };
 
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256) void zslice_kernel(ZsliceParams p) {
         const int gi = (int)(it % p.gpr);
         const int64_t rowi = it / p.gpr;
         const int y = (int)(rowi % p.H);
-        const int64_t img = rowi / p.H;
+        const int64_t img = p.slots[rowi / p.H];
         const uint32_t *src = reinterpret_cast<const uint32_t *>(p.zgap + (size_t)img * p.img_stride + (size_t)y * p.pitch + (size_t)gi * 12);
         const uint32_t a = src[0], b = src[1], c = src[2];
         const int px[4][3] = {{(int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255)},
@@ -472,22 +475,49 @@ __global__ __launch_bounds__(256) void gradscore_kernel(ShapeParams p) {
     }
 }
 
-int refresh_zslice(cds_library *lib, int64_t first, int64_t count) {
-    if (count <= 0) return CDS_OK;
+void zgap_written(cds_library *lib, int64_t first, int64_t count) {
+    for (int64_t i = 0; i < count; i++) {
+        lib->has_zgap[(size_t)(first + i)] = 1;
+        lib->zslice_ok[(size_t)(first + i)] = 0;
+    }
+}
+
+// The zslice entries of `slots` (distinct, with a zgap image) that are stale or were never made: one conversion launch over that
+// list, on `st` (the scoring kernel follows on the same stream).  Called by a scoring call that has decided for the converted plane.
+static int ensure_zslice(cds_library *lib, const std::vector<int64_t> &slots, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(lib->mu);
+    std::vector<int32_t> todo;
+    for (int64_t sl : slots)
+        if (!lib->zslice_ok[(size_t)sl]) todo.push_back((int32_t)sl);
+    if (todo.empty()) return CDS_OK;
     int rc = ensure_slice_lut(lib->ctx);
     if (rc) return rc;
-    ZsliceParams p{};
-    p.zgap = lib->d_zgap + (size_t)first * lib->img_stride;
-    p.zslice = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(lib->d_zslice) + (size_t)first * lib->grad_stride);
-    p.slice_lut = lib->ctx->d_slice_lut;
-    p.img_stride = lib->img_stride; p.grad_stride = lib->grad_stride;
-    p.pitch = lib->pitch; p.gpitch = lib->gpitch; p.H = lib->H;
-    p.gpr = std::min(lib->pitch / 12, lib->gpitch / 8);
-    p.count = count;
-    const int64_t items = count * p.H * p.gpr;
-    const int grid = (int)std::min<int64_t>((items + 255) / 256, (int64_t)lib->ctx->n_cus * 64);
-    hipLaunchKernelGGL(zslice_kernel, dim3(grid), dim3(256), 0, lib->ctx->stream, p);
-    CDS_HIP(hipGetLastError());
+    if (!lib->d_zslice) {
+        const size_t bytes = (size_t)lib->capacity * lib->grad_stride;
+        CDS_HIP(hipMalloc(&lib->d_zslice, bytes));
+    }
+    int32_t *d_slots = nullptr;
+    CDS_HIP(hipMallocAsync((void **)&d_slots, todo.size() * sizeof(int32_t), st));
+    hipError_t e = hipMemcpyAsync(d_slots, todo.data(), todo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);   // (`todo` is pageable host memory and leaves scope)
+    if (e == hipSuccess) {
+        ZsliceParams p{};
+        p.zgap = lib->d_zgap;
+        p.zslice = lib->d_zslice;
+        p.slice_lut = lib->ctx->d_slice_lut;
+        p.img_stride = lib->img_stride; p.grad_stride = lib->grad_stride;
+        p.pitch = lib->pitch; p.gpitch = lib->gpitch; p.H = lib->H;
+        p.gpr = std::min(lib->pitch / 12, lib->gpitch / 8);
+        p.slots = d_slots;
+        p.count = (int64_t)todo.size();
+        const int64_t items = p.count * p.H * p.gpr;
+        const int grid = (int)std::min<int64_t>((items + 255) / 256, (int64_t)lib->ctx->n_cus * 64);
+        hipLaunchKernelGGL(zslice_kernel, dim3(grid), dim3(256), 0, st, p);
+        e = hipGetLastError();
+    }
+    hipFreeAsync(d_slots, st);
+    if (e != hipSuccess) return hip_fail(e, "zslice conversion");
+    for (int32_t sl : todo) lib->zslice_ok[(size_t)sl] = 1;
     return CDS_OK;
 }
 
@@ -507,6 +537,18 @@ using namespace cds;
 // entry -> planes, gradient, zslice (plain and reversed) -> the gap arithmetic, all lanes busy, no queue.
 // One workgroup per pair, the four waves take alternate 64-entry chunks.
 // ---------------------------------------------------------------------------------------------
+// S(z) of a zgap pixel under ColorTransformation.mask(thr), straight from its RGB bytes: what zs_of() reads out of a zslice entry
+__device__ __forceinline__ int zs_rgb(const uint8_t *lut, int r, int g, int b, int thr) {
+    const int mx = max(r, max(g, b));
+    return (mx > thr && mx > 0) ? dev_slice(lut, r, g, b, -1) : 0;
+}
+typedef uint32_t u32_any_align __attribute__((aligned(1)));
+
+// ZRGB = false: S(z) comes from the zslice plane (one conversion pass per uploaded zgap, zslice_kernel: worth it when a target
+// serves many pairs).  ZRGB = true: the gap groups read the zgap image's own bytes and look the slice number up here (12 instead
+// of 8 bytes per group and orientation plus up to 8 table gathers from L2, but NO pass over the ~685 K pixels of every zgap
+// image -- a selected target of BASELINE configs[4] serves 2.2 pairs x ~3.5 K gap groups).  Same sums either way (tests).
+template <bool ZRGB>
 __global__ __launch_bounds__(256) void gradscore_list_kernel(ShapeParams p) {
     __shared__ long long red[4][4];
     __shared__ uint32_t hq[4][128];  // per wave: the queued high-expression entries whose target group is not black
@@ -517,7 +559,7 @@ __global__ __launch_bounds__(256) void gradscore_list_kernel(ShapeParams p) {
         if (slot < 0) continue;  // uniform per block
         const int m = p.pair_mask[pi];
         const uint8_t *timg = p.rgb + (size_t)slot * p.img_stride;
-        const uint8_t *zimg = reinterpret_cast<const uint8_t *>(p.zslice) + (size_t)slot * p.grad_stride;
+        const uint8_t *zimg = ZRGB ? p.zgap + (size_t)slot * p.img_stride : reinterpret_cast<const uint8_t *>(p.zslice) + (size_t)slot * p.grad_stride;
         const uint8_t *gimg = reinterpret_cast<const uint8_t *>(p.grad) + (size_t)slot * p.grad_stride;
         const uint32_t g0 = p.list_off[2 * m], g1 = p.list_off[2 * m + 2], h0 = p.list_off[2 * m + 1], h1 = p.list_off[2 * m + 3];
         unsigned gap0 = 0, gap1 = 0;  // per lane < 2^31 for H*W <= 2M pixels (gap <= 65535 per pixel)
@@ -577,27 +619,64 @@ __global__ __launch_bounds__(256) void gradscore_list_kernel(ShapeParams p) {
                 const int y = (int)(e >> 9), x0 = 4 * (int)(e & 511);
                 const ushort4 qa = p.gl_a[i], qb = p.gl_b[i];   // (the mirrored orientation's plane is all zero without mirroring)
                 const int pa[4] = {qa.x, qa.y, qa.z, qa.w}, pb[4] = {qb.x, qb.y, qb.z, qb.w};
-                const uint16_t *zrow = reinterpret_cast<const uint16_t *>(zimg + (size_t)y * p.gpitch);
                 const ushort4 g = *reinterpret_cast<const ushort4 *>(gimg + (size_t)y * p.gpitch + (size_t)x0 * 2);
-                const ushort4 z = *reinterpret_cast<const ushort4 *>(zrow + x0);
-                const int gg[4] = {g.x, g.y, g.z, g.w}, zz[4] = {z.x, z.y, z.z, z.w};
-                int zm[4] = {0, 0, 0, 0};  // zslice at W-1-x for x = x0 .. x0+3
-                if (p.mirror) {
-                    const int xm = p.W - 4 - x0;  // element index of the reversed run (may be < 0 at the far right)
-                    if (even_w && xm >= 0) {
-                        const uint2 r = *reinterpret_cast<const uint2 *>(zrow + xm);  // xm even: 4-byte aligned
-                        zm[3] = r.x & 0xffff; zm[2] = r.x >> 16; zm[1] = r.y & 0xffff; zm[0] = r.y >> 16;
-                    } else {
+                const int gg[4] = {g.x, g.y, g.z, g.w};
+                int sz[4] = {0, 0, 0, 0}, szm[4] = {0, 0, 0, 0};   // S(z) at x0 .. x0+3, and at W-1-x for the mirrored orientation
+                if (!ZRGB) {
+                    const uint16_t *zrow = reinterpret_cast<const uint16_t *>(zimg + (size_t)y * p.gpitch);
+                    const ushort4 z = *reinterpret_cast<const ushort4 *>(zrow + x0);
+                    const int zz[4] = {z.x, z.y, z.z, z.w};
+                    int zm[4] = {0, 0, 0, 0};  // zslice at W-1-x for x = x0 .. x0+3
+                    if (p.mirror) {
+                        const int xm = p.W - 4 - x0;  // element index of the reversed run (may be < 0 at the far right)
+                        if (even_w && xm >= 0) {
+                            const uint2 r = *reinterpret_cast<const uint2 *>(zrow + xm);  // xm even: 4-byte aligned
+                            zm[3] = r.x & 0xffff; zm[2] = r.x >> 16; zm[1] = r.y & 0xffff; zm[0] = r.y >> 16;
+                        } else {
 #pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if (p.W - 1 - x0 - j >= 0) zm[j] = zrow[p.W - 1 - x0 - j];
+                            for (int j = 0; j < 4; j++)
+                                if (p.W - 1 - x0 - j >= 0) zm[j] = zrow[p.W - 1 - x0 - j];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sz[j] = zs_of(zz[j], p.thr), szm[j] = zs_of(zm[j], p.thr);
+                } else {
+                    const uint8_t *zr = zimg + (size_t)y * p.pitch;
+                    {   // the group's own 12 bytes (4-byte aligned: x0 is a multiple of 4)
+                        const uint32_t *q = reinterpret_cast<const uint32_t *>(zr + (size_t)x0 * 3);
+                        const uint32_t a = q[0], b = q[1], c = q[2];
+                        if (a | b | c) {   // (most zgap groups are black)
+                            sz[0] = zs_rgb(p.slice_lut, (int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255), p.thr);
+                            sz[1] = zs_rgb(p.slice_lut, (int)(a >> 24), (int)(b & 255), (int)((b >> 8) & 255), p.thr);
+                            sz[2] = zs_rgb(p.slice_lut, (int)((b >> 16) & 255), (int)(b >> 24), (int)(c & 255), p.thr);
+                            sz[3] = zs_rgb(p.slice_lut, (int)((c >> 8) & 255), (int)((c >> 16) & 255), (int)(c >> 24), p.thr);
+                        }
+                    }
+                    if (p.mirror) {
+                        const int xm = p.W - 4 - x0;  // first pixel of the reversed run W-4-x0 .. W-1-x0 (may be < 0 at the far right)
+                        if (xm >= 0) {   // its 12 bytes start at any byte alignment (gfx950 serves unaligned global loads)
+                            const u32_any_align *q = reinterpret_cast<const u32_any_align *>(zr + (size_t)xm * 3);
+                            const uint32_t a = q[0], b = q[1], c = q[2];
+                            if (a | b | c) {
+                                szm[3] = zs_rgb(p.slice_lut, (int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255), p.thr);
+                                szm[2] = zs_rgb(p.slice_lut, (int)(a >> 24), (int)(b & 255), (int)((b >> 8) & 255), p.thr);
+                                szm[1] = zs_rgb(p.slice_lut, (int)((b >> 16) & 255), (int)(b >> 24), (int)(c & 255), p.thr);
+                                szm[0] = zs_rgb(p.slice_lut, (int)((c >> 8) & 255), (int)((c >> 16) & 255), (int)(c >> 24), p.thr);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int xx = p.W - 1 - x0 - j;
+                                if (xx >= 0) szm[j] = zs_rgb(p.slice_lut, zr[3 * xx], zr[3 * xx + 1], zr[3 * xx + 2], p.thr);
+                            }
+                        }
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (x0 + j >= p.W) break;
-                    gap0 += gap_of(pa[j], zs_of(zz[j], p.thr), gg[j]);
-                    if (p.mirror) gap1 += gap_of(pb[j], zs_of(zm[j], p.thr), gg[j]);
+                    gap0 += gap_of(pa[j], sz[j], gg[j]);
+                    if (p.mirror) gap1 += gap_of(pb[j], szm[j], gg[j]);
                 }
             }
         }
@@ -829,6 +908,9 @@ struct cds_shapeset {
     mutable std::mutex mu;
     mutable double last_ms = 0;
     mutable int last_launches = 0;
+    mutable double last_convert_ms = 0;   // zgap -> zslice conversion of the last call (0 when it read the zgap bytes directly)
+    mutable int last_mode = 0;            // 0: zgap bytes read by the scorer (ZRGB), 1: converted zslice plane
+    mutable int64_t last_converted_slots = 0;
     mutable cds::PairSlotPool pair_pool;  // cds_shape_score_pair: resident slots (own streams), created on first use
 };
 
@@ -883,8 +965,8 @@ int cds_library_make_zgap_variants(cds_library *lib, int64_t first, int64_t coun
     hipFree(d_tmp);
     if (d_hw) hipFree(d_hw);
     if (e != hipSuccess) return hip_fail(e, "make_zgap_variants");
-    for (int64_t i = 0; i < count; i++) lib->has_zgap[(size_t)(first + i)] = 1;
-    rc = refresh_zslice(lib, first, count);
+    zgap_written(lib, first, count);
+    rc = CDS_OK;
     if (rc) return rc;
     CDS_HIP(hipStreamSynchronize(st));
     return CDS_OK;
@@ -1092,7 +1174,9 @@ struct GradscoreJob {
     int32_t *d_pm = nullptr;
     int64_t *d_ps = nullptr, *d_out = nullptr;
     int64_t *h_res = nullptr;        // pinned: [n_pairs][4]
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evc = nullptr, evd = nullptr;   // kernel start / end; start / end of the zslice conversion (if any)
+    int mode = 0;                    // 0: the scorer reads the zgap bytes, 1: the converted zslice plane
+    int64_t converted = 0;
     void release() {
         if (d_pm) hipFree(d_pm);
         if (d_ps) hipFree(d_ps);
@@ -1100,7 +1184,9 @@ struct GradscoreJob {
         if (h_res) hipHostFree(h_res);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
-        d_pm = nullptr; d_ps = d_out = h_res = nullptr; ev0 = ev1 = nullptr;
+        if (evc) hipEventDestroy(evc);
+        if (evd) hipEventDestroy(evd);
+        d_pm = nullptr; d_ps = d_out = h_res = nullptr; ev0 = ev1 = evc = evd = nullptr;
     }
 };
 
@@ -1132,6 +1218,44 @@ int gradscore_begin(const cds_shapeset *ss, const cds_library *lib, int64_t n_pa
     hipStream_t st = on_stream ? on_stream : ctx->stream;
     job->st = st;
     GradscoreJob *j = job.get();
+    // Where S(z) comes from.  Converting a zgap image into its zslice plane is a pass over all of its ~685 K pixels (3.4 MB of
+    // traffic: about what THREE pairs cost the scorer); reading the zgap bytes in the scorer costs a pair a few more bytes and table
+    // gathers.  So: the plane for slots that already have it or that serve many pairs of this call, the bytes otherwise -- BASELINE
+    // configs[4] (top-500 of 1,024 masks: 2.2 pairs per selected target) and the per-pair entry point read the bytes.
+    {
+        std::vector<int64_t> distinct;
+        int64_t n_ok = 0;
+        for (int64_t v : j->slots)
+            if (v >= 0) distinct.push_back(v), n_ok++;
+        std::sort(distinct.begin(), distinct.end());
+        distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+        int64_t stale = 0;
+        {
+            std::lock_guard<std::mutex> lk(const_cast<cds_library *>(lib)->mu);
+            for (int64_t v : distinct) stale += lib->zslice_ok[(size_t)v] ? 0 : 1;
+        }
+        int pairs_per_conversion = 8;   // convert when the call brings at least this many pairs per slot that still needs it
+        if (const char *e = getenv("CDS_SHAPE_PAIRS_PER_CONVERSION")) pairs_per_conversion = std::max(0, atoi(e));
+        bool plane = !distinct.empty() && (stale == 0 || n_ok >= (int64_t)pairs_per_conversion * stale);
+        if (const char *e = getenv("CDS_SHAPE_ZSLICE")) plane = atoi(e) != 0;      // (A/B runs: 1 always convert, 0 never)
+        if (getenv("CDS_SHAPE_SCAN_KERNEL")) plane = true;                          // (the plane-window scan reads zslice only)
+        if (plane && !distinct.empty()) {
+            hipError_t e = hipEventCreate(&j->evc);
+            if (e == hipSuccess) e = hipEventRecord(j->evc, st);
+            if (e != hipSuccess) { j->release(); return hip_fail(e, "hipEventRecord"); }
+            const int rc = ensure_zslice(const_cast<cds_library *>(lib), distinct, st);
+            if (rc) { hipStreamSynchronize(st); j->release(); return rc; }
+            e = hipEventCreate(&j->evd);
+            if (e == hipSuccess) e = hipEventRecord(j->evd, st);
+            if (e != hipSuccess) { hipStreamSynchronize(st); j->release(); return hip_fail(e, "hipEventRecord"); }
+            j->converted = stale;
+        }
+        j->mode = plane ? 1 : 0;
+        if (!plane) {
+            const int rc = ensure_slice_lut(ctx);
+            if (rc) { j->release(); return rc; }
+        }
+    }
 #define GS_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { hipStreamSynchronize(st); j->release(); return hip_fail(_e, #call); } } while (0)
     GS_HIP(hipMalloc(&j->d_pm, (size_t)n_pairs * 4));
     GS_HIP(hipMalloc(&j->d_ps, (size_t)n_pairs * 8));
@@ -1145,6 +1269,7 @@ int gradscore_begin(const cds_shapeset *ss, const cds_library *lib, int64_t n_pa
     GS_HIP(hipMemsetAsync(j->d_out, 0, (size_t)n_pairs * 32, st));
     ShapeParams p{};
     p.rgb = lib->d_rgb; p.zslice = lib->d_zslice; p.grad = lib->d_grad;
+    p.zgap = lib->d_zgap; p.slice_lut = ctx->d_slice_lut;
     p.img_stride = lib->img_stride; p.grad_stride = lib->grad_stride;
     p.pitch = lib->pitch; p.gpitch = lib->gpitch; p.W = ss->W; p.H = ss->H; p.wp = ss->wp;
     p.planes = ss->d_planes; p.boxes = ss->d_boxes; p.rowflags = ss->d_rowflags;
@@ -1160,7 +1285,8 @@ int gradscore_begin(const cds_shapeset *ss, const cds_library *lib, int64_t n_pa
     GS_HIP(hipEventRecord(j->ev0, st));
     p.glist = ss->d_glist; p.hlist = ss->d_hlist; p.list_off = ss->d_list_off; p.gl_a = ss->d_gl_a; p.gl_b = ss->d_gl_b;
     if (getenv("CDS_SHAPE_SCAN_KERNEL")) hipLaunchKernelGGL(gradscore_kernel, dim3(grid), dim3(256), 0, st, p);   // (the plane-window scan, for A/B runs)
-    else hipLaunchKernelGGL(gradscore_list_kernel, dim3(grid), dim3(256), 0, st, p);
+    else if (j->mode) hipLaunchKernelGGL(gradscore_list_kernel<false>, dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gradscore_list_kernel<true>, dim3(grid), dim3(256), 0, st, p);
     GS_HIP(hipGetLastError());
     GS_HIP(hipEventRecord(j->ev1, st));
     GS_HIP(hipMemcpyAsync(j->h_res, j->d_out, (size_t)n_pairs * 32, hipMemcpyDeviceToHost, st));
@@ -1178,12 +1304,16 @@ int gradscore_end(GradscoreJob *j, int64_t *gradient_area_gap, int64_t *high_exp
     int rc = CDS_OK;
     if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize (gradscore)");
     if (rc == CDS_OK && gradient_area_gap) {
-        float t = 0;
+        float t = 0, tc = 0;
         hipEventElapsedTime(&t, j->ev0, j->ev1);
+        if (j->evc && j->evd) hipEventElapsedTime(&tc, j->evc, j->evd);
         {
             std::lock_guard<std::mutex> lk(ss->mu);
             ss->last_ms = t;
             ss->last_launches = 1;
+            ss->last_convert_ms = j->converted ? tc : 0;
+            ss->last_mode = j->mode;
+            ss->last_converted_slots = j->converted;
         }
         for (int64_t i = 0; i < j->n_pairs; i++) {
             if (j->slots[(size_t)i] < 0) {
@@ -1240,6 +1370,15 @@ int cds_shape_score_pair(const cds_shapeset *ss, int32_t mask_index, const uint8
     int64_t s0 = 0;
     if (rc == CDS_OK) rc = gradscore_impl(ss, slot->lib, 1, &mask_index, &s0, gradient_area_gap, high_expression_area, mirrored, slot->sub->stream);
     return rc;
+}
+
+int cds_shapeset_last_call_info(const cds_shapeset *ss, int32_t *used_zslice_plane, int64_t *converted_slots, double *conversion_ms) {
+    if (!ss) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(ss->mu);
+    if (used_zslice_plane) *used_zslice_plane = ss->last_mode;
+    if (converted_slots) *converted_slots = ss->last_converted_slots;
+    if (conversion_ms) *conversion_ms = ss->last_convert_ms;
+    return CDS_OK;
 }
 
 int cds_shapeset_last_kernel_ms(const cds_shapeset *ss, double *avg_ms, int32_t *launches) {

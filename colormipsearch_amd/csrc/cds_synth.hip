@@ -199,9 +199,8 @@ extern "C" int cds_library_generate_synthetic(cds_library *lib, uint64_t seed, i
         CDS_HIP(hipGetLastError());
     }
     if (with_variants) {
-        for (int64_t i = 0; i < count; i++) lib->has_grad[(size_t)(first_slot + i)] = lib->has_zgap[(size_t)(first_slot + i)] = 1;
-        int rc = refresh_zslice(lib, first_slot, count);
-        if (rc) return rc;
+        for (int64_t i = 0; i < count; i++) lib->has_grad[(size_t)(first_slot + i)] = 1;
+        zgap_written(lib, first_slot, count);
     }
     CDS_HIP(hipStreamSynchronize(lib->ctx->stream));
     return CDS_OK;

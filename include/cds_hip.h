@@ -331,6 +331,11 @@ int64_t cds_shape_score_value(int64_t gradient_area_gap, int64_t high_expression
 double cds_normalized_score(int32_t pixel_match_score, int64_t shape_score, int64_t max_pixel_match,
                             int64_t max_shape_score);
 int cds_shapeset_last_kernel_ms(const cds_shapeset *ss, double *avg_ms, int32_t *launches);
+/* How the last cds_gradscore / cds_shape_score_pair call on this set got S(z) of the zgap pixels: from the zgap bytes inside the
+ * scorer (used_zslice_plane = 0: no conversion pass; chosen when the targets serve few pairs) or from the derived zslice plane
+ * (1), in which case converted_slots images were converted by this call, in conversion_ms of device time.  Results are identical;
+ * CDS_SHAPE_PAIRS_PER_CONVERSION (default 8 pairs per slot still to convert) moves the switch. */
+int cds_shapeset_last_call_info(const cds_shapeset *ss, int32_t *used_zslice_plane, int64_t *converted_slots, double *conversion_ms);
 
 /* Host helper used by tests and by callers that have no ZGapImage file: clearRegion -> mask(thr) ->
  * circular max filter (API/imageprocessing/ImageTransformation.java:353-572), computed on the GPU. */
