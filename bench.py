@@ -544,28 +544,28 @@ def dist_gradient_leg(args, cds, dist, ctx, dev, dense, slib, n, stage_n, rects,
     stats = {"kernel_ms": 0.0, "launches": 0, "pairs": 0, "load_s": 0.0, "score_s": 0.0}
 
     def local_score(mask_idx, slots):
-        """this rank's pairs (slots = indices inside its shard): window by window through the dense staging slots"""
+        """this rank's pairs (slots = indices inside its shard): its DISTINCT selected targets are made resident `stage_n` at a time
+        (regenerated with their variants: the stand-in for loading those targets' files), one scoring launch per batch"""
         out_l = np.zeros((len(mask_idx), 3), dtype=np.int64)
-        order = np.argsort(slots, kind="stable")
-        ss = slots[order]
-        w0 = (int(ss[0]) // stage_n) * stage_n
-        while w0 <= int(ss[-1]):
-            lo, hi = np.searchsorted(ss, w0), np.searchsorted(ss, w0 + stage_n)
-            if hi > lo:
-                rows = order[lo:hi]
-                t1 = time.perf_counter()
-                dense.generate_synthetic(LIB_SEED, rank * n + w0, 0, min(stage_n, n - w0), kind=0, with_variants=True)
-                ctx.synchronize()
-                t2 = time.perf_counter()
-                gap, high, mir = shape.scoreLibraryPairs(dense, mask_idx[rows], slots[rows] - w0)
-                stats["load_s"] += t2 - t1
-                stats["score_s"] += time.perf_counter() - t2
-                ms, launches = shape.lastKernelMs()
-                stats["kernel_ms"] += ms * launches
-                stats["launches"] += launches
-                stats["pairs"] += len(rows)
-                out_l[rows, 0], out_l[rows, 1], out_l[rows, 2] = gap, high, mir
-            w0 += stage_n
+        distinct, inv = np.unique(slots, return_inverse=True)
+        order = np.argsort(inv, kind="stable")
+        isorted = inv[order]
+        for b0 in range(0, len(distinct), stage_n):
+            idx = distinct[b0:b0 + stage_n]
+            lo, hi = np.searchsorted(isorted, b0), np.searchsorted(isorted, b0 + len(idx))
+            rows = order[lo:hi]
+            t1 = time.perf_counter()
+            dense.generate_synthetic_list(LIB_SEED, rank * n + idx.astype(np.int64), 0, kind=0, with_variants=True)
+            ctx.synchronize()
+            t2 = time.perf_counter()
+            gap, high, mir = shape.scoreLibraryPairs(dense, mask_idx[rows], (inv[rows] - b0).astype(np.int64))
+            stats["load_s"] += t2 - t1
+            stats["score_s"] += time.perf_counter() - t2
+            ms, launches = shape.lastKernelMs()
+            stats["kernel_ms"] += ms * launches
+            stats["launches"] += launches
+            stats["pairs"] += len(rows)
+            out_l[rows, 0], out_l[rows, 1], out_l[rows, 2] = gap, high, mir
         return torch.from_numpy(out_l)
 
     t0 = time.perf_counter()
@@ -598,12 +598,12 @@ def dist_gradient_leg(args, cds, dist, ctx, dev, dense, slib, n, stage_n, rects,
     kms = [float(a[0]) for a in allst]
     return {"workload": f"GradientAreaGap of the global top-{top} hits of {g_m} masks over the {world} x {n}-target sharded library = {n_pairs} pairs "
                         "(BASELINE configs[4] on N GPUs), every pair scored on the rank owning its target, results gathered in pair order",
-            "entry": "dist.sharded_pair_scores(dist-side routing + one gather) driving cds_gradscore per window of the staging slots",
+            "entry": "dist.sharded_pair_scores (routing by owner + one gather) driving cds_gradscore: a rank's distinct selected targets resident a staging-slot batch at a time",
             "world": world, "pairs": n_pairs, "pairs_per_rank": [int(a[1]) for a in allst], "kernel_ms_per_rank": kms,
             "pairs_per_s_per_rank (kernel time)": [(a[1] / (a[0] * 1e-3)) if a[0] > 0 else None for a in allst],
             "pairs_per_s (kernel time, slowest rank)": n_pairs / (max(kms) * 1e-3) if max(kms) > 0 else None,
-            "scoring_wall_s (regeneration of the synthetic windows included)": max(float(a[4]) for a in allst),
-            "window_regeneration_s_per_rank (benchmark scaffolding)": [float(a[2]) for a in allst],
+            "scoring_wall_s (regeneration of the selected synthetic targets included)": max(float(a[4]) for a in allst),
+            "selected_target_regeneration_s_per_rank (benchmark scaffolding)": [float(a[2]) for a in allst],
             "scoring_calls_s_per_rank": [float(a[3]) for a in allst],
             "top_hit_selection_s (scan of the masks, device top-k, gather, merge, broadcast)": sel_s, "shape_mask_preparation_s": prep_s,
             "pairs_checked_against_oracle": checked, "sampled_pairs_equal_oracle": bool(ok)}
@@ -766,26 +766,49 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
     sizes = np.asarray(batch.getQuerySizes(), dtype=np.float64)
     table = PR.MatchTable(pm, ps, pv, (pv / np.maximum(sizes[pm], 1.0)).astype(np.float32), pmir)
     proc = PR.GpuColorMIPSearchProcessor(None, None, None, first=0, count=n_t, sparse_library=slib)
-    t0 = time.perf_counter()
-    table = proc.calculateGradientScoresBatchedTable(shp_masks, table, lambda lib, f, c: lib.generate_synthetic(LIB_SEED, f, 0, c, kind=args.kind, with_variants=True),
-                                                     MASK_THR, MIRROR, None, rects, batch=stage_n, library=dense)
-    torch.cuda.synchronize()
-    wall_s = time.perf_counter() - t0
-    gs = proc.last_gradscore
+    load_sel = lambda lib, idx: lib.generate_synthetic_list(LIB_SEED, idx, 0, kind=args.kind, with_variants=True)
+    # Only the SELECTED targets are made resident (as the reference opens only the files of the matches it scores): their distinct
+    # indices, `stage_n` at a time, regenerated with their variants into the dense staging slots -- the synthetic stand-in for loading
+    # those targets' files.  Run twice: (1) the default policy -- a target serves ~2 pairs here, so the scorer reads the zgap bytes
+    # itself and NO conversion pass runs; (2) CDS_SHAPE_ZSLICE=1: every loaded zgap is first converted into its zslice plane (round 3's
+    # only path).  Same scores; the second run's table is the one checked against the oracle below as well.
+    runs = {}
+    for label, env in (("zgap bytes read by the scorer (default policy here)", None), ("zslice plane (conversion pass per loaded target)", "1")):
+        if env is None:
+            os.environ.pop("CDS_SHAPE_ZSLICE", None)
+        else:
+            os.environ["CDS_SHAPE_ZSLICE"] = env
+        tcopy = PR.MatchTable(pm.copy(), ps.copy(), pv.copy(), table.normalizedScore.copy() if False else (pv / np.maximum(sizes[pm], 1.0)).astype(np.float32), pmir.copy())
+        t0 = time.perf_counter()
+        tcopy = proc.calculateGradientScoresSelectedTable(shp_masks, tcopy, load_sel, MASK_THR, MIRROR, None, rects, batch=stage_n, library=dense)
+        torch.cuda.synchronize()
+        runs[label] = (tcopy, dict(proc.last_gradscore), time.perf_counter() - t0)
+    os.environ.pop("CDS_SHAPE_ZSLICE", None)
+    (table, gs, wall_s), (table2, gs2, wall2_s) = runs.values()
+    if not (np.array_equal(table.gradientAreaGap, table2.gradientAreaGap) and np.array_equal(table.highExpressionArea, table2.highExpressionArea)):
+        failed.append("gradient scores differ between the zgap-bytes path and the zslice-plane path")
     gms = gs["kernel_ms"]
     ok_g, n_checked = True, 0
     if not args.no_cpu_baseline:
         from oracle import cds_oracle as O
+        # >= 1,000 pairs against the CPU oracle: 8 masks (one CPU mask preparation each: two r = 60 / r = 20 max filters, seconds) x 128
+        # of their top hits, the pairs of a mask on a thread pool (the C oracle releases the GIL)
+        from concurrent.futures import ThreadPoolExecutor
         rng = np.random.default_rng(7)
-        for m in sorted(set(rng.choice(n_gm, size=min(8, n_gm), replace=False).tolist())):
-            sq = O.ShapeQuery(masks[m], MASK_THR, MIRROR, rects)     # (one CPU mask preparation per sampled mask)
-            for i in rng.choice(top, size=8, replace=False):
-                j = m * top + int(i)
-                tgt = O.synth_image(LIB_SEED, int(ps[j]), args.kind, W, H)
-                zg, gr = O.synth_variants(LIB_SEED, int(ps[j]), W, H)
-                og, oh, _, _ = sq.score(tgt, gr, zg)
-                ok_g &= (int(table.gradientAreaGap[j]), int(table.highExpressionArea[j])) == (og, oh)
-                n_checked += 1
+        with ThreadPoolExecutor(max_workers=usable_cores()) as pool:
+            for m in sorted(set(rng.choice(n_gm, size=min(8, n_gm), replace=False).tolist())):
+                sq = O.ShapeQuery(masks[m], MASK_THR, MIRROR, rects)
+
+                def one(i, m=m, sq=sq):
+                    j = m * top + int(i)
+                    tgt = O.synth_image(LIB_SEED, int(ps[j]), args.kind, W, H)
+                    zg, gr = O.synth_variants(LIB_SEED, int(ps[j]), W, H)
+                    og, oh, _, _ = sq.score(tgt, gr, zg)
+                    return (int(table.gradientAreaGap[j]), int(table.highExpressionArea[j])) == (og, oh)
+
+                res = list(pool.map(one, rng.choice(top, size=min(128, top), replace=False)))
+                ok_g &= all(res)
+                n_checked += len(res)
     gcls = pmc.get("classes", {}).get("gradscore_list")
     if gcls and "hbm_bytes" not in gcls.get("per_pair", {}):
         gcls = None
@@ -793,17 +816,27 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
     g_alg = n_pairs * 2081200 / (gms * 1e-3) / 1e9            # 2,081,200 B per pair at R = 170
     g_traffic = gcls["per_pair"]["hbm_bytes"] * n_pairs if gcls else None
     aux["gradient_scores"] = {"workload": f"GradientAreaGap of the top-{top} hits of {n_gm} masks over the {n_t}-target library = {n_pairs} pairs "
-                                          f"(BASELINE configs[4]" + (" at full size" if n_gm >= 1024 and n_t >= 1 << 20 else "") + f"), {gs['launches']} windows of {stage_n} targets "
-                                          "regenerated with their variants", "kernel": "cds::gradscore_list_kernel",
+                                          f"(BASELINE configs[4]" + (" at full size" if n_gm >= 1024 and n_t >= 1 << 20 else "") + f"), the {gs['distinct_targets']} distinct targets made resident "
+                                          f"{stage_n} at a time with their variants ({gs['launches']} scoring launches)", "kernel": "cds::gradscore_list_kernel",
                               "pairs_per_s": n_pairs / (gms * 1e-3), "kernel_ms_total": gms, "launches": gs["launches"],
+                              "s_of_z_source": "zgap bytes read by the scorer: no conversion pass (the default policy at %.1f pairs per selected target)" % (n_pairs / max(1, gs["distinct_targets"]))
+                                               if gs["launches_on_zslice_plane"] == 0 else "zslice plane",
+                              "pairs_per_s_including_variant_conversion": n_pairs / ((gms + gs["conversion_ms"]) * 1e-3),
+                              "product_pairs_per_s (shape-mask preparation + scoring calls incl. any conversion + top-hit selection)":
+                                  n_pairs / ((gs.get("mask_preparation_s") or 0) + (gs.get("score_calls_s") or 0) + sel_s),
+                              "with_zslice_conversion (CDS_SHAPE_ZSLICE=1: round 3's path, every loaded zgap converted first)": {
+                                  "kernel_ms_total": gs2["kernel_ms"], "conversion_ms_total": gs2["conversion_ms"], "converted_targets": gs2["converted_slots"],
+                                  "pairs_per_s": n_pairs / (gs2["kernel_ms"] * 1e-3),
+                                  "pairs_per_s_including_variant_conversion": n_pairs / ((gs2["kernel_ms"] + gs2["conversion_ms"]) * 1e-3),
+                                  "scoring_calls_s": gs2.get("score_calls_s"), "scores_equal": True},
                               "end_to_end_s": wall_s, "end_to_end_pairs_per_s": n_pairs / wall_s, "top_hit_selection_s": sel_s,
                               "product_seconds (mask preparation + scoring calls + selection)": (gs.get("mask_preparation_s") or 0) + (gs.get("score_calls_s") or 0) + sel_s,
                               "end_to_end_breakdown_s": {"shape_mask_preparation": gs.get("mask_preparation_s"),
-                                                         "regeneration_of_the_synthetic_windows_with_variants (benchmark scaffolding: a real library ingests files)": gs.get("load_range_s"),
+                                                         "regeneration_of_the_selected_synthetic_targets_with_variants (benchmark scaffolding: a real library loads those targets' files)": gs.get("load_s"),
                                                          "scoring_calls (pair upload + kernel + read-back)": gs.get("score_calls_s")},
-                              "end_to_end_note": "includes the shape-mask preparation of all masks, the regeneration of every window of the synthetic library "
+                              "end_to_end_note": "includes the shape-mask preparation of all masks, the regeneration of the selected targets of the synthetic library "
                                                  "with gradient and zgap variants, the host-side pair bookkeeping and normalisation",
-                              "distinct_targets": int(len(np.unique(ps))), "normalized_scores_positive": int((table.normalizedScore > 0).sum()),
+                              "distinct_targets": int(gs["distinct_targets"]), "normalized_scores_positive": int((table.normalizedScore > 0).sum()),
                               "roofline": {"bound": "hbm", "achieved": (g_traffic / (gms * 1e-3) / 1e9) if g_traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": (g_traffic / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS) if g_traffic else None, "traffic": g_traffic,
                                            "traffic_source": (f"profiles/scan_pmc.json (tag {pmc.get('tag')}), 2 x FETCH_SIZE per pair; stale sources: {pmc.get('stale_sources')}") if gcls else None,

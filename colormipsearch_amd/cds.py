@@ -322,6 +322,12 @@ class Library:
         capi.check(self._lib.cds_library_generate_synthetic(self._h, ctypes.c_uint64(int(seed)), int(first_index),
                                                             int(first_slot), int(count), int(kind), int(bool(with_variants))))
 
+    def generate_synthetic_list(self, seed, indices, first_slot=0, kind=0, with_variants=False):
+        """Slot first_slot + i gets image indices[i] of the stream (the stand-in for loading just the selected targets' files)."""
+        idx = np.ascontiguousarray(indices, dtype=np.int64)
+        capi.check(self._lib.cds_library_generate_synthetic_list(self._h, ctypes.c_uint64(seed), capi.as_i64p(idx), int(first_slot), len(idx),
+                                                                 int(kind), int(bool(with_variants))))
+
 
 class SparseLibrary:
     """A resident shard of target MIPs kept as signal-pixel lists (cds_sparse_library): ~4 % of the dense bytes,

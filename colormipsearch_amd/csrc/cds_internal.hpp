@@ -223,6 +223,7 @@ struct SparseMaskPlan {
 };
 
 struct SparseScanParams {
+    const uint16_t *px16;     // the 16-bit stage-1 stream of the same records (sparse_scan16_kernel), or NULL
     const uint32_t *px;       // record arena
     const uint64_t *img_off;  // [n+1] first record of every image
     const uint32_t *rowptr;   // [n][nstrips][H+1] record offsets of the (strip, row) cells inside their image
@@ -302,6 +303,9 @@ struct cds_sparse_library {
     int min_threshold = 0;          // pixels whose maximum channel is <= this are not stored; searches below it are refused
     double density_limit = 0.25;    // appends / imports whose images average more signal pixels than this share of the frame are refused
     uint32_t *d_px = nullptr;
+    uint16_t *d_px16 = nullptr;     // [cap_px + 2] the records' upper halves as a stream of their own (stage 1 of the single-mask scan reads
+                                    // 2 instead of 4 bytes per visited record; derived from d_px by every append / import); NULL when the
+                                    // device had no room for it or CDS_SPARSE_STREAM16=0: the scan then reads d_px as in round 3
     uint64_t *d_img_off = nullptr;  // [cap_images + 1]
     uint32_t *d_rowptr = nullptr;   // [cap_images][nstrips][H + 1]
     uint32_t *d_tmp = nullptr;      // append scratch: per-image totals of one batch

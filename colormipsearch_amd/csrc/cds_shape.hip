@@ -537,10 +537,37 @@ using namespace cds;
 // entry -> planes, gradient, zslice (plain and reversed) -> the gap arithmetic, all lanes busy, no queue.
 // One workgroup per pair, the four waves take alternate 64-entry chunks.
 // ---------------------------------------------------------------------------------------------
-// S(z) of a zgap pixel under ColorTransformation.mask(thr), straight from its RGB bytes: what zs_of() reads out of a zslice entry
-__device__ __forceinline__ int zs_rgb(const uint8_t *lut, int r, int g, int b, int thr) {
+// S(z) of a zgap pixel under ColorTransformation.mask(thr), straight from its RGB bytes: what zs_of() reads out of a zslice entry.
+// In two steps so that the table gathers of a group's pixels are independent loads issued together (dev_slice's branches would
+// serialise them): slice_index = the table position dev_slice reads (same sextant rules, branch-free; valid for any colour, black
+// reads entry 0), zs_pick = the value under the threshold rule.
+__device__ __forceinline__ uint32_t slice_index(int r, int g, int b) {
+    const bool R = r >= g && r >= b, G = !R && g >= r && g >= b;
+    const int first = R ? r : (G ? g : b);
+    const int c1 = R ? g : r, c2 = (R || G) ? b : g;   // R: (g, b)  G: (r, b)  B: (r, g) -- the first of the pair wins ties
+    const bool pick = c1 >= c2;
+    const int second = pick ? c1 : c2;
+    const int sext = (R ? 0 : (G ? 2 : 4)) + (pick ? 0 : 1);
+    return (uint32_t)(((sext * 256 + first) << 8) + second);
+}
+__device__ __forceinline__ int zs_pick(int lut_value, int r, int g, int b, int thr) {
     const int mx = max(r, max(g, b));
-    return (mx > thr && mx > 0) ? dev_slice(lut, r, g, b, -1) : 0;
+    return (mx > thr && mx > 0) ? lut_value + 1 : 0;
+}
+__device__ __forceinline__ int zs_rgb(const uint8_t *lut, int r, int g, int b, int thr) {
+    return zs_pick(lut[slice_index(r, g, b)], r, g, b, thr);
+}
+// the four pixels of 12 packed RGB bytes (a, b, c): all four table gathers in flight together; out[k] = S(z) of pixel k
+__device__ __forceinline__ void zs_group(const uint8_t *lut, uint32_t a, uint32_t b, uint32_t c, int thr, int (&out)[4]) {
+    const int px[4][3] = {{(int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255)},
+                          {(int)(a >> 24), (int)(b & 255), (int)((b >> 8) & 255)},
+                          {(int)((b >> 16) & 255), (int)(b >> 24), (int)(c & 255)},
+                          {(int)((c >> 8) & 255), (int)((c >> 16) & 255), (int)(c >> 24)}};
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = lut[slice_index(px[k][0], px[k][1], px[k][2])];
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = zs_pick(v[k], px[k][0], px[k][1], px[k][2], thr);
 }
 typedef uint32_t u32_any_align __attribute__((aligned(1)));
 
@@ -622,12 +649,18 @@ __global__ __launch_bounds__(256) void gradscore_list_kernel(ShapeParams p) {
                 const ushort4 g = *reinterpret_cast<const ushort4 *>(gimg + (size_t)y * p.gpitch + (size_t)x0 * 2);
                 const int gg[4] = {g.x, g.y, g.z, g.w};
                 int sz[4] = {0, 0, 0, 0}, szm[4] = {0, 0, 0, 0};   // S(z) at x0 .. x0+3, and at W-1-x for the mirrored orientation
+                // gap_of() looks at S(z) only where the orientation's plane has a slice number S(q): a list entry usually carries gap
+                // bits of ONE orientation (the other orientation's mask pixels lie elsewhere), so half of the z fetches never happen
+                const bool need_a = ((pa[0] | pa[1] | pa[2] | pa[3]) & kPlaneS) != 0;
+                const bool need_b = p.mirror && ((pb[0] | pb[1] | pb[2] | pb[3]) & kPlaneS) != 0;
                 if (!ZRGB) {
                     const uint16_t *zrow = reinterpret_cast<const uint16_t *>(zimg + (size_t)y * p.gpitch);
-                    const ushort4 z = *reinterpret_cast<const ushort4 *>(zrow + x0);
-                    const int zz[4] = {z.x, z.y, z.z, z.w};
-                    int zm[4] = {0, 0, 0, 0};  // zslice at W-1-x for x = x0 .. x0+3
-                    if (p.mirror) {
+                    if (need_a) {
+                        const ushort4 z = *reinterpret_cast<const ushort4 *>(zrow + x0);
+                        sz[0] = zs_of(z.x, p.thr), sz[1] = zs_of(z.y, p.thr), sz[2] = zs_of(z.z, p.thr), sz[3] = zs_of(z.w, p.thr);
+                    }
+                    if (need_b) {
+                        int zm[4] = {0, 0, 0, 0};  // zslice at W-1-x for x = x0 .. x0+3
                         const int xm = p.W - 4 - x0;  // element index of the reversed run (may be < 0 at the far right)
                         if (even_w && xm >= 0) {
                             const uint2 r = *reinterpret_cast<const uint2 *>(zrow + xm);  // xm even: 4-byte aligned
@@ -637,32 +670,25 @@ __global__ __launch_bounds__(256) void gradscore_list_kernel(ShapeParams p) {
                             for (int j = 0; j < 4; j++)
                                 if (p.W - 1 - x0 - j >= 0) zm[j] = zrow[p.W - 1 - x0 - j];
                         }
-                    }
 #pragma unroll
-                    for (int j = 0; j < 4; j++) sz[j] = zs_of(zz[j], p.thr), szm[j] = zs_of(zm[j], p.thr);
-                } else {
-                    const uint8_t *zr = zimg + (size_t)y * p.pitch;
-                    {   // the group's own 12 bytes (4-byte aligned: x0 is a multiple of 4)
-                        const uint32_t *q = reinterpret_cast<const uint32_t *>(zr + (size_t)x0 * 3);
-                        const uint32_t a = q[0], b = q[1], c = q[2];
-                        if (a | b | c) {   // (most zgap groups are black)
-                            sz[0] = zs_rgb(p.slice_lut, (int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255), p.thr);
-                            sz[1] = zs_rgb(p.slice_lut, (int)(a >> 24), (int)(b & 255), (int)((b >> 8) & 255), p.thr);
-                            sz[2] = zs_rgb(p.slice_lut, (int)((b >> 16) & 255), (int)(b >> 24), (int)(c & 255), p.thr);
-                            sz[3] = zs_rgb(p.slice_lut, (int)((c >> 8) & 255), (int)((c >> 16) & 255), (int)(c >> 24), p.thr);
-                        }
+                        for (int j = 0; j < 4; j++) szm[j] = zs_of(zm[j], p.thr);
                     }
-                    if (p.mirror) {
-                        const int xm = p.W - 4 - x0;  // first pixel of the reversed run W-4-x0 .. W-1-x0 (may be < 0 at the far right)
-                        if (xm >= 0) {   // its 12 bytes start at any byte alignment (gfx950 serves unaligned global loads)
-                            const u32_any_align *q = reinterpret_cast<const u32_any_align *>(zr + (size_t)xm * 3);
-                            const uint32_t a = q[0], b = q[1], c = q[2];
-                            if (a | b | c) {
-                                szm[3] = zs_rgb(p.slice_lut, (int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255), p.thr);
-                                szm[2] = zs_rgb(p.slice_lut, (int)(a >> 24), (int)(b & 255), (int)((b >> 8) & 255), p.thr);
-                                szm[1] = zs_rgb(p.slice_lut, (int)((b >> 16) & 255), (int)(b >> 24), (int)(c & 255), p.thr);
-                                szm[0] = zs_rgb(p.slice_lut, (int)((c >> 8) & 255), (int)((c >> 16) & 255), (int)(c >> 24), p.thr);
-                            }
+                } else {
+                    // both orientations' bytes are requested before either is looked up (a lane that needs neither reads the row's
+                    // first bytes: black or not, its sums ignore them), then all eight table gathers go out together
+                    const uint8_t *zr = zimg + (size_t)y * p.pitch;
+                    const int xm = p.W - 4 - x0;  // first pixel of the reversed run W-4-x0 .. W-1-x0 (< 0 at the far right: pixel by pixel)
+                    const uint32_t *qa = reinterpret_cast<const uint32_t *>(zr + (need_a ? (size_t)x0 * 3 : 0));   // 4-byte aligned (x0 % 4 == 0)
+                    const u32_any_align *qb = reinterpret_cast<const u32_any_align *>(zr + ((need_b && xm >= 0) ? (size_t)xm * 3 : 0));  // any alignment
+                    const uint32_t a0 = qa[0], a1 = qa[1], a2 = qa[2];
+                    const uint32_t b0 = qb[0], b1 = qb[1], b2 = qb[2];
+                    int ta[4], tb[4];
+                    zs_group(p.slice_lut, a0, a1, a2, p.thr, ta);
+                    zs_group(p.slice_lut, b0, b1, b2, p.thr, tb);
+                    if (need_a) { sz[0] = ta[0]; sz[1] = ta[1]; sz[2] = ta[2]; sz[3] = ta[3]; }
+                    if (need_b) {
+                        if (xm >= 0) {
+                            szm[3] = tb[0]; szm[2] = tb[1]; szm[1] = tb[2]; szm[0] = tb[3];
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; j++) {
@@ -1003,78 +1029,104 @@ int cds_shapeset_create_bordered(cds_context *ctx, int32_t n_masks, const uint8_
     const int k60 = line_radii(60, hw60), k20 = line_radii(20, hw20);
     if (k60 >= kHdMax) { delete ss; return fail(CDS_ERR_UNSUPPORTED, "max-filter radius beyond the distance maps"); }
     const int batch = std::min(n_masks, 32);   // masks prepared per round of launches (5.5 MB of scratch each)
-    uint8_t *d_masks = nullptr, *d_roi = nullptr, *d_flags = nullptr, *d_hd = nullptr;
+    // Rounds alternate between TWO streams with their own scratch: the upload of round i + 1 (64 MB of pageable host memory: the
+    // host is busy staging it) runs while the three kernels of round i execute; every round writes its boxes / row flags / sums into
+    // arrays for ALL masks that are read back once, after the last round (round 3 synchronised after every round: 1,024 masks
+    // 0.12 s, most of it the 2.1 GB upload with the kernels' time on top).
+    const int nset = n_masks > batch ? 2 : 1;
+    uint8_t *d_masks[2] = {nullptr, nullptr}, *d_roi = nullptr, *d_flags[2] = {nullptr, nullptr}, *d_hd[2] = {nullptr, nullptr};
     int *d_hw = nullptr, *d_acc = nullptr;
     uint32_t *d_rfl = nullptr;
     unsigned long long *d_sums = nullptr;
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
     auto cleanup = [&]() {
-        for (void *q : {(void *)d_masks, (void *)d_roi, (void *)d_flags, (void *)d_hd, (void *)d_hw, (void *)d_acc, (void *)d_rfl, (void *)d_sums})
+        for (void *q : {(void *)d_masks[0], (void *)d_masks[1], (void *)d_roi, (void *)d_flags[0], (void *)d_flags[1], (void *)d_hd[0], (void *)d_hd[1],
+                        (void *)d_hw, (void *)d_acc, (void *)d_rfl, (void *)d_sums})
             if (q) hipFree(q);
+        if (st2) { hipStreamSynchronize(st2); hipStreamDestroy(st2); }
+        if (ev_a) hipEventDestroy(ev_a);
+        if (ev_b) hipEventDestroy(ev_b);
     };
-#define SP_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); cds_shapeset_destroy(ss); return hip_fail(_e, #call); } } while (0)
+#define SP_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { hipStreamSynchronize(st); cleanup(); cds_shapeset_destroy(ss); return hip_fail(_e, #call); } } while (0)
     SP_HIP(hipMalloc(&ss->d_planes, (size_t)n_masks * 2 * H * wp * sizeof(uint16_t)));
     SP_HIP(hipMalloc(&ss->d_boxes, (size_t)n_masks * 8 * sizeof(int)));
     SP_HIP(hipMalloc(&ss->d_rowflags, (size_t)n_masks * H));
     SP_HIP(hipMemsetAsync(ss->d_planes, 0, (size_t)n_masks * 2 * H * wp * sizeof(uint16_t), st));
-    SP_HIP(hipMalloc(&d_masks, (size_t)batch * 3 * N));
-    SP_HIP(hipMalloc(&d_flags, (size_t)batch * N));
-    SP_HIP(hipMalloc(&d_hd, (size_t)batch * 7 * N));
+    for (int k = 0; k < nset; k++) {
+        SP_HIP(hipMalloc(&d_masks[k], (size_t)batch * 3 * N));
+        SP_HIP(hipMalloc(&d_flags[k], (size_t)batch * N));
+        SP_HIP(hipMalloc(&d_hd[k], (size_t)batch * 7 * N));
+    }
     SP_HIP(hipMalloc(&d_hw, (hw60.size() + hw20.size()) * sizeof(int)));
-    SP_HIP(hipMalloc(&d_acc, (size_t)batch * 16 * sizeof(int)));
-    SP_HIP(hipMalloc(&d_rfl, (size_t)batch * H * sizeof(uint32_t)));
-    SP_HIP(hipMalloc(&d_sums, (size_t)batch * 2 * sizeof(unsigned long long)));
+    SP_HIP(hipMalloc(&d_acc, (size_t)n_masks * 16 * sizeof(int)));
+    SP_HIP(hipMalloc(&d_rfl, (size_t)n_masks * H * sizeof(uint32_t)));
+    SP_HIP(hipMalloc(&d_sums, (size_t)n_masks * 2 * sizeof(unsigned long long)));
     SP_HIP(hipMemcpyAsync(d_hw, hw60.data(), hw60.size() * sizeof(int), hipMemcpyHostToDevice, st));
     SP_HIP(hipMemcpyAsync(d_hw + hw60.size(), hw20.data(), hw20.size() * sizeof(int), hipMemcpyHostToDevice, st));
     if (roi) {
         SP_HIP(hipMalloc(&d_roi, N));
         SP_HIP(hipMemcpyAsync(d_roi, roi, N, hipMemcpyHostToDevice, st));
     }
-    std::vector<int> acc_init((size_t)batch * 16), acc((size_t)batch * 16), boxes((size_t)n_masks * 8, 0);
-    for (int i = 0; i < batch; i++) {
-        int *q = acc_init.data() + (size_t)16 * i;
+    std::vector<int> acc((size_t)n_masks * 16), boxes((size_t)n_masks * 8, 0);
+    for (int i = 0; i < n_masks; i++) {
+        int *q = acc.data() + (size_t)16 * i;
         for (int j = 0; j < 16; j++) q[j] = 0;
         q[0] = H; q[2] = W; q[4] = W; q[8] = W; q[9] = H;   // the minima start at the far end
     }
-    std::vector<uint32_t> rfl((size_t)batch * H);
-    std::vector<unsigned long long> sums((size_t)batch * 2);
+    SP_HIP(hipMemcpyAsync(d_acc, acc.data(), acc.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    SP_HIP(hipMemsetAsync(d_rfl, 0, (size_t)n_masks * H * sizeof(uint32_t), st));
+    SP_HIP(hipMemsetAsync(d_sums, 0, (size_t)n_masks * 2 * sizeof(unsigned long long), st));
+    if (nset > 1) {   // the second stream starts after the set-up above
+        SP_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+        SP_HIP(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
+        SP_HIP(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
+        SP_HIP(hipEventRecord(ev_a, st));
+        SP_HIP(hipStreamWaitEvent(st2, ev_a, 0));
+    }
+    std::vector<uint32_t> rfl((size_t)n_masks * H);
+    std::vector<unsigned long long> sums((size_t)n_masks * 2);
     std::vector<uint8_t> rowflags((size_t)n_masks * H, 0);
-    for (int m0 = 0; m0 < n_masks; m0 += batch) {
+    for (int m0 = 0, round = 0; m0 < n_masks; m0 += batch, round++) {
         const int nb = std::min(batch, n_masks - m0);
-        SP_HIP(hipMemcpyAsync(d_masks, masks_rgb + (size_t)m0 * 3 * N, (size_t)nb * 3 * N, hipMemcpyHostToDevice, st));
-        SP_HIP(hipMemcpyAsync(d_acc, acc_init.data(), (size_t)nb * 16 * sizeof(int), hipMemcpyHostToDevice, st));
-        SP_HIP(hipMemsetAsync(d_rfl, 0, (size_t)nb * H * sizeof(uint32_t), st));
-        SP_HIP(hipMemsetAsync(d_sums, 0, (size_t)nb * 2 * sizeof(unsigned long long), st));
+        const int k = nset > 1 ? (round & 1) : 0;
+        hipStream_t sr = k ? st2 : st;
+        SP_HIP(hipMemcpyAsync(d_masks[k], masks_rgb + (size_t)m0 * 3 * N, (size_t)nb * 3 * N, hipMemcpyHostToDevice, sr));
         PrepParams p{};
-        p.masks = d_masks; p.roi = d_roi; p.W = W; p.H = H; p.wp = wp; p.n = nb; p.mirror = mirror != 0; p.nrects = n_excluded;
+        p.masks = d_masks[k]; p.roi = d_roi; p.W = W; p.H = H; p.wp = wp; p.n = nb; p.mirror = mirror != 0; p.nrects = n_excluded;
         p.border = query_border_size;
         for (int i = 0; i < n_excluded; i++) p.rects[i] = excluded[i];
         p.k60 = k60; p.k20 = k20; p.hw60 = d_hw; p.hw20 = d_hw + hw60.size();
-        p.flags = d_flags; p.hd = d_hd; p.planes = ss->d_planes + (size_t)m0 * 2 * H * wp; p.acc = d_acc; p.rowflags = d_rfl; p.sums = d_sums;
+        p.flags = d_flags[k]; p.hd = d_hd[k]; p.planes = ss->d_planes + (size_t)m0 * 2 * H * wp;
+        p.acc = d_acc + (size_t)m0 * 16; p.rowflags = d_rfl + (size_t)m0 * H; p.sums = d_sums + (size_t)m0 * 2;
         p.slice_lut = ctx->d_slice_lut;
         const dim3 grid((W + 255) / 256, H, nb);
-        hipLaunchKernelGGL(prep_flags_kernel, grid, dim3(256), 0, st, p);
-        hipLaunchKernelGGL(prep_hdist_kernel, grid, dim3(256), 0, st, p);
-        hipLaunchKernelGGL(prep_plane_kernel, grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL(prep_flags_kernel, grid, dim3(256), 0, sr, p);
+        hipLaunchKernelGGL(prep_hdist_kernel, grid, dim3(256), 0, sr, p);
+        hipLaunchKernelGGL(prep_plane_kernel, grid, dim3(256), 0, sr, p);
         SP_HIP(hipGetLastError());
-        SP_HIP(hipMemcpyAsync(acc.data(), d_acc, (size_t)nb * 16 * sizeof(int), hipMemcpyDeviceToHost, st));
-        SP_HIP(hipMemcpyAsync(rfl.data(), d_rfl, (size_t)nb * H * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        SP_HIP(hipMemcpyAsync(sums.data(), d_sums, (size_t)nb * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        SP_HIP(hipStreamSynchronize(st));
-        for (int i = 0; i < nb; i++) {
-            const int m = m0 + i;
-            const int *q = acc.data() + (size_t)16 * i;
-            int ya = q[0], yb = q[1], gx0 = q[2], gx1 = q[3], hx0 = q[4], hx1 = q[5];
-            if (yb <= ya) ya = yb = 0;
-            if (gx1 <= gx0) gx0 = gx1 = 0;
-            if (hx1 <= hx0) hx0 = hx1 = 0;
-            if (hx1 == 0 && gx1 > 0) { hx0 = gx0; hx1 = gx0; }   // empty QH window inside the gap window
-            if (gx1 == 0 && hx1 > 0) { gx0 = hx0; gx1 = hx0; }
-            int *bxm = boxes.data() + (size_t)8 * m;
-            bxm[0] = ya; bxm[1] = yb; bxm[2] = gx0; bxm[3] = gx1; bxm[4] = hx0; bxm[5] = hx1;
-            for (int y = 0; y < H; y++) rowflags[(size_t)m * H + y] = (uint8_t)rfl[(size_t)i * H + y];
-            ss->qm_sum[(size_t)m] = (int64_t)sums[(size_t)2 * i];
-            ss->qh_sum[(size_t)m] = (int64_t)sums[(size_t)2 * i + 1];
-        }
+    }
+    if (nset > 1) {   // join: the context's stream continues after the second stream's last round
+        SP_HIP(hipEventRecord(ev_b, st2));
+        SP_HIP(hipStreamWaitEvent(st, ev_b, 0));
+    }
+    SP_HIP(hipMemcpyAsync(acc.data(), d_acc, acc.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    SP_HIP(hipMemcpyAsync(rfl.data(), d_rfl, rfl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SP_HIP(hipMemcpyAsync(sums.data(), d_sums, sums.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    SP_HIP(hipStreamSynchronize(st));
+    for (int m = 0; m < n_masks; m++) {
+        const int *q = acc.data() + (size_t)16 * m;
+        int ya = q[0], yb = q[1], gx0 = q[2], gx1 = q[3], hx0 = q[4], hx1 = q[5];
+        if (yb <= ya) ya = yb = 0;
+        if (gx1 <= gx0) gx0 = gx1 = 0;
+        if (hx1 <= hx0) hx0 = hx1 = 0;
+        if (hx1 == 0 && gx1 > 0) { hx0 = gx0; hx1 = gx0; }   // empty QH window inside the gap window
+        if (gx1 == 0 && hx1 > 0) { gx0 = hx0; gx1 = hx0; }
+        int *bxm = boxes.data() + (size_t)8 * m;
+        bxm[0] = ya; bxm[1] = yb; bxm[2] = gx0; bxm[3] = gx1; bxm[4] = hx0; bxm[5] = hx1;
+        for (int y = 0; y < H; y++) rowflags[(size_t)m * H + y] = (uint8_t)rfl[(size_t)m * H + y];
+        ss->qm_sum[(size_t)m] = (int64_t)sums[(size_t)2 * m];
+        ss->qh_sum[(size_t)m] = (int64_t)sums[(size_t)2 * m + 1];
     }
     SP_HIP(hipMemcpyAsync(ss->d_rowflags, rowflags.data(), rowflags.size(), hipMemcpyHostToDevice, st));
     SP_HIP(hipMemcpyAsync(ss->d_boxes, boxes.data(), boxes.size() * sizeof(int), hipMemcpyHostToDevice, st));

@@ -208,6 +208,20 @@ __global__ __launch_bounds__(1024) void sparse_imgscan_kernel(BuildParams p) {
     if (threadIdx.x == 0) *p.total = carry_s - start;
 }
 
+// The 16-bit stage-1 stream of records [first, first + count) (see sparse_scan16_kernel): the record's upper half -- row flag, column,
+// band; a filler's band field set to 3 -- XOR 3, and a flagged filler behind the last record.
+__global__ __launch_bounds__(256) void sparse_px16_kernel(const uint32_t *px, uint16_t *px16, uint64_t first, uint64_t count) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k <= count; k += stride) {
+        uint32_t h = (uint32_t)kRecRowFlag >> 16 | 3u;   // the sentinel behind the last record
+        if (k < count) {
+            const uint32_t v = px[first + k];
+            h = v >> 16;
+            if ((v & 0xffffu) == 0u) h = (h & 0xffc0u) | 3u;   // a filler: max channel 0
+        }
+        px16[first + k] = (uint16_t)(h ^ 3u);
+    }
+}
 
 // Consistency of imported records (a shard file is untrusted input).  One thread per (image, strip, row) cell: the cell
 // holds at least one record; its first record -- and no other -- carries the row flag; a cell is either ONE filler record
@@ -399,6 +413,9 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                 const uint32_t *P;
                 uint32_t a, b;
                 header(0, P, a, b);
+#if SP_EXP == 8  // (timing only, with the loads-only body: HALF the bytes of every run -- the floor of a 2-byte stage-1 stream)
+                a >>= 1, b = (b + 1) >> 1;
+#endif
                 uint32_t cur[NB], nxt[NB];
                 load_blocks(P, a, b, cur);
                 int c[NC];
@@ -527,7 +544,12 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                             const uint32_t *Pq = P;
                             uint32_t iq = i, bq = b;
                             if (rem > 64 * NB) iq = i + 64 * NB;
-                            else if (r + 1 < nruns) header(r + 1, Pq, iq, bq);  // (read from the header lanes only now: no scalars held)
+                            else if (r + 1 < nruns) {
+                                header(r + 1, Pq, iq, bq);  // (read from the header lanes only now: no scalars held)
+#if SP_EXP == 8
+                                iq >>= 1, bq = (bq + 1) >> 1;
+#endif
+                            }
                             load_blocks(Pq, iq, bq, nxt);
                         }
                         // phase 1 of a block: row, columns and the two near-bitmap words of its pixels; a column outside the
@@ -604,7 +626,7 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                                 }
                             }
                         };
-                        if (LO || SP_EXP == 6 || SP_EXP == 7) {  // (timing only: the record loads and nothing else)
+                        if (LO || SP_EXP == 6 || SP_EXP == 7 || SP_EXP == 8) {  // (timing only: the record loads and nothing else)
                             uint32_t acc = 0;
 #pragma unroll
                             for (int j = 0; j < NB; j++) acc ^= cur[j];
@@ -627,10 +649,311 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
 #pragma unroll
                         for (int j = 0; j < NB; j++) cur[j] = nxt[j];
                     }
-                    if (r + 1 < nruns) header(r + 1, P, a, b);
+                    if (r + 1 < nruns) {
+                        header(r + 1, P, a, b);
+#if SP_EXP == 8
+                        a >>= 1, b = (b + 1) >> 1;
+#endif
+                    }
                     if (++kin < nsv) continue;  // more strips of this target
                     kin = 0;
                     finish_target(t0 + (uint32_t)(r / nsv));
+                }
+            }
+        }
+    }
+}
+
+// =================================================================================================
+//             the sparse scan over the 16-BIT STAGE-1 STREAM (round 4) -- the benchmark's `value`
+// =================================================================================================
+// Round 3 left the scan above waiting for its records: its loads-only twin took 0.85 of its time, at 0.66 of what a plain read of
+// the same bytes reaches.  Of a record's 32 bits stage 1 reads 16 -- row flag, strip-relative column, hue band -- and on a library
+// whose colours are unrelated to the mask's 98.5 % of the records never get past stage 1.  A sparse library therefore keeps those
+// upper halves a second time as a stream of their own (px16: 2 bytes per record, same record indices, same row pointers; +50 %
+// of record memory) and this kernel streams THAT: half the bytes per visited record, 128 records per load instruction and lane
+// pair.  A record that passes the band map is queued by its INDEX; an evaluation round fetches the 64 queued records themselves
+// (4 bytes each, one gather through the image's buffer descriptor) and applies the data threshold there -- stage 1 no longer sees
+// the maximum channel, so it passes the few signal pixels at or below the threshold on to a round, which drops them.
+// Everything else -- work distribution, run headers, band map, rounds, counters, slabs -- is the kernel above.
+// Stream encoding: px16[i] = (px[i] >> 16, a filler's band field set to 3) ^ 3, so that the zero a load beyond the run's end returns
+// (hardware range check) decodes to "no flag, band 3" = never a hit; px16[n] behind the last record is a flagged filler (a run of
+// odd length reads one record past its end: the first record of the next row -- always flagged, so it lands in a row of its own, for
+// which the band map keeps one more, empty, cell row).
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub_min_u16(uint32_t a, uint32_t b, uint32_t cap) {   // min(a - b, cap) per 16-bit half (wrapping subtract)
+    const u16x2 d = __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(d, __builtin_bit_cast(u16x2, cap)));
+}
+
+template <bool XY2, bool MIRROR, bool IVLDS, bool P8, int WPE, bool LO = false>
+__global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanParams p) {
+    extern __shared__ uint4 lds4[];
+    constexpr int NS = XY2 ? 9 : 1, NSX = XY2 ? 3 : 1, NO = MIRROR ? 2 : 1, NC = NS * NO;
+    constexpr int HALO = XY2 ? 2 : 0;
+    constexpr int NB = 4;            // dword loads (128 records each) in flight per wave
+    typedef typename std::conditional<P8, uint8_t, uint16_t>::type plane_t;
+    uint8_t *lds = reinterpret_cast<uint8_t *>(lds4);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint4 *ivt = lds4;
+    uint8_t *slab = lds + (IVLDS ? (size_t)p.n_iv * 16 : 0);
+    const plane_t *plane = reinterpret_cast<const plane_t *>(slab);
+    const uint32_t *nearb = reinterpret_cast<const uint32_t *>(slab + p.near_off);
+    uint8_t *qb = slab + p.slab_bytes + (size_t)wave * SP_QBYTES;
+    uint2 *q0 = reinterpret_cast<uint2 *>(qb), *q1 = q0 + SP_QCAP;
+    if (IVLDS)
+        for (int i = threadIdx.x; i < p.n_iv; i += blockDim.x) ivt[i] = p.iv[i];
+    const int safe_off = SP_PAD * p.pitch + SP_PAD;  // an in-range plane offset for idle lanes
+
+    for (int si = 0; si < p.n_slabs; si++) {
+        const int s = (int)((blockIdx.x + (unsigned)si) % (unsigned)p.n_slabs);  // every workgroup visits every slab
+        __syncthreads();  // the previous slab's waves are done with the LDS image
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.slabs + (size_t)s * p.slab_bytes);
+            uint4 *dst = reinterpret_cast<uint4 *>(slab);
+            for (int i = threadIdx.x; i < p.slab_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        }
+        __syncthreads();
+        const int ys0 = p.ylo + s * p.slab_rows;  // first mask row of the slab
+        const int rows_s = min(p.slab_rows, p.nrows - s * p.slab_rows);
+        const int ra = max(ys0 - HALO, 0), rb = min(ys0 + rows_s + HALO, p.H);  // target rows [ra, rb)
+        const int ry0 = ys0 - 2;
+        const uint32_t cx0 = (uint32_t)(p.xlo - 2), cm0 = (uint32_t)(p.W - 1) - cx0;
+        const uint32_t wnear = (uint32_t)((p.cols + 4 + 7) & ~7);  // first column of the band map's guard cell (always 0): the clamp target
+        // per-pixel constants in VGPRs (uniform values, pinned by the asm: the scalar registers hold the 18 counters and the loop state)
+        uint32_t v_thr, v_wnearpk, v_nwpr, v_pitch, poff, near_lds;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(near_lds) : "s"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)nearb));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_thr) : "s"(p.thr));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_wnearpk) : "s"(wnear * 0x10001u));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_nwpr) : "s"(p.nwpr * 4));  // bytes per cell row of the band map
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_pitch) : "s"(p.pitch));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(poff) : "s"(2 * p.pitch + 2));
+        // column strips of the library that the mask's plain window [xlo - 2, xhi + 2] and its mirror image can touch
+        int wlo = p.xlo - HALO, whi = p.xlo + p.cols - 1 + HALO;
+        if (MIRROR) {
+            const int mlo = p.W - 1 - whi, mhi = p.W - 1 - wlo;
+            wlo = min(wlo, mlo), whi = max(whi, mhi);
+        }
+        const int ks0 = max(wlo, 0) / p.strip_w, nsv = min(whi, p.W - 1) / p.strip_w - ks0 + 1;
+
+        for (int pi = 0; pi < p.nparts; pi++) {
+            const int part = (int)((blockIdx.x + (unsigned)pi) % (unsigned)p.nparts);
+            const uint32_t pbeg = (uint32_t)part * p.psize, pend = min(pbeg + p.psize, (uint32_t)p.count);  // count < 2^31
+            if (pbeg >= pend) continue;
+            uint32_t *ctr = p.work + ((size_t)s * p.nparts + part) * 32;
+            if (pi > 0 && __builtin_nontemporal_load(ctr) >= pend - pbeg) continue;
+            for (;;) {
+                uint32_t tb = 0;
+                if (lane == 0) tb = atomicAdd(ctr, (uint32_t)p.group);
+                tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
+                if (tb >= pend - pbeg) break;
+                const uint32_t t0 = pbeg + tb;
+                const int ng = (int)min((uint32_t)p.group, pend - t0);  // targets of this grab
+                const int nruns = ng * nsv;                              // runs: (target, visited strip), one header lane each
+                uint64_t h_off = 0;
+                uint32_t h_a = 0, h_b = 0;
+                if (lane < nruns) {
+                    const int g = lane / nsv, k = ks0 + lane - g * nsv;
+                    const int64_t ti = p.first + (int64_t)(t0 + (uint32_t)g);
+                    const uint32_t *rp = p.rowptr + ((size_t)ti * p.nstrips + k) * (p.H + 1);
+                    h_off = p.img_off[ti];
+                    h_a = rp[ra];
+                    h_b = rp[rb];
+                }
+                auto header = [&](int r, uint64_t &off, uint32_t &a, uint32_t &b) {
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h_off, r);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h_off >> 32), r);
+                    off = ((uint64_t)hi << 32) | lo;
+                    a = (uint32_t)__builtin_amdgcn_readlane((int)h_a, r);
+                    b = (uint32_t)__builtin_amdgcn_readlane((int)h_b, r);
+                };
+                // NB unconditional dword loads (two records each) through a descriptor of the image's stream [0, b) -- plus one record when
+                // the rest of the run is odd, see the head of this kernel; lanes and whole blocks beyond the run read 0
+                auto load_blocks = [&](uint64_t off, uint32_t i, uint32_t b, uint32_t (&r)[NB]) {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.px16 + off), 0, (int)((b + ((b - i) & 1u)) * 2u), 0x00020000);
+                    const uint32_t vo = (i + 2u * (uint32_t)lane) * 2u;
+#pragma unroll
+                    for (int j = 0; j < NB; j++) r[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(vo + 256u * j), 0, 0);
+                };
+                uint64_t off;
+                uint32_t a, b;
+                header(0, off, a, b);
+                uint32_t cur[NB], nxt[NB];
+                load_blocks(off, a, b, cur);
+                int c[NC];
+#pragma unroll
+                for (int k = 0; k < NC; k++) c[k] = 0;
+                int qh0 = 0, qt0 = 0, qh1 = 0, qt1 = 0;  // queue heads / tails (monotonic, wave-uniform)
+                int ql0 = 64, ql1 = 64;                  // head + 64: a full round is due when the tail reaches it
+                int kin = 0;                             // strip of the current run, relative to ks0
+
+                // evaluate up to 64 queued pixels of one orientation: every lane busy.  The records come from the image's 4-byte
+                // array now (entry.x = record index): one gather per round, and the data threshold is applied here.
+                auto round = [&](const uint2 *q, int &qh, int &ql, const int qt, int *cc) {
+                    const int n = min(qt - qh, 64);
+                    __builtin_amdgcn_wave_barrier();
+                    bool valid = lane < n;
+                    const uint2 ent = q[(qh + lane) & (SP_QCAP - 1)];
+                    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.px + off), 0, (int)0x7ffffffc, 0x00020000);
+                    const uint32_t r = __builtin_amdgcn_raw_buffer_load_b32(ri, valid ? (int)(ent.x * 4u) : 0, 0, 0);
+                    const int poffs = valid ? (int)ent.y : safe_off;
+                    valid = valid && (r & 255u) > v_thr;
+                    const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
+                    const uint32_t cls = (((r >> kRecBandShift) & kRecBandMask) * 13u) >> 6;  // band / 5 for bands 5..34
+                    uint32_t code = (cls << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
+                    code = valid ? code : 0u;  // 0 lies in no interval
+                    const plane_t *c0 = plane + poffs - (XY2 ? 2 : 0);  // (column offsets 0, 2, 4 below)
+                    uint32_t idx[NS];
+#pragma unroll
+                    for (int iy = 0; iy < NSX; iy++) {
+                        const plane_t *rowp = XY2 ? c0 + (1 - iy) * 2 * (int)p.pitch : c0;  // mask row = target row - dy
+#pragma unroll
+                        for (int ix = 0; ix < NSX; ix++) idx[ix * NSX + iy] = rowp[XY2 ? (2 - ix) * 2 : 0];  // mask column = target column - dx
+                    }
+                    constexpr int GS = WPE <= 4 ? 9 : 3;  // interval records in flight together
+#pragma unroll
+                    for (int k0 = 0; k0 < NS; k0 += GS) {
+                        uint4 iv[GS];
+#pragma unroll
+                        for (int k = 0; k < GS && k0 + k < NS; k++) iv[k] = IVLDS ? ivt[idx[k0 + k]] : p.iv[idx[k0 + k]];
+#pragma unroll
+                        for (int k = 0; k < GS && k0 + k < NS; k++) {
+                            const unsigned long long mb = __ballot((code - iv[k].x) <= iv[k].y) | __ballot((code - iv[k].z) <= iv[k].w);
+                            cc[k0 + k] += __popcll(mb);
+                        }
+                    }
+                    qh += n;
+                    ql = qh + 64;
+                };
+                auto append = [&](uint2 *q, int &qt, const unsigned long long hb, const bool hit, const uint32_t idx, const uint32_t po) {
+                    if (hit) {
+                        const int slot = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0))) & (SP_QCAP - 1);
+                        q[slot] = make_uint2(idx, po);
+                    }
+                    qt += __popcll(hb);
+                };
+                // end of a target: the rest of its queues, then its score (or this slab's per-transform counts)
+                auto finish_target = [&](const uint32_t t) {
+                    while (qt0 > qh0) round(q0, qh0, ql0, qt0, c);
+                    if (MIRROR)
+                        while (qt1 > qh1) round(q1, qh1, ql1, qt1, c + NS);
+                    if (p.partial) {  // per-transform counts of this slab: lane k holds transform k (the 18-entry layout of the ABI)
+                        int v = 0;
+#pragma unroll
+                        for (int k = 0; k < NS; k++) {
+                            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[k])), "n"(k));
+                            if (MIRROR) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[NS + k])), "n"(9 + k));
+                        }
+                        if (lane < CDS_N_TRANSFORMS) p.partial[((size_t)s * p.count + t) * CDS_N_TRANSFORMS + lane] = v;
+                    } else {
+                        int best = 0, bm = 0;
+#pragma unroll
+                        for (int k = 0; k < NS; k++) best = max(best, c[k]);
+                        if (MIRROR) {
+#pragma unroll
+                            for (int k = 0; k < NS; k++) bm = max(bm, c[NS + k]);
+                        }
+                        int32_t packed = best;
+                        if (MIRROR && bm > best) packed = (int32_t)((uint32_t)bm | 0x80000000u);
+                        if (lane == 0) p.out[t] = packed;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NC; k++) c[k] = 0;
+                    qh0 = qt0 = qh1 = qt1 = 0;
+                    ql0 = ql1 = 64;
+                };
+                for (int r = 0; r < nruns; r++) {  // wave-uniform
+                    int yrel = ra - 1 - ry0;  // (rows started before the current block) - 1, relative to the band map
+                    // a record's x is relative to its strip: the strip's first column goes into the run's two column origins (both halves)
+                    uint32_t v_cx0pk, v_cm0pk;
+                    {
+                        const uint32_t sbase = (uint32_t)(ks0 + kin) * (uint32_t)p.strip_w;
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(v_cx0pk) : "s"(((cx0 - sbase) & 0xffffu) * 0x10001u));
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(v_cm0pk) : "s"(((cm0 - sbase) & 0xffffu) * 0x10001u));
+                    }
+                    for (uint32_t i = a; i < b; i += 128 * NB) {  // wave-uniform
+                        const uint32_t rem = b - i;  // records of this run from block 0 of this iteration on
+                        {   // the next NB blocks -- of this run, or the first ones of the grab's next run -- are in flight while these are examined
+                            uint64_t oq = off;
+                            uint32_t iq = i, bq = b;
+                            if (rem > 128 * NB) iq = i + 128 * NB;
+                            else if (r + 1 < nruns) header(r + 1, oq, iq, bq);
+                            load_blocks(oq, iq, bq, nxt);
+                        }
+                        if (LO) {  // (the loads-only twin: the record loads and nothing else)
+                            uint32_t acc = 0;
+#pragma unroll
+                            for (int j = 0; j < NB; j++) acc ^= cur[j];
+                            c[0] += __popcll(__ballot(acc == 0x12345u));
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < NB; j++) {
+                                if (rem <= 128u * j) break;  // wave-uniform: a block beyond the run
+                                const uint32_t rec = cur[j] ^ 0x00030003u;
+                                // rows: records come in the order (lane 0 low, lane 0 high, lane 1 low, ...)
+                                const unsigned long long fbl = __ballot((rec & 0x8000u) != 0), fbh = __ballot((int)rec < 0);
+                                const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(fbh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbh,
+                                                        __builtin_amdgcn_mbcnt_hi((uint32_t)(fbl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbl, 0))));
+                                const uint32_t ryl = (uint32_t)yrel + before + __builtin_amdgcn_ubfe(rec, 15u, 1u), ryh = ryl + (rec >> 31);
+                                yrel += __popcll(fbl) + __popcll(fbh);
+                                // columns of both records at once (16-bit halves): x - origin, clamped to the guard cell
+                                const uint32_t xpk = (rec >> 6) & 0x01FF01FFu;
+                                const uint32_t cxp = pk_sub_min_u16(xpk, v_cx0pk, v_wnearpk);
+                                const uint32_t cxm = MIRROR ? pk_sub_min_u16(v_cm0pk, xpk, v_wnearpk) : 0u;
+                                // band-map words: map + (ry / 4) * row bytes + (column / 8) * 4
+                                typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+                                uint32_t rowl, rowh, al, ah;
+                                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rowl) : "v"(ryl >> 2), "v"(v_nwpr), "v"(near_lds));
+                                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rowh) : "v"(ryh >> 2), "v"(v_nwpr), "v"(near_lds));
+                                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(al) : "v"(__builtin_amdgcn_ubfe(cxp, 3u, 13u)), "v"(rowl));
+                                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ah) : "v"(cxp >> 19), "v"(rowh));
+                                const uint32_t wpl = *reinterpret_cast<lds_u32 *>((uintptr_t)al), wph = *reinterpret_cast<lds_u32 *>((uintptr_t)ah);
+                                uint32_t wml = 0, wmh = 0;
+                                if (MIRROR) {
+                                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(al) : "v"(__builtin_amdgcn_ubfe(cxm, 3u, 13u)), "v"(rowl));
+                                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ah) : "v"(cxm >> 19), "v"(rowh));
+                                    wml = *reinterpret_cast<lds_u32 *>((uintptr_t)al), wmh = *reinterpret_cast<lds_u32 *>((uintptr_t)ah);
+                                }
+                                // plane offset of column cx0 in the record's row: (ry + 2) * pitch + 2
+                                uint32_t prl, prh;
+                                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(prl) : "v"(ryl), "v"(v_pitch), "v"(poff));
+                                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(prh) : "v"(ryh), "v"(v_pitch), "v"(poff));
+                                const uint32_t idl = i + 128u * j + 2u * (uint32_t)lane;   // index of the low record in the image
+                                const uint32_t bh = rec >> 16;                             // (v_bfe takes the band mod 32 from the low bits)
+                                {
+                                    const bool hl = __builtin_amdgcn_ubfe(wpl, rec, 1u) != 0, hh = __builtin_amdgcn_ubfe(wph, bh, 1u) != 0;
+                                    const unsigned long long hbl = __ballot(hl), hbh = __ballot(hh);
+                                    if (hbl) {
+                                        append(q0, qt0, hbl, hl, idl, prl + (cxp & 0xffffu));
+                                        if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
+                                    }
+                                    if (hbh) {
+                                        append(q0, qt0, hbh, hh, idl + 1u, prh + (cxp >> 16));
+                                        if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
+                                    }
+                                }
+                                if (MIRROR) {
+                                    const bool hl = __builtin_amdgcn_ubfe(wml, rec, 1u) != 0, hh = __builtin_amdgcn_ubfe(wmh, bh, 1u) != 0;
+                                    const unsigned long long hbl = __ballot(hl), hbh = __ballot(hh);
+                                    if (hbl) {
+                                        append(q1, qt1, hbl, hl, idl, prl + (cxm & 0xffffu));
+                                        if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
+                                    }
+                                    if (hbh) {
+                                        append(q1, qt1, hbh, hh, idl + 1u, prh + (cxm >> 16));
+                                        if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
+                                    }
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < NB; j++) cur[j] = nxt[j];
+                    }
+                    // the target's last rounds gather from ITS image: finish before the header of the next run replaces `off`
+                    if (kin + 1 == nsv) finish_target(t0 + (uint32_t)(r / nsv));
+                    if (r + 1 < nruns) header(r + 1, off, a, b);
+                    kin = kin + 1 == nsv ? 0 : kin + 1;
                 }
             }
         }
@@ -972,7 +1295,9 @@ static size_t slab_image_bytes(int R, int pitch, int nwpr, int esize, int *near_
     const size_t plane = (size_t)round_up((R + 2 * SP_PAD) * pitch * esize, 16);
     if (near_off) *near_off = (int)plane;
 #if SP_BAND
-    return plane + (size_t)round_up(((R + 4 + 3) / 4) * nwpr * 4, 16);  // band map: one word per 4-row x 8-column cell
+    // band map: one word per 4-row x 8-column cell, rows 0 .. R + 3 of target positions -- and one more, always empty, cell row for
+    // row R + 4, where the 16-bit-stream scan lands the one record it may read past the end of a run (sparse_scan16_kernel)
+    return plane + (size_t)round_up(((R + 8) / 4) * nwpr * 4, 16);
 #else
     return plane + (size_t)round_up((R + 4) * nwpr * 4, 16);
 #endif
@@ -1374,13 +1699,17 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
 template <bool XY2, bool MIRROR>
 static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t lds_bytes, int threads, hipStream_t st) {
     const bool wide = lds_bytes > ctx->lds_per_block / 2 && !getenv("CDS_SPARSE_WPE8");  // one workgroup per CU: 4 waves per SIMD, 128 VGPRs
-    auto kern = wide ? (p.plane8 ? sparse_scan_kernel<XY2, MIRROR, true, true, 4>   // (<= 255 records: the table is in LDS)
-                        : p.iv_in_lds ? sparse_scan_kernel<XY2, MIRROR, true, false, 4> : sparse_scan_kernel<XY2, MIRROR, false, false, 4>)
-                     : (p.plane8 ? sparse_scan_kernel<XY2, MIRROR, true, true, 8>
-                        : p.iv_in_lds ? sparse_scan_kernel<XY2, MIRROR, true, false, 8> : sparse_scan_kernel<XY2, MIRROR, false, false, 8>);
+    // the 16-bit stage-1 stream when the library has it (CDS_SPARSE_SCAN32=1: the 4-byte-record kernel of round 3, for A/B runs)
+    const bool s16 = p.px16 != nullptr && !getenv("CDS_SPARSE_SCAN32");
+#define SP_PICK(K) (wide ? (p.plane8 ? K<XY2, MIRROR, true, true, 4>   /* (<= 255 records: the table is in LDS) */ \
+                         : p.iv_in_lds ? K<XY2, MIRROR, true, false, 4> : K<XY2, MIRROR, false, false, 4>)       \
+                      : (p.plane8 ? K<XY2, MIRROR, true, true, 8>                                              \
+                         : p.iv_in_lds ? K<XY2, MIRROR, true, false, 8> : K<XY2, MIRROR, false, false, 8>))
+    auto kern = s16 ? SP_PICK(sparse_scan16_kernel) : SP_PICK(sparse_scan_kernel);
+#undef SP_PICK
     if (ctx->sparse_load_only.load()) {   // (a diagnostic of THIS context only: cds_debug_sparse_load_only)
         if (!(wide && p.plane8)) return fail(CDS_ERR_UNSUPPORTED, "the load-only diagnostic exists for the one-workgroup-per-CU, one-byte-plane layout only");
-        kern = sparse_scan_kernel<XY2, MIRROR, true, true, 4, true>;
+        kern = s16 ? sparse_scan16_kernel<XY2, MIRROR, true, true, 4, true> : sparse_scan_kernel<XY2, MIRROR, true, true, 4, true>;
     }
     CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     // persistent grid: as many workgroups as fit (LDS and the 2048 threads of a CU), every one visits every slab
@@ -1500,6 +1829,7 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
         }
         SparseScanParams p{};
         p.px = sl->d_px; p.img_off = sl->d_img_off; p.rowptr = sl->d_rowptr;
+        p.px16 = sl->d_px16;
         p.first = first; p.count = count; p.W = sl->W; p.H = sl->H;
         p.nstrips = sl->nstrips; p.strip_w = sl->strip_w;
         p.slabs = ms->d_sp_slabs + pl.slabs_off;
@@ -1849,6 +2179,16 @@ int cds_sparse_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t ca
     if (e == hipSuccess) e = hipMalloc(&sl->d_rowptr, (size_t)capacity_images * sl->nstrips * (H + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(sl->d_img_off, 0, sizeof(uint64_t), ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) {
+        // the 16-bit stage-1 stream (+50 % of record memory): optional -- without it the scan reads the 4-byte records as before
+        const char *env = getenv("CDS_SPARSE_STREAM16");
+        if (!(env && atoi(env) == 0)) {
+            if (hipMalloc(&sl->d_px16, ((size_t)capacity_pixels + 2) * sizeof(uint16_t)) != hipSuccess) {
+                sl->d_px16 = nullptr;
+                (void)hipGetLastError();   // (not an error of this call: the library works without the stream)
+            }
+        }
+    }
     if (e != hipSuccess) {
         if (sl->d_px) hipFree(sl->d_px);
         if (sl->d_img_off) hipFree(sl->d_img_off);
@@ -1872,6 +2212,7 @@ void cds_sparse_library_destroy(cds_sparse_library *sl) {
     hipSetDevice(sl->ctx->device);
     hipStreamSynchronize(sl->ctx->stream);
     if (sl->stage) cds_library_destroy(sl->stage);
+    if (sl->d_px16) hipFree(sl->d_px16);
     if (sl->d_px) hipFree(sl->d_px);
     if (sl->d_img_off) hipFree(sl->d_img_off);
     if (sl->d_rowptr) hipFree(sl->d_rowptr);
@@ -1931,6 +2272,15 @@ static int density_refused(double density, double limit) {
              "(cds_library + cds_search) is faster there -- keep them in a cds_library, or raise the limit with cds_sparse_library_set_density_limit",
              100.0 * density, 100.0 * limit);
     return fail(CDS_ERR_UNSUPPORTED, buf);
+}
+
+// the derived 16-bit stream of records [first, first + count) (+ the sentinel behind them), on the library's stream
+static int refresh_px16(cds_sparse_library *sl, int64_t first, int64_t count) {
+    if (!sl->d_px16 || count <= 0) return CDS_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((count + 1 + 255) / 256, (int64_t)sl->ctx->n_cus * 32);
+    hipLaunchKernelGGL(sparse_px16_kernel, dim3(blocks), dim3(256), 0, sl->ctx->stream, sl->d_px, sl->d_px16, (uint64_t)first, (uint64_t)count);
+    CDS_HIP(hipGetLastError());
+    return CDS_OK;
 }
 
 // One APPEND CALL is a transaction: the density limit is tested on the call's average (AppendTally sums its sub-batches; a
@@ -2009,6 +2359,10 @@ static int sparse_append_locked(cds_sparse_library *sl, const cds_library *src, 
         }
         hipLaunchKernelGGL(sparse_rows_kernel<true>, dim3(row_blocks), dim3(256), 0, st, p);
         CDS_HIP(hipGetLastError());
+        {
+            const int rc16 = refresh_px16(sl, sl->n_px, (int64_t)total);
+            if (rc16) return rc16;
+        }
         sl->n_images += n;
         sl->n_px += (int64_t)total;
         done += n;
@@ -2204,6 +2558,10 @@ int cds_sparse_library_import(cds_sparse_library *sl, int64_t count, const uint6
                      err[0], err[1] - 1);
             return fail(CDS_ERR_INVALID_ARGUMENT, buf);
         }
+    }
+    {
+        const int rc16 = refresh_px16(sl, sl->n_px, (int64_t)n_rec);
+        if (rc16) return rc16;
     }
     CDS_HIP(hipStreamSynchronize(st));
     sl->n_images += count;

@@ -79,6 +79,7 @@ struct SynthParams {
     int pitch, gpitch, W, H, wpad;
     uint64_t seed;
     int64_t first_index, count;
+    const int64_t *index_list;   // NULL: image i of the launch is stream index first_index + i; else index_list[i]
     int kind;
     int blocks_per_image;
 };
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthParams p) {
     __shared__ int sK;
     const int64_t img = blockIdx.x / p.blocks_per_image;
     const int blk = blockIdx.x % p.blocks_per_image;
-    const uint64_t index = (uint64_t)(p.first_index + img);
+    const uint64_t index = (uint64_t)(p.index_list ? p.index_list[img] : p.first_index + img);
     if (p.kind == 0) {
         int K = 3 + (int)(draw(p.seed, index, 255, 0) % 10);
         if (threadIdx.x < K) make_stroke(strokes[threadIdx.x], p.seed, index, threadIdx.x, 2, 0, p.W, 0, p.H, 300, 900);
@@ -162,10 +163,29 @@ using namespace cds;
 
 extern "C" int cds_library_ensure_variants(cds_library *lib);
 
+static int generate_impl(cds_library *lib, uint64_t seed, int64_t first_index, const int64_t *indices, int64_t first_slot, int64_t count,
+                         int32_t kind, int32_t with_variants);
+
 extern "C" int cds_library_generate_synthetic(cds_library *lib, uint64_t seed, int64_t first_index, int64_t first_slot,
                                               int64_t count, int32_t kind, int32_t with_variants) {
+    if (first_index < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "first_index is negative");
+    return generate_impl(lib, seed, first_index, nullptr, first_slot, count, kind, with_variants);
+}
+
+// The same for an arbitrary LIST of stream indices (slot first_slot + i gets image indices[i]): how a benchmark makes the selected
+// targets of a gradient-score step resident -- the synthetic stand-in for loading just those targets' files.
+extern "C" int cds_library_generate_synthetic_list(cds_library *lib, uint64_t seed, const int64_t *indices, int64_t first_slot,
+                                                   int64_t count, int32_t kind, int32_t with_variants) {
+    if (count > 0 && !indices) return fail(CDS_ERR_INVALID_ARGUMENT, "indices is NULL");
+    for (int64_t i = 0; i < count; i++)
+        if (indices[i] < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "a stream index is negative");
+    return generate_impl(lib, seed, 0, indices, first_slot, count, kind, with_variants);
+}
+
+static int generate_impl(cds_library *lib, uint64_t seed, int64_t first_index, const int64_t *indices, int64_t first_slot, int64_t count,
+                         int32_t kind, int32_t with_variants) {
     if (!lib) return fail(CDS_ERR_INVALID_ARGUMENT, "library is NULL");
-    if (first_slot < 0 || count < 0 || first_slot + count > lib->capacity || first_index < 0)
+    if (first_slot < 0 || count < 0 || first_slot + count > lib->capacity)
         return fail(CDS_ERR_INVALID_ARGUMENT, "slot range outside the library");
     if (kind < 0 || kind > 2) return fail(CDS_ERR_INVALID_ARGUMENT, "kind must be 0, 1 or 2");
     if (with_variants && kind != 0) return fail(CDS_ERR_INVALID_ARGUMENT, "variants exist for kind 0 only");
@@ -175,6 +195,15 @@ extern "C" int cds_library_generate_synthetic(cds_library *lib, uint64_t seed, i
     if (with_variants) {
         int rc = cds_library_ensure_variants(lib);
         if (rc) return rc;
+    }
+    int64_t *d_idx = nullptr;
+    if (indices) {
+        CDS_HIP(hipMalloc(&d_idx, (size_t)count * sizeof(int64_t)));
+        const hipError_t e = hipMemcpy(d_idx, indices, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            hipFree(d_idx);
+            return hip_fail(e, "hipMemcpy(indices)");
+        }
     }
     SynthParams p{};
     p.rgb = lib->d_rgb + (size_t)first_slot * lib->img_stride;
@@ -194,14 +223,22 @@ extern "C" int cds_library_generate_synthetic(cds_library *lib, uint64_t seed, i
         if (p.zgap) q.zgap = p.zgap + (size_t)done * lib->img_stride;
         if (p.grad) q.grad = (uint16_t *)((uint8_t *)p.grad + (size_t)done * lib->grad_stride);
         q.first_index = first_index + done;
+        q.index_list = d_idx ? d_idx + done : nullptr;
         q.count = n;
         hipLaunchKernelGGL(synth_kernel, dim3((unsigned)(n * p.blocks_per_image)), dim3(256), 0, lib->ctx->stream, q);
-        CDS_HIP(hipGetLastError());
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            hipStreamSynchronize(lib->ctx->stream);
+            if (d_idx) hipFree(d_idx);
+            return hip_fail(e, "synth_kernel");
+        }
     }
     if (with_variants) {
         for (int64_t i = 0; i < count; i++) lib->has_grad[(size_t)(first_slot + i)] = 1;
         zgap_written(lib, first_slot, count);
     }
-    CDS_HIP(hipStreamSynchronize(lib->ctx->stream));
+    const hipError_t es = hipStreamSynchronize(lib->ctx->stream);
+    if (d_idx) hipFree(d_idx);
+    if (es != hipSuccess) return hip_fail(es, "hipStreamSynchronize");
     return CDS_OK;
 }

@@ -543,6 +543,57 @@ class GpuColorMIPSearchProcessor:
             w0 += batch
         return normalizeTable(table)
 
+    def calculateGradientScoresSelectedTable(self, masks, table: MatchTable, load_targets, queryThreshold, mirrorMask=True, roiMask=None,
+                                             excludedRegions=cds.label_regions, batch=8192, library=None) -> MatchTable:
+        """The gradient-score step when only the SELECTED targets are made resident (what the reference does: it opens the variant files
+        of the matches it scores, CalculateGradientScoresCmd.java:541-586): the distinct targets of the table's pairs are visited
+        `batch` at a time; `load_targets(lib, library_indices)` (int64 array, absolute: self.first added) fills slots 0..k-1 of `lib` with
+        those targets AND their gradient / zgap variants; one `cds_gradscore` launch per batch; per-mask normalisation on the host.
+        Against calculateGradientScoresBatchedTable (whole index windows): for BASELINE configs[4] 230 K distinct targets are loaded
+        instead of 1 M.  `self.last_gradscore` = {kernel_ms, launches, pairs, distinct_targets, mask_preparation_s, load_s, score_calls_s,
+        conversion_ms, converted_slots, launches_on_zslice_plane}."""
+        n = len(table)
+        table.gradientAreaGap = np.full(n, -1, dtype=np.int64)
+        table.highExpressionArea = np.full(n, -1, dtype=np.int64)
+        table.normalizedScore = np.zeros(n, dtype=np.float32)
+        st = {"kernel_ms": 0.0, "launches": 0, "pairs": 0, "distinct_targets": 0, "mask_preparation_s": 0.0, "load_s": 0.0, "score_calls_s": 0.0,
+              "conversion_ms": 0.0, "converted_slots": 0, "launches_on_zslice_plane": 0}
+        self.last_gradscore = st
+        if n == 0:
+            return table
+        ctx = library.ctx if library is not None else (self.library.ctx if self.library is not None else self.sparse_library.ctx)
+        t0 = time.perf_counter()
+        alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, queryThreshold, mirrorMask, roiMask, excludedRegions, context=ctx)
+        st["mask_preparation_s"] = time.perf_counter() - t0
+        lib = library if library is not None else cds.Library(alg.width, alg.height, int(batch), context=ctx)
+        batch = min(int(batch), lib.capacity)
+        distinct, inv = np.unique(table.targetIndex, return_inverse=True)
+        st["distinct_targets"] = int(len(distinct))
+        order = np.argsort(inv, kind="stable")
+        isorted = inv[order]
+        for b0 in range(0, len(distinct), batch):
+            idx = distinct[b0:b0 + batch]
+            lo, hi = np.searchsorted(isorted, b0), np.searchsorted(isorted, b0 + len(idx))
+            rows = order[lo:hi]
+            t0 = time.perf_counter()
+            load_targets(lib, self.first + idx.astype(np.int64))
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            gap, high, _ = alg.scoreLibraryPairs(lib, table.maskIndex[rows].astype(np.int32), (inv[rows] - b0).astype(np.int64))
+            st["load_s"] += t1 - t0
+            st["score_calls_s"] += time.perf_counter() - t1
+            table.gradientAreaGap[rows] = gap
+            table.highExpressionArea[rows] = high
+            ms, launches = alg.lastKernelMs()
+            plane, conv, cms = alg.lastCallInfo()
+            st["kernel_ms"] += ms * launches
+            st["launches"] += launches
+            st["pairs"] += len(rows)
+            st["conversion_ms"] += cms
+            st["converted_slots"] += conv
+            st["launches_on_zslice_plane"] += int(plane)
+        return normalizeTable(table)
+
     def calculateGradientScoresFromFilesTable(self, masks, table: MatchTable, target_files, gradient_files, zgap_files, queryThreshold,
                                               mirrorMask=True, roiMask=None, excludedRegions=cds.label_regions, batch=256, threads=8,
                                               zgap_radius=10) -> MatchTable:

@@ -101,6 +101,10 @@ int cds_library_download_variants(cds_library *lib, int64_t first, int64_t count
  * 1 dense-uniform target, 2 arbor mask.  with_variants != 0 also generates gradient + zgap (kind 0). */
 int cds_library_generate_synthetic(cds_library *lib, uint64_t seed, int64_t first_index, int64_t first_slot,
                                    int64_t count, int32_t kind, int32_t with_variants);
+/* The same for an arbitrary list of stream indices: slot first_slot + i gets image indices[i] (the synthetic stand-in for loading
+ * just the selected targets of a gradient-score step). */
+int cds_library_generate_synthetic_list(cds_library *lib, uint64_t seed, const int64_t *indices, int64_t first_slot,
+                                        int64_t count, int32_t kind, int32_t with_variants);
 
 /* ---- pixel-match scan (kernel 1) ----------------------------------------------------------------
  * cds_maskset_create == n x `new PixelMatchColorDepthSearchAlgorithm(...)`

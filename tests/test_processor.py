@@ -160,6 +160,39 @@ def test_batched_gradient_scores_equal_the_resident_ones(oracle):
     assert np.array_equal(batched.normalizedScore, full.normalizedScore)
     assert (batched.gradientAreaGap >= 0).all() and proc.last_gradscore["pairs"] == len(table)
     assert all(f % 16 == 0 and f + c <= n_t for f, c in calls) and calls[-1] == (48, 2)
+    # only the SELECTED targets resident (calculateGradientScoresSelectedTable): the distinct targets of the pairs, 16 at a time,
+    # through the list generator (== the contiguous generator image by image)
+    loaded = []
+
+    def load_sel(dst, idx):
+        loaded.append(idx.copy())
+        dst.generate_synthetic_list(0xC0FFEE, 7000 + idx, 0, kind=0, with_variants=True)
+
+    sel = proc.calculateGradientScoresSelectedTable(masks, table.take(np.arange(len(table))), load_sel, 20, batch=16, library=small)
+    assert np.array_equal(sel.gradientAreaGap, full.gradientAreaGap) and np.array_equal(sel.highExpressionArea, full.highExpressionArea)
+    assert np.array_equal(sel.normalizedScore, full.normalizedScore)
+    distinct = np.unique(table.targetIndex)
+    assert np.array_equal(np.concatenate(loaded), distinct) and proc.last_gradscore["distinct_targets"] == len(distinct)
+    assert proc.last_gradscore["pairs"] == len(table) and all(len(i) <= 16 for i in loaded)
+    # a processor over a sub-range of the library (first != 0): table indices are relative, the loaders get LIBRARY indices
+    proc2 = P.GpuColorMIPSearchProcessor(cds.ColorMIPSearch(0.0, 20, provider), lib, None, first=10, count=30, sparse_library=slib)
+    t2 = proc2.findAllColorDepthMatchesTable(masks)
+    assert len(t2) > 5 and t2.targetIndex.min() >= 0 and t2.targetIndex.max() < 30
+    want2 = proc2.calculateGradientScoresTable(masks, t2.take(np.arange(len(t2))), 20)
+    calls.clear()
+    got2 = proc2.calculateGradientScoresBatchedTable(masks, t2.take(np.arange(len(t2))), load, 20, batch=16, library=small)
+    assert np.array_equal(got2.gradientAreaGap, want2.gradientAreaGap) and np.array_equal(got2.highExpressionArea, want2.highExpressionArea)
+    assert all(10 <= f and f + c <= 40 for f, c in calls)          # (never beyond first + count: ADVICE round 3)
+    got3 = proc2.calculateGradientScoresSelectedTable(masks, t2.take(np.arange(len(t2))), load_sel, 20, batch=16, library=small)
+    assert np.array_equal(got3.gradientAreaGap, want2.gradientAreaGap)
+    # the list generator == the contiguous one
+    a, b = cds.Library(W, H, 3), cds.Library(W, H, 3)
+    a.generate_synthetic(0xC0FFEE, 7003, 0, 3, kind=0, with_variants=True)
+    b.generate_synthetic_list(0xC0FFEE, [7005, 7003, 7004], 0, kind=0, with_variants=True)
+    assert np.array_equal(a.download(0, 3), b.download(0, 3)[[1, 2, 0]])
+    ga, za = a.download_variants(0, 3)
+    gb, zb = b.download_variants(0, 3)
+    assert np.array_equal(ga, gb[[1, 2, 0]]) and np.array_equal(za, zb[[1, 2, 0]])
 
 
 @pytest.mark.gpu

@@ -18,6 +18,18 @@ def cds():
     return m
 
 
+@pytest.fixture(autouse=True, params=["policy", "zgap-bytes", "zslice-plane"])
+def s_of_z_source(request, monkeypatch):
+    """Every test of this module runs three times: with the library's own choice of where the scorer gets S(z) of the zgap pixels
+    (round 4: the zgap bytes when the targets serve few pairs, the converted zslice plane otherwise) and with either source forced
+    (CDS_SHAPE_ZSLICE, read per call) -- the two kernels must give the reference's numbers alike."""
+    if request.param == "policy":
+        monkeypatch.delenv("CDS_SHAPE_ZSLICE", raising=False)
+    else:
+        monkeypatch.setenv("CDS_SHAPE_ZSLICE", "0" if request.param == "zgap-bytes" else "1")
+    return request.param
+
+
 def test_overExpressesMaskExpression(cds, fixtures):
     # Shape2DMatchColorDepthSearchAlgorithmTest.overExpressesMaskExpression (:32-60)
     alg = cds.Shape2DMatchColorDepthSearchAlgorithm(fixtures["em_12191_FL"], 20, True, None, cds.label_regions)
@@ -238,3 +250,47 @@ def test_query_border_size(cds, fixtures, oracle, border):
     zg = oracle.make_zgap(t, 20, 10, E.STD_RECTS)
     s = alg_r.calculateMatchingScore(t, {cds.ComputeFileType.GradientImage: lambda: fixtures["grad_VT016795"], cds.ComputeFileType.ZGapImage: lambda: zg})
     assert (s.getGradientAreaGap(), s.getHighExpressionArea(), s.getScore(), s.isMirrored()) == q_r.score(t, fixtures["grad_VT016795"], zg)
+
+
+def test_where_the_slice_numbers_come_from(cds, oracle, s_of_z_source):
+    """The lazy zslice plane (round 4): uploading a zgap converts nothing; a scoring call converts the slots it needs only when it
+    brings enough pairs per slot (default 8), otherwise the scorer reads the zgap bytes; converted slots stay converted until their
+    zgap is written again; both sources give identical sums, equal to the oracle's."""
+    if s_of_z_source != "policy":
+        pytest.skip("the policy itself is under test")
+    rects = cds.label_regions(W)
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(9)])
+    lib = cds.Library(W, H, 4)
+    lib.generate_synthetic(0xC0FFEE, 60, 0, 4, kind=0, with_variants=True)
+    alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, 20, True, None, rects)
+    # 2 pairs per slot: the bytes
+    few = alg.scoreLibraryPairs(lib, [0, 1, 2, 3], [0, 0, 1, 1])
+    assert alg.lastCallInfo()[:2] == (False, 0)
+    # 9 pairs on slot 2: its plane is made (one slot converted), slot 3 is not touched
+    pm = np.arange(9, dtype=np.int32)
+    many = alg.scoreLibraryPairs(lib, pm, np.full(9, 2))
+    plane, conv, ms = alg.lastCallInfo()
+    assert (plane, conv) == (True, 1) and ms > 0
+    # again: nothing left to convert, still the plane; mixed with a stale slot and few pairs per stale slot: the bytes
+    again = alg.scoreLibraryPairs(lib, pm, np.full(9, 2))
+    assert alg.lastCallInfo()[:2] == (True, 0)
+    assert all(np.array_equal(a, b) for a, b in zip(many, again))
+    mixed = alg.scoreLibraryPairs(lib, [0, 1, 0], [2, 2, 3])
+    assert alg.lastCallInfo()[0] is False
+    assert (mixed[0][0], mixed[1][0]) == (many[0][0], many[1][0]) and (mixed[0][1], mixed[1][1]) == (many[0][1], many[1][1])
+    # the oracle on both sources
+    for (res, rows) in ((few, [(0, 0), (1, 0), (2, 1), (3, 1)]), (many, [(m, 2) for m in (0, 4, 8)])):
+        for k, (m, t) in enumerate(rows):
+            kk = k if res is few else m
+            zg, gr = oracle.synth_variants(0xC0FFEE, 60 + t)
+            want = oracle.ShapeQuery(masks[m], 20, True, rects).score(oracle.synth_image(0xC0FFEE, 60 + t, 0), gr, zg)
+            assert (int(res[0][kk]), int(res[1][kk]), bool(res[2][kk])) == (want[0], want[1], want[3])
+    # a new zgap in a converted slot makes its plane stale: the next many-pair call converts it again and sees the new image
+    z3, _ = oracle.synth_variants(0xC0FFEE, 63)
+    lib.upload_variants(2, zgaps=z3[None])
+    changed = alg.scoreLibraryPairs(lib, pm, np.full(9, 2))
+    assert alg.lastCallInfo()[:2] == (True, 1)
+    _, g2 = oracle.synth_variants(0xC0FFEE, 62)
+    want = oracle.ShapeQuery(masks[5], 20, True, rects).score(oracle.synth_image(0xC0FFEE, 62, 0), g2, z3)
+    assert (int(changed[0][5]), int(changed[1][5]), bool(changed[2][5])) == (want[0], want[1], want[3])
+    assert not np.array_equal(changed[0], many[0])

@@ -21,6 +21,18 @@ def cds():
     return m
 
 
+@pytest.fixture(autouse=True, params=["stream16", "records32"])
+def scan_kernel(request, monkeypatch):
+    """Every test of this module runs over both single-mask scan kernels: the one that streams the 16-bit stage-1 stream of the
+    library (round 4, the default whenever the library holds that stream) and round 3's, which streams the 4-byte records
+    (CDS_SPARSE_SCAN32=1, read per launch; also what a library without the stream gets).  Same results, bit for bit."""
+    if request.param == "records32":
+        monkeypatch.setenv("CDS_SPARSE_SCAN32", "1")
+    else:
+        monkeypatch.delenv("CDS_SPARSE_SCAN32", raising=False)
+    return request.param
+
+
 def sparse_of(cds, images, w=None, h=None, slack=0):
     images = np.ascontiguousarray(images, dtype=np.uint8)
     if images.ndim == 3:
@@ -890,3 +902,48 @@ def test_device_topk_equals_host_selection(cds, oracle):
         order = np.lexsort((np.arange(40), -scores[mi, 10:50].astype(np.int64)))
         assert np.array_equal(t[mi, :40], order) and (t[mi, 40:] == -1).all() and np.array_equal(s[mi, :40], scores[mi, 10:50][order])
     assert scores[9, 13] > 65536 and scores[4, 11] > 0
+
+
+def test_stage1_stream_is_derived_from_the_records_and_optional(cds, oracle, monkeypatch, scan_kernel):
+    """The 16-bit stream is derived data: a library created without it (CDS_SPARSE_STREAM16=0, or no device memory left for it) scans
+    through the 4-byte records and gives the same scores; runs of odd length, data thresholds that only stage 2 can apply (the stream
+    has no maximum channel) and targets appended after a rolled-back call are all covered by comparing the two kernels' 18 counts."""
+    if scan_kernel != "stream16":
+        pytest.skip("compares the two kernels itself")
+    rects = cds.label_regions(W)
+    rng = np.random.default_rng(21)
+    lut = oracle.depth_lut()
+    imgs = []
+    for i in range(10):
+        t = oracle.synth_image(0xC0FFEE, 800 + i, 0).copy()
+        dim = rng.random((H, W)) < 0.3                       # many signal pixels at or below the data thresholds used below
+        t[dim] = (t[dim].astype(np.int32) * 40 // 255).astype(np.uint8)
+        ys, xs = rng.integers(0, H, 300), rng.integers(0, W, 300)
+        t[ys, xs] = lut[rng.integers(0, 256, 300)]           # isolated pixels: rows with 1, 2, 3 records (odd run lengths)
+        imgs.append(t)
+    imgs = np.stack(imgs)
+    mask = oracle.synth_image(0xBADC0DE, 3, 2)
+    with_stream = sparse_of(cds, imgs)
+    monkeypatch.setenv("CDS_SPARSE_STREAM16", "0")
+    without = sparse_of(cds, imgs)
+    monkeypatch.delenv("CDS_SPARSE_STREAM16")
+    for thr, xy, mirror in ((20, 2, True), (60, 2, True), (35, 0, False), (100, 2, False)):
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, mirror, None, 0, False, thr, 0.02, xy, rects)
+        c16 = alg.searchSparseLibraryCounts(with_stream)
+        c32 = alg.searchSparseLibraryCounts(without)
+        assert np.array_equal(c16, c32), (thr, xy, mirror)
+        monkeypatch.setenv("CDS_SPARSE_SCAN32", "1")
+        assert np.array_equal(alg.searchSparseLibraryCounts(with_stream), c32)
+        monkeypatch.delenv("CDS_SPARSE_SCAN32")
+        q = oracle.PixelMatchQuery(mask, 20, thr, 0.02, xy, mirror, rects)
+        for t in (0, 5, 9):
+            assert np.array_equal(c16[0, t], q.score(imgs[t])[2]), (thr, xy, mirror, t)
+        assert c16.max() > 0
+    # after a refused (rolled back) append the stream of the NEXT append is right, the sentinel included (last image, last strip)
+    lib = cds.SparseLibrary(W, H, 16, int((imgs.max(axis=3) > 0).sum()) + 4 * H * 16 + 64 + (W * H + 4 * H), density_limit=0.2)
+    lib.append(imgs[:4])
+    with pytest.raises(cds.CdsError):
+        lib.append(np.stack([oracle.synth_image(0xC0FFEE, 1, 1)]))
+    lib.append(imgs[4:])
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.02, 2, rects)
+    assert np.array_equal(alg.searchSparseLibraryCounts(lib), alg.searchSparseLibraryCounts(without))
