@@ -283,6 +283,9 @@ __global__ __launch_bounds__(256) void sparse_validate_kernel(ValidateParams p) 
 #ifndef SP_NB
 #define SP_NB 4
 #endif
+#ifndef SP16_EXP
+#define SP16_EXP 0  // (timing experiments of sparse_scan16_kernel only: 1 = no rounds, 2 = rounds without the record gather, 3 = nothing queued)
+#endif
 #ifndef SP_EXP
 #define SP_EXP 0  // (timing experiments only: 1 = no evaluation rounds, 2 = nothing queued, 3 = no interval reads, 4 = no plane reads,
                   // 5 = interval reads on a quarter of the lanes, 6 = record loads only; the scores are wrong in all of them)
@@ -677,9 +680,9 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
 // the maximum channel, so it passes the few signal pixels at or below the threshold on to a round, which drops them.
 // Everything else -- work distribution, run headers, band map, rounds, counters, slabs -- is the kernel above.
 // Stream encoding: px16[i] = (px[i] >> 16, a filler's band field set to 3) ^ 3, so that the zero a load beyond the run's end returns
-// (hardware range check) decodes to "no flag, band 3" = never a hit; px16[n] behind the last record is a flagged filler (a run of
-// odd length reads one record past its end: the first record of the next row -- always flagged, so it lands in a row of its own, for
-// which the band map keeps one more, empty, cell row).
+// (hardware range check) decodes to "no flag, band 3" = never a hit.  A run whose rest is odd reads one record past its end (the
+// dword that holds its last record): the block in which a run ends replaces that record by the same neutral value (a wave-uniform
+// branch, once per run); px16[n] behind the library's last record is a filler, so that this read never sees unwritten memory.
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_sub_min_u16(uint32_t a, uint32_t b, uint32_t cap) {   // min(a - b, cap) per 16-bit half (wrapping subtract)
     const u16x2 d = __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b);
@@ -792,11 +795,18 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                 // array now (entry.x = record index): one gather per round, and the data threshold is applied here.
                 auto round = [&](const uint2 *q, int &qh, int &ql, const int qt, int *cc) {
                     const int n = min(qt - qh, 64);
+#if SP16_EXP == 1   // (timing only: no evaluation rounds)
+                    qh += n; ql = qh + 64; cc[0] += n; return;
+#endif
                     __builtin_amdgcn_wave_barrier();
                     bool valid = lane < n;
                     const uint2 ent = q[(qh + lane) & (SP_QCAP - 1)];
+#if SP16_EXP == 2   // (timing only: rounds without the gather of the records)
+                    const uint32_t r = ent.x * 2654435761u | 0x00050001u;
+#else
                     const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.px + off), 0, (int)0x7ffffffc, 0x00020000);
                     const uint32_t r = __builtin_amdgcn_raw_buffer_load_b32(ri, valid ? (int)(ent.x * 4u) : 0, 0, 0);
+#endif
                     const int poffs = valid ? (int)ent.y : safe_off;
                     valid = valid && (r & 255u) > v_thr;
                     const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
@@ -827,6 +837,9 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                     ql = qh + 64;
                 };
                 auto append = [&](uint2 *q, int &qt, const unsigned long long hb, const bool hit, const uint32_t idx, const uint32_t po) {
+#if SP16_EXP == 3   // (timing only: nothing queued)
+                    c[0] += __popcll(hb); return;
+#endif
                     if (hit) {
                         const int slot = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0))) & (SP_QCAP - 1);
                         q[slot] = make_uint2(idx, po);
@@ -890,7 +903,12 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
 #pragma unroll
                             for (int j = 0; j < NB; j++) {
                                 if (rem <= 128u * j) break;  // wave-uniform: a block beyond the run
-                                const uint32_t rec = cur[j] ^ 0x00030003u;
+                                uint32_t rec = cur[j] ^ 0x00030003u;
+                                if (rem < 128u * (j + 1)) {   // wave-uniform, once per run: the run ends inside this block.  When the rest of the run
+                                    // is odd, the dword holding its last record also holds the record BEHIND it (the first of the next row, strip or
+                                    // image): that one is not part of the scan -- turned into "no flag, band 3" like everything beyond the run
+                                    if (2u * (uint32_t)lane + 1u >= rem - 128u * j) rec = (rec & 0xffffu) | 0x00030000u;
+                                }
                                 // rows: records come in the order (lane 0 low, lane 0 high, lane 1 low, ...)
                                 const unsigned long long fbl = __ballot((rec & 0x8000u) != 0), fbh = __ballot((int)rec < 0);
                                 const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(fbh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbh,
