@@ -147,6 +147,7 @@ SIGNATURES = {
     "cds_debug_valu_issue_ns": (_i, [_vp, ctypes.POINTER(ctypes.c_double)]),
     "cds_debug_sparse_load_only": (_i, [_vp, ctypes.c_int32]),
     "cds_debug_sparse_load_only_state": (ctypes.c_int32, [_vp]),
+    "cds_debug_maskset_scan_kernel": (_i, [_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)]),
     "cds_debug_sparse_stream_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "cds_maskset_sparse_groups": (_i, [_vp, _i32p, _i32p, _i32p]),
     "cds_maskset_sparse_layout": (_i, [_vp, _i32, _i32p]),

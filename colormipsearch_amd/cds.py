@@ -767,6 +767,13 @@ class PixelMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
         capi.check(self._lib.cds_scores_topk(self._h, ctypes.c_void_p(int(d_scores_ptr)), int(count), int(k), capi.as_i32p(t), capi.as_i32p(s)))
         return t, (s & 0x7FFFFFFF).astype(np.int32), s < 0
 
+    def lastScanKernel(self):
+        """(kernel of the last single-mask sparse launch: 0 = 4-byte records, 1 = 16-bit stage-1 stream, -1 = none; share of visited records
+        that reached a round in the last pilot, -1 = no pilot yet) -- diagnostic."""
+        k, r = ctypes.c_int32(), ctypes.c_double()
+        capi.check(self._lib.cds_debug_maskset_scan_kernel(self._h, ctypes.byref(k), ctypes.byref(r)))
+        return k.value, r.value
+
     def sparseLayout(self, mask_index=0):
         """How the mask is laid out for the sparse scan (diagnostic): dict of slabs, rows per slab, LDS bytes, ..."""
         out = np.zeros(8, dtype=np.int32)

@@ -220,6 +220,7 @@ cds_context *clone_context_for_slot(cds_context *parent) {
         return nullptr;
     }
     c->stream = c->own_stream;
+    c->upload_stream = nullptr;   // (a pair-slot context prepares no mask sets)
     return c;
 }
 
@@ -307,10 +308,17 @@ int cds_context_create(int device_id, cds_context **out) {
         return hip_fail(se, "hipStreamCreate");
     }
     ctx->stream = ctx->own_stream;
+    se = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return hip_fail(se, "hipStreamCreate");
+    }
     int rc = init_rcp_table(ctx);
     if (rc == CDS_OK) rc = build_ratio_table(ctx->rcp, ctx->ratios);
     if (rc != CDS_OK) {
         hipStreamDestroy(ctx->own_stream);
+        hipStreamDestroy(ctx->upload_stream);
         delete ctx;
         return rc;
     }
@@ -323,6 +331,7 @@ void cds_context_destroy(cds_context *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->d_slice_lut && ctx->owns_lut) hipFree(ctx->d_slice_lut);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    if (ctx->upload_stream) hipStreamDestroy(ctx->upload_stream);
     delete ctx;
 }
 

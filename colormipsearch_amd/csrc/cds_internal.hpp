@@ -63,6 +63,9 @@ struct cds_context {
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t upload_stream = nullptr;   // mask-set uploads (own non-blocking stream: a mask set is prepared while earlier ones are being
+                                           // scanned on `stream`; its copies must neither queue behind those scans nor go through the
+                                           // legacy default stream's implicit synchronisation)
     int n_cus = 0;
     size_t lds_per_block = 0;
     float rcp[256];                        // v_rcp_f32 of 0..255 as THIS device computes it
@@ -239,6 +242,8 @@ struct SparseScanParams {
     int nparts;               // partitions of the targets, each with its own work counter
     uint32_t psize;           // targets per partition (the last one may hold fewer)
     uint32_t *work;           // [n_slabs][nparts] x 32 dwords: next target of the partition (zero before the launch)
+    int use16;                // scan through the 16-bit stage-1 stream (sparse_scan16_kernel) instead of the 4-byte records
+    unsigned long long *stat; // pilot launches of sparse_scan16_kernel: [0] += records visited, [1] += records queued for a round; else NULL
     int32_t *out;             // [count] score | mirrored << 31 (written directly when there is one slab and no partial)
     int32_t *partial;         // [n_slabs][count][18] per-transform counts of every slab, or NULL
 };
@@ -342,10 +347,26 @@ struct cds_maskset {
     uint8_t *d_sp_slabs = nullptr;
     uint4 *d_sp_iv = nullptr;
     uint32_t *d_sp_work = nullptr;   // work counters of one launch
+    // The single-mask slab images and interval tables go to the device when a single-mask launch first needs them: a mask set of the
+    // processor is scanned by the multi-mask kernel only (its groups have their own arrays) and never pays for that upload (20 MB per
+    // 128 masks).  Until then they wait here (guarded by sp_mu).
+    mutable std::vector<std::vector<uint8_t>> sp_host_slabs;
+    mutable std::vector<std::vector<uint4>> sp_host_iv;
+    mutable size_t sp_slab_total = 0, sp_iv_total = 0;
+    mutable bool sp_uploaded = false;
     std::vector<cds::SparseGroupPlan> sg_plans;   // multi-mask scan: groups of consecutive masks (empty for a single mask)
     uint8_t *d_sg_planes = nullptr, *d_sg_tmap = nullptr;
     uint4 *d_sg_iv = nullptr;
     mutable std::mutex sp_mu;        // one sparse search at a time per mask set (the work counters are shared)
+    // Which single-mask kernel scans a library that has the 16-bit stage-1 stream (cds_sparse.hip): decided per mask by a PILOT over
+    // the first targets of the first large search -- the share of visited records that reach an evaluation round -- and remembered
+    // for later searches of the same library (guarded by sp_mu).  -1 undecided, 0 the 4-byte-record kernel, 1 the stream kernel.
+    mutable std::vector<int8_t> s16_choice;
+    mutable const void *s16_lib = nullptr;
+    mutable int64_t s16_lib_images = -1;
+    mutable unsigned long long *d_s16_stat = nullptr;
+    mutable double last_pilot_ratio = -1;   // queued / (visited x orientations) of the last pilot (diagnostic)
+    mutable int last_scan_kernel = -1;      // kernel of the last single-mask launch: 0 / 1 as above
     // cds_score_pair: resident slots + device scores, created on first use
     mutable cds::PairSlotPool pair_pool;
     // timing of the last search

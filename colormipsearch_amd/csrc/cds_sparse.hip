@@ -45,6 +45,7 @@ namespace cds {
 
 constexpr int SP_QCAP = 128;                          // queue entries per wave and orientation (appends <= 64, drained at >= 64)
 constexpr int SP_QBYTES = 2 * SP_QCAP * 8;            // two queues of (u32 record, u32 plane offset): one 8-byte LDS access per entry
+constexpr int S16_QCAP = 256;                         // sparse_scan16_kernel: the same bytes as 256 one-dword entries per queue
 constexpr int SP_MAX_IV_LDS = 2048;                   // interval records kept in LDS (32 KB); larger tables are read from L2
 constexpr int SP_MAX_SLABS = 256;
 constexpr int SP_MAX_PARTS = 64;                      // work counters per slab (one per partition of the targets, 128 B apart)
@@ -739,6 +740,10 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
             wlo = min(wlo, mlo), whi = max(whi, mhi);
         }
         const int ks0 = max(wlo, 0) / p.strip_w, nsv = min(whi, p.W - 1) / p.strip_w - ks0 + 1;
+        uint32_t st_visited = 0, st_queued = 0;   // (pilot launches only: p.stat)
+        uint32_t v_hi1[4];   // position of the lane's HIGH record of block j, counted from block 0 of an iteration
+#pragma unroll
+        for (int j = 0; j < 4; j++) asm volatile("v_mov_b32 %0, %1" : "=v"(v_hi1[j]) : "v"(2u * (uint32_t)lane + 1u + 128u * j));
 
         for (int pi = 0; pi < p.nparts; pi++) {
             const int part = (int)((blockIdx.x + (unsigned)pi) % (unsigned)p.nparts);
@@ -791,24 +796,40 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                 int ql0 = 64, ql1 = 64;                  // head + 64: a full round is due when the tail reaches it
                 int kin = 0;                             // strip of the current run, relative to ks0
 
-                // evaluate up to 64 queued pixels of one orientation: every lane busy.  The records come from the image's 4-byte
-                // array now (entry.x = record index): one gather per round, and the data threshold is applied here.
-                auto round = [&](const uint2 *q, int &qh, int &ql, const int qt, int *cc) {
-                    const int n = min(qt - qh, 64);
-#if SP16_EXP == 1   // (timing only: no evaluation rounds)
-                    qh += n; ql = qh + 64; cc[0] += n; return;
-#endif
+                // A queue entry is ONE dword: record index (20 bits) | row << 20 (10 bits) | visited strip << 30; a queue holds 256 of
+                // them (the LDS bytes of the 128 x 8-byte entries of the kernel above), so that both halves of a block are appended
+                // before the queue is looked at: one "is a round due" test per block and orientation.
+                // An evaluation round = up to 64 queued pixels of one orientation, every lane busy, in two halves: FETCH reads the entries
+                // and requests the records themselves from the image's 4-byte array (one gather); EVAL applies the data threshold (stage
+                // 1 never saw the maximum channel), finds the pixel's column from the record and its strip, makes the hue code and runs the
+                // nine plane / interval lookups.  Apart so that a target's two last rounds have both gathers in flight together.
+                uint32_t *e0 = reinterpret_cast<uint32_t *>(q0), *e1 = e0 + S16_QCAP;
+                struct Fetched {
+                    uint32_t r, ent;
+                    bool valid;
+                };
+                auto fetch = [&](const uint32_t *q, const int qh, const int n) -> Fetched {
                     __builtin_amdgcn_wave_barrier();
-                    bool valid = lane < n;
-                    const uint2 ent = q[(qh + lane) & (SP_QCAP - 1)];
+                    Fetched f;
+                    f.valid = lane < n;
+                    f.ent = q[(qh + lane) & (S16_QCAP - 1)];
 #if SP16_EXP == 2   // (timing only: rounds without the gather of the records)
-                    const uint32_t r = ent.x * 2654435761u | 0x00050001u;
+                    f.r = f.ent * 2654435761u | 0x00050001u;
 #else
                     const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.px + off), 0, (int)0x7ffffffc, 0x00020000);
-                    const uint32_t r = __builtin_amdgcn_raw_buffer_load_b32(ri, valid ? (int)(ent.x * 4u) : 0, 0, 0);
+                    f.r = __builtin_amdgcn_raw_buffer_load_b32(ri, f.valid ? (int)((f.ent & 0xfffffu) * 4u) : 0, 0, 0);
 #endif
-                    const int poffs = valid ? (int)ent.y : safe_off;
-                    valid = valid && (r & 255u) > v_thr;
+                    return f;
+                };
+                auto eval = [&](const Fetched &f, const bool mirrored, int *cc) {
+                    const uint32_t r = f.r;
+                    const bool valid = f.valid && (r & 255u) > v_thr;
+                    // column: the record's strip-relative x + its strip's first column, relative to the window (mirrored: from the far end)
+                    const uint32_t xs = ((r >> kRecXShift) & kRecXMask) + (f.ent >> 30) * (uint32_t)p.strip_w + (uint32_t)ks0 * (uint32_t)p.strip_w;
+                    const uint32_t cx = mirrored ? cm0 - xs : xs - cx0;
+                    uint32_t po;
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(po) : "v"((f.ent >> 20) & 1023u), "v"(v_pitch), "v"(poff));   // (row + 2) * pitch + 2
+                    const int poffs = f.valid ? (int)(po + cx) : safe_off;
                     const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
                     const uint32_t cls = (((r >> kRecBandShift) & kRecBandMask) * 13u) >> 6;  // band / 5 for bands 5..34
                     uint32_t code = (cls << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
@@ -833,24 +854,46 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                             cc[k0 + k] += __popcll(mb);
                         }
                     }
+                };
+                auto round = [&](const uint32_t *q, int &qh, int &ql, const int qt, const bool mirrored, int *cc) {
+                    const int n = min(qt - qh, 64);
+#if SP16_EXP == 1   // (timing only: no evaluation rounds)
+                    qh += n; ql = qh + 64; cc[0] += n; return;
+#endif
+                    const Fetched f = fetch(q, qh, n);
+                    eval(f, mirrored, cc);
                     qh += n;
                     ql = qh + 64;
                 };
-                auto append = [&](uint2 *q, int &qt, const unsigned long long hb, const bool hit, const uint32_t idx, const uint32_t po) {
+                auto append = [&](uint32_t *q, int &qt, const unsigned long long hb, const bool hit, const uint32_t entry) {
 #if SP16_EXP == 3   // (timing only: nothing queued)
                     c[0] += __popcll(hb); return;
 #endif
                     if (hit) {
-                        const int slot = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0))) & (SP_QCAP - 1);
-                        q[slot] = make_uint2(idx, po);
+                        const int slot = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0))) & (S16_QCAP - 1);
+                        q[slot] = entry;
                     }
                     qt += __popcll(hb);
                 };
                 // end of a target: the rest of its queues, then its score (or this slab's per-transform counts)
                 auto finish_target = [&](const uint32_t t) {
-                    while (qt0 > qh0) round(q0, qh0, ql0, qt0, c);
+#if SP16_EXP == 1
+                    while (qt0 > qh0) round(e0, qh0, ql0, qt0, false, c);
                     if (MIRROR)
-                        while (qt1 > qh1) round(q1, qh1, ql1, qt1, c + NS);
+                        while (qt1 > qh1) round(e1, qh1, ql1, qt1, true, c + NS);
+#else
+                    while (qt0 - qh0 > 64) round(e0, qh0, ql0, qt0, false, c);
+                    if (MIRROR)
+                        while (qt1 - qh1 > 64) round(e1, qh1, ql1, qt1, true, c + NS);
+                    {   // the last (partial) round of either orientation: both gathers are requested before either is evaluated
+                        const int n0 = qt0 - qh0, n1 = MIRROR ? qt1 - qh1 : 0;
+                        Fetched f0{0u, 0u, false}, f1{0u, 0u, false};
+                        if (n0 > 0) f0 = fetch(e0, qh0, n0);
+                        if (n1 > 0) f1 = fetch(e1, qh1, n1);
+                        if (n0 > 0) eval(f0, false, c);
+                        if (n1 > 0) eval(f1, true, c + NS);
+                    }
+#endif
                     if (p.partial) {  // per-transform counts of this slab: lane k holds transform k (the 18-entry layout of the ABI)
                         int v = 0;
 #pragma unroll
@@ -873,11 +916,13 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                     }
 #pragma unroll
                     for (int k = 0; k < NC; k++) c[k] = 0;
+                    if (p.stat) st_queued += (uint32_t)(qt0 + qt1);
                     qh0 = qt0 = qh1 = qt1 = 0;
                     ql0 = ql1 = 64;
                 };
                 for (int r = 0; r < nruns; r++) {  // wave-uniform
                     int yrel = ra - 1 - ry0;  // (rows started before the current block) - 1, relative to the band map
+                    if (p.stat) st_visited += b - a;
                     // a record's x is relative to its strip: the strip's first column goes into the run's two column origins (both halves)
                     uint32_t v_cx0pk, v_cm0pk;
                     {
@@ -885,6 +930,7 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                         asm volatile("v_mov_b32 %0, %1" : "=v"(v_cx0pk) : "s"(((cx0 - sbase) & 0xffffu) * 0x10001u));
                         asm volatile("v_mov_b32 %0, %1" : "=v"(v_cm0pk) : "s"(((cm0 - sbase) & 0xffffu) * 0x10001u));
                     }
+                    const uint32_t kbits = (uint32_t)kin << 30;
                     for (uint32_t i = a; i < b; i += 128 * NB) {  // wave-uniform
                         const uint32_t rem = b - i;  // records of this run from block 0 of this iteration on
                         {   // the next NB blocks -- of this run, or the first ones of the grab's next run -- are in flight while these are examined
@@ -903,18 +949,18 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
 #pragma unroll
                             for (int j = 0; j < NB; j++) {
                                 if (rem <= 128u * j) break;  // wave-uniform: a block beyond the run
+                                // When the rest of the run is odd, the dword holding its last record also holds the record BEHIND it (the first
+                                // of the next row, strip or image): not part of the scan -- it becomes the neutral value, like everything beyond the
+                                // run.  (In a block the run does not end in, no lane's high record lies at or beyond `rem`.)
                                 uint32_t rec = cur[j] ^ 0x00030003u;
-                                if (rem < 128u * (j + 1)) {   // wave-uniform, once per run: the run ends inside this block.  When the rest of the run
-                                    // is odd, the dword holding its last record also holds the record BEHIND it (the first of the next row, strip or
-                                    // image): that one is not part of the scan -- turned into "no flag, band 3" like everything beyond the run
-                                    if (2u * (uint32_t)lane + 1u >= rem - 128u * j) rec = (rec & 0xffffu) | 0x00030000u;
-                                }
-                                // rows: records come in the order (lane 0 low, lane 0 high, lane 1 low, ...)
-                                const unsigned long long fbl = __ballot((rec & 0x8000u) != 0), fbh = __ballot((int)rec < 0);
+                                rec = (v_hi1[j] >= rem) ? ((rec & 0xffffu) | 0x00030000u) : rec;
+                                // rows: the records come in the order (lane 0 low half, lane 0 high half, lane 1 low half, ...)
+                                const uint32_t fl = __builtin_amdgcn_ubfe(rec, 15u, 1u);
+                                const unsigned long long fbl = __ballot(fl != 0), fbh = __ballot((int)rec < 0);
                                 const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(fbh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbh,
                                                         __builtin_amdgcn_mbcnt_hi((uint32_t)(fbl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbl, 0))));
-                                const uint32_t ryl = (uint32_t)yrel + before + __builtin_amdgcn_ubfe(rec, 15u, 1u), ryh = ryl + (rec >> 31);
-                                yrel += __popcll(fbl) + __popcll(fbh);
+                                const uint32_t ryl = (uint32_t)yrel + before + fl, ryh = ryl + (rec >> 31);
+                                yrel = __builtin_amdgcn_readlane((int)ryh, 63);   // (the last record's row: no scalar popcounts and adds)
                                 // columns of both records at once (16-bit halves): x - origin, clamped to the guard cell
                                 const uint32_t xpk = (rec >> 6) & 0x01FF01FFu;
                                 const uint32_t cxp = pk_sub_min_u16(xpk, v_cx0pk, v_wnearpk);
@@ -933,34 +979,25 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                                     asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ah) : "v"(cxm >> 19), "v"(rowh));
                                     wml = *reinterpret_cast<lds_u32 *>((uintptr_t)al), wmh = *reinterpret_cast<lds_u32 *>((uintptr_t)ah);
                                 }
-                                // plane offset of column cx0 in the record's row: (ry + 2) * pitch + 2
-                                uint32_t prl, prh;
-                                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(prl) : "v"(ryl), "v"(v_pitch), "v"(poff));
-                                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(prh) : "v"(ryh), "v"(v_pitch), "v"(poff));
-                                const uint32_t idl = i + 128u * j + 2u * (uint32_t)lane;   // index of the low record in the image
-                                const uint32_t bh = rec >> 16;                             // (v_bfe takes the band mod 32 from the low bits)
+                                const uint32_t idl = (i + 128u * j + 2u * (uint32_t)lane) | kbits;   // index of the low record in the image | strip
+                                const uint32_t bh = rec >> 16;                                        // (v_bfe takes the band mod 32 from the low bits)
+                                const uint32_t enl = idl | (ryl << 20), enh = (idl + 1u) | (ryh << 20);
                                 {
                                     const bool hl = __builtin_amdgcn_ubfe(wpl, rec, 1u) != 0, hh = __builtin_amdgcn_ubfe(wph, bh, 1u) != 0;
                                     const unsigned long long hbl = __ballot(hl), hbh = __ballot(hh);
-                                    if (hbl) {
-                                        append(q0, qt0, hbl, hl, idl, prl + (cxp & 0xffffu));
-                                        if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
-                                    }
-                                    if (hbh) {
-                                        append(q0, qt0, hbh, hh, idl + 1u, prh + (cxp >> 16));
-                                        if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
+                                    if (hbl | hbh) {
+                                        if (hbl) append(e0, qt0, hbl, hl, enl);
+                                        if (hbh) append(e0, qt0, hbh, hh, enh);
+                                        while (qt0 >= ql0) round(e0, qh0, ql0, qt0, false, c);
                                     }
                                 }
                                 if (MIRROR) {
                                     const bool hl = __builtin_amdgcn_ubfe(wml, rec, 1u) != 0, hh = __builtin_amdgcn_ubfe(wmh, bh, 1u) != 0;
                                     const unsigned long long hbl = __ballot(hl), hbh = __ballot(hh);
-                                    if (hbl) {
-                                        append(q1, qt1, hbl, hl, idl, prl + (cxm & 0xffffu));
-                                        if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
-                                    }
-                                    if (hbh) {
-                                        append(q1, qt1, hbh, hh, idl + 1u, prh + (cxm >> 16));
-                                        if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
+                                    if (hbl | hbh) {
+                                        if (hbl) append(e1, qt1, hbl, hl, enl);
+                                        if (hbh) append(e1, qt1, hbh, hh, enh);
+                                        while (qt1 >= ql1) round(e1, qh1, ql1, qt1, true, c + NS);
                                     }
                                 }
                             }
@@ -974,6 +1011,10 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                     kin = kin + 1 == nsv ? 0 : kin + 1;
                 }
             }
+        }
+        if (p.stat && lane == 0 && (st_visited | st_queued)) {   // (pilot launches: this wave's share of the statistics)
+            atomicAdd(p.stat, (unsigned long long)st_visited);
+            atomicAdd(p.stat + 1, (unsigned long long)st_queued);
         }
     }
 }
@@ -1343,6 +1384,8 @@ static uint32_t band_bits_of(uint32_t lo, uint32_t len) {
 #endif
 
 void free_sparse_plans(cds_maskset *ms) {
+    if (ms->d_s16_stat) hipFree(ms->d_s16_stat);
+    ms->d_s16_stat = nullptr;
     if (ms->d_sp_slabs) hipFree(ms->d_sp_slabs);
     if (ms->d_sp_iv) hipFree(ms->d_sp_iv);
     if (ms->d_sp_work) hipFree(ms->d_sp_work);
@@ -1356,6 +1399,9 @@ void free_sparse_plans(cds_maskset *ms) {
     ms->d_sp_iv = nullptr;
     ms->d_sp_work = nullptr;
     ms->sp_plans.clear();
+    std::vector<std::vector<uint8_t>>().swap(ms->sp_host_slabs);
+    std::vector<std::vector<uint4>>().swap(ms->sp_host_iv);
+    ms->sp_uploaded = false;
 }
 
 static int sparse_threads() {
@@ -1542,18 +1588,54 @@ static int build_group_plans(cds_maskset *ms, const std::vector<std::vector<Mask
         ms->sg_plans.clear();
         return CDS_OK;
     }
+    hipStream_t up = ms->ctx->upload_stream ? ms->ctx->upload_stream : ms->ctx->stream;
     hipError_t e = hipMalloc(&ms->d_sg_planes, planes_total);
     if (e == hipSuccess) e = hipMalloc(&ms->d_sg_tmap, tmap_total);
     if (e == hipSuccess) e = hipMalloc(&ms->d_sg_iv, iv_total * sizeof(uint4));
     for (size_t g = 0; g < n_groups && e == hipSuccess; g++) {
         const SparseGroupPlan &gp = ms->sg_plans[g];
         if (!gp.ok) continue;
-        e = hipMemcpy(ms->d_sg_planes + gp.planes_off, planes_of[g].data(), planes_of[g].size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(ms->d_sg_tmap + gp.tmap_off, tmap_of[g].data(), tmap_of[g].size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(ms->d_sg_iv + gp.iv_off, iv_of[g].data(), iv_of[g].size() * sizeof(uint4), hipMemcpyHostToDevice);
+        // (on the context's upload stream: these copies neither wait for the scans of earlier mask sets nor stall them)
+        e = hipMemcpyAsync(ms->d_sg_planes + gp.planes_off, planes_of[g].data(), planes_of[g].size(), hipMemcpyHostToDevice, up);
+        if (e == hipSuccess) e = hipMemcpyAsync(ms->d_sg_tmap + gp.tmap_off, tmap_of[g].data(), tmap_of[g].size(), hipMemcpyHostToDevice, up);
+        if (e == hipSuccess) e = hipMemcpyAsync(ms->d_sg_iv + gp.iv_off, iv_of[g].data(), iv_of[g].size() * sizeof(uint4), hipMemcpyHostToDevice, up);
+    }
+    {
+        const hipError_t es = hipStreamSynchronize(up);   // (the host vectors go out of scope; later searches run on another stream)
+        if (e == hipSuccess) e = es;
     }
     if (e != hipSuccess) return hip_fail(e, "sparse group plans");
 #endif
+    return CDS_OK;
+}
+
+// the single-mask plans' slab images and interval tables -> device (once; the caller holds sp_mu or is the creating thread)
+static int upload_single_plans(const cds_maskset *ms) {
+    if (ms->sp_uploaded) return CDS_OK;
+    cds_context *ctx = ms->ctx;
+    cds_maskset *w = const_cast<cds_maskset *>(ms);
+    hipSetDevice(ctx->device);
+    hipStream_t up = ctx->upload_stream ? ctx->upload_stream : ctx->stream;   // (neither behind the scans of `stream` nor stalling them)
+    hipError_t e = hipMalloc(&w->d_sp_slabs, std::max<size_t>(ms->sp_slab_total, 16));
+    if (e == hipSuccess) e = hipMalloc(&w->d_sp_iv, std::max<size_t>(ms->sp_iv_total, 1) * sizeof(uint4));
+    for (size_t m = 0; m < ms->sp_host_slabs.size() && e == hipSuccess; m++) {
+        if (ms->sp_host_slabs[m].empty()) continue;
+        e = hipMemcpyAsync(w->d_sp_slabs + ms->sp_plans[m].slabs_off, ms->sp_host_slabs[m].data(), ms->sp_host_slabs[m].size(), hipMemcpyHostToDevice, up);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(w->d_sp_iv + ms->sp_plans[m].iv_off, ms->sp_host_iv[m].data(), ms->sp_host_iv[m].size() * sizeof(uint4), hipMemcpyHostToDevice, up);
+    }
+    const hipError_t es = hipStreamSynchronize(up);
+    if (e == hipSuccess) e = es;
+    if (e != hipSuccess) {
+        if (w->d_sp_slabs) hipFree(w->d_sp_slabs);
+        if (w->d_sp_iv) hipFree(w->d_sp_iv);
+        w->d_sp_slabs = nullptr;
+        w->d_sp_iv = nullptr;
+        return hip_fail(e, "sparse mask plans (upload)");
+    }
+    std::vector<std::vector<uint8_t>>().swap(w->sp_host_slabs);
+    std::vector<std::vector<uint4>>().swap(w->sp_host_iv);
+    w->sp_uploaded = true;
     return CDS_OK;
 }
 
@@ -1687,20 +1769,22 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
     }
     hipSetDevice(ctx->device);
     hipError_t e = hipSuccess;
-    if (slab_total > 0) {
-        e = hipMalloc(&ms->d_sp_slabs, slab_total);
-        if (e == hipSuccess) e = hipMalloc(&ms->d_sp_iv, iv_total * sizeof(uint4));
-        if (e == hipSuccess) e = hipMalloc(&ms->d_sp_work, (size_t)SP_MAX_SLABS * SP_MAX_PARTS * 32 * sizeof(uint32_t));
-        for (size_t m = 0; m < n_masks && e == hipSuccess; m++) {
-            if (slab_of[m].empty()) continue;
-            e = hipMemcpy(ms->d_sp_slabs + ms->sp_plans[m].slabs_off, slab_of[m].data(), slab_of[m].size(), hipMemcpyHostToDevice);
-            if (e == hipSuccess)
-                e = hipMemcpy(ms->d_sp_iv + ms->sp_plans[m].iv_off, iv_of[m].data(), iv_of[m].size() * sizeof(uint4), hipMemcpyHostToDevice);
-        }
-    }
+    if (slab_total > 0) e = hipMalloc(&ms->d_sp_work, (size_t)SP_MAX_SLABS * SP_MAX_PARTS * 32 * sizeof(uint32_t));
     if (e != hipSuccess) {
         free_sparse_plans(ms);
         return hip_fail(e, "sparse mask plans");
+    }
+    ms->sp_host_slabs = std::move(slab_of);
+    ms->sp_host_iv = std::move(iv_of);
+    ms->sp_slab_total = slab_total;
+    ms->sp_iv_total = iv_total;
+    ms->sp_uploaded = slab_total == 0;
+    if (n_masks == 1 || getenv("CDS_SPARSE_EAGER_UPLOAD")) {   // a single mask is scanned by the single-mask kernel: upload now
+        const int rc = upload_single_plans(ms);
+        if (rc) {
+            free_sparse_plans(ms);
+            return rc;
+        }
     }
     pt.lap("  single-mask plans (upload)");
     if (slab_total > 0) {
@@ -1714,11 +1798,16 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
     return CDS_OK;
 }
 
+// can a library / mask pair go through sparse_scan16_kernel at all?  (The library holds the stream; the kernel's queue entries hold record
+// index, row and visited strip in one dword: images of up to 2^20 records, 1,016 rows, 4 strips.)
+static bool stream16_possible(const SparseScanParams &p) {
+    return p.px16 != nullptr && p.nstrips <= 4 && p.H <= 1016 && (int64_t)p.W * p.H + (int64_t)p.nstrips * p.H < ((int64_t)1 << 20);
+}
+
 template <bool XY2, bool MIRROR>
 static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t lds_bytes, int threads, hipStream_t st) {
     const bool wide = lds_bytes > ctx->lds_per_block / 2 && !getenv("CDS_SPARSE_WPE8");  // one workgroup per CU: 4 waves per SIMD, 128 VGPRs
-    // the 16-bit stage-1 stream when the library has it (CDS_SPARSE_SCAN32=1: the 4-byte-record kernel of round 3, for A/B runs)
-    const bool s16 = p.px16 != nullptr && !getenv("CDS_SPARSE_SCAN32");
+    const bool s16 = p.use16 != 0;   // (decided by the caller: sparse_search_impl)
 #define SP_PICK(K) (wide ? (p.plane8 ? K<XY2, MIRROR, true, true, 4>   /* (<= 255 records: the table is in LDS) */ \
                          : p.iv_in_lds ? K<XY2, MIRROR, true, false, 4> : K<XY2, MIRROR, false, false, 4>)       \
                       : (p.plane8 ? K<XY2, MIRROR, true, true, 8>                                              \
@@ -1845,6 +1934,13 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
             if (cnt) SP_HIP(hipMemsetAsync(cnt, 0, (size_t)count * CDS_N_TRANSFORMS * sizeof(int32_t), st));
             return CDS_OK;
         }
+        if (!ms->sp_uploaded) {   // (first single-mask launch of a set prepared for the multi-mask kernel)
+            const int urc = upload_single_plans(ms);
+            if (urc) {
+                cleanup();
+                return urc;
+            }
+        }
         SparseScanParams p{};
         p.px = sl->d_px; p.img_off = sl->d_img_off; p.rowptr = sl->d_rowptr;
         p.px16 = sl->d_px16;
@@ -1863,6 +1959,64 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
         p.out = out;
         const bool use_partial = cnt != nullptr || pl.n_slabs > 1;
         p.partial = use_partial ? partial : nullptr;
+        // Which kernel.  A library with the 16-bit stage-1 stream can be scanned through it (half the bytes per visited record; a round
+        // then gathers its 64 records) or through the 4-byte records as before.  The stream wins when few visited records reach a round
+        // (a library whose colours are unrelated to the mask's: 1.5 % on the synthetic one, or a mask much narrower than the strips) and
+        // loses when many do (the reference's LM images against the EM masks that overlap them: a third to a half).  That share is a
+        // property of the (mask, library) pair, so the first large single-slab search MEASURES it on a pilot of its first targets
+        // (p.stat) and the choice is remembered for later searches of the same library.  CDS_SPARSE_SCAN16=1 / CDS_SPARSE_SCAN32=1
+        // force a kernel (tests, A/B runs).  Small searches and multi-slab masks take the 4-byte records.
+        int use16 = 0;
+        int64_t pilot = 0;
+        if (stream16_possible(p)) {
+            if (getenv("CDS_SPARSE_SCAN32")) use16 = 0;
+            else if (getenv("CDS_SPARSE_SCAN16")) use16 = 1;
+            else {
+                if (ms->s16_lib != (const void *)sl || ms->s16_lib_images != sl->n_images || ms->s16_choice.size() != (size_t)ms->n_masks) {
+                    ms->s16_choice.assign((size_t)ms->n_masks, (int8_t)-1);
+                    ms->s16_lib = (const void *)sl;
+                    ms->s16_lib_images = sl->n_images;
+                }
+                const int known = ms->s16_choice[(size_t)m];
+                if (known >= 0) use16 = known;
+                else if (!use_partial && count >= 16384 && !ctx->sparse_load_only.load()) pilot = 4096;
+            }
+        }
+        if (pilot > 0) {
+            if (!ms->d_s16_stat) SP_HIP(hipMalloc(&ms->d_s16_stat, 2 * sizeof(unsigned long long)));
+            SP_HIP(hipMemsetAsync(ms->d_s16_stat, 0, 2 * sizeof(unsigned long long), st));
+            SparseScanParams q = p;
+            q.count = pilot;
+            q.nparts = 1;
+            q.psize = (uint32_t)pilot;
+            q.group = 1;
+            q.use16 = 1;
+            q.stat = ms->d_s16_stat;
+            SP_HIP(hipMemsetAsync(ms->d_sp_work, 0, (size_t)pl.n_slabs * 32 * sizeof(uint32_t), st));
+            const int prc = launch_sparse(ctx, q, pl.lds_bytes, threads, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
+            if (prc) {
+                cleanup();
+                return prc;
+            }
+            unsigned long long stat[2] = {0, 0};
+            SP_HIP(hipMemcpyAsync(stat, ms->d_s16_stat, sizeof stat, hipMemcpyDeviceToHost, st));
+            SP_HIP(hipStreamSynchronize(st));
+            const double ratio = stat[0] ? (double)stat[1] / ((double)stat[0] * (ms->params.mirror ? 2 : 1)) : 0.0;
+            double limit = 0.05;
+            if (const char *e = getenv("CDS_SPARSE_PILOT_LIMIT")) limit = atof(e);
+            use16 = ratio <= limit ? 1 : 0;
+            ms->s16_choice[(size_t)m] = (int8_t)use16;
+            ms->last_pilot_ratio = ratio;
+            launches++;
+            // the rest of the range with the chosen kernel (the pilot's scores stand: both kernels give the same)
+            p.first = first + pilot;
+            p.count = count - pilot;
+            p.out = out + pilot;
+            p.psize = (uint32_t)((p.count + nparts - 1) / nparts);
+        }
+        p.use16 = use16;
+        p.stat = nullptr;
+        ms->last_scan_kernel = use16;
         SP_HIP(hipMemsetAsync(ms->d_sp_work, 0, (size_t)pl.n_slabs * nparts * 32 * sizeof(uint32_t), st));
         const int lrc = launch_sparse(ctx, p, pl.lds_bytes, threads, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
         if (lrc) {
@@ -2915,6 +3069,16 @@ int cds_search_sparse_counts(const cds_maskset *ms, const cds_sparse_library *sl
     return sparse_search_host(ms, sl, first, count, nullptr, nullptr, counts);
 }
 
+
+// which single-mask kernel the last sparse search of this mask set launched (0: 4-byte records, 1: the 16-bit stage-1 stream, -1: none yet)
+// and the share of visited records that reached an evaluation round in its last pilot (-1: no pilot yet)
+int cds_debug_maskset_scan_kernel(const cds_maskset *ms, int32_t *kernel, double *pilot_ratio) {
+    if (!ms) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(ms->sp_mu);
+    if (kernel) *kernel = ms->last_scan_kernel;
+    if (pilot_ratio) *pilot_ratio = ms->last_pilot_ratio;
+    return CDS_OK;
+}
 
 // per CONTEXT: another context's searches (another thread's, another GPU's) are never affected
 int cds_debug_sparse_load_only(cds_context *ctx, int32_t on) {

@@ -41,6 +41,11 @@ int cds_debug_valu_issue_ns(cds_context *ctx, double *ns_per_wave_instruction_pe
  * another GPU's, a mask set's pair slots) are never affected.  cds_debug_sparse_load_only_state reads it back. */
 int cds_debug_sparse_load_only(cds_context *ctx, int32_t on);
 int32_t cds_debug_sparse_load_only_state(const cds_context *ctx);
+/* Which single-mask kernel the last sparse search of this mask set launched: 0 = over the 4-byte records, 1 = over the library's 16-bit
+ * stage-1 stream (half the bytes per visited record), -1 = none yet; pilot_ratio = the share of visited records that reached an evaluation
+ * round in the set's last pilot (the first 4,096 targets of the first search of >= 16,384 targets of a library holding the stream; the
+ * stream is used when it is <= 0.05), -1 = no pilot yet.  CDS_SPARSE_SCAN16=1 / CDS_SPARSE_SCAN32=1 force a kernel. */
+int cds_debug_maskset_scan_kernel(const cds_maskset *ms, int32_t *kernel, double *pilot_ratio);
 /* Reference point of the same measurement: a plain streaming read of the library's whole record arena (16 bytes per lane, four loads in
  * flight, fastest of three launches) -- the rate THIS device's HBM delivers for the simplest pattern over the same memory. */
 int cds_debug_sparse_stream_read(const cds_sparse_library *slib, double *gb_per_s, double *bytes_read);

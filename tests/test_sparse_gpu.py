@@ -26,10 +26,9 @@ def scan_kernel(request, monkeypatch):
     """Every test of this module runs over both single-mask scan kernels: the one that streams the 16-bit stage-1 stream of the
     library (round 4, the default whenever the library holds that stream) and round 3's, which streams the 4-byte records
     (CDS_SPARSE_SCAN32=1, read per launch; also what a library without the stream gets).  Same results, bit for bit."""
-    if request.param == "records32":
-        monkeypatch.setenv("CDS_SPARSE_SCAN32", "1")
-    else:
-        monkeypatch.delenv("CDS_SPARSE_SCAN32", raising=False)
+    monkeypatch.delenv("CDS_SPARSE_SCAN32", raising=False)
+    monkeypatch.delenv("CDS_SPARSE_SCAN16", raising=False)
+    monkeypatch.setenv("CDS_SPARSE_SCAN32" if request.param == "records32" else "CDS_SPARSE_SCAN16", "1")   # (forced: small searches default to the records)
     return request.param
 
 
@@ -930,11 +929,15 @@ def test_stage1_stream_is_derived_from_the_records_and_optional(cds, oracle, mon
     for thr, xy, mirror in ((20, 2, True), (60, 2, True), (35, 0, False), (100, 2, False)):
         alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, mirror, None, 0, False, thr, 0.02, xy, rects)
         c16 = alg.searchSparseLibraryCounts(with_stream)
+        assert alg.lastScanKernel()[0] == 1
         c32 = alg.searchSparseLibraryCounts(without)
+        assert alg.lastScanKernel()[0] == 0                      # (no stream in that library: nothing to force)
         assert np.array_equal(c16, c32), (thr, xy, mirror)
+        monkeypatch.delenv("CDS_SPARSE_SCAN16")
         monkeypatch.setenv("CDS_SPARSE_SCAN32", "1")
         assert np.array_equal(alg.searchSparseLibraryCounts(with_stream), c32)
         monkeypatch.delenv("CDS_SPARSE_SCAN32")
+        monkeypatch.setenv("CDS_SPARSE_SCAN16", "1")
         q = oracle.PixelMatchQuery(mask, 20, thr, 0.02, xy, mirror, rects)
         for t in (0, 5, 9):
             assert np.array_equal(c16[0, t], q.score(imgs[t])[2]), (thr, xy, mirror, t)
@@ -947,3 +950,52 @@ def test_stage1_stream_is_derived_from_the_records_and_optional(cds, oracle, mon
     lib.append(imgs[4:])
     alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.02, 2, rects)
     assert np.array_equal(alg.searchSparseLibraryCounts(lib), alg.searchSparseLibraryCounts(without))
+
+
+def test_the_pilot_picks_the_scan_kernel_per_mask_and_library(cds, oracle, fixtures, monkeypatch, scan_kernel):
+    """Without a forced kernel the first search of >= 16,384 targets measures, on its first 4,096 targets, the share of visited records
+    that reach an evaluation round, and scans the rest (and every later search of that library) through the 16-bit stream when the
+    share is small -- the synthetic library, whose colours are unrelated to the mask's -- or through the 4-byte records when it is
+    large -- the reference's LM images against an EM mask that overlaps them.  Scores equal the forced kernels' either way."""
+    if scan_kernel != "stream16":
+        pytest.skip("policy test: runs once")
+    monkeypatch.delenv("CDS_SPARSE_SCAN16")
+    n = 16384
+    rects = cds.label_regions(W)
+    # (a) synthetic library
+    dense = cds.Library(W, H, 4096)
+    sl = cds.SparseLibrary(W, H, n, 24000 * n + 4_000_000)
+    for f in range(0, n, 4096):
+        dense.generate_synthetic(0xC0FFEE, f, 0, 4096, kind=0)
+        sl.append_from(dense, 0, 4096)
+    mask = oracle.synth_image(0xBADC0DE, 0, 2)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    assert alg.lastScanKernel() == (-1, -1.0)
+    s_auto, m_auto = alg.searchSparseLibrary(sl)
+    k, ratio = alg.lastScanKernel()
+    assert k == 1 and 0 < ratio < 0.05, (k, ratio)
+    s_again, _ = alg.searchSparseLibrary(sl, 100, 9000)            # (remembered: no second pilot, same kernel, any range)
+    assert alg.lastScanKernel() == (1, ratio) and np.array_equal(s_again[0], s_auto[0, 100:9100])
+    monkeypatch.setenv("CDS_SPARSE_SCAN32", "1")
+    s32, m32 = alg.searchSparseLibrary(sl)
+    monkeypatch.delenv("CDS_SPARSE_SCAN32")
+    assert np.array_equal(s_auto, s32) and np.array_equal(m_auto, m32) and s_auto.max() > 0
+    # (b) the reference's LM test images, replicated, against the EM mask they were chosen for
+    lms = np.stack([fixtures[k] for k in ("lm_BJD", "lm_GMR", "lm_VT016795", "lm_VT033614")])
+    dense.upload(0, lms)
+    rl = cds.SparseLibrary(W, H, n, int((lms.max(axis=3) > 0).sum()) * (n // 4) + 4 * H * n + 64)
+    for _ in range(n // 4):
+        rl.append_from(dense, 0, 4)
+    em = cds.PixelMatchColorDepthSearchAlgorithm(fixtures["em_12191"], 20, True, None, 0, False, 20, 0.01, 2, E.STD_RECTS)
+    r_auto, rm_auto = em.searchSparseLibrary(rl)
+    k, ratio = em.lastScanKernel()
+    assert k == 0 and ratio > 0.05, (k, ratio)
+    monkeypatch.setenv("CDS_SPARSE_SCAN16", "1")
+    r16, rm16 = em.searchSparseLibrary(rl)
+    assert em.lastScanKernel()[0] == 1
+    assert np.array_equal(r_auto, r16) and np.array_equal(rm_auto, rm16)
+    assert np.array_equal(r_auto[0, :4], r_auto[0, -4:]) and r_auto.max() > 400   # (the JUnit pairs are among them)
+    # the synthetic mask over the SAME real library decides for itself (a choice belongs to a mask set, per library)
+    monkeypatch.delenv("CDS_SPARSE_SCAN16")
+    alg.searchSparseLibrary(rl)
+    assert alg.lastScanKernel()[1] != ratio
