@@ -164,7 +164,8 @@ def main():
         torch.cuda.synchronize()
         conv_s += time.perf_counter() - t1
     gen_s = time.time() - t0
-    lib_bytes = 4 * slib.pixels + n * (4 * slib.n_strips * (H + 1) + 8)
+    has_stream16 = os.environ.get("CDS_SPARSE_STREAM16", "1") != "0"
+    lib_bytes = (6 if has_stream16 else 4) * slib.pixels + n * (4 * slib.n_strips * (H + 1) + 8)   # records (+ their 16-bit stage-1 stream) + row pointers
     mlib = cds.Library(W, H, 1, context=ctx)
     mlib.generate_synthetic(MASK_SEED, 0, 0, 1, kind=2)
     mask = mlib.download(0, 1)[0]
@@ -344,7 +345,12 @@ def main():
         # The bound is HBM: the scan's loads-only twin takes 0.8-0.9 of the scan's time, i.e. the kernel waits for its records
         # (DESIGN.md 4b).  achieved = MEASURED HBM traffic per launch (PMC: 2 x FETCH_SIZE per target x targets) / kernel time of
         # this run; the instruction-issue fraction and the loads-only twin are secondary fields.
-        roof = {"bound": "hbm", "kernel": "cds::sparse_scan_kernel<xy2,mirror>", "achieved": None, "peak": HBM_PEAK_GBS,
+        scan_kernel, pilot_ratio = alg.lastScanKernel()
+        roof = {"bound": "hbm", "kernel": "cds::sparse_scan16_kernel<xy2,mirror> (16-bit stage-1 stream, chosen by the pilot)" if scan_kernel == 1
+                else "cds::sparse_scan_kernel<xy2,mirror> (4-byte records)", "achieved": None, "peak": HBM_PEAK_GBS,
+                "pilot": {"share_of_visited_records_reaching_a_round": pilot_ratio, "kernel_chosen": "stream16" if scan_kernel == 1 else "records32",
+                          "what": "the first search measures this share on its first 4,096 targets: <= 0.05 -> the 16-bit stream kernel "
+                                  "(CDS_SPARSE_SCAN16=1 / CDS_SPARSE_SCAN32=1 force one)"},
                 "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel_ms_per_launch": kern_ms, "kernel_ms_min_median_max": [float(np.min(step_ms)), float(np.median(step_ms)), float(np.max(step_ms))],
                 "targets_per_launch": n,
@@ -360,11 +366,13 @@ def main():
                     "kernel_ms_per_launch": load_only_ms, "scan_time_over_load_only_time": kern_ms / load_only_ms, "hbm_gbs": None,
                     "frac_of_stream_read_in_this_run": None},
                 "dense_layout_bytes_per_target": dense_bytes_per_target,
-                "note": "bound = hbm: frac = measured HBM traffic of the launch (PMC counters of profiles/scan_pmc.json, 2 x FETCH_SIZE per "
-                        "target, keyed by the kernel sources' hash) / kernel time of this run / the 8 TB/s spec.  The kernel reads a record "
-                        "library (signal pixels only), not packed-RGB rows: SURVEY 8(d)'s byte model (dense_layout_bytes_per_target) describes "
-                        "aux.dense_layout, not this kernel.  load_only = the memory floor of this access pattern (runs of ~7 KB behind two "
-                        "dependent header loads) measured in this run; stream_read = a plain read of the same arena in this run."}
+                "note": "bound = hbm by the task's convention: frac = measured HBM traffic of the launch (PMC counters of profiles/scan_pmc.json, "
+                        "2 x FETCH_SIZE per target, keyed by the kernel sources' hash) / kernel time of this run / the 8 TB/s spec.  The kernel "
+                        "reads a record library (signal pixels only), not packed-RGB rows: SURVEY 8(d)'s byte model "
+                        "(dense_layout_bytes_per_target) describes aux.dense_layout, not this kernel.  Round 4 halved the streamed bytes (the "
+                        "16-bit stage-1 stream), so the fraction of the HBM peak FELL while `value` rose: the stream kernel is bound by "
+                        "instruction issue (roofline.issue: vector and scalar pipes), its loads-only twin (load_only) takes about half its time.  "
+                        "stream_read = a plain read of the 4-byte record arena in this run."}
         cls = (pmc or {}).get("classes", {}).get("sparse_scan_headline") if args.kind == 0 else None
         if cls and {"SQ_INSTS_VALU", "hbm_bytes"} <= set(cls.get("per_target", {})):
             pt = cls["per_target"]
@@ -401,7 +409,7 @@ def main():
                 "workload": "1 mask x 1M synthetic 1210x566 RGB targets, xyShift=2, mirror on (BASELINE configs[1]); "
                             f"step = scan of the whole HBM-resident library of {n} targets per GPU (sparse layout)",
                 "targets_per_step_per_gpu": n,
-                "library_layout": "sparse (signal-pixel records, 4 column strips)",
+                "library_layout": "sparse (signal-pixel records, 4 column strips" + (" + their 16-bit stage-1 stream)" if has_stream16 else ")"),
                 "library_bytes_per_gpu": lib_bytes,
                 "library_bytes_per_target": round(lib_bytes / n, 1),
                 "target_kind": "sparse-lut" if args.kind == 0 else "dense-uniform",

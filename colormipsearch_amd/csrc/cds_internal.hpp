@@ -242,6 +242,7 @@ struct SparseScanParams {
     int nparts;               // partitions of the targets, each with its own work counter
     uint32_t psize;           // targets per partition (the last one may hold fewer)
     uint32_t *work;           // [n_slabs][nparts] x 32 dwords: next target of the partition (zero before the launch)
+    int plane_global;         // sparse_scan16_kernel: the plane is read from global memory (the LDS image is the band map alone)
     int use16;                // scan through the 16-bit stage-1 stream (sparse_scan16_kernel) instead of the 4-byte records
     unsigned long long *stat; // pilot launches of sparse_scan16_kernel: [0] += records visited, [1] += records queued for a round; else NULL
     int32_t *out;             // [count] score | mirrored << 31 (written directly when there is one slab and no partial)

@@ -45,7 +45,6 @@ namespace cds {
 
 constexpr int SP_QCAP = 128;                          // queue entries per wave and orientation (appends <= 64, drained at >= 64)
 constexpr int SP_QBYTES = 2 * SP_QCAP * 8;            // two queues of (u32 record, u32 plane offset): one 8-byte LDS access per entry
-constexpr int S16_QCAP = 256;                         // sparse_scan16_kernel: the same bytes as 256 one-dword entries per queue
 constexpr int SP_MAX_IV_LDS = 2048;                   // interval records kept in LDS (32 KB); larger tables are read from L2
 constexpr int SP_MAX_SLABS = 256;
 constexpr int SP_MAX_PARTS = 64;                      // work counters per slab (one per partition of the targets, 128 B apart)
@@ -690,7 +689,10 @@ __device__ __forceinline__ uint32_t pk_sub_min_u16(uint32_t a, uint32_t b, uint3
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(d, __builtin_bit_cast(u16x2, cap)));
 }
 
-template <bool XY2, bool MIRROR, bool IVLDS, bool P8, int WPE, bool LO = false>
+// PG ("plane global"): the mask's plane stays in global memory (L2-resident: every workgroup reads the same ~100 KB) and only the band map,
+// the interval table and the queues live in LDS -- a third of the LDS, so two workgroups share a CU (8 waves per SIMD instead of 4).  Rounds
+// read the plane from L2 then; right when rounds are rare (the pilot's low-hit-rate case).
+template <bool XY2, bool MIRROR, bool IVLDS, bool P8, int WPE, bool LO = false, bool PG = false>
 __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanParams p) {
     extern __shared__ uint4 lds4[];
     constexpr int NS = XY2 ? 9 : 1, NSX = XY2 ? 3 : 1, NO = MIRROR ? 2 : 1, NC = NS * NO;
@@ -702,9 +704,9 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint4 *ivt = lds4;
     uint8_t *slab = lds + (IVLDS ? (size_t)p.n_iv * 16 : 0);
-    const plane_t *plane = reinterpret_cast<const plane_t *>(slab);
-    const uint32_t *nearb = reinterpret_cast<const uint32_t *>(slab + p.near_off);
-    uint8_t *qb = slab + p.slab_bytes + (size_t)wave * SP_QBYTES;
+    const plane_t *plane = reinterpret_cast<const plane_t *>(slab);   // (PG: set per slab, below)
+    const uint32_t *nearb = reinterpret_cast<const uint32_t *>(slab + (PG ? 0 : p.near_off));
+    uint8_t *qb = slab + (PG ? p.slab_bytes - p.near_off : p.slab_bytes) + (size_t)wave * SP_QBYTES;
     uint2 *q0 = reinterpret_cast<uint2 *>(qb), *q1 = q0 + SP_QCAP;
     if (IVLDS)
         for (int i = threadIdx.x; i < p.n_iv; i += blockDim.x) ivt[i] = p.iv[i];
@@ -714,10 +716,11 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
         const int s = (int)((blockIdx.x + (unsigned)si) % (unsigned)p.n_slabs);  // every workgroup visits every slab
         __syncthreads();  // the previous slab's waves are done with the LDS image
         {
-            const uint4 *src = reinterpret_cast<const uint4 *>(p.slabs + (size_t)s * p.slab_bytes);
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.slabs + (size_t)s * p.slab_bytes + (PG ? p.near_off : 0));
             uint4 *dst = reinterpret_cast<uint4 *>(slab);
-            for (int i = threadIdx.x; i < p.slab_bytes / 16; i += blockDim.x) dst[i] = src[i];
+            for (int i = threadIdx.x; i < (p.slab_bytes - (PG ? p.near_off : 0)) / 16; i += blockDim.x) dst[i] = src[i];
         }
+        if (PG) plane = reinterpret_cast<const plane_t *>(p.slabs + (size_t)s * p.slab_bytes);
         __syncthreads();
         const int ys0 = p.ylo + s * p.slab_rows;  // first mask row of the slab
         const int rows_s = min(p.slab_rows, p.nrows - s * p.slab_rows);
@@ -741,9 +744,6 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
         }
         const int ks0 = max(wlo, 0) / p.strip_w, nsv = min(whi, p.W - 1) / p.strip_w - ks0 + 1;
         uint32_t st_visited = 0, st_queued = 0;   // (pilot launches only: p.stat)
-        uint32_t v_hi1[4];   // position of the lane's HIGH record of block j, counted from block 0 of an iteration
-#pragma unroll
-        for (int j = 0; j < 4; j++) asm volatile("v_mov_b32 %0, %1" : "=v"(v_hi1[j]) : "v"(2u * (uint32_t)lane + 1u + 128u * j));
 
         for (int pi = 0; pi < p.nparts; pi++) {
             const int part = (int)((blockIdx.x + (unsigned)pi) % (unsigned)p.nparts);
@@ -796,40 +796,24 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                 int ql0 = 64, ql1 = 64;                  // head + 64: a full round is due when the tail reaches it
                 int kin = 0;                             // strip of the current run, relative to ks0
 
-                // A queue entry is ONE dword: record index (20 bits) | row << 20 (10 bits) | visited strip << 30; a queue holds 256 of
-                // them (the LDS bytes of the 128 x 8-byte entries of the kernel above), so that both halves of a block are appended
-                // before the queue is looked at: one "is a round due" test per block and orientation.
-                // An evaluation round = up to 64 queued pixels of one orientation, every lane busy, in two halves: FETCH reads the entries
-                // and requests the records themselves from the image's 4-byte array (one gather); EVAL applies the data threshold (stage
-                // 1 never saw the maximum channel), finds the pixel's column from the record and its strip, makes the hue code and runs the
-                // nine plane / interval lookups.  Apart so that a target's two last rounds have both gathers in flight together.
-                uint32_t *e0 = reinterpret_cast<uint32_t *>(q0), *e1 = e0 + S16_QCAP;
-                struct Fetched {
-                    uint32_t r, ent;
-                    bool valid;
-                };
-                auto fetch = [&](const uint32_t *q, const int qh, const int n) -> Fetched {
+                // evaluate up to 64 queued pixels of one orientation: every lane busy.  The records come from the image's 4-byte
+                // array now (entry.x = record index): one gather per round, and the data threshold is applied here.
+                auto round = [&](const uint2 *q, int &qh, int &ql, const int qt, int *cc) {
+                    const int n = min(qt - qh, 64);
+#if SP16_EXP == 1   // (timing only: no evaluation rounds)
+                    qh += n; ql = qh + 64; cc[0] += n; return;
+#endif
                     __builtin_amdgcn_wave_barrier();
-                    Fetched f;
-                    f.valid = lane < n;
-                    f.ent = q[(qh + lane) & (S16_QCAP - 1)];
+                    bool valid = lane < n;
+                    const uint2 ent = q[(qh + lane) & (SP_QCAP - 1)];
 #if SP16_EXP == 2   // (timing only: rounds without the gather of the records)
-                    f.r = f.ent * 2654435761u | 0x00050001u;
+                    const uint32_t r = ent.x * 2654435761u | 0x00050001u;
 #else
                     const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.px + off), 0, (int)0x7ffffffc, 0x00020000);
-                    f.r = __builtin_amdgcn_raw_buffer_load_b32(ri, f.valid ? (int)((f.ent & 0xfffffu) * 4u) : 0, 0, 0);
+                    const uint32_t r = __builtin_amdgcn_raw_buffer_load_b32(ri, valid ? (int)(ent.x * 4u) : 0, 0, 0);
 #endif
-                    return f;
-                };
-                auto eval = [&](const Fetched &f, const bool mirrored, int *cc) {
-                    const uint32_t r = f.r;
-                    const bool valid = f.valid && (r & 255u) > v_thr;
-                    // column: the record's strip-relative x + its strip's first column, relative to the window (mirrored: from the far end)
-                    const uint32_t xs = ((r >> kRecXShift) & kRecXMask) + (f.ent >> 30) * (uint32_t)p.strip_w + (uint32_t)ks0 * (uint32_t)p.strip_w;
-                    const uint32_t cx = mirrored ? cm0 - xs : xs - cx0;
-                    uint32_t po;
-                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(po) : "v"((f.ent >> 20) & 1023u), "v"(v_pitch), "v"(poff));   // (row + 2) * pitch + 2
-                    const int poffs = f.valid ? (int)(po + cx) : safe_off;
+                    const int poffs = valid ? (int)ent.y : safe_off;
+                    valid = valid && (r & 255u) > v_thr;
                     const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
                     const uint32_t cls = (((r >> kRecBandShift) & kRecBandMask) * 13u) >> 6;  // band / 5 for bands 5..34
                     uint32_t code = (cls << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
@@ -854,46 +838,24 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                             cc[k0 + k] += __popcll(mb);
                         }
                     }
-                };
-                auto round = [&](const uint32_t *q, int &qh, int &ql, const int qt, const bool mirrored, int *cc) {
-                    const int n = min(qt - qh, 64);
-#if SP16_EXP == 1   // (timing only: no evaluation rounds)
-                    qh += n; ql = qh + 64; cc[0] += n; return;
-#endif
-                    const Fetched f = fetch(q, qh, n);
-                    eval(f, mirrored, cc);
                     qh += n;
                     ql = qh + 64;
                 };
-                auto append = [&](uint32_t *q, int &qt, const unsigned long long hb, const bool hit, const uint32_t entry) {
+                auto append = [&](uint2 *q, int &qt, const unsigned long long hb, const bool hit, const uint32_t idx, const uint32_t po) {
 #if SP16_EXP == 3   // (timing only: nothing queued)
                     c[0] += __popcll(hb); return;
 #endif
                     if (hit) {
-                        const int slot = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0))) & (S16_QCAP - 1);
-                        q[slot] = entry;
+                        const int slot = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0))) & (SP_QCAP - 1);
+                        q[slot] = make_uint2(idx, po);
                     }
                     qt += __popcll(hb);
                 };
                 // end of a target: the rest of its queues, then its score (or this slab's per-transform counts)
                 auto finish_target = [&](const uint32_t t) {
-#if SP16_EXP == 1
-                    while (qt0 > qh0) round(e0, qh0, ql0, qt0, false, c);
+                    while (qt0 > qh0) round(q0, qh0, ql0, qt0, c);
                     if (MIRROR)
-                        while (qt1 > qh1) round(e1, qh1, ql1, qt1, true, c + NS);
-#else
-                    while (qt0 - qh0 > 64) round(e0, qh0, ql0, qt0, false, c);
-                    if (MIRROR)
-                        while (qt1 - qh1 > 64) round(e1, qh1, ql1, qt1, true, c + NS);
-                    {   // the last (partial) round of either orientation: both gathers are requested before either is evaluated
-                        const int n0 = qt0 - qh0, n1 = MIRROR ? qt1 - qh1 : 0;
-                        Fetched f0{0u, 0u, false}, f1{0u, 0u, false};
-                        if (n0 > 0) f0 = fetch(e0, qh0, n0);
-                        if (n1 > 0) f1 = fetch(e1, qh1, n1);
-                        if (n0 > 0) eval(f0, false, c);
-                        if (n1 > 0) eval(f1, true, c + NS);
-                    }
-#endif
+                        while (qt1 > qh1) round(q1, qh1, ql1, qt1, c + NS);
                     if (p.partial) {  // per-transform counts of this slab: lane k holds transform k (the 18-entry layout of the ABI)
                         int v = 0;
 #pragma unroll
@@ -930,7 +892,6 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                         asm volatile("v_mov_b32 %0, %1" : "=v"(v_cx0pk) : "s"(((cx0 - sbase) & 0xffffu) * 0x10001u));
                         asm volatile("v_mov_b32 %0, %1" : "=v"(v_cm0pk) : "s"(((cm0 - sbase) & 0xffffu) * 0x10001u));
                     }
-                    const uint32_t kbits = (uint32_t)kin << 30;
                     for (uint32_t i = a; i < b; i += 128 * NB) {  // wave-uniform
                         const uint32_t rem = b - i;  // records of this run from block 0 of this iteration on
                         {   // the next NB blocks -- of this run, or the first ones of the grab's next run -- are in flight while these are examined
@@ -949,18 +910,18 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
 #pragma unroll
                             for (int j = 0; j < NB; j++) {
                                 if (rem <= 128u * j) break;  // wave-uniform: a block beyond the run
-                                // When the rest of the run is odd, the dword holding its last record also holds the record BEHIND it (the first
-                                // of the next row, strip or image): not part of the scan -- it becomes the neutral value, like everything beyond the
-                                // run.  (In a block the run does not end in, no lane's high record lies at or beyond `rem`.)
                                 uint32_t rec = cur[j] ^ 0x00030003u;
-                                rec = (v_hi1[j] >= rem) ? ((rec & 0xffffu) | 0x00030000u) : rec;
-                                // rows: the records come in the order (lane 0 low half, lane 0 high half, lane 1 low half, ...)
-                                const uint32_t fl = __builtin_amdgcn_ubfe(rec, 15u, 1u);
-                                const unsigned long long fbl = __ballot(fl != 0), fbh = __ballot((int)rec < 0);
+                                if (rem < 128u * (j + 1)) {   // wave-uniform, once per run: the run ends inside this block.  When the rest of the run
+                                    // is odd, the dword holding its last record also holds the record BEHIND it (the first of the next row, strip or
+                                    // image): that one is not part of the scan -- turned into "no flag, band 3" like everything beyond the run
+                                    if (2u * (uint32_t)lane + 1u >= rem - 128u * j) rec = (rec & 0xffffu) | 0x00030000u;
+                                }
+                                // rows: records come in the order (lane 0 low, lane 0 high, lane 1 low, ...)
+                                const unsigned long long fbl = __ballot((rec & 0x8000u) != 0), fbh = __ballot((int)rec < 0);
                                 const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(fbh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbh,
                                                         __builtin_amdgcn_mbcnt_hi((uint32_t)(fbl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbl, 0))));
-                                const uint32_t ryl = (uint32_t)yrel + before + fl, ryh = ryl + (rec >> 31);
-                                yrel = __builtin_amdgcn_readlane((int)ryh, 63);   // (the last record's row: no scalar popcounts and adds)
+                                const uint32_t ryl = (uint32_t)yrel + before + __builtin_amdgcn_ubfe(rec, 15u, 1u), ryh = ryl + (rec >> 31);
+                                yrel += __popcll(fbl) + __popcll(fbh);
                                 // columns of both records at once (16-bit halves): x - origin, clamped to the guard cell
                                 const uint32_t xpk = (rec >> 6) & 0x01FF01FFu;
                                 const uint32_t cxp = pk_sub_min_u16(xpk, v_cx0pk, v_wnearpk);
@@ -979,25 +940,34 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                                     asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ah) : "v"(cxm >> 19), "v"(rowh));
                                     wml = *reinterpret_cast<lds_u32 *>((uintptr_t)al), wmh = *reinterpret_cast<lds_u32 *>((uintptr_t)ah);
                                 }
-                                const uint32_t idl = (i + 128u * j + 2u * (uint32_t)lane) | kbits;   // index of the low record in the image | strip
-                                const uint32_t bh = rec >> 16;                                        // (v_bfe takes the band mod 32 from the low bits)
-                                const uint32_t enl = idl | (ryl << 20), enh = (idl + 1u) | (ryh << 20);
+                                // plane offset of column cx0 in the record's row: (ry + 2) * pitch + 2
+                                uint32_t prl, prh;
+                                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(prl) : "v"(ryl), "v"(v_pitch), "v"(poff));
+                                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(prh) : "v"(ryh), "v"(v_pitch), "v"(poff));
+                                const uint32_t idl = i + 128u * j + 2u * (uint32_t)lane;   // index of the low record in the image
+                                const uint32_t bh = rec >> 16;                             // (v_bfe takes the band mod 32 from the low bits)
                                 {
                                     const bool hl = __builtin_amdgcn_ubfe(wpl, rec, 1u) != 0, hh = __builtin_amdgcn_ubfe(wph, bh, 1u) != 0;
                                     const unsigned long long hbl = __ballot(hl), hbh = __ballot(hh);
-                                    if (hbl | hbh) {
-                                        if (hbl) append(e0, qt0, hbl, hl, enl);
-                                        if (hbh) append(e0, qt0, hbh, hh, enh);
-                                        while (qt0 >= ql0) round(e0, qh0, ql0, qt0, false, c);
+                                    if (hbl) {
+                                        append(q0, qt0, hbl, hl, idl, prl + (cxp & 0xffffu));
+                                        if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
+                                    }
+                                    if (hbh) {
+                                        append(q0, qt0, hbh, hh, idl + 1u, prh + (cxp >> 16));
+                                        if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
                                     }
                                 }
                                 if (MIRROR) {
                                     const bool hl = __builtin_amdgcn_ubfe(wml, rec, 1u) != 0, hh = __builtin_amdgcn_ubfe(wmh, bh, 1u) != 0;
                                     const unsigned long long hbl = __ballot(hl), hbh = __ballot(hh);
-                                    if (hbl | hbh) {
-                                        if (hbl) append(e1, qt1, hbl, hl, enl);
-                                        if (hbh) append(e1, qt1, hbh, hh, enh);
-                                        while (qt1 >= ql1) round(e1, qh1, ql1, qt1, true, c + NS);
+                                    if (hbl) {
+                                        append(q1, qt1, hbl, hl, idl, prl + (cxm & 0xffffu));
+                                        if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
+                                    }
+                                    if (hbh) {
+                                        append(q1, qt1, hbh, hh, idl + 1u, prh + (cxm >> 16));
+                                        if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
                                     }
                                 }
                             }
@@ -1798,11 +1768,8 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
     return CDS_OK;
 }
 
-// can a library / mask pair go through sparse_scan16_kernel at all?  (The library holds the stream; the kernel's queue entries hold record
-// index, row and visited strip in one dword: images of up to 2^20 records, 1,016 rows, 4 strips.)
-static bool stream16_possible(const SparseScanParams &p) {
-    return p.px16 != nullptr && p.nstrips <= 4 && p.H <= 1016 && (int64_t)p.W * p.H + (int64_t)p.nstrips * p.H < ((int64_t)1 << 20);
-}
+// can a library go through sparse_scan16_kernel at all?  (It holds the 16-bit stream.)
+static bool stream16_possible(const SparseScanParams &p) { return p.px16 != nullptr; }
 
 template <bool XY2, bool MIRROR>
 static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t lds_bytes, int threads, hipStream_t st) {
@@ -1814,6 +1781,10 @@ static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t
                          : p.iv_in_lds ? K<XY2, MIRROR, true, false, 8> : K<XY2, MIRROR, false, false, 8>))
     auto kern = s16 ? SP_PICK(sparse_scan16_kernel) : SP_PICK(sparse_scan_kernel);
 #undef SP_PICK
+    if (s16 && p.plane_global) {   // (the plane in L2: the LDS image is the band map alone, two workgroups per CU)
+        kern = p.plane8 ? sparse_scan16_kernel<XY2, MIRROR, true, true, 8, false, true>
+             : p.iv_in_lds ? sparse_scan16_kernel<XY2, MIRROR, true, false, 8, false, true> : sparse_scan16_kernel<XY2, MIRROR, false, false, 8, false, true>;
+    }
     if (ctx->sparse_load_only.load()) {   // (a diagnostic of THIS context only: cds_debug_sparse_load_only)
         if (!(wide && p.plane8)) return fail(CDS_ERR_UNSUPPORTED, "the load-only diagnostic exists for the one-workgroup-per-CU, one-byte-plane layout only");
         kern = s16 ? sparse_scan16_kernel<XY2, MIRROR, true, true, 4, true> : sparse_scan_kernel<XY2, MIRROR, true, true, 4, true>;
@@ -2017,8 +1988,15 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
         p.use16 = use16;
         p.stat = nullptr;
         ms->last_scan_kernel = use16;
+        size_t lds_launch = pl.lds_bytes;
+        // the stream kernel runs where rounds are rare: its plane stays in L2 and two workgroups share a CU (+4 % on the 1 M-target scan;
+        // CDS_SPARSE_PLANE_LDS=1: the plane in LDS, one workgroup per CU, as the 4-byte-record kernel has it)
+        if (use16 && !getenv("CDS_SPARSE_PLANE_LDS") && !ctx->sparse_load_only.load()) {
+            p.plane_global = 1;
+            lds_launch = pl.lds_bytes - (size_t)pl.near_off;
+        }
         SP_HIP(hipMemsetAsync(ms->d_sp_work, 0, (size_t)pl.n_slabs * nparts * 32 * sizeof(uint32_t), st));
-        const int lrc = launch_sparse(ctx, p, pl.lds_bytes, threads, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
+        const int lrc = launch_sparse(ctx, p, lds_launch, threads, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
         if (lrc) {
             cleanup();
             return lrc;

@@ -930,6 +930,9 @@ def test_stage1_stream_is_derived_from_the_records_and_optional(cds, oracle, mon
         alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, mirror, None, 0, False, thr, 0.02, xy, rects)
         c16 = alg.searchSparseLibraryCounts(with_stream)
         assert alg.lastScanKernel()[0] == 1
+        monkeypatch.setenv("CDS_SPARSE_PLANE_LDS", "1")        # (the stream kernel with the plane in LDS instead of L2: same counts)
+        assert np.array_equal(alg.searchSparseLibraryCounts(with_stream), c16)
+        monkeypatch.delenv("CDS_SPARSE_PLANE_LDS")
         c32 = alg.searchSparseLibraryCounts(without)
         assert alg.lastScanKernel()[0] == 0                      # (no stream in that library: nothing to force)
         assert np.array_equal(c16, c32), (thr, xy, mirror)

@@ -23,6 +23,12 @@ run pmc_headline_fetch 300 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv 
 run pmc_headline_write 300 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_headline_write -- python3 $H_ARGS
 run pmc_headline_sq 300 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_headline_sq -- python3 $H_ARGS
 run pmc_headline_sq2 300 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc_headline_sq2 -- python3 $H_ARGS
+# the same headline through round 3's kernel (the 4-byte records), for the side-by-side class sparse_scan_records32
+export CDS_SPARSE_SCAN32=1
+run trace_headline32 300 --kernel-trace --stats --output-format csv -d $OUT/trace_headline32 -- python3 $H_ARGS
+run pmc_headline32_fetch 300 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_headline32_fetch -- python3 $H_ARGS
+run pmc_headline32_sq 300 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_headline32_sq -- python3 $H_ARGS
+unset CDS_SPARSE_SCAN32
 if [ -n "$FULL" ]; then
     run trace_full 500 --kernel-trace --stats --output-format csv -d $OUT/trace_full -- python3 $F_ARGS
     run pmc_full_fetch 500 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_full_fetch -- python3 $F_ARGS

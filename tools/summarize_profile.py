@@ -51,13 +51,15 @@ def pmc_rows(dirs):
 
 
 LOAD_ONLY = ", true>(cds::SparseScanParams)"   # the loads-only twin of the scan kernel (template flag LO): a class of its own
+LOAD_ONLY16 = ", true, false>(cds::SparseScanParams)"   # ... of sparse_scan16_kernel<..., LO, PG>
 
 
 def pick(seq, name, last=None, every=False):
     """dispatches of kernel `name` with the class's (= the largest) grid -- or every one of them --, optionally only the
     last `last`; `name` = "A&B" asks for both substrings, the loads-only twin is only picked when asked for by LOAD_ONLY"""
     parts = name.split("&")
-    sel = [x for x in seq if all(q in x[1] for q in parts) and (LOAD_ONLY in parts or LOAD_ONLY not in x[1])]
+    sel = [x for x in seq if all(q in x[1] for q in parts) and (LOAD_ONLY in parts or LOAD_ONLY not in x[1])
+           and (LOAD_ONLY16 in parts or LOAD_ONLY16 not in x[1])]
     if sel and not every:
         g = max(x[3] for x in sel)
         sel = [x for x in sel if x[3] == g]
@@ -132,10 +134,19 @@ def main():
             lines.append(f"   HBM traffic = 2 x FETCH_SIZE = {per['hbm_bytes']:.1f} B per {unit_name[:-1]} = {gbs:.0f} GB/s at the traced duration = {gbs / 8000:.3f} of the 8 TB/s peak")
         classes[key] = cls
 
-    add_class("sparse_scan_headline", "sparse_scan_kernel", "headline", "targets", a.targets, last=a.steps,
-              desc=f"the {a.steps} timed 1-mask scans of the resident library (bench.py `value`)")
-    add_class("sparse_scan_load_only", "sparse_scan_kernel&" + LOAD_ONLY, "headline", "targets", a.targets, last=5,
-              desc="the loads-only twin of the scan kernel (bench.py roofline.load_only): same grabs, headers, record loads, no examination")
+    # the headline kernel: the 16-bit-stream scan when the run's pilot chose it (round 4), else the 4-byte-record scan
+    add_class("sparse_scan_headline", "sparse_scan16_kernel", "headline", "targets", a.targets, last=a.steps,
+              desc=f"the {a.steps} timed 1-mask scans of the resident library (bench.py `value`): cds::sparse_scan16_kernel over the 16-bit stage-1 stream")
+    if "sparse_scan_headline" in classes:
+        add_class("sparse_scan_load_only", "sparse_scan16_kernel&" + LOAD_ONLY16, "headline", "targets", a.targets, last=5,
+                  desc="the loads-only twin of the stream kernel (bench.py roofline.load_only): same grabs, headers, stream loads, no examination")
+    else:
+        add_class("sparse_scan_headline", "sparse_scan_kernel", "headline", "targets", a.targets, last=a.steps,
+                  desc=f"the {a.steps} timed 1-mask scans of the resident library (bench.py `value`)")
+        add_class("sparse_scan_load_only", "sparse_scan_kernel&" + LOAD_ONLY, "headline", "targets", a.targets, last=5,
+                  desc="the loads-only twin of the scan kernel (bench.py roofline.load_only): same grabs, headers, record loads, no examination")
+    add_class("sparse_scan_records32", "sparse_scan_kernel", "headline32", "targets", a.targets, last=a.steps,
+              desc=f"the same {a.steps} scans with CDS_SPARSE_SCAN32=1: cds::sparse_scan_kernel over the 4-byte records (round 3's headline kernel)")
     add_class("dense_scan", "cds::scan_kernel", "headline", "targets", a.stage, desc="the dense-layout kernel over the verification windows")
     add_class("sparse_multi", "sparse_multi_kernel", "full", "comparisons", None, units_total=a.multi_masks * a.targets + a.extra_multi,
               desc=f"aux.mask_batch + the scans aux.gradient_scores' selection needs: every multi-mask launch of the command ({a.multi_masks} masks x {a.targets} targets)")
