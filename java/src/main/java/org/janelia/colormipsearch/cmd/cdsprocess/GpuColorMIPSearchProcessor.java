@@ -24,7 +24,7 @@ import org.slf4j.LoggerFactory;
  * wants.  The reference makes one calculateMatchingScore call per (mask, target) pair from a thread pool; here
  *   1. the target MIPs are decoded once (through the reference's own loader / cache) and made resident as a sparse
  *      library on the GPU, partition by partition,
- *   2. the masks are prepared in sets of up to 64 and every set scans the whole resident library in a few launches (groups of
+ *   2. the masks are prepared in sets of up to 128 (-Dcds.gpu.maskset, the size the measured pipeline uses) and every set scans the whole resident library in a few launches (groups of
  *      masks share one pass over the records),
  *   3. ColorMIPSearch.isMatch and the compaction run on the device: only the matches come back,
  * and each match becomes the CDMatchEntity findPixelMatch would have produced (same fields, same tags, same "mask is empty /
@@ -34,7 +34,7 @@ import org.slf4j.LoggerFactory;
 public class GpuColorMIPSearchProcessor<M extends AbstractNeuronEntity, T extends AbstractNeuronEntity> extends AbstractColorMIPSearchProcessor<M, T> {
 
     private static final Logger LOG = LoggerFactory.getLogger(GpuColorMIPSearchProcessor.class);
-    private static final int MASKS_PER_SET = 64;
+    private static final int MASKS_PER_SET = Integer.getInteger("cds.gpu.maskset", 128);   // a multiple of 8 (the multi-mask kernel's groups)
 
     private final ImageRegionDefinition excludedRegions;
     private final int[] devices;

@@ -208,3 +208,46 @@ def test_sharded_pair_scores_with_the_real_kernel(oracle):
         assert (int(got[2, 0]), int(got[2, 1]), bool(got[2, 2])) == (og, oh, bool(om))
     finally:
         dist.destroy_process_group()
+
+
+def test_two_distinct_gpus_through_rccl(oracle):
+    """The branch no one-GPU box reaches: cds_comm over contexts of DIFFERENT devices (ncclCommInitAll over two GPUs, the grouped
+    ncclGather with a NULL receive buffer on the non-root rank, per-device streams and host threads).  Skipped where fewer than two
+    GPUs are visible -- the round's evidence for that branch is this test on the driver's multi-GPU node, nothing else."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (the one-GPU box rehearses the sharding logic through same-device contexts only)")
+    from colormipsearch_amd import cds
+    rects = cds.label_regions(W)
+    n = 23
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(2)])
+    targets = np.stack([oracle.synth_image(0xC0FFEE, 300 + i, 0) for i in range(n - 1)] + [masks[0]])
+    want_s, want_m = [], []
+    for m in range(2):
+        ws, wm = oracle.PixelMatchQuery(masks[m], 20, 20, 0.01, 2, True, rects).scan(targets, n_threads=8)
+        want_s.append(ws), want_m.append(wm.astype(bool))
+    ctxs = [cds.Context(0), cds.Context(1)]
+    comm = cds.Comm(ctxs)
+    assert comm.uses_rccl and len(comm) == 2
+    bounds = [0, 9, n]
+    algs = [cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects, context=c) for c in ctxs]
+    libs = []
+    for r in range(2):
+        imgs = targets[bounds[r]:bounds[r + 1]]
+        sl = cds.SparseLibrary(W, H, len(imgs), int((imgs.max(axis=3) > 0).sum()) + 4 * H * len(imgs) + 64, context=ctxs[r])
+        sl.append(imgs)
+        libs.append(sl)
+    s, mir, offs = comm.searchSparseLibrarySharded(algs, libs)
+    assert offs.tolist() == bounds and np.array_equal(s, np.stack(want_s)) and np.array_equal(mir, np.stack(want_m))
+    mm, tt, sc, mr, _ = comm.searchSparseLibraryShardedMatches(algs, libs, 0.0)
+    assert len(mm) == int((np.stack(want_s) > 0).sum())
+    # kernel 2 over the two GPUs
+    shapes = [cds.Shape2DMatchColorDepthSearchAlgorithm(masks, 20, True, None, rects, context=c) for c in ctxs]
+    dl = [_variant_shard(cds, ctxs[0], 0xC0FFEE, 500, 5), _variant_shard(cds, ctxs[1], 0xC0FFEE, 505, 4)]
+    whole = _variant_shard(cds, ctxs[0], 0xC0FFEE, 500, 9)
+    pm = np.array([0, 1, 1, 0, 1, 0], dtype=np.int32)
+    pt = np.array([8, 0, 5, 4, 3, 6], dtype=np.int64)
+    want = shapes[0].scoreLibraryPairs(whole, pm, pt)
+    gap, high, gm, goffs = comm.scoreLibraryPairsSharded(shapes, dl, pm, pt, shard_sizes=[5, 4])
+    assert goffs.tolist() == [0, 5, 9] and np.array_equal(gap, want[0]) and np.array_equal(high, want[1]) and np.array_equal(gm, want[2])
+    comm.close()

@@ -58,8 +58,10 @@ def pick(seq, name, last=None, every=False):
     """dispatches of kernel `name` with the class's (= the largest) grid -- or every one of them --, optionally only the
     last `last`; `name` = "A&B" asks for both substrings, the loads-only twin is only picked when asked for by LOAD_ONLY"""
     parts = name.split("&")
-    sel = [x for x in seq if all(q in x[1] for q in parts) and (LOAD_ONLY in parts or LOAD_ONLY not in x[1])
-           and (LOAD_ONLY16 in parts or LOAD_ONLY16 not in x[1])]
+    def twin(name_):   # is this dispatch a loads-only twin?  (the flag's position differs between the two kernels' template lists)
+        return (LOAD_ONLY16 in name_) if "sparse_scan16_kernel<" in name_ else (LOAD_ONLY in name_ and "sparse_scan_kernel<" in name_)
+    want_twin = LOAD_ONLY in parts or LOAD_ONLY16 in parts
+    sel = [x for x in seq if all(q in x[1] for q in parts) and twin(x[1]) == want_twin]
     if sel and not every:
         g = max(x[3] for x in sel)
         sel = [x for x in sel if x[3] == g]
@@ -150,8 +152,12 @@ def main():
     add_class("dense_scan", "cds::scan_kernel", "headline", "targets", a.stage, desc="the dense-layout kernel over the verification windows")
     add_class("sparse_multi", "sparse_multi_kernel", "full", "comparisons", None, units_total=a.multi_masks * a.targets + a.extra_multi,
               desc=f"aux.mask_batch + the scans aux.gradient_scores' selection needs: every multi-mask launch of the command ({a.multi_masks} masks x {a.targets} targets)")
-    add_class("gradscore_list", "gradscore_list_kernel", "full", "pairs", None, units_total=a.pairs or (a.multi_masks * 500 + 1),
-              desc="aux.gradient_scores (one launch per window of targets) + the one fixture pair")
+    add_class("gradscore_list", "gradscore_list_kernel<true>", "full", "pairs", None, units_total=a.pairs or (a.multi_masks * 500 + 1),
+              desc="aux.gradient_scores, the default path at 2.2 pairs per target: the scorer reads the zgap bytes itself, no conversion pass (one launch per batch of selected targets) + the one fixture pair")
+    add_class("gradscore_list_zslice_plane", "gradscore_list_kernel<false>", "full", "pairs", None, units_total=a.pairs or (a.multi_masks * 500),
+              desc="the same pairs with CDS_SHAPE_ZSLICE=1 (round 3's path): S(z) from the converted zslice plane")
+    add_class("zslice_conversion", "zslice_kernel", "full", "targets", None, units_total=230693,
+              desc="... and the conversion pass that path needs first: one zgap image -> zslice plane per selected target (230,693 distinct targets)")
     for tagc in ("headline", "full"):
         for f in glob.glob(os.path.join(o, "trace_" + tagc, "**", "*kernel_stats.csv"), recursive=True):
             lines.append(f"== rocprofv3 --kernel-trace --stats (kernel_stats.csv), command `{tagc}` -- ALL dispatches of the run, mixed sizes")
