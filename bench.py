@@ -497,6 +497,9 @@ def main():
         ri = out["aux"].get("real_images", {}).get("masks")
         if ri:   # next to the headline: the same kernel on the reference's own (dense, mask-overlapping) images is 5-20x slower
             out["real_image_comparisons_per_s"] = {k: v["sparse_comparisons_per_s"] for k, v in ri.items()}
+            ov = out["aux"].get("overlapping_synthetic")
+            if ov:
+                out["overlapping_synthetic_comparisons_per_s"] = ov["comparisons_per_s"]
             out["real_image_note"] = ("`value` is measured on BASELINE's synthetic library, whose targets' colours are unrelated to the mask's; on the reference's LM "
                                       "test MIPs -- every one chosen because it overlaps these EM masks -- the same single-mask scan runs at the rates above")
     if rank == 0:
@@ -615,6 +618,93 @@ def dist_gradient_leg(args, cds, dist, ctx, dev, dense, slib, n, stage_n, rects,
             "scoring_calls_s_per_rank": [float(a[3]) for a in allst],
             "top_hit_selection_s (scan of the masks, device top-k, gather, merge, broadcast)": sel_s, "shape_mask_preparation_s": prep_s,
             "pairs_checked_against_oracle": checked, "sampled_pairs_equal_oracle": bool(ok)}
+
+
+def overlapping_leg(args, cds, ctx, dev, stream, mask, rects, failed, n_o=262144, n_w=2048):
+    """A synthetic library that OVERLAPS the benchmark mask the way real libraries overlap real masks (the four LM test
+    images x 8,192 copies give every wave one of four workloads).  Every target is a sparse-lut target of the headline stream with a
+    thinned, slightly displaced, dimmed copy of the mask's own arbor laid over it: half of the mask's pixels (one of 4 fixed random
+    patterns), shifted by (dx, dy) in {-1, 0, 1}^2, brightness x {1, 0.85, 0.7, 0.55} -- so the target's depth colour FOLLOWS the mask's
+    wherever they overlap (what makes real images expensive: stage 1 passes a third to a half of the visited records) while no two
+    targets are alike.  Built on the device (torch ops over the dense staging slots), 262,144 targets; scores checked against the
+    dense-layout kernel on 8 windows and against the CPU oracle on 16 targets."""
+    n_o = min(n_o, max(n_w, args.targets // 4 // n_w * n_w))
+    pitch_px = ((3 * W + 47) // 48 * 48) // 3
+    tbuf = torch.zeros(cds.Library.bytes_required(W, H, n_w), dtype=torch.uint8, device=dev)
+    lib_w = cds.Library(W, H, n_w, context=ctx, device_buffer=tbuf)
+    view = tbuf[: n_w * H * pitch_px * 3].view(n_w, H, pitch_px, 3)
+    mdev = torch.zeros((H, pitch_px, 3), dtype=torch.uint8, device=dev)
+    mdev[:, :W] = torch.from_numpy(mask).to(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(20240)
+    patterns = torch.rand((4, H, pitch_px), generator=g, device=dev) < 0.5
+    scales = torch.tensor([1.0, 0.85, 0.7, 0.55], device=dev)
+    combos = [(dx, dy) for dx in (-1, 0, 1) for dy in (-1, 0, 1)]
+
+    def make_window(w0):
+        """targets w0 .. w0 + n_w - 1 of the overlapping library into the staging slots (a pure function of w0)"""
+        lib_w.generate_synthetic(LIB_SEED, 5_000_000 + w0, 0, n_w, kind=0)
+        torch.cuda.synchronize()
+        t = torch.arange(w0, w0 + n_w, device=dev)
+        for c, (dx, dy) in enumerate(combos):
+            idx = torch.nonzero((t * 7 + 3) % 9 == c).flatten()
+            if idx.numel() == 0:
+                continue
+            ms = torch.roll(mdev, shifts=(dy, dx), dims=(0, 1))
+            has = ms.max(dim=2).values > 0
+            tt = t[idx]
+            sel = patterns[(tt // 9) % 4] & has                                           # [k, H, pitch]
+            col = (ms.to(torch.float32)[None] * scales[(tt // 36) % 4][:, None, None, None]).to(torch.uint8)
+            sub = view[idx]
+            view[idx] = torch.where(sel[..., None], col, sub)
+        torch.cuda.synchronize()
+
+    so = cds.SparseLibrary(W, H, n_o, 40000 * n_o + 4_000_000, context=ctx)
+    t0 = time.perf_counter()
+    for w0 in range(0, n_o, n_w):
+        make_window(w0)
+        so.append_from(lib_w, 0, n_w)
+    build_s = time.perf_counter() - t0
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, MASK_THR, MIRROR, None, 0, False, DATA_THR, ZTOL, XY_SHIFT, rects, context=ctx)
+    sc = torch.empty(n_o, dtype=torch.int32, device=dev)
+    alg.searchSparseLibraryDevice(so, 0, n_o, sc.data_ptr())                              # (the pilot runs here)
+    kernel, ratio = alg.lastScanKernel()
+    ms_auto = timed(stream, lambda: alg.searchSparseLibraryDevice(so, 0, n_o, sc.data_ptr()), 3)
+    rates = {}
+    for name, env in (("stream16", "CDS_SPARSE_SCAN16"), ("records32", "CDS_SPARSE_SCAN32")):
+        os.environ[env] = "1"
+        alg.searchSparseLibraryDevice(so, 0, n_o, sc.data_ptr())
+        rates[name] = n_o / (timed(stream, lambda: alg.searchSparseLibraryDevice(so, 0, n_o, sc.data_ptr()), 3) * 1e-3)
+        del os.environ[env]
+    alg.searchSparseLibraryDevice(so, 0, n_o, sc.data_ptr())
+    # verification: 8 windows against the dense-layout kernel, 16 targets against the oracle
+    dsc = torch.empty(n_w, dtype=torch.int32, device=dev)
+    wins = sorted({(i * (n_o // n_w - 1) // 7) * n_w for i in range(8)})
+    same, ok_or, checked = True, True, 0
+    for w0 in wins:
+        make_window(w0)
+        alg.searchLibraryDevice(lib_w, 0, n_w, dsc.data_ptr())
+        same &= bool(torch.equal(dsc, sc[w0:w0 + n_w]))
+        if not args.no_cpu_baseline and w0 in (wins[0], wins[-1]):
+            from oracle import cds_oracle as O
+            imgs = lib_w.download(0, 8)
+            ws, wm = O.PixelMatchQuery(mask, MASK_THR, DATA_THR, ZTOL, XY_SHIFT, MIRROR, rects).scan(imgs, n_threads=usable_cores(), partition=2)
+            hs = sc[w0:w0 + 8].cpu().numpy()
+            ok_or &= bool(np.array_equal(ws, hs & 0x7FFFFFFF) and np.array_equal(wm.astype(np.int64), ((hs >> 31) & 1).astype(np.int64)))
+            checked += 8
+    if not same:
+        failed.append("overlapping-synthetic leg: sparse and dense scans disagree")
+    if not ok_or:
+        failed.append("overlapping-synthetic leg: scores differ from the CPU oracle's")
+    hs = (sc & 0x7FFFFFFF).cpu().numpy()
+    return {"workload": f"1 mask x {n_o} synthetic targets that overlap it (sparse-lut targets + a thinned, displaced, dimmed copy of the mask's arbor: depth colour follows "
+                        "the mask's where they overlap), xyShift 2, mirror on", "records_per_target": so.pixels / n_o,
+            "comparisons_per_s": n_o / (ms_auto * 1e-3), "ms_per_pass": ms_auto,
+            "kernel_chosen_by_the_pilot": "stream16" if kernel == 1 else "records32", "share_of_visited_records_reaching_a_round": ratio,
+            "comparisons_per_s_by_kernel": rates, "library_build_s": build_s,
+            "score_quartiles": [int(v) for v in np.percentile(hs, [0, 25, 50, 75, 100])], "mask_pixels": int(alg.getQuerySize()),
+            "windows_equal_dense_scan": same, "windows_checked": len(wins), "targets_checked_against_oracle": checked,
+            "targets_equal_oracle": bool(ok_or) if checked else None}
 
 
 def timed(stream, fn, reps):
@@ -937,8 +1027,9 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
             cli["masks"][mk] = {"sparse_comparisons_per_s": n_r / (ms0 * 1e-3), "sparse_comparisons_per_s_with_minimum_data_threshold_100": n_r / (ms1 * 1e-3),
                                 "scores_equal (both libraries, dense scan)": same_c}
         real["reference_cli_defaults"] = cli
-        del rs100
+        del rs100, rs
         aux["real_images"] = real
+        aux["overlapping_synthetic"] = overlapping_leg(args, cds, ctx, dev, stream, mask, rects, failed)
         if not ok_r:
             failed.append("sparse and dense scans disagree on the reference's images")
         if not ok_f:
