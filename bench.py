@@ -384,6 +384,13 @@ def main():
                 roof["frac_of_stream_read_in_this_run"] = roof["achieved"] / stream_gbs
             roof["issue"]["achieved"] = pt["SQ_INSTS_VALU"] * n / (kern_ms * 1e6)     # G wave-instructions / s
             roof["issue"]["frac"] = roof["issue"]["achieved"] / roof["issue"]["peak"]
+            if {"SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"} <= set(pt):
+                # how busy the vector pipes were in the PROFILED launches, from the counters alone: SQ_ACTIVE_INST_VALU counts quad-cycles
+                # summed over the SIMDs, GRBM_GUI_ACTIVE the launch's cycles summed over the 8 XCDs
+                roof["issue"]["valu_pipe_active_frac_in_the_profile"] = pt["SQ_ACTIVE_INST_VALU"] * 4.0 / (simds * pt["GRBM_GUI_ACTIVE"] / 8.0)
+                roof["issue"]["valu_note"] = ("this kernel's instruction mix (three-operand and packed encodings, v_mbcnt, compares into scalar registers) occupies a "
+                                              "SIMD for about 4 cycles per wave64 instruction, against the ~2.5 of the plain v_add / v_xor chains that `peak` "
+                                              "is calibrated with: by pipe-active cycles the vector pipes are nearly saturated although `frac` says half")
             if roof["load_only"]:
                 roof["load_only"]["hbm_gbs"] = roof["traffic"] / (load_only_ms * 1e-3) / 1e9
                 if stream_gbs:

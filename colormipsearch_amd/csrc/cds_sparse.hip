@@ -812,7 +812,9 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                     const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.px + off), 0, (int)0x7ffffffc, 0x00020000);
                     const uint32_t r = __builtin_amdgcn_raw_buffer_load_b32(ri, valid ? (int)(ent.x * 4u) : 0, 0, 0);
 #endif
-                    const int poffs = valid ? (int)ent.y : safe_off;
+                    uint32_t po;   // plane offset of the pixel: (row + 2) * pitch + 2 + column
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(po) : "v"(ent.y >> 16), "v"(v_pitch), "v"(poff));
+                    const int poffs = valid ? (int)(po + (ent.y & 0xffffu)) : safe_off;
                     valid = valid && (r & 255u) > v_thr;
                     const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
                     const uint32_t cls = (((r >> kRecBandShift) & kRecBandMask) * 13u) >> 6;  // band / 5 for bands 5..34
@@ -913,11 +915,13 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                                 uint32_t rec = cur[j] ^ 0x00030003u;
                                 if (rem < 128u * (j + 1)) {   // wave-uniform, once per run: the run ends inside this block.  When the rest of the run
                                     // is odd, the dword holding its last record also holds the record BEHIND it (the first of the next row, strip or
-                                    // image): that one is not part of the scan -- turned into "no flag, band 3" like everything beyond the run
+                                    // image): that one is not part of the scan -- turned into "no flag, band 3" like everything beyond the run.
+                                    // (The empty asm keeps this a scalar branch: as a select it would cost every block four vector instructions.)
                                     if (2u * (uint32_t)lane + 1u >= rem - 128u * j) rec = (rec & 0xffffu) | 0x00030000u;
+                                    asm volatile("" : "+v"(rec));
                                 }
                                 // rows: records come in the order (lane 0 low, lane 0 high, lane 1 low, ...)
-                                const unsigned long long fbl = __ballot((rec & 0x8000u) != 0), fbh = __ballot((int)rec < 0);
+                                const unsigned long long fbl = __ballot((short)(rec & 0xffffu) < 0), fbh = __ballot((int)rec < 0);   // (v_cmp_lt_i16 / _i32)
                                 const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(fbh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbh,
                                                         __builtin_amdgcn_mbcnt_hi((uint32_t)(fbl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbl, 0))));
                                 const uint32_t ryl = (uint32_t)yrel + before + __builtin_amdgcn_ubfe(rec, 15u, 1u), ryh = ryl + (rec >> 31);
@@ -940,21 +944,19 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                                     asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ah) : "v"(cxm >> 19), "v"(rowh));
                                     wml = *reinterpret_cast<lds_u32 *>((uintptr_t)al), wmh = *reinterpret_cast<lds_u32 *>((uintptr_t)ah);
                                 }
-                                // plane offset of column cx0 in the record's row: (ry + 2) * pitch + 2
-                                uint32_t prl, prh;
-                                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(prl) : "v"(ryl), "v"(v_pitch), "v"(poff));
-                                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(prh) : "v"(ryh), "v"(v_pitch), "v"(poff));
+                                // (an entry carries row << 16 | column, one v_perm; the round turns it into the plane offset: the vector pipe is
+                                // the kernel's bottleneck, and two multiply-adds per block here cost more than one per round there)
                                 const uint32_t idl = i + 128u * j + 2u * (uint32_t)lane;   // index of the low record in the image
                                 const uint32_t bh = rec >> 16;                             // (v_bfe takes the band mod 32 from the low bits)
                                 {
                                     const bool hl = __builtin_amdgcn_ubfe(wpl, rec, 1u) != 0, hh = __builtin_amdgcn_ubfe(wph, bh, 1u) != 0;
                                     const unsigned long long hbl = __ballot(hl), hbh = __ballot(hh);
                                     if (hbl) {
-                                        append(q0, qt0, hbl, hl, idl, prl + (cxp & 0xffffu));
+                                        append(q0, qt0, hbl, hl, idl, __builtin_amdgcn_perm(ryl, cxp, 0x05040100u));
                                         if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
                                     }
                                     if (hbh) {
-                                        append(q0, qt0, hbh, hh, idl + 1u, prh + (cxp >> 16));
+                                        append(q0, qt0, hbh, hh, idl + 1u, __builtin_amdgcn_perm(ryh, cxp, 0x05040302u));
                                         if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
                                     }
                                 }
@@ -962,11 +964,11 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                                     const bool hl = __builtin_amdgcn_ubfe(wml, rec, 1u) != 0, hh = __builtin_amdgcn_ubfe(wmh, bh, 1u) != 0;
                                     const unsigned long long hbl = __ballot(hl), hbh = __ballot(hh);
                                     if (hbl) {
-                                        append(q1, qt1, hbl, hl, idl, prl + (cxm & 0xffffu));
+                                        append(q1, qt1, hbl, hl, idl, __builtin_amdgcn_perm(ryl, cxm, 0x05040100u));
                                         if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
                                     }
                                     if (hbh) {
-                                        append(q1, qt1, hbh, hh, idl + 1u, prh + (cxm >> 16));
+                                        append(q1, qt1, hbh, hh, idl + 1u, __builtin_amdgcn_perm(ryh, cxm, 0x05040302u));
                                         if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
                                     }
                                 }
