@@ -763,6 +763,12 @@ def test_device_match_list_equals_host_filter(cds, oracle, monkeypatch):
     scores, mir = alg.searchSparseLibrary(sl)
     sizes = alg.getQuerySizes()
     assert sizes[10] == 0
+    # the oracle's side of the list: the scores the filter runs over are the oracle's for two masks on the first 96 targets
+    # (the planted copies among them), so for those rows the device list below IS the oracle pipeline scan -> isMatch
+    imgs96 = dense.download(0, 96)
+    for m_or in (2, 5):
+        ws, wm = oracle.PixelMatchQuery(masks[m_or], 20, 20, 0.01, 2, True, rects).scan(imgs96, n_threads=8)
+        assert np.array_equal(ws, scores[m_or, :96]) and np.array_equal(wm.astype(bool), mir[m_or, :96])
     for pct in (0.0, 0.01, 0.5, 2.0, 50.0):
         want = [(m, t, int(scores[m, t]), bool(mir[m, t])) for m in range(len(masks)) for t in range(n_t)
                 if sizes[m] > 0 and oracle.is_match(int(scores[m, t]), int(sizes[m]), pct)]
