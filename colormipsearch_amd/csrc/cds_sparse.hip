@@ -920,11 +920,21 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                                     if (2u * (uint32_t)lane + 1u >= rem - 128u * j) rec = (rec & 0xffffu) | 0x00030000u;
                                     asm volatile("" : "+v"(rec));
                                 }
-                                // rows: records come in the order (lane 0 low, lane 0 high, lane 1 low, ...)
-                                const unsigned long long fbl = __ballot((short)(rec & 0xffffu) < 0), fbh = __ballot((int)rec < 0);   // (v_cmp_lt_i16 / _i32)
-                                const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(fbh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbh,
-                                                        __builtin_amdgcn_mbcnt_hi((uint32_t)(fbl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbl, 0))));
-                                const uint32_t ryl = (uint32_t)yrel + before + __builtin_amdgcn_ubfe(rec, 15u, 1u), ryh = ryl + (rec >> 31);
+                                // rows: records come in the order (lane 0 low, lane 0 high, lane 1 low, ...).  Row of lane L's LOW record = rows
+                                // started before the block + flags of all records of lanes < L + its own flag = flags of the low records of lanes
+                                // <= L + flags of the high records of lanes < L: one mbcnt chain over (low flags >> 1) and the high flags, lane 0's
+                                // low flag added on the scalar side; the HIGH record's row = that + its own flag, an add-with-carry whose carry-in
+                                // is the high-flag mask itself.  (Two vector instructions fewer than extracting both flags per lane: the vector
+                                // pipes are what this kernel is bound by.)
+                                unsigned long long fbl;
+                                asm("v_cmp_gt_i16_e64 %0, 0, %1" : "=s"(fbl) : "v"(rec));   // sign of the low 16 bits = the low record's row flag
+                                const unsigned long long fbh = __ballot((int)rec < 0);
+                                const unsigned long long fbl1 = fbl >> 1;
+                                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(fbh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbh,
+                                                       __builtin_amdgcn_mbcnt_hi((uint32_t)(fbl1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbl1, 0))));
+                                const uint32_t ryl = below + (uint32_t)(yrel + (int)((uint32_t)fbl & 1u));
+                                uint32_t ryh;
+                                asm("v_addc_co_u32_e64 %0, vcc, %1, 0, %2" : "=v"(ryh) : "v"(ryl), "s"(fbh) : "vcc");
                                 yrel += __popcll(fbl) + __popcll(fbh);
                                 // columns of both records at once (16-bit halves): x - origin, clamped to the guard cell
                                 const uint32_t xpk = (rec >> 6) & 0x01FF01FFu;
