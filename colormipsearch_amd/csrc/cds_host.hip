@@ -594,32 +594,55 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
                 const uint8_t *img = masks_rgb + (size_t)m * img_bytes;
                 std::vector<MaskPx> &list = per_mask[(size_t)m];
                 int32_t size = 0;
-                for (int y = 0; y < H; y++)
-                    for (int x = 0; x < W; x++) {
-                        if (in_rects(excluded, n_excluded, x, y)) continue;
-                        const uint8_t *p = img + 3 * ((size_t)y * W + x);
-                        int r = p[0], g = p[1], b = p[2];
-                        if (!(r > params->mask_threshold || g > params->mask_threshold || b > params->mask_threshold)) continue;
-                        size++;  // getQuerySize counts every position, class or not
-                        double a;
-                        int c1 = hue_class(r, g, b, &a);
-                        if (c1 == C_NONE) continue;  // pxGap is 10000 against everything
-                        uint64_t key;
-                        memcpy(&key, &a, 8);
-                        key ^= (uint64_t)c1 << 61;   // a < 1 so the top bits of its encoding are free
-                        auto it = cache.find(key);
-                        Intervals iv;
-                        if (it == cache.end()) {
-                            iv = intervals_for(ctx->ratios, c1, a, params->z_tolerance);
-                            cache.emplace(key, iv);
-                        } else {
-                            iv = it->second;
-                        }
-                        if (iv.len1 == 0 && iv.lo1 == 1 && iv.len2 == 0 && iv.lo2 == 1) continue;  // can never match
-                        list.push_back({x, y, iv.lo1, iv.len1, iv.lo2, iv.len2});
-                        lm0 = std::min(lm0, y); lm1 = std::max(lm1, y + 1);
-                        lxlo = std::min(lxlo, x); lxhi = std::max(lxhi, x + 1);
+                auto one_pixel = [&](int x, int y) {
+                    const uint8_t *p = img + 3 * ((size_t)y * W + x);
+                    int r = p[0], g = p[1], b = p[2];
+                    if (!(r > params->mask_threshold || g > params->mask_threshold || b > params->mask_threshold)) return;
+                    if (in_rects(excluded, n_excluded, x, y)) return;
+                    size++;  // getQuerySize counts every position, class or not
+                    double a;
+                    int c1 = hue_class(r, g, b, &a);
+                    if (c1 == C_NONE) return;  // pxGap is 10000 against everything
+                    uint64_t key;
+                    memcpy(&key, &a, 8);
+                    key ^= (uint64_t)c1 << 61;   // a < 1 so the top bits of its encoding are free
+                    auto it = cache.find(key);
+                    Intervals iv;
+                    if (it == cache.end()) {
+                        iv = intervals_for(ctx->ratios, c1, a, params->z_tolerance);
+                        cache.emplace(key, iv);
+                    } else {
+                        iv = it->second;
                     }
+                    if (iv.len1 == 0 && iv.lo1 == 1 && iv.len2 == 0 && iv.lo2 == 1) return;  // can never match
+                    list.push_back({x, y, iv.lo1, iv.len1, iv.lo2, iv.len2});
+                    lm0 = std::min(lm0, y); lm1 = std::max(lm1, y + 1);
+                    lxlo = std::min(lxlo, x); lxhi = std::max(lxhi, x + 1);
+                };
+                // a mask is a few percent signal on black and a black pixel is above no threshold (>= 0): whole runs of 8 black pixels
+                // (24 zero bytes) are skipped with three 64-bit compares -- the scan of the frame was most of a single mask's preparation
+                const bool skip_black = params->mask_threshold >= 0;
+                for (int y = 0; y < H; y++) {
+                    const uint8_t *row = img + (size_t)3 * y * W;
+                    int x = 0;
+                    while (x < W) {
+                        if (skip_black && x + 8 <= W) {
+                            uint64_t w0, w1, w2;
+                            memcpy(&w0, row + 3 * x, 8);
+                            memcpy(&w1, row + 3 * x + 8, 8);
+                            memcpy(&w2, row + 3 * x + 16, 8);
+                            if ((w0 | w1 | w2) == 0) {
+                                x += 8;
+                                continue;
+                            }
+                            for (int k = 0; k < 8; k++) one_pixel(x + k, y);
+                            x += 8;
+                        } else {
+                            one_pixel(x, y);
+                            x++;
+                        }
+                    }
+                }
                 sizes[(size_t)m] = size;
             }
             std::lock_guard<std::mutex> lk(merge);
