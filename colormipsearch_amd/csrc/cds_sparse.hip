@@ -440,7 +440,8 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan_kernel(SparseScanParams
                     const uint32_t r = ent.x;
                     const int off = valid ? (int)ent.y : safe_off;
                     const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
-                    const uint32_t cls = (((r >> kRecBandShift) & kRecBandMask) * 13u) >> 6;  // band / 5 for bands 5..34
+                    uint32_t cls = __umul24((r >> kRecBandShift) & kRecBandMask, 13u) >> 6;  // band / 5 for bands 5..34 (kept apart from the << 29:
+                    asm volatile("" : "+v"(cls));                                                // folded, it becomes a quarter-rate 32-bit multiply)
                     uint32_t code = (cls << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
                     code = valid ? code : 0u;  // 0 lies in no interval
                     const plane_t *c0 = plane + off - (XY2 ? 2 : 0);  // (column offsets 0, 2, 4 below)
@@ -817,7 +818,8 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                     const int poffs = valid ? (int)(po + (ent.y & 0xffffu)) : safe_off;
                     valid = valid && (r & 255u) > v_thr;
                     const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
-                    const uint32_t cls = (((r >> kRecBandShift) & kRecBandMask) * 13u) >> 6;  // band / 5 for bands 5..34
+                    uint32_t cls = __umul24((r >> kRecBandShift) & kRecBandMask, 13u) >> 6;  // band / 5 for bands 5..34 (kept apart from the << 29:
+                    asm volatile("" : "+v"(cls));                                                // folded, it becomes a quarter-rate 32-bit multiply)
                     uint32_t code = (cls << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
                     code = valid ? code : 0u;  // 0 lies in no interval
                     const plane_t *c0 = plane + poffs - (XY2 ? 2 : 0);  // (column offsets 0, 2, 4 below)
@@ -1148,12 +1150,15 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                 const uint32_t e = valid ? ent.y : safe_off;
                 const uint32_t off = e & 0xFFFFFu, bit = e >> 20, m = bit & 7u, o = bit >> 3;
                 const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
-                const uint32_t rcls = (((r >> kRecBandShift) & kRecBandMask) * 13u) >> 6;  // band / 5 for bands 5..34
+                // band / 5 for bands 5..34 -- as a 24-bit multiply and two shifts: hipcc folds `(band * 13 >> 6) << 29` into ONE full 32-bit
+                // multiply by 13 << 23, a quarter-rate instruction, and the vector pipes are this kernel's tightest resource
+                uint32_t rcls = __umul24((r >> kRecBandShift) & kRecBandMask, 13u) >> 6;
+                asm volatile("" : "+v"(rcls));
                 uint32_t code = (rcls << 29) | (__float_as_uint(fn * __builtin_amdgcn_rcpf(fd)) >> 1);
                 code = valid ? code : 0u;  // 0 lies in no interval
                 // plane bytes of the entry's own mask: mask row = target row - dy, mask column = target column - dx
                 const uint4 *ivm = ivt + ivb[m];  // (requested before the plane reads: the asm below is a memory barrier to hipcc)
-                const uint32_t top = (m * pcells + off + (XY2 ? 2u * pitch - 2u : 0u)) * ES;  // byte offset of cell (row + 2, column - 2) of mask m's plane
+                const uint32_t top = (__umul24(m, pcells) + off + (XY2 ? 2u * pitch - 2u : 0u)) * ES;  // byte offset of cell (row + 2, column - 2) of mask m's plane (< 2^24)
                 uint32_t idx[NS];
 #if defined(SM_EXP) && SM_EXP == 4   // (timing experiment: no plane gathers)
                 for (int k = 0; k < NS; k++) idx[k] = (top + 13u * k) & 127u;
@@ -1247,7 +1252,7 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                         const float hf = (float)((rec >> 8) & 255u) * __builtin_amdgcn_rcpf((float)(rec & 255u));
                         const uint32_t band = (rec >> kRecBandShift) & kRecBandMask;
                         const bool bright = (rec & 255u) > thr;
-                        uint32_t bin = (((band * 13u) >> 6) << kSparseGroupBinsLog2) + (uint32_t)(hf * (float)kSparseGroupBins);
+                        uint32_t bin = ((__umul24(band, 13u) >> 6) << kSparseGroupBinsLog2) + (uint32_t)(hf * (float)kSparseGroupBins);
                         bin = bright ? bin : 0u;
                         bool passp = true, passm = MIRROR;
                         if (PF) {
