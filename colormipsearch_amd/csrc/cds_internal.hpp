@@ -223,6 +223,12 @@ struct SparseMaskPlan {
     size_t slabs_off = 0; // byte offset of this mask's slab images in cds_maskset::d_sp_slabs
     size_t iv_off = 0;    // element offset of its interval table in cds_maskset::d_sp_iv
     size_t lds_bytes = 0; // dynamic LDS of one workgroup
+    // the two-orientation band map of sparse_scan16_kernel (8-byte cells: plain word, mirrored word; columns relative to ux0, the
+    // left end of the union of the mask's window and its mirror image), one image per slab BEHIND the slab images of the mask
+    int ux0 = 0;          // first column of the union window (target coordinates; may be negative)
+    int g64 = 0;          // first column (relative to ux0) of the always-empty guard cell
+    int rowb64 = 0;       // bytes per cell row (cells x 8)
+    int map64_bytes = 0;  // bytes of one slab's map (multiple of 16); 0 = the mask cannot go through the 16-bit stream
 };
 
 struct SparseScanParams {
@@ -243,6 +249,7 @@ struct SparseScanParams {
     uint32_t psize;           // targets per partition (the last one may hold fewer)
     uint32_t *work;           // [n_slabs][nparts] x 32 dwords: next target of the partition (zero before the launch)
     int plane_global;         // sparse_scan16_kernel: the plane is read from global memory (the LDS image is the band map alone)
+    int ux0, g64, rowb64, map64_bytes;   // sparse_scan16_kernel's two-orientation band map (SparseMaskPlan); its images follow the n_slabs slab images
     int use16;                // scan through the 16-bit stage-1 stream (sparse_scan16_kernel) instead of the 4-byte records
     unsigned long long *stat; // pilot launches of sparse_scan16_kernel: [0] += records visited, [1] += records queued for a round; else NULL
     int32_t *out;             // [count] score | mirrored << 31 (written directly when there is one slab and no partial)

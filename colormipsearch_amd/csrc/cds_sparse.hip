@@ -689,6 +689,10 @@ __device__ __forceinline__ uint32_t pk_sub_min_u16(uint32_t a, uint32_t b, uint3
     const u16x2 d = __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b);
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(d, __builtin_bit_cast(u16x2, cap)));
 }
+__device__ __forceinline__ uint32_t pk_shr2_mad_u16(uint32_t a, uint32_t b, uint32_t c) {   // (a >> 2) * b + c per 16-bit half
+    const u16x2 d = (__builtin_bit_cast(u16x2, a) >> (uint16_t)2) * __builtin_bit_cast(u16x2, b) + __builtin_bit_cast(u16x2, c);
+    return __builtin_bit_cast(uint32_t, d);
+}
 
 // PG ("plane global"): the mask's plane stays in global memory (L2-resident: every workgroup reads the same ~100 KB) and only the band map,
 // the interval table and the queues live in LDS -- a third of the LDS, so two workgroups share a CU (8 waves per SIMD instead of 4).  Rounds
@@ -703,11 +707,13 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
     uint8_t *lds = reinterpret_cast<uint8_t *>(lds4);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint4 *ivt = lds4;
-    uint8_t *slab = lds + (IVLDS ? (size_t)p.n_iv * 16 : 0);
+    // LDS: [two-orientation map (8-byte cells)] [interval table] [plane, unless PG] [queues].  The map comes FIRST: its cell addresses are then
+    // the 16-bit offsets themselves -- the dynamic LDS of a kernel without static LDS starts at address 0, which launch_sparse_one checks
+    // (hipFuncGetAttributes: sharedSizeBytes == 0) before it launches this kernel
+    uint4 *ivt = reinterpret_cast<uint4 *>(lds + p.map64_bytes);
+    uint8_t *slab = lds + p.map64_bytes + (IVLDS ? (size_t)p.n_iv * 16 : 0);
     const plane_t *plane = reinterpret_cast<const plane_t *>(slab);   // (PG: set per slab, below)
-    const uint32_t *nearb = reinterpret_cast<const uint32_t *>(slab + (PG ? 0 : p.near_off));
-    uint8_t *qb = slab + (PG ? p.slab_bytes - p.near_off : p.slab_bytes) + (size_t)wave * SP_QBYTES;
+    uint8_t *qb = slab + (PG ? 0 : p.near_off) + (size_t)wave * SP_QBYTES;
     uint2 *q0 = reinterpret_cast<uint2 *>(qb), *q1 = q0 + SP_QCAP;
     if (IVLDS)
         for (int i = threadIdx.x; i < p.n_iv; i += blockDim.x) ivt[i] = p.iv[i];
@@ -716,10 +722,14 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
     for (int si = 0; si < p.n_slabs; si++) {
         const int s = (int)((blockIdx.x + (unsigned)si) % (unsigned)p.n_slabs);  // every workgroup visits every slab
         __syncthreads();  // the previous slab's waves are done with the LDS image
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(p.slabs + (size_t)s * p.slab_bytes + (PG ? p.near_off : 0));
+        if (!PG) {   // the plane
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.slabs + (size_t)s * p.slab_bytes);
             uint4 *dst = reinterpret_cast<uint4 *>(slab);
-            for (int i = threadIdx.x; i < (p.slab_bytes - (PG ? p.near_off : 0)) / 16; i += blockDim.x) dst[i] = src[i];
+            for (int i = threadIdx.x; i < p.near_off / 16; i += blockDim.x) dst[i] = src[i];
+        }
+        {   // this slab's two-orientation map: the images follow the mask's n_slabs slab images
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.slabs + (size_t)p.n_slabs * p.slab_bytes + (size_t)s * p.map64_bytes);
+            for (int i = threadIdx.x; i < p.map64_bytes / 16; i += blockDim.x) lds4[i] = src[i];
         }
         if (PG) plane = reinterpret_cast<const plane_t *>(p.slabs + (size_t)s * p.slab_bytes);
         __syncthreads();
@@ -728,15 +738,21 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
         const int ra = max(ys0 - HALO, 0), rb = min(ys0 + rows_s + HALO, p.H);  // target rows [ra, rb)
         const int ry0 = ys0 - 2;
         const uint32_t cx0 = (uint32_t)(p.xlo - 2), cm0 = (uint32_t)(p.W - 1) - cx0;
-        const uint32_t wnear = (uint32_t)((p.cols + 4 + 7) & ~7);  // first column of the band map's guard cell (always 0): the clamp target
+        const uint32_t ux0 = (uint32_t)p.ux0;   // map columns: u = x - ux0, clamped to g64 = the first column of the guard cell (always 0)
         // per-pixel constants in VGPRs (uniform values, pinned by the asm: the scalar registers hold the 18 counters and the loop state)
-        uint32_t v_thr, v_wnearpk, v_nwpr, v_pitch, poff, near_lds;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(near_lds) : "s"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)nearb));
+        uint32_t v_thr, v_wnearpk, v_rowbpk, v_pitch, poff, v_colmax, v_kp, v_km, v_k10000, v_k10001;
+        asm volatile("v_mov_b32 %0, 0x10000" : "=v"(v_k10000));
+        asm volatile("v_mov_b32 %0, 0x10001" : "=v"(v_k10001));
         asm volatile("v_mov_b32 %0, %1" : "=v"(v_thr) : "s"(p.thr));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(v_wnearpk) : "s"(wnear * 0x10001u));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(v_nwpr) : "s"(p.nwpr * 4));  // bytes per cell row of the band map
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_wnearpk) : "s"((uint32_t)p.g64 * 0x10001u));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_rowbpk) : "s"((uint32_t)p.rowb64 * 0x10001u));  // bytes per cell row of the map (both halves)
         asm volatile("v_mov_b32 %0, %1" : "=v"(v_pitch) : "s"(p.pitch));
         asm volatile("v_mov_b32 %0, %1" : "=v"(poff) : "s"(2 * p.pitch + 2));
+        // a queued pixel's window column from its map column u: plain u - (cx0 - ux0), mirrored (cm0 - ux0) - u; both within [0, cols + 3]
+        // or the pixel sits in a cell shared with the window's edge and is dropped by the round
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_kp) : "s"(cx0 - ux0));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_km) : "s"(cm0 - ux0));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v_colmax) : "s"(p.cols + 3));
         // column strips of the library that the mask's plain window [xlo - 2, xhi + 2] and its mirror image can touch
         int wlo = p.xlo - HALO, whi = p.xlo + p.cols - 1 + HALO;
         if (MIRROR) {
@@ -799,7 +815,7 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
 
                 // evaluate up to 64 queued pixels of one orientation: every lane busy.  The records come from the image's 4-byte
                 // array now (entry.x = record index): one gather per round, and the data threshold is applied here.
-                auto round = [&](const uint2 *q, int &qh, int &ql, const int qt, int *cc) {
+                auto round = [&](const uint2 *q, int &qh, int &ql, const int qt, int *cc, const bool mirrored) {
                     const int n = min(qt - qh, 64);
 #if SP16_EXP == 1   // (timing only: no evaluation rounds)
                     qh += n; ql = qh + 64; cc[0] += n; return;
@@ -813,9 +829,11 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                     const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.px + off), 0, (int)0x7ffffffc, 0x00020000);
                     const uint32_t r = __builtin_amdgcn_raw_buffer_load_b32(ri, valid ? (int)(ent.x * 4u) : 0, 0, 0);
 #endif
-                    uint32_t po;   // plane offset of the pixel: (row + 2) * pitch + 2 + column
+                    uint32_t po;   // plane offset of the pixel: (row + 2) * pitch + 2 + window column
                     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(po) : "v"(ent.y >> 16), "v"(v_pitch), "v"(poff));
-                    const int poffs = valid ? (int)(po + (ent.y & 0xffffu)) : safe_off;
+                    const uint32_t col = mirrored ? v_km - (ent.y & 0xffffu) : (ent.y & 0xffffu) - v_kp;
+                    valid = valid && col <= v_colmax;   // (outside the window nothing can match: all nine probes miss the mask)
+                    const int poffs = valid ? (int)(po + col) : safe_off;
                     valid = valid && (r & 255u) > v_thr;
                     const float fn = (float)((r >> 8) & 255u), fd = (float)(r & 255u);
                     uint32_t cls = __umul24((r >> kRecBandShift) & kRecBandMask, 13u) >> 6;  // band / 5 for bands 5..34 (kept apart from the << 29:
@@ -827,8 +845,22 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
 #pragma unroll
                     for (int iy = 0; iy < NSX; iy++) {
                         const plane_t *rowp = XY2 ? c0 + (1 - iy) * 2 * (int)p.pitch : c0;  // mask row = target row - dy
+                        if (PG && XY2) {
+                            // the plane is in global memory: ONE unaligned load per mask row brings the three columns (elements 0, 2, 4 of a
+                            // five-element span) -- a round is a chain of gathers, and 64 scattered lanes cost the texture path the same per
+                            // instruction whether they ask for one byte or eight: 3 gathers instead of 9.  (The elements behind the span are the
+                            // row's zero padding or the next row's, always inside the mask's slab images.)
+                            uint32_t w[4];
+                            __builtin_memcpy(w, rowp, P8 ? 8 : 16);
 #pragma unroll
-                        for (int ix = 0; ix < NSX; ix++) idx[ix * NSX + iy] = rowp[XY2 ? (2 - ix) * 2 : 0];  // mask column = target column - dx
+                            for (int ix = 0; ix < NSX; ix++) {
+                                const int e = (2 - ix) * 2;   // mask column = target column - dx
+                                idx[ix * NSX + iy] = P8 ? (w[e >> 2] >> ((e & 3) * 8)) & 255u : (w[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                            }
+                        } else {
+#pragma unroll
+                            for (int ix = 0; ix < NSX; ix++) idx[ix * NSX + iy] = rowp[XY2 ? (2 - ix) * 2 : 0];  // mask column = target column - dx
+                        }
                     }
                     constexpr int GS = WPE <= 4 ? 9 : 3;  // interval records in flight together
 #pragma unroll
@@ -857,9 +889,9 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                 };
                 // end of a target: the rest of its queues, then its score (or this slab's per-transform counts)
                 auto finish_target = [&](const uint32_t t) {
-                    while (qt0 > qh0) round(q0, qh0, ql0, qt0, c);
+                    while (qt0 > qh0) round(q0, qh0, ql0, qt0, c, false);
                     if (MIRROR)
-                        while (qt1 > qh1) round(q1, qh1, ql1, qt1, c + NS);
+                        while (qt1 > qh1) round(q1, qh1, ql1, qt1, c + NS, true);
                     if (p.partial) {  // per-transform counts of this slab: lane k holds transform k (the 18-entry layout of the ABI)
                         int v = 0;
 #pragma unroll
@@ -890,11 +922,10 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                     int yrel = ra - 1 - ry0;  // (rows started before the current block) - 1, relative to the band map
                     if (p.stat) st_visited += b - a;
                     // a record's x is relative to its strip: the strip's first column goes into the run's two column origins (both halves)
-                    uint32_t v_cx0pk, v_cm0pk;
+                    uint32_t v_ux0pk;
                     {
                         const uint32_t sbase = (uint32_t)(ks0 + kin) * (uint32_t)p.strip_w;
-                        asm volatile("v_mov_b32 %0, %1" : "=v"(v_cx0pk) : "s"(((cx0 - sbase) & 0xffffu) * 0x10001u));
-                        asm volatile("v_mov_b32 %0, %1" : "=v"(v_cm0pk) : "s"(((cm0 - sbase) & 0xffffu) * 0x10001u));
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(v_ux0pk) : "s"(((ux0 - sbase) & 0xffffu) * 0x10001u));
                     }
                     for (uint32_t i = a; i < b; i += 128 * NB) {  // wave-uniform
                         const uint32_t rem = b - i;  // records of this run from block 0 of this iteration on
@@ -914,74 +945,68 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
 #pragma unroll
                             for (int j = 0; j < NB; j++) {
                                 if (rem <= 128u * j) break;  // wave-uniform: a block beyond the run
-                                uint32_t rec = cur[j] ^ 0x00030003u;
+                                uint32_t rec = cur[j];   // (band fields as the stream has them, XOR 3: the map's bits are laid out for that)
                                 if (rem < 128u * (j + 1)) {   // wave-uniform, once per run: the run ends inside this block.  When the rest of the run
                                     // is odd, the dword holding its last record also holds the record BEHIND it (the first of the next row, strip or
-                                    // image): that one is not part of the scan -- turned into "no flag, band 3" like everything beyond the run.
-                                    // (The empty asm keeps this a scalar branch: as a select it would cost every block four vector instructions.)
-                                    if (2u * (uint32_t)lane + 1u >= rem - 128u * j) rec = (rec & 0xffffu) | 0x00030000u;
+                                    // image): that one is not part of the scan -- turned into 0, "no flag, bit 0 of the map", like everything beyond
+                                    // the run.  (The empty asm keeps this a scalar branch: as a select it would cost every block vector instructions.)
+                                    if (2u * (uint32_t)lane + 1u >= rem - 128u * j) rec &= 0xffffu;
                                     asm volatile("" : "+v"(rec));
                                 }
                                 // rows: records come in the order (lane 0 low, lane 0 high, lane 1 low, ...).  Row of lane L's LOW record = rows
                                 // started before the block + flags of all records of lanes < L + its own flag = flags of the low records of lanes
                                 // <= L + flags of the high records of lanes < L: one mbcnt chain over (low flags >> 1) and the high flags, lane 0's
                                 // low flag added on the scalar side; the HIGH record's row = that + its own flag, an add-with-carry whose carry-in
-                                // is the high-flag mask itself.  (Two vector instructions fewer than extracting both flags per lane: the vector
-                                // pipes are what this kernel is bound by.)
-                                unsigned long long fbl;
+                                // is the high-flag mask itself.  Both rows then live in ONE register (16-bit halves), like the columns.
+                                // (gfx950 issues the two-operand encodings -- add, and, shifts, cndmask with vcc -- in ~2.5 cycles per wave and the
+                                // three-operand, packed, SDWA and compare ones in ~4.2, tools/valubench/opbench: the choices below follow that)
+                                unsigned long long fbl, fbh;
+                                uint32_t hf16;   // 0x10000 where the high record starts a row
                                 asm("v_cmp_gt_i16_e64 %0, 0, %1" : "=s"(fbl) : "v"(rec));   // sign of the low 16 bits = the low record's row flag
-                                const unsigned long long fbh = __ballot((int)rec < 0);
+                                asm("v_cmp_gt_i32_e32 vcc, 0, %2\n\tv_cndmask_b32_e32 %0, 0, %3, vcc\n\ts_mov_b64 %1, vcc" : "=&v"(hf16), "=s"(fbh) : "v"(rec), "v"(v_k10000) : "vcc");
                                 const unsigned long long fbl1 = fbl >> 1;
                                 const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(fbh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbh,
                                                        __builtin_amdgcn_mbcnt_hi((uint32_t)(fbl1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fbl1, 0))));
                                 const uint32_t ryl = below + (uint32_t)(yrel + (int)((uint32_t)fbl & 1u));
-                                uint32_t ryh;
-                                asm("v_addc_co_u32_e64 %0, vcc, %1, 0, %2" : "=v"(ryh) : "v"(ryl), "s"(fbh) : "vcc");
+                                uint32_t rypk;   // both rows: ryl | (ryl + high flag) << 16
+                                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rypk) : "v"(ryl), "v"(v_k10001), "v"(hf16));
                                 yrel += __popcll(fbl) + __popcll(fbh);
-                                // columns of both records at once (16-bit halves): x - origin, clamped to the guard cell
+                                // map columns of both records at once: x - ux0, clamped to the guard cell; the cell's byte offset in its row is
+                                // (u / 8) * 8 = u with the low three bits cleared; the row's = (ry / 4) * row bytes: one packed multiply-add
                                 const uint32_t xpk = (rec >> 6) & 0x01FF01FFu;
-                                const uint32_t cxp = pk_sub_min_u16(xpk, v_cx0pk, v_wnearpk);
-                                const uint32_t cxm = MIRROR ? pk_sub_min_u16(v_cm0pk, xpk, v_wnearpk) : 0u;
-                                // band-map words: map + (ry / 4) * row bytes + (column / 8) * 4
-                                typedef __attribute__((address_space(3))) const uint32_t lds_u32;
-                                uint32_t rowl, rowh, al, ah;
-                                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rowl) : "v"(ryl >> 2), "v"(v_nwpr), "v"(near_lds));
-                                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rowh) : "v"(ryh >> 2), "v"(v_nwpr), "v"(near_lds));
-                                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(al) : "v"(__builtin_amdgcn_ubfe(cxp, 3u, 13u)), "v"(rowl));
-                                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ah) : "v"(cxp >> 19), "v"(rowh));
-                                const uint32_t wpl = *reinterpret_cast<lds_u32 *>((uintptr_t)al), wph = *reinterpret_cast<lds_u32 *>((uintptr_t)ah);
-                                uint32_t wml = 0, wmh = 0;
-                                if (MIRROR) {
-                                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(al) : "v"(__builtin_amdgcn_ubfe(cxm, 3u, 13u)), "v"(rowl));
-                                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ah) : "v"(cxm >> 19), "v"(rowh));
-                                    wml = *reinterpret_cast<lds_u32 *>((uintptr_t)al), wmh = *reinterpret_cast<lds_u32 *>((uintptr_t)ah);
-                                }
-                                // (an entry carries row << 16 | column, one v_perm; the round turns it into the plane offset: the vector pipe is
-                                // the kernel's bottleneck, and two multiply-adds per block here cost more than one per round there)
+                                const uint32_t upk = pk_sub_min_u16(xpk, v_ux0pk, v_wnearpk);
+                                const uint32_t offpk = pk_shr2_mad_u16(rypk, v_rowbpk, upk & 0xFFF8FFF8u);
+                                const uint32_t bh = rec >> 16;                             // the high record alone (v_bfe takes the band mod 32 from the low bits)
                                 const uint32_t idl = i + 128u * j + 2u * (uint32_t)lane;   // index of the low record in the image
-                                const uint32_t bh = rec >> 16;                             // (v_bfe takes the band mod 32 from the low bits)
+                                // one 8-byte cell per record: .x = the bands the plain mask accepts around here, .y = the mirrored mask's
+                                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                                typedef __attribute__((address_space(3))) const u32x2 lds_u64;
+                                const uint32_t al = offpk & 0xffffu, ah = offpk >> 16;   // (the map starts at LDS address 0: checked by the host, launch_sparse_one)
+                                const u32x2 wl = *reinterpret_cast<lds_u64 *>((uintptr_t)al), wh = *reinterpret_cast<lds_u64 *>((uintptr_t)ah);
+                                // (an entry carries row << 16 | map column, one v_perm; the round turns it into the plane offset: the vector pipe is
+                                // the kernel's bottleneck, and two multiply-adds per block here cost more than one per round there)
                                 {
-                                    const bool hl = __builtin_amdgcn_ubfe(wpl, rec, 1u) != 0, hh = __builtin_amdgcn_ubfe(wph, bh, 1u) != 0;
+                                    const bool hl = (int)(wl.x << (rec & 31u)) < 0, hh = (int)(wh.x << (bh & 31u)) < 0;   // (bit 31 - field: see the map)
                                     const unsigned long long hbl = __ballot(hl), hbh = __ballot(hh);
                                     if (hbl) {
-                                        append(q0, qt0, hbl, hl, idl, __builtin_amdgcn_perm(ryl, cxp, 0x05040100u));
-                                        if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
+                                        append(q0, qt0, hbl, hl, idl, __builtin_amdgcn_perm(rypk, upk, 0x05040100u));
+                                        if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c, false);
                                     }
                                     if (hbh) {
-                                        append(q0, qt0, hbh, hh, idl + 1u, __builtin_amdgcn_perm(ryh, cxp, 0x05040302u));
-                                        if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c);
+                                        append(q0, qt0, hbh, hh, idl + 1u, __builtin_amdgcn_perm(rypk, upk, 0x07060302u));
+                                        if (qt0 >= ql0) round(q0, qh0, ql0, qt0, c, false);
                                     }
                                 }
                                 if (MIRROR) {
-                                    const bool hl = __builtin_amdgcn_ubfe(wml, rec, 1u) != 0, hh = __builtin_amdgcn_ubfe(wmh, bh, 1u) != 0;
+                                    const bool hl = (int)(wl.y << (rec & 31u)) < 0, hh = (int)(wh.y << (bh & 31u)) < 0;
                                     const unsigned long long hbl = __ballot(hl), hbh = __ballot(hh);
                                     if (hbl) {
-                                        append(q1, qt1, hbl, hl, idl, __builtin_amdgcn_perm(ryl, cxm, 0x05040100u));
-                                        if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
+                                        append(q1, qt1, hbl, hl, idl, __builtin_amdgcn_perm(rypk, upk, 0x05040100u));
+                                        if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS, true);
                                     }
                                     if (hbh) {
-                                        append(q1, qt1, hbh, hh, idl + 1u, __builtin_amdgcn_perm(ryh, cxm, 0x05040302u));
-                                        if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS);
+                                        append(q1, qt1, hbh, hh, idl + 1u, __builtin_amdgcn_perm(rypk, upk, 0x07060302u));
+                                        if (qt1 >= ql1) round(q1, qh1, ql1, qt1, c + NS, true);
                                     }
                                 }
                             }
@@ -1704,17 +1729,43 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
         pl.slab_rows = R;
         pl.slab_bytes = (int)slab_image_bytes(R, pl.pitch, pl.nwpr, esize, &pl.near_off);
         pl.lds_bytes = fixed + (size_t)pl.slab_bytes;
+#if SP_BAND
+        {   // the two-orientation map of sparse_scan16_kernel: columns relative to the union of the mask's window and its mirror image
+            const int cx0 = xlo - 2, cm0 = ms->W - 1 - cx0;
+            int ulo = cx0, uhi = cx0 + pl.cols + 3;
+            if (ms->params.mirror) ulo = std::min(ulo, cm0 - (pl.cols + 3)), uhi = std::max(uhi, cm0);
+            pl.ux0 = ulo;
+            pl.g64 = round_up(uhi - ulo + 1, 8);
+            pl.rowb64 = (pl.g64 / 8 + 1) * 8;
+            const size_t mb = (size_t)round_up(((R + 8) / 4) * pl.rowb64, 16);
+            pl.map64_bytes = mb <= 65528 ? (int)mb : 0;   // (cell addresses are 16-bit offsets; a wider or taller map: the 4-byte records)
+        }
+#endif
         std::vector<uint8_t> &slabs = slab_of[m];
-        slabs.assign((size_t)pl.n_slabs * pl.slab_bytes, 0);
+        slabs.assign((size_t)pl.n_slabs * ((size_t)pl.slab_bytes + (size_t)pl.map64_bytes), 0);
 #if SP_BAND
         std::vector<uint32_t> tab_bits(tab.size());
         for (size_t k = 0; k < tab.size(); k++) tab_bits[k] = band_bits_of(tab[k].x, tab[k].y) | band_bits_of(tab[k].z, tab[k].w);
+        // the stream's band field is the record's XOR 3 (sparse_px16_kernel) and the kernel tests it by shifting the word LEFT by the field and
+        // looking at the sign: bit 31 - ((b ^ 3) & 31) = (b ^ 28) & 31 for band b -- and bit 31 for the field 0 that everything beyond a run
+        // decodes to, which is band 3's: never set
+        std::vector<uint32_t> tab_bits16(pl.map64_bytes ? tab.size() : 0);
+        for (size_t k = 0; k < tab_bits16.size(); k++) {
+            uint32_t w = 0;
+            for (uint32_t b = 0; b < 32; b++)
+                if (tab_bits[k] >> b & 1u) w |= 1u << (b ^ 28u);
+            tab_bits16[k] = w;
+        }
 #endif
         for (int s = 0; s < pl.n_slabs; s++) {
             uint8_t *img = slabs.data() + (size_t)s * pl.slab_bytes;
             uint16_t *plane16 = reinterpret_cast<uint16_t *>(img);
             uint32_t *nearb = reinterpret_cast<uint32_t *>(img + pl.near_off);
             const int ys0 = ylo + s * R;
+#if SP_BAND
+            uint32_t *map64 = pl.map64_bytes ? reinterpret_cast<uint32_t *>(slabs.data() + (size_t)pl.n_slabs * pl.slab_bytes + (size_t)s * pl.map64_bytes) : nullptr;
+            const int w64 = pl.rowb64 / 4;   // dwords per cell row
+#endif
             for (size_t i = 0; i < L.size(); i++) {
                 const int rr = L[i].y - ys0;
                 if (rr < 0 || rr >= R) continue;
@@ -1727,6 +1778,11 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
                         const int ry = rr + 2 + dy, cx = (L[i].x - xlo) + 2 + dx;  // bitmap origin = (xlo - 2, ys0 - 2)
 #if SP_BAND
                         nearb[(size_t)(ry >> 2) * pl.nwpr + (cx >> 3)] |= tab_bits[pidx[i]];
+                        if (map64) {   // target column x + dx as it is, and where the mirrored mask has this pixel: W - 1 - x, shifted
+                            const int up = L[i].x + dx - pl.ux0, um = ms->W - 1 - L[i].x + dx - pl.ux0;
+                            map64[(size_t)(ry >> 2) * w64 + (size_t)(up >> 3) * 2] |= tab_bits16[pidx[i]];
+                            if (ms->params.mirror) map64[(size_t)(ry >> 2) * w64 + (size_t)(um >> 3) * 2 + 1] |= tab_bits16[pidx[i]];
+                        }
 #else
                         nearb[(size_t)ry * pl.nwpr + (cx >> 5)] |= 1u << (cx & 31);
 #endif
@@ -1786,7 +1842,7 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
 }
 
 // can a library go through sparse_scan16_kernel at all?  (It holds the 16-bit stream.)
-static bool stream16_possible(const SparseScanParams &p) { return p.px16 != nullptr; }
+static bool stream16_possible(const SparseScanParams &p) { return p.px16 != nullptr && p.map64_bytes > 0; }
 
 template <bool XY2, bool MIRROR>
 static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t lds_bytes, int threads, hipStream_t st) {
@@ -1803,8 +1859,17 @@ static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t
              : p.iv_in_lds ? sparse_scan16_kernel<XY2, MIRROR, true, false, 8, false, true> : sparse_scan16_kernel<XY2, MIRROR, false, false, 8, false, true>;
     }
     if (ctx->sparse_load_only.load()) {   // (a diagnostic of THIS context only: cds_debug_sparse_load_only)
-        if (!(wide && p.plane8)) return fail(CDS_ERR_UNSUPPORTED, "the load-only diagnostic exists for the one-workgroup-per-CU, one-byte-plane layout only");
-        kern = s16 ? sparse_scan16_kernel<XY2, MIRROR, true, true, 4, true> : sparse_scan_kernel<XY2, MIRROR, true, true, 4, true>;
+        // the twin runs in the layout of the scan it stands for: the stream kernel's with the plane in L2 (two workgroups per CU) or in LDS,
+        // the 4-byte-record kernel's with one workgroup per CU; one-byte planes only
+        const bool twin = p.plane8 && (s16 ? (p.plane_global || wide) : wide);
+        if (!twin) return fail(CDS_ERR_UNSUPPORTED, "the load-only diagnostic exists for one-byte-plane layouts only (4-byte records: one workgroup per CU only)");
+        if (s16 && p.plane_global) kern = sparse_scan16_kernel<XY2, MIRROR, true, true, 8, true, true>;
+        else kern = s16 ? sparse_scan16_kernel<XY2, MIRROR, true, true, 4, true> : sparse_scan_kernel<XY2, MIRROR, true, true, 4, true>;
+    }
+    if (s16) {   // the stream kernel addresses its map from LDS address 0: true as long as the kernel has no static LDS in front of the dynamic one
+        hipFuncAttributes fa{};
+        CDS_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
+        if (fa.sharedSizeBytes != 0) return fail(CDS_ERR_HIP, "sparse_scan16_kernel was built with static LDS: its map would not start at LDS address 0");
     }
     CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     // persistent grid: as many workgroups as fit (LDS and the 2048 threads of a CU), every one visits every slab
@@ -1939,6 +2004,7 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
         p.n_iv = pl.n_iv; p.iv_in_lds = pl.iv_in_lds ? 1 : 0; p.plane8 = pl.plane8 ? 1 : 0;
         p.xlo = pl.xlo; p.cols = pl.cols; p.ylo = pl.ylo; p.nrows = pl.nrows; p.pitch = pl.pitch; p.nwpr = pl.nwpr;
         p.slab_rows = pl.slab_rows; p.n_slabs = pl.n_slabs; p.near_off = pl.near_off; p.slab_bytes = pl.slab_bytes;
+        p.ux0 = pl.ux0; p.g64 = pl.g64; p.rowb64 = pl.rowb64; p.map64_bytes = pl.map64_bytes;
         p.thr = std::max(0, ms->params.data_threshold);  // a pixel whose maximum is 0 is black and has no hue class anyway
         p.group = group;
         p.nparts = nparts;
@@ -1981,7 +2047,8 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
             q.use16 = 1;
             q.stat = ms->d_s16_stat;
             SP_HIP(hipMemsetAsync(ms->d_sp_work, 0, (size_t)pl.n_slabs * 32 * sizeof(uint32_t), st));
-            const int prc = launch_sparse(ctx, q, pl.lds_bytes, threads, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
+            q.plane_global = 1;
+            const int prc = launch_sparse(ctx, q, pl.lds_bytes - (size_t)pl.slab_bytes + (size_t)pl.map64_bytes, threads, ms->params.xy_shift == 2, ms->params.mirror != 0, st);
             if (prc) {
                 cleanup();
                 return prc;
@@ -2008,9 +2075,10 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
         size_t lds_launch = pl.lds_bytes;
         // the stream kernel runs where rounds are rare: its plane stays in L2 and two workgroups share a CU (+4 % on the 1 M-target scan;
         // CDS_SPARSE_PLANE_LDS=1: the plane in LDS, one workgroup per CU, as the 4-byte-record kernel has it)
-        if (use16 && !getenv("CDS_SPARSE_PLANE_LDS") && !ctx->sparse_load_only.load()) {
-            p.plane_global = 1;
-            lds_launch = pl.lds_bytes - (size_t)pl.near_off;
+        if (use16) {   // LDS of the stream kernel: interval table, queues, its own map -- and the plane unless that stays in L2
+            const size_t fixed16 = pl.lds_bytes - (size_t)pl.slab_bytes + (size_t)pl.map64_bytes;
+            p.plane_global = getenv("CDS_SPARSE_PLANE_LDS") && fixed16 + (size_t)pl.near_off <= ctx->lds_per_block ? 0 : 1;
+            lds_launch = fixed16 + (p.plane_global ? 0 : (size_t)pl.near_off);
         }
         SP_HIP(hipMemsetAsync(ms->d_sp_work, 0, (size_t)pl.n_slabs * nparts * 32 * sizeof(uint32_t), st));
         const int lrc = launch_sparse(ctx, p, lds_launch, threads, ms->params.xy_shift == 2, ms->params.mirror != 0, st);

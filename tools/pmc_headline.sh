@@ -19,11 +19,18 @@ for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
         if "sparse_scan" in k:
-            short = ("scan16" if "scan16" in k else "scan32") + ("_loads_only" if "Li4ELb1EE" in k.replace(" ", "") or k.rstrip(">)").rstrip().endswith("true") else "")
-            agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            import re
+            if "scan16" in k:
+                m = re.search(r", (\d+), (true|false), (true|false)>\(", k)
+                short = "scan16" + ("_loads_only" if m and m.group(2) == "true" else "") + ("_plane_in_L2" if m and m.group(3) == "true" else "")
+            else:
+                short = "scan32" + ("_loads_only" if re.search(r", \d+, true>\(", k) else "")
+            agg[short][row["Counter_Name"]].append((float(row.get("Grid_Size", 0) or 0), float(row["Counter_Value"])))
 for k, cs in sorted(agg.items()):
     print("==", k)
-    for c, v in sorted(cs.items()):
+    for c, gv in sorted(cs.items()):
+        g = max(x[0] for x in gv)
+        v = [x[1] for x in gv if x[0] == g]   # (the pilot launch of the first search has a smaller grid)
         print(f"   {c:24s} {sum(v)/len(v)/1048576:12.1f} per target   ({len(v)} dispatches)")
 PY
 find $OUT -name '*.csv' -size +4M -delete

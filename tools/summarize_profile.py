@@ -21,6 +21,7 @@ import glob
 import hashlib
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -59,8 +60,11 @@ def pick(seq, name, last=None, every=False):
     last `last`; `name` = "A&B" asks for both substrings, the loads-only twin is only picked when asked for by LOAD_ONLY"""
     parts = name.split("&")
     def twin(name_):   # is this dispatch a loads-only twin?  (the flag's position differs between the two kernels' template lists)
-        return (LOAD_ONLY16 in name_) if "sparse_scan16_kernel<" in name_ else (LOAD_ONLY in name_ and "sparse_scan_kernel<" in name_)
+        if "sparse_scan16_kernel<" in name_:   # <..., WPE, LO, PG>
+            return re.search(r", \d+, true, (true|false)>\(cds::SparseScanParams\)", name_) is not None
+        return LOAD_ONLY in name_ and "sparse_scan_kernel<" in name_
     want_twin = LOAD_ONLY in parts or LOAD_ONLY16 in parts
+    parts = [q for q in parts if q not in (LOAD_ONLY, LOAD_ONLY16)]
     sel = [x for x in seq if all(q in x[1] for q in parts) and twin(x[1]) == want_twin]
     if sel and not every:
         g = max(x[3] for x in sel)
