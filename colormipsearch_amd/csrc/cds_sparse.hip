@@ -702,7 +702,10 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
     extern __shared__ uint4 lds4[];
     constexpr int NS = XY2 ? 9 : 1, NSX = XY2 ? 3 : 1, NO = MIRROR ? 2 : 1, NC = NS * NO;
     constexpr int HALO = XY2 ? 2 : 0;
-    constexpr int NB = 4;            // dword loads (128 records each) in flight per wave
+#ifndef SP16_NB
+#define SP16_NB 4
+#endif
+    constexpr int NB = SP16_NB;      // dword loads (128 records each) in flight per wave
     typedef typename std::conditional<P8, uint8_t, uint16_t>::type plane_t;
     uint8_t *lds = reinterpret_cast<uint8_t *>(lds4);
     const int lane = threadIdx.x & 63;
