@@ -110,6 +110,7 @@ SIGNATURES = {
     "cds_search_sparse_match_list": (_i, [_vp, _vp, _i64, _i64, ctypes.c_double, ctypes.POINTER(_vp), _i64p]),
     "cds_match_list_size": (_i64, [_vp]),
     "cds_match_list_fetch": (_i, [_vp, _i64, _i64, _vp]),
+    "cds_match_list_fetch_columns": (_i, [_vp, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "cds_match_list_destroy": (None, [_vp]),
     "cds_search_sparse_topk": (_i, [_vp, _vp, _i64, _i64, _i32, _i32p, _i32p]),
     "cds_scores_topk": (_i, [_vp, _vp, _i64, _i32, _i32p, _i32p]),

@@ -751,6 +751,25 @@ class PixelMatchColorDepthSearchAlgorithm(ColorDepthSearchAlgorithm):
             self._lib.cds_match_list_destroy(h)
         return buf[:, 0].copy(), buf[:, 1].copy(), (buf[:, 2] & 0x7FFFFFFF).astype(np.int32), (buf[:, 2] < 0)
 
+    def searchSparseLibraryMatchColumns(self, sparse_library, pctPositivePixels, first=0, count=None, mask_offset=0):
+        """searchSparseLibraryMatches as the five columns of a result table, split and converted by the library's host threads while the
+        list comes down (cds_match_list_fetch_columns): (mask + mask_offset int32[n], target int64[n], matching pixels int32[n],
+        matchingPixelsRatio float32[n] = (float)((double) pixels / max(query size, 1)), mirrored bool[n])."""
+        count = len(sparse_library) - first if count is None else int(count)
+        h, n = ctypes.c_void_p(), ctypes.c_int64()
+        capi.check(self._lib.cds_search_sparse_match_list(self._h, sparse_library._h, int(first), count, float(pctPositivePixels or 0.0),
+                                                          ctypes.byref(h), ctypes.byref(n)))
+        try:
+            rows = n.value
+            m, t, sc = np.empty(rows, np.int32), np.empty(rows, np.int64), np.empty(rows, np.int32)
+            ratio, mir = np.empty(rows, np.float32), np.empty(rows, np.uint8)
+            sizes = np.ascontiguousarray(self.getQuerySizes(), dtype=np.int32)
+            vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+            capi.check(self._lib.cds_match_list_fetch_columns(h, 0, rows, vp(sizes), len(sizes), int(mask_offset), vp(m), vp(t), vp(sc), vp(ratio), vp(mir)))
+        finally:
+            self._lib.cds_match_list_destroy(h)
+        return m, t, sc, ratio, mir.view(bool)
+
     def searchSparseLibraryTopK(self, sparse_library, k, first=0, count=None):
         """Per mask the k best-scoring targets (score descending, equal scores by ascending target), selected on the device:
         (targets int32[n_masks, k] with -1 behind the last one, scores int32[n_masks, k], mirrored bool[n_masks, k])."""

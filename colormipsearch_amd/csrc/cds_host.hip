@@ -326,9 +326,67 @@ int cds_context_create(int device_id, cds_context **out) {
     return CDS_OK;
 }
 
+}  // extern "C"
+namespace cds {
+hipError_t cache_alloc(cds_context *ctx, void **p, size_t bytes) {
+    bytes = std::max<size_t>(bytes, 256);
+    {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        size_t best = SIZE_MAX, at = 0;
+        for (size_t i = 0; i < ctx->cache_idle.size(); i++) {
+            const size_t b = ctx->cache_idle[i].second;
+            if (b >= bytes && b <= 2 * bytes + ((size_t)1 << 20) && b < best) best = b, at = i;
+        }
+        if (best != SIZE_MAX) {
+            *p = ctx->cache_idle[at].first;
+            ctx->cache_idle.erase(ctx->cache_idle.begin() + (std::ptrdiff_t)at);
+            ctx->cache_idle_bytes -= best;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {   // out of memory with idle blocks lying around: give them back and try once more
+        cache_drop(ctx);
+        (void)hipGetLastError();
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        ctx->cache_sizes[*p] = bytes;
+    }
+    return e;
+}
+void cache_free(cds_context *ctx, void *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        auto it = ctx->cache_sizes.find(p);
+        if (it != ctx->cache_sizes.end() && ctx->cache_idle_bytes + it->second <= ctx->cache_cap) {
+            ctx->cache_idle.push_back({p, it->second});
+            ctx->cache_idle_bytes += it->second;
+            return;
+        }
+        if (it != ctx->cache_sizes.end()) ctx->cache_sizes.erase(it);
+    }
+    hipFree(p);
+}
+void cache_drop(cds_context *ctx) {
+    std::vector<std::pair<void *, size_t>> idle;
+    {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        idle.swap(ctx->cache_idle);
+        ctx->cache_idle_bytes = 0;
+        for (auto &b : idle) ctx->cache_sizes.erase(b.first);
+    }
+    for (auto &b : idle) hipFree(b.first);
+}
+}  // namespace cds
+extern "C" {
+
 void cds_context_destroy(cds_context *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    cds::cache_drop(ctx);
     if (ctx->d_slice_lut && ctx->owns_lut) hipFree(ctx->d_slice_lut);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     if (ctx->upload_stream) hipStreamDestroy(ctx->upload_stream);

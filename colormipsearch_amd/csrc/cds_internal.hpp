@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/cds_hip.h"
@@ -74,6 +75,16 @@ struct cds_context {
     bool owns_lut = true;                  // false in a pair-slot context (clone_context_for_slot): the table is the parent's
     std::atomic<int> sparse_load_only{0};  // cds_debug_sparse_load_only: THIS context's single-mask sparse searches launch the loads-only twin
     std::mutex mu;
+    // Device blocks of mask sets, match lists and per-call temporaries are RECYCLED through the context (cds::cache_alloc / cache_free):
+    // hipFree waits for every stream of the device, so a caller that pipelines mask sets -- one being scanned while the previous one's
+    // results are fetched and its buffers released -- stalled behind the running scan after every set (measured: 60 ms of idle device
+    // per two sets of 128 masks x 1 M targets).  A released block is kept (up to cache_cap bytes) and handed to the next request it
+    // fits; the caller releases a block only when its work on the device is complete.
+    std::atomic<long long> match_rows_hint{0};   // rows of the last device match list (cds_search_sparse_match_list sizes the next one by it)
+    std::mutex cache_mu;
+    std::vector<std::pair<void *, size_t>> cache_idle;       // (block, bytes)
+    std::unordered_map<void *, size_t> cache_sizes;          // every block handed out by cache_alloc
+    size_t cache_idle_bytes = 0, cache_cap = (size_t)6 << 30;
 };
 
 struct cds_library {
@@ -99,6 +110,21 @@ struct cds_library {
 };
 
 namespace cds {
+
+// Wait for the work enqueued on `st` UP TO NOW -- an event, not hipStreamSynchronize: when several host threads feed one stream (the
+// processor's pipeline of mask sets), the stream-wide wait of one thread also waits for the scan another thread enqueued meanwhile.
+inline hipError_t sync_here(hipStream_t st) {
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(ev, st);
+    if (e == hipSuccess) e = hipEventSynchronize(ev);
+    hipEventDestroy(ev);
+    return e;
+}
+hipError_t cache_alloc(cds_context *ctx, void **p, size_t bytes);   // a recycled block of >= bytes (at most twice that), or a fresh hipMalloc
+void cache_free(cds_context *ctx, void *p);                         // back to the context's idle list -- or hipFree when that is full / p is foreign
+void cache_drop(cds_context *ctx);                                  // hipFree of every idle block (context destruction)
 
 // Device-side view of a prepared pixel-match mask set.
 struct ScanParams {
@@ -358,6 +384,7 @@ struct cds_maskset {
     // The single-mask slab images and interval tables go to the device when a single-mask launch first needs them: a mask set of the
     // processor is scanned by the multi-mask kernel only (its groups have their own arrays) and never pays for that upload (20 MB per
     // 128 masks).  Until then they wait here (guarded by sp_mu).
+    mutable hipEvent_t sp_last_use = nullptr;   // behind the last sparse launch that reads this set's device blocks: waited for before they are recycled
     mutable std::vector<std::vector<uint8_t>> sp_host_slabs;
     mutable std::vector<std::vector<uint4>> sp_host_iv;
     mutable size_t sp_slab_total = 0, sp_iv_total = 0;

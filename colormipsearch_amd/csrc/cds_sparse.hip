@@ -1399,14 +1399,22 @@ static uint32_t band_bits_of(uint32_t lo, uint32_t len) {
 #endif
 
 void free_sparse_plans(cds_maskset *ms) {
-    if (ms->d_s16_stat) hipFree(ms->d_s16_stat);
+    // (back to the context's block cache: hipFree would wait for every stream of the device, i.e. for the scan of the NEXT mask set when
+    // the caller pipelines them; a mask set is destroyed only when no search of it is in flight)
+    cds_context *cx = ms->ctx;
+    if (ms->sp_last_use) {   // an asynchronous search (cds_search_sparse_device) may still be reading them: wait for THAT launch, not for the stream
+        hipEventSynchronize(ms->sp_last_use);
+        hipEventDestroy(ms->sp_last_use);
+        ms->sp_last_use = nullptr;
+    }
+    cache_free(cx, ms->d_s16_stat);
     ms->d_s16_stat = nullptr;
-    if (ms->d_sp_slabs) hipFree(ms->d_sp_slabs);
-    if (ms->d_sp_iv) hipFree(ms->d_sp_iv);
-    if (ms->d_sp_work) hipFree(ms->d_sp_work);
-    if (ms->d_sg_planes) hipFree(ms->d_sg_planes);
-    if (ms->d_sg_tmap) hipFree(ms->d_sg_tmap);
-    if (ms->d_sg_iv) hipFree(ms->d_sg_iv);
+    cache_free(cx, ms->d_sp_slabs);
+    cache_free(cx, ms->d_sp_iv);
+    cache_free(cx, ms->d_sp_work);
+    cache_free(cx, ms->d_sg_planes);
+    cache_free(cx, ms->d_sg_tmap);
+    cache_free(cx, ms->d_sg_iv);
     ms->d_sg_planes = ms->d_sg_tmap = nullptr;
     ms->d_sg_iv = nullptr;
     ms->sg_plans.clear();
@@ -1604,9 +1612,9 @@ static int build_group_plans(cds_maskset *ms, const std::vector<std::vector<Mask
         return CDS_OK;
     }
     hipStream_t up = ms->ctx->upload_stream ? ms->ctx->upload_stream : ms->ctx->stream;
-    hipError_t e = hipMalloc(&ms->d_sg_planes, planes_total);
-    if (e == hipSuccess) e = hipMalloc(&ms->d_sg_tmap, tmap_total);
-    if (e == hipSuccess) e = hipMalloc(&ms->d_sg_iv, iv_total * sizeof(uint4));
+    hipError_t e = cache_alloc(ms->ctx, (void **)&ms->d_sg_planes, planes_total);
+    if (e == hipSuccess) e = cache_alloc(ms->ctx, (void **)&ms->d_sg_tmap, tmap_total);
+    if (e == hipSuccess) e = cache_alloc(ms->ctx, (void **)&ms->d_sg_iv, iv_total * sizeof(uint4));
     for (size_t g = 0; g < n_groups && e == hipSuccess; g++) {
         const SparseGroupPlan &gp = ms->sg_plans[g];
         if (!gp.ok) continue;
@@ -1631,8 +1639,8 @@ static int upload_single_plans(const cds_maskset *ms) {
     cds_maskset *w = const_cast<cds_maskset *>(ms);
     hipSetDevice(ctx->device);
     hipStream_t up = ctx->upload_stream ? ctx->upload_stream : ctx->stream;   // (neither behind the scans of `stream` nor stalling them)
-    hipError_t e = hipMalloc(&w->d_sp_slabs, std::max<size_t>(ms->sp_slab_total, 16));
-    if (e == hipSuccess) e = hipMalloc(&w->d_sp_iv, std::max<size_t>(ms->sp_iv_total, 1) * sizeof(uint4));
+    hipError_t e = cache_alloc(ctx, (void **)&w->d_sp_slabs, std::max<size_t>(ms->sp_slab_total, 16));
+    if (e == hipSuccess) e = cache_alloc(ctx, (void **)&w->d_sp_iv, std::max<size_t>(ms->sp_iv_total, 1) * sizeof(uint4));
     for (size_t m = 0; m < ms->sp_host_slabs.size() && e == hipSuccess; m++) {
         if (ms->sp_host_slabs[m].empty()) continue;
         e = hipMemcpyAsync(w->d_sp_slabs + ms->sp_plans[m].slabs_off, ms->sp_host_slabs[m].data(), ms->sp_host_slabs[m].size(), hipMemcpyHostToDevice, up);
@@ -1642,8 +1650,8 @@ static int upload_single_plans(const cds_maskset *ms) {
     const hipError_t es = hipStreamSynchronize(up);
     if (e == hipSuccess) e = es;
     if (e != hipSuccess) {
-        if (w->d_sp_slabs) hipFree(w->d_sp_slabs);
-        if (w->d_sp_iv) hipFree(w->d_sp_iv);
+        cache_free(ctx, w->d_sp_slabs);
+        cache_free(ctx, w->d_sp_iv);
         w->d_sp_slabs = nullptr;
         w->d_sp_iv = nullptr;
         return hip_fail(e, "sparse mask plans (upload)");
@@ -1815,7 +1823,7 @@ int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &
     }
     hipSetDevice(ctx->device);
     hipError_t e = hipSuccess;
-    if (slab_total > 0) e = hipMalloc(&ms->d_sp_work, (size_t)SP_MAX_SLABS * SP_MAX_PARTS * 32 * sizeof(uint32_t));
+    if (slab_total > 0) e = cache_alloc(ctx, (void **)&ms->d_sp_work, (size_t)SP_MAX_SLABS * SP_MAX_PARTS * 32 * sizeof(uint32_t));
     if (e != hipSuccess) {
         free_sparse_plans(ms);
         return hip_fail(e, "sparse mask plans");
@@ -1870,9 +1878,16 @@ static int launch_sparse_one(cds_context *ctx, const SparseScanParams &p, size_t
         else kern = s16 ? sparse_scan16_kernel<XY2, MIRROR, true, true, 4, true> : sparse_scan_kernel<XY2, MIRROR, true, true, 4, true>;
     }
     if (s16) {   // the stream kernel addresses its map from LDS address 0: true as long as the kernel has no static LDS in front of the dynamic one
-        hipFuncAttributes fa{};
-        CDS_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
-        if (fa.sharedSizeBytes != 0) return fail(CDS_ERR_HIP, "sparse_scan16_kernel was built with static LDS: its map would not start at LDS address 0");
+        static std::mutex mu;
+        static std::vector<const void *> checked;   // (one driver query per kernel variant and process)
+        std::lock_guard<std::mutex> lk(mu);
+        const void *kp = reinterpret_cast<const void *>(kern);
+        if (std::find(checked.begin(), checked.end(), kp) == checked.end()) {
+            hipFuncAttributes fa{};
+            CDS_HIP(hipFuncGetAttributes(&fa, kp));
+            if (fa.sharedSizeBytes != 0) return fail(CDS_ERR_HIP, "sparse_scan16_kernel was built with static LDS: its map would not start at LDS address 0");
+            checked.push_back(kp);
+        }
     }
     CDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     // persistent grid: as many workgroups as fit (LDS and the 2048 threads of a CU), every one visits every slab
@@ -2040,7 +2055,7 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
             }
         }
         if (pilot > 0) {
-            if (!ms->d_s16_stat) SP_HIP(hipMalloc(&ms->d_s16_stat, 2 * sizeof(unsigned long long)));
+            if (!ms->d_s16_stat) SP_HIP(cache_alloc(ctx, (void **)&ms->d_s16_stat, 2 * sizeof(unsigned long long)));
             SP_HIP(hipMemsetAsync(ms->d_s16_stat, 0, 2 * sizeof(unsigned long long), st));
             SparseScanParams q = p;
             q.count = pilot;
@@ -2142,6 +2157,10 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
             }
             launches++;
         }
+    }
+    if (launches > 0) {   // (free_sparse_plans waits for this before the set's blocks go back to the context's cache)
+        if (!ms->sp_last_use) SP_HIP(hipEventCreateWithFlags(&ms->sp_last_use, hipEventDisableTiming));
+        SP_HIP(hipEventRecord(ms->sp_last_use, st));
     }
     if (timed) {
         SP_HIP(hipEventRecord(ev1, st));
@@ -2835,7 +2854,7 @@ static int sparse_search_host(const cds_maskset *ms, const cds_sparse_library *s
         hipError_t e = hipMemcpyAsync(packed.data(), d_scores, n * sizeof(int32_t), hipMemcpyDeviceToHost, ms->ctx->stream);
         if (e == hipSuccess && counts)
             e = hipMemcpyAsync(counts, d_counts, n * CDS_N_TRANSFORMS * sizeof(int32_t), hipMemcpyDeviceToHost, ms->ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ms->ctx->stream);
+        if (e == hipSuccess) e = sync_here(ms->ctx->stream);
         if (e != hipSuccess) rc = hip_fail(e, "copy scores");
         else
             for (size_t i = 0; i < n; i++) {
@@ -2909,11 +2928,12 @@ int cds_search_sparse_match_list(const cds_maskset *ms, const cds_sparse_library
     int32_t *d_scores = nullptr, *d_min = nullptr;
     uint32_t *d_blockcnt = nullptr;
     unsigned long long *d_total = nullptr;
-    auto cleanup = [&]() {
-        if (d_scores) hipFree(d_scores);
-        if (d_min) hipFree(d_min);
-        if (d_blockcnt) hipFree(d_blockcnt);
-        if (d_total) hipFree(d_total);
+    auto cleanup = [&](bool in_flight = true) {   // (error paths: the launches that use these blocks may still be running)
+        if (in_flight) hipStreamSynchronize(st);
+        cache_free(ctx, d_scores);
+        cache_free(ctx, d_min);
+        cache_free(ctx, d_blockcnt);
+        cache_free(ctx, d_total);
     };
 #define MT_HIP(call)                         \
     do {                                     \
@@ -2924,12 +2944,63 @@ int cds_search_sparse_match_list(const cds_maskset *ms, const cds_sparse_library
             return cds::hip_fail(_e, #call); \
         }                                    \
     } while (0)
-    MT_HIP(hipMalloc(&d_scores, (size_t)widest * count * sizeof(int32_t)));
-    MT_HIP(hipMalloc(&d_min, (size_t)ms->n_masks * sizeof(int32_t)));
-    MT_HIP(hipMalloc(&d_blockcnt, (size_t)widest * nblk * sizeof(uint32_t)));
-    MT_HIP(hipMalloc(&d_total, 2 * sizeof(unsigned long long)));
+    MT_HIP(cache_alloc(ctx, (void **)&d_scores, (size_t)widest * count * sizeof(int32_t)));
+    MT_HIP(cache_alloc(ctx, (void **)&d_min, (size_t)ms->n_masks * sizeof(int32_t)));
+    MT_HIP(cache_alloc(ctx, (void **)&d_blockcnt, (size_t)widest * nblk * sizeof(uint32_t)));
+    MT_HIP(cache_alloc(ctx, (void **)&d_total, 2 * sizeof(unsigned long long)));
     MT_HIP(hipMemcpyAsync(d_min, min_score.data(), min_score.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     MT_HIP(hipMemsetAsync(d_total, 0, 2 * sizeof(unsigned long long), st));
+    // ONE chunk (up to 128 masks: what a pipelining caller sends): scan, count, offsets and fill are enqueued back to back into a list
+    // sized by the previous call's length (or an eighth of the pairs) and the host waits once.  With the length read back BETWEEN count
+    // and fill, the fill of this set queued behind the scan that another host thread had enqueued meanwhile for the NEXT set -- 45 ms of
+    // idle device after every second set of the processor's pipeline.  A list that turns out too short is filled again at its exact size
+    // (the scores are still there); CDS_MATCH_GUESS_ROWS sets the first guess (tests).
+    if (chunks.size() == 1 && !getenv("CDS_MATCH_TWO_PHASE")) {
+        const auto &c = chunks[0];
+        const int64_t pairs = (int64_t)(c.second - c.first) * count;
+        int64_t guess = std::max<int64_t>((int64_t)ctx->match_rows_hint.load(), pairs / 8);
+        if (const char *e = getenv("CDS_MATCH_GUESS_ROWS")) guess = atoll(e);
+        guess = std::max<int64_t>(1, std::min<int64_t>(pairs, std::max<int64_t>(guess, 1 << 16)));
+        if (const char *e = getenv("CDS_MATCH_GUESS_ROWS")) guess = std::max<int64_t>(1, atoll(e));
+        MT_HIP(cache_alloc(ctx, (void **)&ml->d, (size_t)guess * sizeof(cds_match)));
+        ml->cap = guess;
+        rc = sparse_search_impl(ms, sl, first, count, d_scores, nullptr, false, c.first, c.second);
+        if (rc) {
+            cleanup();
+            cds_match_list_destroy(ml);
+            return rc;
+        }
+        MatchParams p{};
+        p.scores = d_scores; p.min_score = d_min + c.first; p.n_masks = c.second - c.first; p.mask0 = c.first;
+        p.count = count; p.nblk = nblk; p.blockcnt = d_blockcnt; p.total = d_total;
+        p.out = ml->d; p.capacity = ml->cap;
+        const unsigned grid = (unsigned)((int64_t)p.n_masks * nblk);
+        hipLaunchKernelGGL(match_count_kernel, dim3(grid), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, st, p);
+        hipLaunchKernelGGL(match_fill_kernel, dim3(grid), dim3(256), 0, st, p);
+        MT_HIP(hipGetLastError());
+        unsigned long long total[2] = {0, 0};
+        MT_HIP(hipMemcpyAsync(total, d_total, sizeof total, hipMemcpyDeviceToHost, st));
+        MT_HIP(sync_here(st));
+        const int64_t need = (int64_t)total[1];
+        if (need > ml->cap) {   // (the guess was too small: the rows beyond it were not written -- once more, at the exact size)
+            cds_match *nd = nullptr;
+            MT_HIP(cache_alloc(ctx, (void **)&nd, (size_t)need * sizeof(cds_match)));
+            cache_free(ctx, ml->d);
+            ml->d = nd;
+            ml->cap = need;
+            p.out = ml->d; p.capacity = ml->cap;
+            hipLaunchKernelGGL(match_fill_kernel, dim3(grid), dim3(256), 0, st, p);
+            MT_HIP(hipGetLastError());
+            MT_HIP(sync_here(st));
+        }
+        ml->n = need;
+        ctx->match_rows_hint.store((long long)(need + need / 4 + 65536));
+        cleanup(false);
+        if (n_matches) *n_matches = ml->n;
+        *out = ml;
+        return CDS_OK;
+    }
     for (auto &c : chunks) {
         rc = sparse_search_impl(ms, sl, first, count, d_scores, nullptr, false, c.first, c.second);
         if (rc) {
@@ -2946,15 +3017,15 @@ int cds_search_sparse_match_list(const cds_maskset *ms, const cds_sparse_library
         MT_HIP(hipGetLastError());
         unsigned long long total[2] = {0, 0};   // the chunk's length: the list grows to hold it before it is written
         MT_HIP(hipMemcpyAsync(total, d_total, sizeof total, hipMemcpyDeviceToHost, st));
-        MT_HIP(hipStreamSynchronize(st));
+        MT_HIP(sync_here(st));
         const int64_t need = (int64_t)(total[0] + total[1]);
         if (need > ml->cap) {
             const int64_t cap = std::max<int64_t>(need, std::max<int64_t>(1 << 16, ml->cap * 2));
             cds_match *nd = nullptr;
-            MT_HIP(hipMalloc(&nd, (size_t)cap * sizeof(cds_match)));
+            MT_HIP(cache_alloc(ctx, (void **)&nd, (size_t)cap * sizeof(cds_match)));
             if (ml->n) MT_HIP(hipMemcpyAsync(nd, ml->d, (size_t)ml->n * sizeof(cds_match), hipMemcpyDeviceToDevice, st));
-            MT_HIP(hipStreamSynchronize(st));
-            if (ml->d) hipFree(ml->d);
+            MT_HIP(sync_here(st));
+            cache_free(ctx, ml->d);
             ml->d = nd;
             ml->cap = cap;
         }
@@ -2964,8 +3035,8 @@ int cds_search_sparse_match_list(const cds_maskset *ms, const cds_sparse_library
         MT_HIP(hipGetLastError());
         ml->n = need;
     }
-    MT_HIP(hipStreamSynchronize(st));
-    cleanup();
+    MT_HIP(sync_here(st));
+    cleanup(false);
 #undef MT_HIP
     if (n_matches) *n_matches = ml->n;
     *out = ml;
@@ -2984,11 +3055,61 @@ int cds_match_list_fetch(const cds_match_list *ml, int64_t first, int64_t count,
     return CDS_OK;
 }
 
+int cds_match_list_fetch_columns(const cds_match_list *ml, int64_t first, int64_t count, const int32_t *query_sizes, int32_t n_masks,
+                                 int32_t mask_offset, int32_t *mask, int64_t *target, int32_t *score, float *ratio, uint8_t *mirrored) {
+    if (!ml) return fail(CDS_ERR_INVALID_ARGUMENT, "match list is NULL");
+    if (first < 0 || count < 0 || first + count > ml->n) return fail(CDS_ERR_INVALID_ARGUMENT, "range outside the match list");
+    if (ratio && (!query_sizes || n_masks <= 0)) return fail(CDS_ERR_INVALID_ARGUMENT, "ratio wanted without the query sizes");
+    if (count == 0) return CDS_OK;
+    CDS_HIP(hipSetDevice(ml->ctx->device));
+    // the rows come down in pieces of 4 M (48 MB) and are split into the columns by a few host threads while the next piece is copied
+    const int64_t piece = (int64_t)4 << 20;
+    std::vector<cds_match> buf[2];
+    std::atomic<int> bad{0};
+    auto split = [&](const cds_match *src, int64_t at, int64_t n) {
+        const unsigned hc = std::thread::hardware_concurrency();
+        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hc ? hc : 1u, 8u), n / 65536 + 1));
+        auto work = [&](int k) {
+            const int64_t a = n * k / nt, b = n * (k + 1) / nt;
+            for (int64_t i = a; i < b; i++) {
+                const cds_match r = src[i];
+                const int32_t sc = r.score & 0x7fffffff;
+                if (mask) mask[at + i] = r.mask + mask_offset;
+                if (target) target[at + i] = r.target;
+                if (score) score[at + i] = sc;
+                if (mirrored) mirrored[at + i] = (uint8_t)((uint32_t)r.score >> 31);
+                if (ratio) {
+                    if (r.mask < 0 || r.mask >= n_masks) { bad.store(1); continue; }
+                    ratio[at + i] = (float)((double)sc / std::max((double)query_sizes[r.mask], 1.0));
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int k = 1; k < nt; k++) pool.emplace_back(work, k);
+        work(0);
+        for (auto &t : pool) t.join();
+    };
+    std::thread splitter;
+    int which = 0;
+    hipError_t e = hipSuccess;
+    for (int64_t at = 0; at < count && e == hipSuccess; at += piece, which ^= 1) {
+        const int64_t n = std::min(piece, count - at);
+        buf[which].resize((size_t)n);
+        e = hipMemcpy(buf[which].data(), ml->d + first + at, (size_t)n * sizeof(cds_match), hipMemcpyDeviceToHost);
+        if (splitter.joinable()) splitter.join();   // (the other buffer is free again before the next copy goes into it)
+        if (e == hipSuccess) splitter = std::thread(split, buf[which].data(), at, n);
+    }
+    if (splitter.joinable()) splitter.join();
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(match list)");
+    if (bad.load()) return fail(CDS_ERR_INVALID_ARGUMENT, "the match list names a mask beyond n_masks: query_sizes of another mask set?");
+    return CDS_OK;
+}
+
 void cds_match_list_destroy(cds_match_list *ml) {
     if (!ml) return;
     if (ml->d) {
         hipSetDevice(ml->ctx->device);
-        hipFree(ml->d);
+        cache_free(ml->ctx, ml->d);
     }
     delete ml;
 }

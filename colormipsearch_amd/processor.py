@@ -354,15 +354,15 @@ class GpuColorMIPSearchProcessor:
         return (self.first + t) if self.dense_slots is None else self.dense_slots[t]
 
     # ---- colorDepthSearch -------------------------------------------------------------------------
-    def _device_match_table(self, alg) -> MatchTable:
-        """Sparse library: scan, ColorMIPSearch.isMatch and the compaction run on the device (cds_search_sparse_matches); only the
-        match list comes back (rows ordered by mask, then target -- the order of the host-side filter below)."""
-        m, t, sc, mir = alg.searchSparseLibraryMatches(self.sparse_library, self.colorMIPSearch.pctPositivePixels, self.first, self.count)
-        sizes = np.asarray(alg.getQuerySizes(), dtype=np.float64)
-        ratio = (sc.astype(np.float64) / np.maximum(sizes[m], 1.0)).astype(np.float32)
-        return MatchTable(m.astype(np.int32, copy=False), t.astype(np.int64), sc.astype(np.int32, copy=False), ratio, mir.astype(bool, copy=False))
+    def _device_match_table(self, alg, mask_offset=0) -> MatchTable:
+        """Sparse library: scan, ColorMIPSearch.isMatch and the compaction run on the device (cds_search_sparse_match_list); only the
+        match list comes back (rows ordered by mask, then target -- the order of the host-side filter below), already split into the
+        table's columns by the library (cds_match_list_fetch_columns)."""
+        m, t, sc, ratio, mir = alg.searchSparseLibraryMatchColumns(self.sparse_library, self.colorMIPSearch.pctPositivePixels, self.first, self.count,
+                                                                   mask_offset=mask_offset)
+        return MatchTable(m, t, sc, ratio, mir)
 
-    def _pipelined_match_table(self, masks, mask_set_size) -> MatchTable:
+    def _pipelined_match_table(self, masks, mask_set_size, first_set_size=None) -> MatchTable:
         """Many masks against a sparse library: mask sets of `mask_set_size` (a multiple of 8, the multi-mask kernel's group size)
         go through three overlapped stages -- the host-side preparation of a set (acceptance intervals, planes, maps: about as
         long as its scan) on one thread, and two search workers taking the prepared sets in turn, so that the list download and the
@@ -378,11 +378,11 @@ class GpuColorMIPSearchProcessor:
         ahead = threading.Semaphore(3)
         self.last_pipeline = {"prepare_s": 0.0, "search_s": 0.0}
 
-        def prepare(m0):
+        def prepare(m0, m1):
             ahead.acquire()
             t0 = time.perf_counter()
             try:
-                return make(masks[m0:m0 + mask_set_size])
+                return make(masks[m0:m1])
             except BaseException:
                 ahead.release()
                 raise
@@ -393,25 +393,33 @@ class GpuColorMIPSearchProcessor:
             alg = prepared.result()
             t0 = time.perf_counter()
             try:
-                t = self._device_match_table(alg)
+                t = self._device_match_table(alg, mask_offset=m0)
             finally:
                 alg.close()
                 ahead.release()
-            t.maskIndex += np.int32(m0)
             self.last_pipeline["search_s"] += time.perf_counter() - t0
             return t
 
+        # (the device idles while the FIRST set is prepared: that one is a quarter of the size -- still a multiple of the kernel's group of 8 --,
+        # so the first scan starts after a quarter of a preparation; every later preparation hides behind the scan before it)
+        first = max(8, (mask_set_size // 4) // 8 * 8) if n >= 3 * mask_set_size else mask_set_size
+        if first_set_size:
+            first = min(mask_set_size, max(8, int(first_set_size) // 8 * 8))
+        starts = [0] + list(range(first, n, mask_set_size))
+        ends = starts[1:] + [n]
         with ThreadPoolExecutor(max_workers=1) as prep_pool, ThreadPoolExecutor(max_workers=2) as search_pool:
-            prepared = [prep_pool.submit(prepare, m0) for m0 in range(0, n, mask_set_size)]
-            parts = [f.result() for f in [search_pool.submit(search, m0, pf) for m0, pf in zip(range(0, n, mask_set_size), prepared)]]
+            prepared = [prep_pool.submit(prepare, m0, m1) for m0, m1 in zip(starts, ends)]
+            parts = [f.result() for f in [search_pool.submit(search, m0, pf) for m0, pf in zip(starts, prepared)]]
         t0 = time.perf_counter()
         rows = sum(len(t) for t in parts)
         out = MatchTable(np.empty(rows, np.int32), np.empty(rows, np.int64), np.empty(rows, np.int32), np.empty(rows, np.float32), np.empty(rows, bool))
-        at = 0
-        for t in parts:
-            for f in ("maskIndex", "targetIndex", "matchingPixels", "matchingPixelsRatio", "mirrored"):
-                getattr(out, f)[at:at + len(t)] = getattr(t, f)
-            at += len(t)
+        def fill(f):   # (one thread per column: the copies release the GIL; tens of millions of rows for 1,024 masks x 1 M targets)
+            at, col = 0, getattr(out, f)
+            for t in parts:
+                col[at:at + len(t)] = getattr(t, f)
+                at += len(t)
+        with ThreadPoolExecutor(max_workers=5) as pool:
+            list(pool.map(fill, ("maskIndex", "targetIndex", "matchingPixels", "matchingPixelsRatio", "mirrored")))
         self.last_pipeline["assemble_s"] = time.perf_counter() - t0
         return out
 
@@ -431,11 +439,12 @@ class GpuColorMIPSearchProcessor:
                 out.append(CDMatch(m, int(t), int(scores[m, t]), float(ratio[t]), bool(mirrored[m, t])))
         return out
 
-    def findAllColorDepthMatchesTable(self, masks, mask_set_size=128) -> MatchTable:
+    def findAllColorDepthMatchesTable(self, masks, mask_set_size=128, first_set_size=None) -> MatchTable:
         """findAllColorDepthMatches in columnar form (same rows, same order).  Over a sparse library the masks go in sets of
-        `mask_set_size` whose preparation overlaps the previous set's scan."""
+        `mask_set_size` whose preparation overlaps the previous set's scan; the first set is smaller (`first_set_size`, default a
+        quarter of a set when there are at least three sets) so that the device starts early."""
         if self.sparse_library is not None:
-            return self._pipelined_match_table(masks, max(8, int(mask_set_size) // 8 * 8))
+            return self._pipelined_match_table(masks, max(8, int(mask_set_size) // 8 * 8), first_set_size)
         alg = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold(masks)
         scores, mirrored = self._scan(alg)
         sizes = np.asarray(alg.getQuerySizes())

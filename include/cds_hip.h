@@ -252,6 +252,13 @@ int cds_search_sparse_match_list(const cds_maskset *ms, const cds_sparse_library
                                  double pct_positive_pixels, cds_match_list **out, int64_t *n_matches);
 int64_t cds_match_list_size(const cds_match_list *list);
 int cds_match_list_fetch(const cds_match_list *list, int64_t first, int64_t count, cds_match *matches);
+/* The same rows as the columns a caller's result table is made of, written in one pass by the library's host threads (a 1,024-mask x
+ * 1 M-target search lists tens of millions of rows: five numpy passes per mask set were the tail of the processor's pipeline):
+ * mask[i] = row.mask + mask_offset, target[i], score[i] = matching pixels, mirrored[i], and -- when query_sizes (the mask set's,
+ * cds_maskset_query_sizes) is given -- ratio[i] = (float)((double)score / max(query_sizes[row.mask], 1)), the reference's
+ * matchingPixelsRatio (PixelMatchScore; ColorMIPSearch.java:42-45).  Any output pointer may be NULL. */
+int cds_match_list_fetch_columns(const cds_match_list *list, int64_t first, int64_t count, const int32_t *query_sizes, int32_t n_masks,
+                                 int32_t mask_offset, int32_t *mask, int64_t *target, int32_t *score, float *ratio, uint8_t *mirrored);
 void cds_match_list_destroy(cds_match_list *list);
 
 /* ---- several GPUs of one node: the target-sharded search --------------------------------------------------------

@@ -213,6 +213,9 @@ def test_mask_sets_prepared_while_the_previous_one_is_scanned(oracle):
     proc = P.GpuColorMIPSearchProcessor(cds.ColorMIPSearch(0.01, 20, provider), None, None, sparse_library=slib)
     one = proc.findAllColorDepthMatchesTable(masks, mask_set_size=64)
     piped = proc.findAllColorDepthMatchesTable(masks, mask_set_size=8)
+    ramp = proc.findAllColorDepthMatchesTable(masks, mask_set_size=16, first_set_size=8)     # sets of 8 and 13 masks: a smaller first set
+    for f in ("maskIndex", "targetIndex", "matchingPixels", "matchingPixelsRatio", "mirrored"):
+        assert np.array_equal(getattr(ramp, f), getattr(one, f)), f
     for f in ("maskIndex", "targetIndex", "matchingPixels", "matchingPixelsRatio", "mirrored"):
         assert np.array_equal(getattr(one, f), getattr(piped, f)), f
     assert len(one) > 20 and set(one.maskIndex.tolist()) >= {3, 17}

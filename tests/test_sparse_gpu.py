@@ -301,6 +301,53 @@ def test_mask_touching_every_border(cds, oracle, lds_kb, monkeypatch):
             assert np.array_equal(counts[0, t], q.score(targets[t])[2]), (xy, mirror, t)
 
 
+def test_off_centre_masks_and_the_two_orientation_map(cds, oracle, monkeypatch, scan_kernel):
+    """The stream kernel's band map covers the UNION of the mask's window and its mirror image (one 8-byte cell serves both
+    orientations): a mask at the far left or right of the frame makes that union as wide as the frame, a mask hugging the centre
+    makes the two windows overlap cell by cell with different alignments, a mask of one column makes them one cell wide.  All 18 counts
+    against the oracle, targets that hit the window's edge cells included; and a mask whose map would exceed the 64 KB that 16-bit
+    cell offsets can address is scanned through the 4-byte records even when the stream is forced."""
+    rects = cds.label_regions(W)
+    rng = np.random.default_rng(31)
+    lut = oracle.depth_lut()
+    base = [oracle.synth_image(0xC0FFEE, 700 + i, 0) for i in range(3)]
+    cases = []
+    for name, x0, x1, y0, y1 in (("far left", 2, 60, 200, 330), ("far right", W - 75, W - 3, 100, 180), ("centre, odd alignment", W // 2 - 37, W // 2 + 52, 250, 400),
+                                 ("one column", 411, 412, 90, 300), ("left of centre", W // 2 - 150, W // 2 - 20, 20, 90)):
+        mask = np.zeros((H, W, 3), dtype=np.uint8)
+        sel = rng.random((y1 - y0, x1 - x0)) < 0.35
+        mask[y0:y1, x0:x1][sel] = lut[rng.integers(0, 256, int(sel.sum()))]
+        cases.append((name, mask))
+    targets = []
+    for name, mask in cases:
+        for t in base:
+            u = t.copy()
+            m = mask.max(axis=2) > 0
+            u[m] = mask[m]                                   # the mask itself laid over a synthetic target: hits in every window cell
+            targets.append(np.roll(u, rng.integers(-2, 3), axis=1))
+            targets.append(np.fliplr(u))
+    targets = np.stack(targets)
+    sl = sparse_of(cds, targets)
+    for name, mask in cases:
+        alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.02, 2, rects)
+        counts = alg.searchSparseLibraryCounts(sl)
+        if scan_kernel == "stream16":
+            assert alg.lastScanKernel()[0] == 1, name
+        q = oracle.PixelMatchQuery(mask, 20, 20, 0.02, 2, True, rects)
+        for t in range(0, len(targets), 3):
+            assert np.array_equal(counts[0, t], q.score(targets[t])[2]), (name, t)
+        assert counts.max() > 0, name
+    # a tall mask at the left edge: union window = the whole frame, 1,224 bytes per cell row x 130 cell rows > 64 KB -> the 4-byte records
+    tall = np.zeros((H, W, 3), dtype=np.uint8)
+    tall[20:530, 3:40][rng.random((510, 37)) < 0.2] = lut[77]
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(tall, 20, True, None, 0, False, 20, 0.02, 2, rects)
+    counts = alg.searchSparseLibraryCounts(sl)
+    assert alg.lastScanKernel()[0] == 0
+    q = oracle.PixelMatchQuery(tall, 20, 20, 0.02, 2, True, rects)
+    for t in (0, 7, len(targets) - 1):
+        assert np.array_equal(counts[0, t], q.score(targets[t])[2]), t
+
+
 @pytest.mark.parametrize("threads,lds_kb", [(None, None), (256, 12)])
 def test_random_geometry_and_parameter_sweep(cds, oracle, threads, lds_kb, monkeypatch):
     """Seeded random sweep over image sizes, mask counts / shapes, thresholds, tolerances, shift and mirror settings:
@@ -775,15 +822,26 @@ def test_device_match_list_equals_host_filter(cds, oracle, monkeypatch):
     for pct in (0.0, 0.01, 0.5, 2.0, 50.0):
         want = [(m, t, int(scores[m, t]), bool(mir[m, t])) for m in range(len(masks)) for t in range(n_t)
                 if sizes[m] > 0 and oracle.is_match(int(scores[m, t]), int(sizes[m]), pct)]
-        for chunk in (None, "3"):
-            if chunk:
-                monkeypatch.setenv("CDS_MATCH_CHUNK_MASKS", chunk)
-            else:
-                monkeypatch.delenv("CDS_MATCH_CHUNK_MASKS", raising=False)
+        # one chunk of masks: list sized by a guess, one wait (and, with a guess of 1 row, the refill at the exact size); chunks of 3
+        # masks: the length read back between count and fill, the list grown chunk by chunk
+        for chunk, guess in ((None, None), (None, "1"), ("3", None)):
+            for k, v in (("CDS_MATCH_CHUNK_MASKS", chunk), ("CDS_MATCH_GUESS_ROWS", guess)):
+                if v:
+                    monkeypatch.setenv(k, v)
+                else:
+                    monkeypatch.delenv(k, raising=False)
             m, t, s, mr = alg.searchSparseLibraryMatches(sl, pct)
-            assert list(zip(m.tolist(), t.tolist(), s.tolist(), mr.tolist())) == want, (pct, chunk, len(want), len(m))
+            assert list(zip(m.tolist(), t.tolist(), s.tolist(), mr.tolist())) == want, (pct, chunk, guess, len(want), len(m))
     monkeypatch.delenv("CDS_MATCH_CHUNK_MASKS", raising=False)
+    monkeypatch.delenv("CDS_MATCH_GUESS_ROWS", raising=False)
     assert len(want) >= 2                                        # the two planted copies pass even 50 %
+    # the same rows as table columns (cds_match_list_fetch_columns): mask offset applied, ratio = (float)((double) pixels / query size)
+    want0 = [(m, t, int(scores[m, t]), bool(mir[m, t])) for m in range(len(masks)) for t in range(n_t)
+             if sizes[m] > 0 and oracle.is_match(int(scores[m, t]), int(sizes[m]), 0.01)]
+    cm, ct, cs, cr, cmr = alg.searchSparseLibraryMatchColumns(sl, 0.01, mask_offset=40)
+    assert (cm.dtype, ct.dtype, cs.dtype, cr.dtype, cmr.dtype) == (np.int32, np.int64, np.int32, np.float32, np.bool_)
+    assert list(zip((cm - 40).tolist(), ct.tolist(), cs.tolist(), cmr.tolist())) == want0
+    assert np.array_equal(cr, (cs.astype(np.float64) / np.maximum(np.asarray(sizes, dtype=np.float64)[cm - 40], 1.0)).astype(np.float32))
     part = alg.searchSparseLibraryMatches(sl, 0.01, 5, 100)      # a sub-range: target indices are relative to `first`
     want_p = [(m, t - 5) for m in range(len(masks)) for t in range(5, 105) if sizes[m] > 0 and oracle.is_match(int(scores[m, t]), int(sizes[m]), 0.01)]
     assert list(zip(part[0].tolist(), part[1].tolist())) == want_p
