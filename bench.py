@@ -791,9 +791,14 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
     proc0 = PR0.GpuColorMIPSearchProcessor(cds.ColorMIPSearch(1.0, MASK_THR, provider), None, None, first=0, count=n_t, sparse_library=slib)
     torch.cuda.synchronize()
     ctx.reset_stream()        # (the context's own non-blocking stream: the synchronous copies of the preparing thread must not wait for the scans)
-    t0 = time.perf_counter()
-    mtable = proc0.findAllColorDepthMatchesTable(masks[:n_m], mask_set_size=128)
-    e2e_s = time.perf_counter() - t0
+    # (twice: the first call of a process also allocates what later calls recycle -- two 512 MB score matrices, the lists, the sets' plans,
+    # cds::cache_alloc --; a service runs many searches per process, so `seconds` is the second call and the first is reported beside it)
+    e2e_runs = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        mtable = proc0.findAllColorDepthMatchesTable(masks[:n_m], mask_set_size=128)
+        e2e_runs.append(time.perf_counter() - t0)
+    e2e_s = e2e_runs[-1]
     ctx.set_stream(stream.cuda_stream)
     hs = bview.cpu().numpy() if n_m * n_t <= (1 << 26) else None     # (small runs: the whole list against a host-side filter)
     want_matches = None
@@ -831,7 +836,8 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
                                                 "thread; two search workers: scan + isMatch (pctPositivePixels 1) + compaction on the device, then the list "
                                                 "download and the host-side columns of a set while the next set is scanned)",
                                         "pipeline_stage_seconds": getattr(proc0, "last_pipeline", None),
-                                        "seconds": e2e_s, "comparisons_per_s": n_m * n_t / e2e_s, "matches": int(len(mtable)),
+                                        "seconds": e2e_s, "first_call_seconds": e2e_runs[0], "seconds_over_seconds_per_pass": e2e_s / (bms * 1e-3),
+                                        "comparisons_per_s": n_m * n_t / e2e_s, "matches": int(len(mtable)),
                                         "match_list_bytes": int(len(mtable)) * 12, "score_matrix_bytes": int(n_m) * int(n_t) * 4,
                                         "sampled_masks_equal_host_filter": bool(sample_ok)},
                          "mask0_scores_equal_single_mask_scan": same_b,

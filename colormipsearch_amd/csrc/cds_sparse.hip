@@ -2958,7 +2958,8 @@ int cds_search_sparse_match_list(const cds_maskset *ms, const cds_sparse_library
     if (chunks.size() == 1 && !getenv("CDS_MATCH_TWO_PHASE")) {
         const auto &c = chunks[0];
         const int64_t pairs = (int64_t)(c.second - c.first) * count;
-        int64_t guess = std::max<int64_t>((int64_t)ctx->match_rows_hint.load(), pairs / 8);
+        const int64_t hint = (int64_t)ctx->match_rows_hint.load();
+        int64_t guess = hint > 0 ? hint : pairs / 8;
         if (const char *e = getenv("CDS_MATCH_GUESS_ROWS")) guess = atoll(e);
         guess = std::max<int64_t>(1, std::min<int64_t>(pairs, std::max<int64_t>(guess, 1 << 16)));
         if (const char *e = getenv("CDS_MATCH_GUESS_ROWS")) guess = std::max<int64_t>(1, atoll(e));

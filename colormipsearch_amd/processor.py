@@ -400,16 +400,27 @@ class GpuColorMIPSearchProcessor:
             self.last_pipeline["search_s"] += time.perf_counter() - t0
             return t
 
-        # (the device idles while the FIRST set is prepared: that one is a quarter of the size -- still a multiple of the kernel's group of 8 --,
-        # so the first scan starts after a quarter of a preparation; every later preparation hides behind the scan before it)
-        first = max(8, (mask_set_size // 4) // 8 * 8) if n >= 3 * mask_set_size else mask_set_size
+        # (the device idles while the FIRST set is prepared: that one is a quarter of the size -- a multiple of the kernel's group of 8; a
+        # preparation has ~15 ms of fixed cost, smaller or more steps were measured and gain nothing)
+        sizes = [mask_set_size]
         if first_set_size:
-            first = min(mask_set_size, max(8, int(first_set_size) // 8 * 8))
-        starts = [0] + list(range(first, n, mask_set_size))
+            sizes = [min(mask_set_size, max(8, int(first_set_size) // 8 * 8))]
+        elif n >= 3 * mask_set_size and mask_set_size >= 32:
+            sizes = [mask_set_size // 4 // 8 * 8]
+        starts, at = [], 0
+        for k in sizes:
+            if at < n:
+                starts.append(at)
+                at += k
+        starts += list(range(at, n, mask_set_size))
         ends = starts[1:] + [n]
-        with ThreadPoolExecutor(max_workers=1) as prep_pool, ThreadPoolExecutor(max_workers=2) as search_pool:
-            prepared = [prep_pool.submit(prepare, m0, m1) for m0, m1 in zip(starts, ends)]
-            parts = [f.result() for f in [search_pool.submit(search, m0, pf) for m0, pf in zip(starts, prepared)]]
+        # (the pools live as long as the processor: a host thread that has used the GPU runtime is slow to exit -- ~100 ms for the three
+        # of them after every call, measured --, and a processor runs many searches)
+        if getattr(self, "_pools", None) is None:
+            self._pools = (ThreadPoolExecutor(max_workers=1, thread_name_prefix="cds-prepare"), ThreadPoolExecutor(max_workers=2, thread_name_prefix="cds-search"))
+        prep_pool, search_pool = self._pools
+        prepared = [prep_pool.submit(prepare, m0, m1) for m0, m1 in zip(starts, ends)]
+        parts = [f.result() for f in [search_pool.submit(search, m0, pf) for m0, pf in zip(starts, prepared)]]
         t0 = time.perf_counter()
         rows = sum(len(t) for t in parts)
         out = MatchTable(np.empty(rows, np.int32), np.empty(rows, np.int64), np.empty(rows, np.int32), np.empty(rows, np.float32), np.empty(rows, bool))

@@ -197,6 +197,28 @@ public:
         check(rc);
         return out;
     }
+    // the same rows as the columns of a result table (cds_match_list_fetch_columns: split by the library's host threads while the list comes down)
+    struct MatchColumns {
+        std::vector<int32_t> mask, matchingPixels;
+        std::vector<int64_t> target;
+        std::vector<float> matchingPixelsRatio;
+        std::vector<uint8_t> mirrored;
+    };
+    MatchColumns searchLibraryMatchColumns(const SparseLibrary &lib, int64_t first, int64_t count, double pctPositivePixels, int32_t maskOffset = 0) const {
+        cds_match_list *list = nullptr;
+        int64_t n = 0;
+        check(cds_search_sparse_match_list(ms_, lib.handle(), first, count, pctPositivePixels, &list, &n));
+        MatchColumns c;
+        c.mask.resize((size_t)n), c.target.resize((size_t)n), c.matchingPixels.resize((size_t)n), c.matchingPixelsRatio.resize((size_t)n), c.mirrored.resize((size_t)n);
+        std::vector<int32_t> sizes((size_t)cds_maskset_size(ms_));
+        int rc = cds_maskset_query_sizes(ms_, sizes.data());
+        if (rc == CDS_OK)
+            rc = cds_match_list_fetch_columns(list, 0, n, sizes.data(), (int32_t)sizes.size(), maskOffset, c.mask.data(), c.target.data(), c.matchingPixels.data(),
+                                              c.matchingPixelsRatio.data(), c.mirrored.data());
+        cds_match_list_destroy(list);
+        check(rc);
+        return c;
+    }
     // the k best-scoring targets, selected on the device (score descending, equal scores by ascending target)
     void searchLibraryTopK(const SparseLibrary &lib, int64_t first, int64_t count, int k, std::vector<int32_t> &targets, std::vector<int32_t> &packedScores) const {
         targets.assign((size_t)k, -1);

@@ -47,6 +47,11 @@ int main() {
         // match list and top-k on the device: the two targets that match (the mask itself and its mirror image)
         std::vector<cds_match> ml = pm->searchLibraryMatches(slib, 0, 4, 1.0);
         if (ml.size() != 2 || ml[0].target != 0 || ml[1].target != 3 || ml[0].score != scores[0] || ml[1].score != (int32_t)((uint32_t)scores[3] | 0x80000000u)) return 8;
+        {
+            auto mc = pm->searchLibraryMatchColumns(slib, 0, 4, 1.0, 10);   // the same two rows as table columns, mask offset 10
+            if (mc.mask.size() != 2 || mc.mask[0] != 10 || mc.target[1] != 3 || mc.matchingPixels[0] != scores[0] || mc.mirrored[0] != 0 || mc.mirrored[1] != 1 ||
+                mc.matchingPixelsRatio[0] <= 0.0f || mc.matchingPixelsRatio[0] > 1.0f) return 18;
+        }
         std::vector<int32_t> tk, sk;
         pm->searchLibraryTopK(slib, 0, 4, 2, tk, sk);
         if (tk[0] != 0 || tk[1] != 3 || (sk[0] & 0x7fffffff) != scores[0]) return 9;

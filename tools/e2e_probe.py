@@ -62,6 +62,12 @@ def make_logged(m):
         events.append(("search+fetch", threading.get_ident() % 1000, t1, time.perf_counter(), len(m)))
         return r
     a.searchSparseLibraryMatchColumns = cols_logged
+    _close = a.close
+    def close_logged():
+        t2 = time.perf_counter()
+        _close()
+        events.append(("close", threading.get_ident() % 1000, t2, time.perf_counter(), len(m)))
+    a.close = close_logged
     return a
 search.createQueryColorDepthSearchWithDefaultThreshold = make_logged
 for rep in range(2):
