@@ -34,7 +34,7 @@ if [ -n "$FULL" ]; then
     run pmc_full_fetch 500 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_full_fetch -- python3 $F_ARGS
     run pmc_full_sq 500 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_full_sq -- python3 $F_ARGS
 fi
-# (the full command scans the 1,024-mask set twice: aux.mask_batch and its end-to-end leg through the processor)
-cd $R && python3 tools/summarize_profile.py $OUT --tag $TAG --extra-multi 1073741824 --write-json $OUT/scan_pmc.json
+# (the full command scans the 1,024-mask set three times: aux.mask_batch and its end-to-end leg through the processor, which runs twice)
+cd $R && python3 tools/summarize_profile.py $OUT --tag $TAG --extra-multi 2147483648 --write-json $OUT/scan_pmc.json
 # the big per-dispatch CSVs stay on the box: only the logs, the summary and the JSON travel back
 find $OUT -name '*.csv' -size +8M -delete
