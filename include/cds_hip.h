@@ -69,6 +69,10 @@ const char *cds_last_error(void);
 const char *cds_version(void);
 
 /* ---- context ------------------------------------------------------------------------------- */
+/* A context owns a device, its streams and a cache of released device blocks: the device memory of mask sets, match lists and
+ * per-call temporaries is recycled through the context (up to 6 GB idle) instead of going back to the driver, because hipFree
+ * waits for every stream of the device -- a caller that pipelines mask sets would stall behind the running scan after each one.
+ * cds_context_destroy returns the cache; mask sets, libraries and match lists of a context are destroyed BEFORE it. */
 int cds_context_create(int device_id, cds_context **out);
 void cds_context_destroy(cds_context *ctx);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) for all later launches; NULL is
