@@ -65,6 +65,8 @@ SIGNATURES = {
     "cds_context_set_stream": (_i, [_vp, _vp]),
     "cds_context_reset_stream": (_i, [_vp]),
     "cds_context_synchronize": (_i, [_vp]),
+    "cds_context_trim": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    "cds_context_set_cache_limit": (_i, [_vp, ctypes.c_uint64]),
     "cds_library_bytes": (ctypes.c_size_t, [_i32, _i32, _i64]),
     "cds_library_create": (_i, [_vp, _i32, _i32, _i64, ctypes.POINTER(_vp)]),
     "cds_library_wrap": (_i, [_vp, _i32, _i32, _i64, _vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
@@ -88,6 +90,9 @@ SIGNATURES = {
     "cds_maskset_last_kernel_ms": (_i, [_vp, ctypes.POINTER(ctypes.c_double), _i32p]),
     "cds_sparse_library_create": (_i, [_vp, _i32, _i32, _i64, _i64, ctypes.POINTER(_vp)]),
     "cds_sparse_library_destroy": (None, [_vp]),
+    "cds_sparse_library_set_growable": (_i, [_vp, _i32]),
+    "cds_sparse_library_reserve": (_i, [_vp, _i64, _i64]),
+    "cds_sparse_library_capacity": (_i, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i32)]),
     "cds_sparse_library_append": (_i, [_vp, _vp, _i64, _i64]),
     "cds_sparse_library_append_host": (_i, [_vp, _i64, _u8p]),
     "cds_sparse_library_layout": (_i, [_vp, _i32p, _i32p]),

@@ -91,6 +91,16 @@ class Context:
     def synchronize(self):
         capi.check(self._lib.cds_context_synchronize(self._h))
 
+    def trim(self):
+        """Give the context's idle device blocks back to the driver; returns the bytes freed (cds_context_trim)."""
+        freed = ctypes.c_uint64()
+        capi.check(self._lib.cds_context_trim(self._h, ctypes.byref(freed)))
+        return int(freed.value)
+
+    def set_cache_limit(self, nbytes):
+        """Cap the device memory the context may keep idle for recycling (default 6 GB; 0 = none)."""
+        capi.check(self._lib.cds_context_set_cache_limit(self._h, ctypes.c_uint64(int(nbytes))))
+
     def device_rcp_table(self):
         out = np.zeros(256, dtype=np.float32)
         capi.check(self._lib.cds_debug_device_rcp(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
@@ -333,19 +343,29 @@ class SparseLibrary:
     """A resident shard of target MIPs kept as signal-pixel lists (cds_sparse_library): ~4 % of the dense bytes,
     for searches that need the pixel-match score only (`searchSparseLibrary*`)."""
 
-    def __init__(self, width, height, capacity_images, capacity_pixels, context=None, density_limit=None, min_threshold=None):
+    def __init__(self, width, height, capacity_images=None, capacity_pixels=None, context=None, density_limit=None, min_threshold=None,
+                 growable=None):
         """density_limit: images averaging more signal pixels than this share of the frame are refused at append time (default
         0.25: above it the dense layout's scan is faster); pass e.g. 2.0 to accept anything.
         min_threshold: pixels whose brightest channel is <= this are not stored (default 0: every signal pixel); searches with a
-        smaller data threshold are refused -- results never change, the library is smaller and its scan visits fewer records."""
+        smaller data threshold are refused -- results never change, the library is smaller and its scan visits fewer records.
+        growable: appends enlarge the library when a capacity is lacking (the reference's MIP cache sizes itself with use,
+        CachedMIPsUtils.java:60-100); default: growable exactly when no capacities are given (then it starts at 1,024 images)."""
         self.ctx = context or default_context()
         self._lib = capi.load()
         self.width, self.height = int(width), int(height)
-        self.capacity_images, self.capacity_pixels = int(capacity_images), int(capacity_pixels)
+        if growable is None:
+            growable = capacity_images is None
+        if capacity_images is None:
+            capacity_images = 1024
+        if capacity_pixels is None:
+            capacity_pixels = int(capacity_images) * (20000 + 4 * self.height)
         h = ctypes.c_void_p()
-        capi.check(self._lib.cds_sparse_library_create(self.ctx._h, self.width, self.height, self.capacity_images,
-                                                       self.capacity_pixels, ctypes.byref(h)))
+        capi.check(self._lib.cds_sparse_library_create(self.ctx._h, self.width, self.height, int(capacity_images),
+                                                       int(capacity_pixels), ctypes.byref(h)))
         self._h = h
+        if growable:
+            capi.check(self._lib.cds_sparse_library_set_growable(self._h, 1))
         ns, sw = ctypes.c_int32(), ctypes.c_int32()
         capi.check(self._lib.cds_sparse_library_layout(self._h, ctypes.byref(ns), ctypes.byref(sw)))
         self.n_strips, self.strip_width = ns.value, sw.value
@@ -353,6 +373,31 @@ class SparseLibrary:
             self.set_density_limit(density_limit)
         if min_threshold is not None:
             self.set_min_threshold(min_threshold)
+
+    def _capacity(self):
+        ci, cp, s16 = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
+        capi.check(self._lib.cds_sparse_library_capacity(self._h, ctypes.byref(ci), ctypes.byref(cp), ctypes.byref(s16)))
+        return ci.value, cp.value, bool(s16.value)
+
+    @property
+    def capacity_images(self):
+        return self._capacity()[0]
+
+    @property
+    def capacity_pixels(self):
+        return self._capacity()[1]
+
+    @property
+    def has_stream16(self):
+        """Does the library hold the derived 16-bit stage-1 stream (dropped when records + stream would not stay resident)?"""
+        return self._capacity()[2]
+
+    def reserve(self, capacity_images, capacity_pixels):
+        """Grow to at least these capacities at once (cds_sparse_library_reserve; never shrinks)."""
+        capi.check(self._lib.cds_sparse_library_reserve(self._h, int(capacity_images), int(capacity_pixels)))
+
+    def set_growable(self, on=True):
+        capi.check(self._lib.cds_sparse_library_set_growable(self._h, 1 if on else 0))
 
     def set_min_threshold(self, min_data_threshold):
         capi.check(self._lib.cds_sparse_library_set_min_threshold(self._h, int(min_data_threshold)))

@@ -50,7 +50,7 @@ extern "C" int cds_debug_sparse_stream_read(const cds_sparse_library *sl, double
     const size_t n16 = (size_t)sl->n_px / 4;   // records are 4 bytes; the arena is hipMalloc-aligned
     if (n16 < ((size_t)1 << 20)) return fail(CDS_ERR_INVALID_ARGUMENT, "the library is too small for a bandwidth measurement (< 16 MB of records)");
     unsigned long long *d = nullptr;
-    CDS_HIP(hipMalloc(&d, sizeof(unsigned long long)));
+    CDS_HIP(dev_malloc(&d, sizeof(unsigned long long)));
     hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (e == hipSuccess) e = hipEventCreate(&e0);
@@ -80,7 +80,7 @@ extern "C" int cds_debug_valu_issue_ns(cds_context *ctx, double *ns_per_wave_ins
     CDS_HIP(hipSetDevice(ctx->device));
     const int wgs = ctx->n_cus * 2, threads = 1024, iters = 4000;   // 2 x 16 waves per CU = 8 waves per SIMD
     uint32_t *d = nullptr;
-    CDS_HIP(hipMalloc(&d, (size_t)wgs * threads * sizeof(uint32_t)));
+    CDS_HIP(dev_malloc(&d, (size_t)wgs * threads * sizeof(uint32_t)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);

@@ -66,7 +66,13 @@ int build_ratio_table(const float *rcp, std::vector<RatioEntry> &out) {
     }
     for (size_t i = 1; i < out.size(); i++)
         if (!(out[i - 1].code_hi < out[i].code_lo))
-            return fail(CDS_ERR_UNSUPPORTED, "device reciprocal table does not preserve the order of hue ratios");
+            // (the message carries what a report needs: the first offending pair and the head of the table -- round 4's one refusal of
+            // this kind, `s16u` in profiles/README.md, could not be told from a table that was never written)
+            return failf(CDS_ERR_UNSUPPORTED,
+                         "device reciprocal table does not preserve the order of hue ratios: ratio %.9g has codes [%u, %u] but the next ratio %.9g "
+                         "has [%u, %u]; rcp[1..4] = %.9g %.9g %.9g %.9g",
+                         out[i - 1].value, out[i - 1].code_lo, out[i - 1].code_hi, out[i].value, out[i].code_lo, out[i].code_hi,
+                         (double)rcp[1], (double)rcp[2], (double)rcp[3], (double)rcp[4]);
     if (out.back().code_hi >= (1u << 29)) return fail(CDS_ERR_UNSUPPORTED, "hue ratio code overflow");
     return CDS_OK;
 }
@@ -208,6 +214,7 @@ uint32_t host_hue_code(const float *rcp, int r, int g, int b, int thr) {
 cds_context *clone_context_for_slot(cds_context *parent) {
     hipSetDevice(parent->device);
     cds_context *c = new cds_context();
+    c->layout_stamp = sizeof(cds_context);
     c->device = parent->device;
     c->n_cus = parent->n_cus;
     c->lds_per_block = parent->lds_per_block;
@@ -221,6 +228,7 @@ cds_context *clone_context_for_slot(cds_context *parent) {
     }
     c->stream = c->own_stream;
     c->upload_stream = nullptr;   // (a pair-slot context prepares no mask sets)
+    register_context(c);
     return c;
 }
 
@@ -250,7 +258,7 @@ int PairSlotPool::acquire(cds_context *parent, int W, int H, size_t score_elems,
                 int rc = cds_library_create(s->sub, W, H, 1, &s->lib);
                 if (rc) return rc;
                 if (score_elems) {
-                    hipError_t e = hipMalloc(&s->d_scores, score_elems * sizeof(int32_t));
+                    hipError_t e = dev_malloc(&s->d_scores, score_elems * sizeof(int32_t));
                     if (e != hipSuccess) return hip_fail(e, "hipMalloc(pair scores)");
                 }
                 s->mu.lock();
@@ -298,7 +306,9 @@ int cds_context_create(int device_id, cds_context **out) {
         return fail(CDS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
     CDS_HIP(hipSetDevice(device_id));
     cds_context *ctx = new cds_context();
+    ctx->layout_stamp = sizeof(cds_context);
     ctx->device = device_id;
+    if (const char *e = getenv("CDS_CACHE_LIMIT_MB")) ctx->cache_cap = (size_t)std::max(0ll, atoll(e)) << 20;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->lds_per_block = prop.sharedMemPerBlock;
     if (ctx->lds_per_block < 160 * 1024) ctx->lds_per_block = 160 * 1024;  // gfx950: 160 KiB per workgroup
@@ -322,6 +332,7 @@ int cds_context_create(int device_id, cds_context **out) {
         delete ctx;
         return rc;
     }
+    cds::register_context(ctx);
     *out = ctx;
     return CDS_OK;
 }
@@ -370,6 +381,34 @@ void cache_free(cds_context *ctx, void *p) {
     }
     hipFree(p);
 }
+static std::mutex g_ctx_mu;
+static std::vector<cds_context *> g_contexts;
+void register_context(cds_context *ctx) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_contexts.push_back(ctx);
+}
+void unregister_context(cds_context *ctx) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), ctx), g_contexts.end());
+}
+hipError_t dev_malloc_raw(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipErrorOutOfMemory) return e;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return e;
+    size_t dropped = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);   // (a context is unregistered before it is deleted: the pointers are live while we hold this)
+        for (cds_context *c : g_contexts)
+            if (c->device == dev) {
+                dropped += c->cache_idle_bytes;
+                cache_drop(c);
+            }
+    }
+    if (!dropped) return e;
+    (void)hipGetLastError();
+    return hipMalloc(p, bytes);
+}
 void cache_drop(cds_context *ctx) {
     std::vector<std::pair<void *, size_t>> idle;
     {
@@ -383,8 +422,34 @@ void cache_drop(cds_context *ctx) {
 }  // namespace cds
 extern "C" {
 
+int cds_context_trim(cds_context *ctx, uint64_t *freed_bytes) {
+    if (!ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "context is NULL");
+    CDS_HIP(hipSetDevice(ctx->device));
+    CDS_HIP(hipDeviceSynchronize());   // (a released block may still be read by work enqueued before its release)
+    size_t idle;
+    {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        idle = ctx->cache_idle_bytes;
+    }
+    cds::cache_drop(ctx);
+    if (freed_bytes) *freed_bytes = idle;
+    return CDS_OK;
+}
+
+int cds_context_set_cache_limit(cds_context *ctx, uint64_t bytes) {
+    if (!ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "context is NULL");
+    bool over;
+    {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        ctx->cache_cap = (size_t)bytes;
+        over = ctx->cache_idle_bytes > ctx->cache_cap;
+    }
+    return over ? cds_context_trim(ctx, nullptr) : CDS_OK;
+}
+
 void cds_context_destroy(cds_context *ctx) {
     if (!ctx) return;
+    cds::unregister_context(ctx);
     hipSetDevice(ctx->device);
     cds::cache_drop(ctx);
     if (ctx->d_slice_lut && ctx->owns_lut) hipFree(ctx->d_slice_lut);
@@ -441,7 +506,7 @@ int cds_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t capacity,
     if (rc) return rc;
     hipSetDevice(ctx->device);
     size_t bytes = cds_library_bytes(W, H, capacity);
-    hipError_t e = hipMalloc(&lib->d_rgb, bytes);
+    hipError_t e = dev_malloc(&lib->d_rgb, bytes);
     if (e == hipSuccess) e = hipMemsetAsync(lib->d_rgb, 0, bytes, ctx->stream);
     if (e != hipSuccess) {
         if (lib->d_rgb) hipFree(lib->d_rgb);
@@ -500,7 +565,7 @@ static int stage_reserve(cds_library *lib, size_t bytes) {
     if (lib->stage_bytes >= bytes) return CDS_OK;
     if (lib->d_stage) hipFree(lib->d_stage);
     lib->d_stage = nullptr; lib->stage_bytes = 0;
-    CDS_HIP(hipMalloc(&lib->d_stage, bytes));
+    CDS_HIP(dev_malloc(&lib->d_stage, bytes));
     lib->stage_bytes = bytes;
     return CDS_OK;
 }
@@ -561,12 +626,12 @@ int cds_library_ensure_variants(cds_library *lib) {
     CDS_HIP(hipSetDevice(lib->ctx->device));
     if (!lib->d_grad) {
         size_t bytes = (size_t)lib->capacity * lib->grad_stride;
-        CDS_HIP(hipMalloc(&lib->d_grad, bytes));
+        CDS_HIP(dev_malloc(&lib->d_grad, bytes));
         CDS_HIP(hipMemsetAsync(lib->d_grad, 0, bytes, lib->ctx->stream));
     }
     if (!lib->d_zgap) {
         size_t bytes = (size_t)lib->capacity * lib->img_stride;
-        CDS_HIP(hipMalloc(&lib->d_zgap, bytes));
+        CDS_HIP(dev_malloc(&lib->d_zgap, bytes));
         CDS_HIP(hipMemsetAsync(lib->d_zgap, 0, bytes, lib->ctx->stream));
     }
     // (the derived zslice plane is allocated by the first scoring call that wants it: cds_shape.hip, ensure_zslice)
@@ -874,10 +939,10 @@ static int build_dense_layout(cds_maskset *ms) {
     total = pos.size();
     pt.lap("dense layout (host)");
     hipSetDevice(ctx->device);
-    hipError_t e = hipMalloc(&ms->d_bandptr, bandptr.size() * 4);
-    if (e == hipSuccess) e = hipMalloc(&ms->d_chunks, chunks.size() * sizeof(uint4));
-    if (e == hipSuccess) e = hipMalloc(&ms->d_px_pos, total * 4);
-    if (e == hipSuccess) e = hipMalloc(&ms->d_px_iv, total * sizeof(uint4));
+    hipError_t e = dev_malloc(&ms->d_bandptr, bandptr.size() * 4);
+    if (e == hipSuccess) e = dev_malloc(&ms->d_chunks, chunks.size() * sizeof(uint4));
+    if (e == hipSuccess) e = dev_malloc(&ms->d_px_pos, total * 4);
+    if (e == hipSuccess) e = dev_malloc(&ms->d_px_iv, total * sizeof(uint4));
     if (e == hipSuccess) e = hipMemcpy(ms->d_bandptr, bandptr.data(), bandptr.size() * 4, hipMemcpyHostToDevice);
     ms->h_bandptr = bandptr;
     if (e == hipSuccess) e = hipMemcpy(ms->d_chunks, chunks.data(), chunks.size() * sizeof(uint4), hipMemcpyHostToDevice);
@@ -1074,9 +1139,9 @@ static int search_host(const cds_maskset *ms, const cds_library *lib, int64_t fi
     CDS_HIP(hipSetDevice(ms->ctx->device));
     const size_t n = (size_t)ms->n_masks * count;
     int32_t *d_scores = nullptr, *d_counts = nullptr;
-    CDS_HIP(hipMalloc(&d_scores, n * sizeof(int32_t)));
+    CDS_HIP(dev_malloc(&d_scores, n * sizeof(int32_t)));
     if (counts) {
-        hipError_t e = hipMalloc(&d_counts, n * CDS_N_TRANSFORMS * sizeof(int32_t));
+        hipError_t e = dev_malloc(&d_counts, n * CDS_N_TRANSFORMS * sizeof(int32_t));
         if (e != hipSuccess) {
             hipFree(d_scores);
             return hip_fail(e, "hipMalloc(counts)");

@@ -460,8 +460,11 @@ static int append_files_impl(cds_sparse_library *sl, const char *const *paths, i
 int cds_sparse_library_append_files(cds_sparse_library *sl, const char *const *paths, int64_t count, int32_t threads) {
     CDS_NOEXCEPT_BEGIN
     const int64_t n_images0 = sl ? sl->n_images : 0, n_px0 = sl ? sl->n_px : 0;
+    (void)cds::take_density_refusal();
     const int rc = append_files_impl(sl, paths, count, threads);
-    if (rc == CDS_ERR_UNSUPPORTED) {   // a density refusal leaves nothing of the call behind (the message survives: same thread)
+    if (rc != CDS_OK && cds::take_density_refusal()) {   // a DENSITY refusal leaves nothing of the call behind (the message survives: same
+                                                          // thread); any other failure -- an unsupported file among them -- keeps the batches
+                                                          // appended before it, as the header says
         const std::string msg = cds_last_error();
         cds::sparse_library_rollback(sl, n_images0, n_px0);
         return fail(rc, msg);
@@ -474,7 +477,7 @@ static int append_files_impl(cds_sparse_library *sl, const char *const *paths, i
     if (!sl || (count > 0 && !paths)) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (count < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "count is negative");
     if (count == 0) return CDS_OK;
-    if (cds_sparse_library_size(sl) + count > sl->cap_images) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (images)");
+    if (cds_sparse_library_size(sl) + count > sl->cap_images && !sl->growable) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (images)");
     const int nthreads = std::max(1, std::min(threads > 0 ? threads : (int)std::thread::hardware_concurrency(), 64));
     const int64_t batch = 64;  // = the dense staging slots of cds_sparse_library_append_host
     const size_t img_bytes = (size_t)3 * sl->W * sl->H;

@@ -20,6 +20,13 @@ namespace cds {
 void set_error(const std::string &msg);
 int fail(int code, const std::string &msg);
 int hip_fail(hipError_t e, const char *what);
+// fail() with a printf-style message
+template <typename... A>
+inline int failf(int code, const char *fmt, A... a) {
+    char buf[768];
+    snprintf(buf, sizeof buf, fmt, a...);
+    return fail(code, std::string(buf));
+}
 
 #define CDS_HIP(call)                                      \
     do {                                                   \
@@ -61,6 +68,10 @@ struct RatioEntry {
 }  // namespace cds
 
 struct cds_context {
+    // sizeof(cds_context) as the translation unit that CREATED the context saw it.  The library's objects share this header; an object
+    // compiled against another revision of it (a stale .o of an A/B build: round 4's `s16u` run, profiles/README.md) would read the
+    // members at other offsets -- init_rcp_table (cds_scan.hip) checks the stamp before it touches the context.
+    size_t layout_stamp = 0;
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -122,6 +133,14 @@ inline hipError_t sync_here(hipStream_t st) {
     hipEventDestroy(ev);
     return e;
 }
+// Every device allocation of the library that does NOT go through the block cache: hipMalloc, and -- when that reports out of memory
+// while released blocks sit idle in the caches of this device's contexts (up to cache_cap bytes each) -- the caches are dropped and the
+// allocation is tried once more (a library create could fail with gigabytes idle in the same context).
+hipError_t dev_malloc_raw(void **p, size_t bytes);
+template <typename T>
+inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc_raw(reinterpret_cast<void **>(p), bytes); }
+void register_context(cds_context *ctx);     // (the registry dev_malloc_raw walks)
+void unregister_context(cds_context *ctx);
 hipError_t cache_alloc(cds_context *ctx, void **p, size_t bytes);   // a recycled block of >= bytes (at most twice that), or a fresh hipMalloc
 void cache_free(cds_context *ctx, void *p);                         // back to the context's idle list -- or hipFree when that is full / p is foreign
 void cache_drop(cds_context *ctx);                                  // hipFree of every idle block (context destruction)
@@ -207,6 +226,7 @@ int gradscore_begin(const cds_shapeset *ss, const cds_library *lib, int64_t n_pa
 int gradscore_end(GradscoreJob *job, int64_t *gradient_area_gap, int64_t *high_expression_area, uint8_t *mirrored);  // NULL outputs: wait and free
 cds_context *shapeset_context(const cds_shapeset *ss);
 int shapeset_n_masks(const cds_shapeset *ss);
+bool take_density_refusal();   // cds_sparse.hip: did THIS thread's last failing append fail on the density limit (and not on another CDS_ERR_UNSUPPORTED)?  Clears the flag.
 int sparse_library_rollback(cds_sparse_library *sl, int64_t n_images, int64_t n_px);   // cds_sparse.hip (for cds_sparse_library_append_files)
 int build_sparse_plans(cds_maskset *ms, const std::vector<std::vector<MaskPx>> &per_mask);
 void free_sparse_plans(cds_maskset *ms);
@@ -339,6 +359,9 @@ struct cds_sparse_library {
     int nstrips = 1, strip_w = 0;   // an image is stored strip by strip (column strips), a strip row by row
     int64_t cap_images = 0, cap_px = 0;
     int64_t n_images = 0, n_px = 0;
+    bool growable = false;          // an append that finds a capacity lacking enlarges the arrays (cds_sparse_library_set_growable): the
+                                    // counterpart of the reference's MIP cache, which sizes itself with use (cmd/CachedMIPsUtils.java:60-100)
+    bool want_px16 = true;          // (CDS_SPARSE_STREAM16 at creation; the stream is dropped when it would not fit, see px16_fits)
     int min_threshold = 0;          // pixels whose maximum channel is <= this are not stored; searches below it are refused
     double density_limit = 0.25;    // appends / imports whose images average more signal pixels than this share of the frame are refused
     uint32_t *d_px = nullptr;

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <set>
 #include <thread>
 
@@ -36,19 +37,30 @@ struct RcclApi {
 };
 constexpr int kNcclInt32 = 2;  // ncclInt32 (rccl.h ncclDataType_t)
 
+// CDS_RCCL_LIBRARY names the library to bind instead of the default search (a site's own RCCL build; tests/rccl_stub: a stand-in
+// that moves the bytes with hipMemcpyAsync, so that the n > 1 control flow of this file runs on a one-GPU box).  One binding per path
+// and process.
 static RcclApi *load_rccl(std::string &why) {
-    static RcclApi api;
+    static std::map<std::string, RcclApi> bound;
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    if (api.handle) return &api;
+    const char *forced = getenv("CDS_RCCL_LIBRARY");
+    const std::string key = forced && *forced ? forced : "";
+    auto it = bound.find(key);
+    if (it != bound.end()) return &it->second;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
-    for (const char *n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
+    if (!key.empty()) {
+        h = dlopen(key.c_str(), RTLD_NOW | RTLD_LOCAL);
+    } else {
+        for (const char *n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
     }
     if (!h) {
-        why = std::string("librccl.so.1 cannot be loaded: ") + (dlerror() ? dlerror() : "?");
+        const char *de = dlerror();
+        why = (key.empty() ? std::string("librccl.so.1") : key) + " cannot be loaded: " + (de ? de : "?");
         return nullptr;
     }
     RcclApi a;
@@ -60,11 +72,10 @@ static RcclApi *load_rccl(std::string &why) {
     a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
     a.Gather = (decltype(a.Gather))dlsym(h, "ncclGather");
     if (!a.CommInitAll || !a.CommDestroy || !a.GetErrorString || !a.GroupStart || !a.GroupEnd || !a.Gather) {
-        why = "librccl.so.1 lacks an entry point (ncclCommInitAll / ncclGather / ...)";
+        why = (key.empty() ? std::string("librccl.so.1") : key) + " lacks an entry point (ncclCommInitAll / ncclGather / ...)";
         return nullptr;
     }
-    api = a;
-    return &api;
+    return &(bound[key] = a);
 }
 
 }  // namespace cds
@@ -100,7 +111,10 @@ int cds_comm_create(cds_context *const *contexts, int32_t n, cds_comm **out) {
     c->d_send.assign((size_t)n, nullptr);
     c->send_elems.assign((size_t)n, 0);
     const bool distinct = (int)devs.size() == n;
-    if (distinct && !getenv("CDS_COMM_NO_RCCL")) {
+    // CDS_COMM_FORCE_RCCL: the RCCL branch even over contexts that share a device.  Real RCCL answers duplicate devices with an error
+    // (reported below); the stand-in of tests/rccl_stub accepts them -- the one-GPU rehearsal of the grouped gather with NULL receive
+    // buffers on the non-roots and of the ordering of the peers' streams behind it.
+    if ((distinct || getenv("CDS_COMM_FORCE_RCCL")) && !getenv("CDS_COMM_NO_RCCL")) {
         std::string why;
         c->api = load_rccl(why);
         if (!c->api) {
@@ -171,7 +185,7 @@ int cds_search_sparse_sharded(cds_comm *c, const cds_maskset *const *masksets, c
             if (c->d_send[(size_t)r]) hipFree(c->d_send[(size_t)r]);
             c->d_send[(size_t)r] = nullptr;
             c->send_elems[(size_t)r] = 0;
-            CDS_HIP(hipMalloc(&c->d_send[(size_t)r], elems * sizeof(int32_t)));
+            CDS_HIP(dev_malloc(&c->d_send[(size_t)r], elems * sizeof(int32_t)));
             c->send_elems[(size_t)r] = elems;
         }
     }
@@ -180,7 +194,7 @@ int cds_search_sparse_sharded(cds_comm *c, const cds_maskset *const *masksets, c
         if (c->d_recv) hipFree(c->d_recv);
         c->d_recv = nullptr;
         c->recv_elems = 0;
-        CDS_HIP(hipMalloc(&c->d_recv, elems * (size_t)n * sizeof(int32_t)));
+        CDS_HIP(dev_malloc(&c->d_recv, elems * (size_t)n * sizeof(int32_t)));
         c->recv_elems = elems * (size_t)n;
     }
     // Once a scan has been launched, no error path may return while kernels on other GPUs still write into the communicator's
@@ -302,9 +316,17 @@ int cds_search_sparse_sharded_matches(cds_comm *c, const cds_maskset *const *mas
         if (rc) errs[(size_t)r] = cds_last_error();   // (the message lives in this thread)
     };
     {
+        // one host thread per shard; a thread the process cannot have (container limit) is replaced by the calling thread -- no
+        // exception leaves through the C ABI or out of a worker
         std::vector<std::thread> pool;
-        for (int r = 1; r < n; r++) pool.emplace_back(work, r);
+        int started = 1;
+        try {
+            pool.reserve((size_t)n);
+            for (; started < n; started++) pool.emplace_back(work, started);
+        } catch (...) {
+        }
         work(0);
+        for (int r = started; r < n; r++) work(r);
         for (auto &t : pool) t.join();
     }
     for (int r = 0; r < n; r++)
@@ -359,17 +381,30 @@ int cds_search_sparse_sharded_topk(cds_comm *c, const cds_maskset *const *maskse
     std::vector<std::string> errs((size_t)n);
     auto work = [&](int r) {
         const int64_t nl = off[(size_t)r + 1] - off[(size_t)r];
-        tg[(size_t)r].assign(per, -1);
-        sc[(size_t)r].assign(per, 0);
-        if (nl == 0) return;
-        const int rc = cds_search_sparse_topk(masksets[r], slibs[r], 0, nl, k, tg[(size_t)r].data(), sc[(size_t)r].data());
+        int rc = CDS_OK;
+        try {
+            tg[(size_t)r].assign(per, -1);
+            sc[(size_t)r].assign(per, 0);
+            if (nl == 0) return;
+            rc = cds_search_sparse_topk(masksets[r], slibs[r], 0, nl, k, tg[(size_t)r].data(), sc[(size_t)r].data());
+        } catch (const std::bad_alloc &) {
+            rc = fail(CDS_ERR_OUT_OF_MEMORY, "out of host memory for a shard's candidates");
+        }
         rcs[(size_t)r] = rc;
         if (rc) errs[(size_t)r] = cds_last_error();
     };
     {
+        // one host thread per shard; a thread the process cannot have (container limit) is replaced by the calling thread -- no
+        // exception leaves through the C ABI or out of a worker
         std::vector<std::thread> pool;
-        for (int r = 1; r < n; r++) pool.emplace_back(work, r);
+        int started = 1;
+        try {
+            pool.reserve((size_t)n);
+            for (; started < n; started++) pool.emplace_back(work, started);
+        } catch (...) {
+        }
         work(0);
+        for (int r = started; r < n; r++) work(r);
         for (auto &t : pool) t.join();
     }
     for (int r = 0; r < n; r++)

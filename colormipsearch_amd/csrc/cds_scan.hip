@@ -674,13 +674,26 @@ __global__ void rcp_table_kernel(float *out) {
 }
 
 int init_rcp_table(cds_context *ctx) {
+    if (ctx->layout_stamp != sizeof(cds_context))
+        return failf(CDS_ERR_HIP, "libcds_hip.so is linked from objects built against different revisions of cds_internal.hpp "
+                                 "(context layout %zu bytes here, %zu where it was created): rebuild every object", sizeof(cds_context), ctx->layout_stamp);
     float *d = nullptr;
-    CDS_HIP(hipMalloc(&d, 256 * sizeof(float)));
-    hipLaunchKernelGGL(rcp_table_kernel, dim3(1), dim3(256), 0, ctx->stream, d);
-    CDS_HIP(hipGetLastError());
-    CDS_HIP(hipMemcpyAsync(ctx->rcp, d, 256 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    CDS_HIP(hipStreamSynchronize(ctx->stream));
-    CDS_HIP(hipFree(d));
+    CDS_HIP(dev_malloc(&d, 256 * sizeof(float)));
+    // the buffer starts as NaNs (0xff bytes): a kernel that never ran -- no code object for this device, a launch refused -- is told apart
+    // from a table that came back wrong
+    hipError_t e = hipMemsetAsync(d, 0xff, 256 * sizeof(float), ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rcp_table_kernel, dim3(1), dim3(256), 0, ctx->stream, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->rcp, d, 256 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d);
+    if (e != hipSuccess) return hip_fail(e, "reciprocal table kernel (is libcds_hip.so built for this device's architecture?)");
+    // v_rcp_f32 is exact for powers of two: 1, 0.5 and 1/128 come back as themselves on every device that ran the kernel
+    if (!(ctx->rcp[1] == 1.0f && ctx->rcp[2] == 0.5f && ctx->rcp[128] == 0.0078125f))
+        return failf(CDS_ERR_HIP, "the reciprocal table kernel did not write its table (rcp[1], rcp[2], rcp[3], rcp[128] read back as %g, %g, %g, %g; "
+                                 "NaN = never written)", (double)ctx->rcp[1], (double)ctx->rcp[2], (double)ctx->rcp[3], (double)ctx->rcp[128]);
     return CDS_OK;
 }
 

@@ -87,7 +87,7 @@ static int ensure_slice_lut(cds_context *ctx) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (ctx->d_slice_lut) return CDS_OK;
     const std::vector<uint8_t> &t = host_slice_table();
-    CDS_HIP(hipMalloc(&ctx->d_slice_lut, t.size()));
+    CDS_HIP(dev_malloc(&ctx->d_slice_lut, t.size()));
     ctx->owns_lut = true;   // (also for a pair-slot context cloned before its parent had the table)
     CDS_HIP(hipMemcpy(ctx->d_slice_lut, t.data(), t.size(), hipMemcpyHostToDevice));
     return CDS_OK;
@@ -178,9 +178,9 @@ static int max_filter_host(cds_context *ctx, const uint8_t *src, int W, int H, d
     int rc = CDS_OK;
     auto cleanup = [&]() { if (d_a) hipFree(d_a); if (d_b) hipFree(d_b); if (d_hw) hipFree(d_hw); };
 #define MF_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); return hip_fail(_e, #call); } } while (0)
-    MF_HIP(hipMalloc(&d_a, bytes));
-    MF_HIP(hipMalloc(&d_b, bytes));
-    MF_HIP(hipMalloc(&d_hw, hw.size() * sizeof(int)));
+    MF_HIP(dev_malloc(&d_a, bytes));
+    MF_HIP(dev_malloc(&d_b, bytes));
+    MF_HIP(dev_malloc(&d_hw, hw.size() * sizeof(int)));
     MF_HIP(hipMemsetAsync(d_b, 0, bytes, st));
     MF_HIP(hipMemcpyAsync(d_a, src, bytes, hipMemcpyHostToDevice, st));
     MF_HIP(hipMemcpyAsync(d_hw, hw.data(), hw.size() * sizeof(int), hipMemcpyHostToDevice, st));
@@ -494,7 +494,7 @@ static int ensure_zslice(cds_library *lib, const std::vector<int64_t> &slots, hi
     if (rc) return rc;
     if (!lib->d_zslice) {
         const size_t bytes = (size_t)lib->capacity * lib->grad_stride;
-        CDS_HIP(hipMalloc(&lib->d_zslice, bytes));
+        CDS_HIP(dev_malloc(&lib->d_zslice, bytes));
     }
     int32_t *d_slots = nullptr;
     CDS_HIP(hipMallocAsync((void **)&d_slots, todo.size() * sizeof(int32_t), st));
@@ -970,8 +970,8 @@ int cds_library_make_zgap_variants(cds_library *lib, int64_t first, int64_t coun
     const int k = line_radii(radius, hw);
     uint8_t *d_tmp = nullptr;
     int *d_hw = nullptr;
-    CDS_HIP(hipMalloc(&d_tmp, lib->img_stride));
-    hipError_t e = hipMalloc(&d_hw, hw.size() * sizeof(int));
+    CDS_HIP(dev_malloc(&d_tmp, lib->img_stride));
+    hipError_t e = dev_malloc(&d_hw, hw.size() * sizeof(int));
     if (e == hipSuccess) e = hipMemcpyAsync(d_hw, hw.data(), hw.size() * sizeof(int), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(d_tmp, 0, lib->img_stride, st);
     MaxFilterParams p{};
@@ -1049,23 +1049,23 @@ int cds_shapeset_create_bordered(cds_context *ctx, int32_t n_masks, const uint8_
         if (ev_b) hipEventDestroy(ev_b);
     };
 #define SP_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { hipStreamSynchronize(st); cleanup(); cds_shapeset_destroy(ss); return hip_fail(_e, #call); } } while (0)
-    SP_HIP(hipMalloc(&ss->d_planes, (size_t)n_masks * 2 * H * wp * sizeof(uint16_t)));
-    SP_HIP(hipMalloc(&ss->d_boxes, (size_t)n_masks * 8 * sizeof(int)));
-    SP_HIP(hipMalloc(&ss->d_rowflags, (size_t)n_masks * H));
+    SP_HIP(dev_malloc(&ss->d_planes, (size_t)n_masks * 2 * H * wp * sizeof(uint16_t)));
+    SP_HIP(dev_malloc(&ss->d_boxes, (size_t)n_masks * 8 * sizeof(int)));
+    SP_HIP(dev_malloc(&ss->d_rowflags, (size_t)n_masks * H));
     SP_HIP(hipMemsetAsync(ss->d_planes, 0, (size_t)n_masks * 2 * H * wp * sizeof(uint16_t), st));
     for (int k = 0; k < nset; k++) {
-        SP_HIP(hipMalloc(&d_masks[k], (size_t)batch * 3 * N));
-        SP_HIP(hipMalloc(&d_flags[k], (size_t)batch * N));
-        SP_HIP(hipMalloc(&d_hd[k], (size_t)batch * 7 * N));
+        SP_HIP(dev_malloc(&d_masks[k], (size_t)batch * 3 * N));
+        SP_HIP(dev_malloc(&d_flags[k], (size_t)batch * N));
+        SP_HIP(dev_malloc(&d_hd[k], (size_t)batch * 7 * N));
     }
-    SP_HIP(hipMalloc(&d_hw, (hw60.size() + hw20.size()) * sizeof(int)));
-    SP_HIP(hipMalloc(&d_acc, (size_t)n_masks * 16 * sizeof(int)));
-    SP_HIP(hipMalloc(&d_rfl, (size_t)n_masks * H * sizeof(uint32_t)));
-    SP_HIP(hipMalloc(&d_sums, (size_t)n_masks * 2 * sizeof(unsigned long long)));
+    SP_HIP(dev_malloc(&d_hw, (hw60.size() + hw20.size()) * sizeof(int)));
+    SP_HIP(dev_malloc(&d_acc, (size_t)n_masks * 16 * sizeof(int)));
+    SP_HIP(dev_malloc(&d_rfl, (size_t)n_masks * H * sizeof(uint32_t)));
+    SP_HIP(dev_malloc(&d_sums, (size_t)n_masks * 2 * sizeof(unsigned long long)));
     SP_HIP(hipMemcpyAsync(d_hw, hw60.data(), hw60.size() * sizeof(int), hipMemcpyHostToDevice, st));
     SP_HIP(hipMemcpyAsync(d_hw + hw60.size(), hw20.data(), hw20.size() * sizeof(int), hipMemcpyHostToDevice, st));
     if (roi) {
-        SP_HIP(hipMalloc(&d_roi, N));
+        SP_HIP(dev_malloc(&d_roi, N));
         SP_HIP(hipMemcpyAsync(d_roi, roi, N, hipMemcpyHostToDevice, st));
     }
     std::vector<int> acc((size_t)n_masks * 16), boxes((size_t)n_masks * 8, 0);
@@ -1132,7 +1132,7 @@ int cds_shapeset_create_bordered(cds_context *ctx, int32_t n_masks, const uint8_
     SP_HIP(hipMemcpyAsync(ss->d_boxes, boxes.data(), boxes.size() * sizeof(int), hipMemcpyHostToDevice, st));
     {   // the group lists of gradscore_list_kernel: count, prefix on the host, fill
         uint32_t *d_cnt = nullptr;
-        SP_HIP(hipMalloc(&d_cnt, (size_t)n_masks * 2 * sizeof(uint32_t)));
+        SP_HIP(dev_malloc(&d_cnt, (size_t)n_masks * 2 * sizeof(uint32_t)));
         auto free_cnt = [&]() { hipFree(d_cnt); };
         ListParams lp{};
         lp.planes = ss->d_planes; lp.H = H; lp.wp = wp; lp.n = n_masks; lp.counts = d_cnt;
@@ -1150,12 +1150,12 @@ int cds_shapeset_create_bordered(cds_context *ctx, int32_t n_masks, const uint8_
                 off[(size_t)2 * (m + 1)] = off[(size_t)2 * m] + cnt[(size_t)2 * m];
                 off[(size_t)2 * (m + 1) + 1] = off[(size_t)2 * m + 1] + cnt[(size_t)2 * m + 1];
             }
-            e = hipMalloc(&ss->d_glist, std::max<size_t>(1, off[(size_t)2 * n_masks]) * sizeof(uint32_t));
+            e = dev_malloc(&ss->d_glist, std::max<size_t>(1, off[(size_t)2 * n_masks]) * sizeof(uint32_t));
         }
-        if (e == hipSuccess) e = hipMalloc(&ss->d_gl_a, std::max<size_t>(1, off[(size_t)2 * n_masks]) * sizeof(ushort4));
-        if (e == hipSuccess) e = hipMalloc(&ss->d_gl_b, std::max<size_t>(1, off[(size_t)2 * n_masks]) * sizeof(ushort4));
-        if (e == hipSuccess) e = hipMalloc(&ss->d_hlist, std::max<size_t>(1, off[(size_t)2 * n_masks + 1]) * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&ss->d_list_off, off.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = dev_malloc(&ss->d_gl_a, std::max<size_t>(1, off[(size_t)2 * n_masks]) * sizeof(ushort4));
+        if (e == hipSuccess) e = dev_malloc(&ss->d_gl_b, std::max<size_t>(1, off[(size_t)2 * n_masks]) * sizeof(ushort4));
+        if (e == hipSuccess) e = dev_malloc(&ss->d_hlist, std::max<size_t>(1, off[(size_t)2 * n_masks + 1]) * sizeof(uint32_t));
+        if (e == hipSuccess) e = dev_malloc(&ss->d_list_off, off.size() * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemcpyAsync(ss->d_list_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, (size_t)n_masks * 2 * sizeof(uint32_t), st);
         if (e == hipSuccess) {
@@ -1309,9 +1309,9 @@ int gradscore_begin(const cds_shapeset *ss, const cds_library *lib, int64_t n_pa
         }
     }
 #define GS_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { hipStreamSynchronize(st); j->release(); return hip_fail(_e, #call); } } while (0)
-    GS_HIP(hipMalloc(&j->d_pm, (size_t)n_pairs * 4));
-    GS_HIP(hipMalloc(&j->d_ps, (size_t)n_pairs * 8));
-    GS_HIP(hipMalloc(&j->d_out, (size_t)n_pairs * 32));
+    GS_HIP(dev_malloc(&j->d_pm, (size_t)n_pairs * 4));
+    GS_HIP(dev_malloc(&j->d_ps, (size_t)n_pairs * 8));
+    GS_HIP(dev_malloc(&j->d_out, (size_t)n_pairs * 32));
     GS_HIP(hipHostMalloc((void **)&j->h_res, (size_t)n_pairs * 32));
     // (pair_mask is the caller's and may be gone before the copy runs when begin / end are apart: the slots are the job's own copy,
     // the mask indices go through the pinned result buffer's first quarter, which the read-back overwrites later)

@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <system_error>
 #include <climits>
 #include <cstdlib>
 #include <cstring>
@@ -2404,10 +2405,101 @@ __global__ __launch_bounds__(1024) void topk_kernel(TopkParams p) {
 
 using namespace cds;
 
+// The 16-bit stream is worth its +50 % of record memory only while records AND stream stay resident: by policy it is left out when
+// the two together would take more than CDS_SPARSE_STREAM16_MAX_FRACTION (default 0.6) of the device's memory -- a million real LM
+// MIPs (36 K records each) are 144 GB of records; their stream would leave no room for anything else, and the pilot routes such
+// libraries to the 4-byte records anyway.
+static bool px16_fits(int64_t capacity_pixels) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return true;
+    double frac = 0.6;
+    if (const char *e = getenv("CDS_SPARSE_STREAM16_MAX_FRACTION")) frac = atof(e);
+    return (double)capacity_pixels * 6.0 <= frac * (double)total_b;
+}
+
+// Enlarge a growable library's arrays to hold at least need_images images and need_px records: new arrays, device-to-device copies
+// of what is held, the old ones freed after the copies.  The stream is derived data: when its larger copy does not fit (or the policy
+// above says no) the library goes on without it.  On failure the library is what it was.
+static int sparse_grow(cds_sparse_library *sl, int64_t need_images, int64_t need_px) {
+    cds_context *ctx = sl->ctx;
+    hipStream_t st = ctx->stream;
+    auto grown = [](int64_t cap, int64_t need) { return std::max(need, cap + cap / 2 + 1); };
+    if (need_images > sl->cap_images) {
+        const int64_t cap = grown(sl->cap_images, need_images);
+        const size_t per = (size_t)sl->nstrips * (sl->H + 1);
+        uint64_t *off = nullptr;
+        uint32_t *rp = nullptr;
+        hipError_t e = dev_malloc(&off, (size_t)(cap + 1) * sizeof(uint64_t));
+        if (e == hipSuccess) e = dev_malloc(&rp, (size_t)cap * per * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpyAsync(off, sl->d_img_off, (size_t)(sl->n_images + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess && sl->n_images > 0)
+            e = hipMemcpyAsync(rp, sl->d_rowptr, (size_t)sl->n_images * per * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            if (off) hipFree(off);
+            if (rp) hipFree(rp);
+            return hip_fail(e, "growing the sparse library (images)");
+        }
+        hipFree(sl->d_img_off);
+        hipFree(sl->d_rowptr);
+        sl->d_img_off = off, sl->d_rowptr = rp, sl->cap_images = cap;
+    }
+    if (need_px > sl->cap_px) {
+        const int64_t cap = grown(sl->cap_px, need_px);
+        uint32_t *px = nullptr;
+        hipError_t e = dev_malloc(&px, (size_t)cap * sizeof(uint32_t));
+        if (e == hipSuccess && sl->n_px > 0) e = hipMemcpyAsync(px, sl->d_px, (size_t)sl->n_px * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            if (px) hipFree(px);
+            return hip_fail(e, "growing the sparse library (records)");
+        }
+        hipFree(sl->d_px);
+        sl->d_px = px;
+        if (sl->d_px16) {   // the stream follows, or goes
+            uint16_t *p16 = nullptr;
+            hipError_t e16 = px16_fits(cap) ? dev_malloc(&p16, ((size_t)cap + 2) * sizeof(uint16_t)) : hipErrorOutOfMemory;
+            if (e16 == hipSuccess) e16 = hipMemcpyAsync(p16, sl->d_px16, ((size_t)sl->n_px + 1) * sizeof(uint16_t), hipMemcpyDeviceToDevice, st);   // (+ the sentinel)
+            if (e16 == hipSuccess) e16 = hipStreamSynchronize(st);
+            if (e16 != hipSuccess) {
+                (void)hipGetLastError();
+                if (p16) hipFree(p16);
+                p16 = nullptr;
+            }
+            hipFree(sl->d_px16);
+            sl->d_px16 = p16;
+        }
+        sl->cap_px = cap;
+    }
+    return CDS_OK;
+}
+
 // =================================================================================================
 //                                            C ABI
 // =================================================================================================
 extern "C" {
+
+int cds_sparse_library_set_growable(cds_sparse_library *sl, int32_t on) {
+    if (!sl) return fail(CDS_ERR_INVALID_ARGUMENT, "sparse library is NULL");
+    std::lock_guard<std::mutex> lk(sl->mu);
+    sl->growable = on != 0;
+    return CDS_OK;
+}
+
+int cds_sparse_library_reserve(cds_sparse_library *sl, int64_t capacity_images, int64_t capacity_pixels) {
+    if (!sl) return fail(CDS_ERR_INVALID_ARGUMENT, "sparse library is NULL");
+    std::lock_guard<std::mutex> lk(sl->mu);
+    CDS_HIP(hipSetDevice(sl->ctx->device));
+    return sparse_grow(sl, capacity_images, capacity_pixels);
+}
+
+int cds_sparse_library_capacity(const cds_sparse_library *sl, int64_t *capacity_images, int64_t *capacity_pixels, int32_t *has_stream16) {
+    if (!sl) return fail(CDS_ERR_INVALID_ARGUMENT, "sparse library is NULL");
+    if (capacity_images) *capacity_images = sl->cap_images;
+    if (capacity_pixels) *capacity_pixels = sl->cap_px;
+    if (has_stream16) *has_stream16 = sl->d_px16 ? 1 : 0;
+    return CDS_OK;
+}
 
 int cds_sparse_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t capacity_images, int64_t capacity_pixels,
                               cds_sparse_library **out) {
@@ -2431,16 +2523,17 @@ int cds_sparse_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t ca
         delete sl;
         return fail(CDS_ERR_INVALID_ARGUMENT, "CDS_SPARSE_STRIP_W must give at most 16 strips of at most 512 pixels (a record holds its column relative to its strip in 9 bits)");
     }
-    hipError_t e = hipMalloc(&sl->d_px, (size_t)capacity_pixels * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&sl->d_img_off, (size_t)(capacity_images + 1) * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMalloc(&sl->d_rowptr, (size_t)capacity_images * sl->nstrips * (H + 1) * sizeof(uint32_t));
+    hipError_t e = dev_malloc(&sl->d_px, (size_t)capacity_pixels * sizeof(uint32_t));
+    if (e == hipSuccess) e = dev_malloc(&sl->d_img_off, (size_t)(capacity_images + 1) * sizeof(uint64_t));
+    if (e == hipSuccess) e = dev_malloc(&sl->d_rowptr, (size_t)capacity_images * sl->nstrips * (H + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(sl->d_img_off, 0, sizeof(uint64_t), ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) {
         // the 16-bit stage-1 stream (+50 % of record memory): optional -- without it the scan reads the 4-byte records as before
         const char *env = getenv("CDS_SPARSE_STREAM16");
-        if (!(env && atoi(env) == 0)) {
-            if (hipMalloc(&sl->d_px16, ((size_t)capacity_pixels + 2) * sizeof(uint16_t)) != hipSuccess) {
+        sl->want_px16 = !(env && atoi(env) == 0);
+        if (sl->want_px16 && px16_fits(capacity_pixels)) {
+            if (dev_malloc(&sl->d_px16, ((size_t)capacity_pixels + 2) * sizeof(uint16_t)) != hipSuccess) {
                 sl->d_px16 = nullptr;
                 (void)hipGetLastError();   // (not an error of this call: the library works without the stream)
             }
@@ -2523,7 +2616,16 @@ int cds_sparse_library_clear(cds_sparse_library *sl) {
 // layout's kernel is the faster one (measured: 2.1 M comparisons/s against 6.0 M/s on dense-uniform images, 254 against 12 on
 // 2.6 %-dense synthetic ones).  Appends whose images are denser than the library's limit are refused with this message instead
 // of silently running slower than the dense scan; cds_sparse_library_set_density_limit raises or removes the limit.
+static thread_local bool g_density_refusal = false;   // set by the refusal below, taken by cds_sparse_library_append_files' roll-back
+}  // extern "C"
+bool cds::take_density_refusal() {
+    const bool v = g_density_refusal;
+    g_density_refusal = false;
+    return v;
+}
+extern "C" {
 static int density_refused(double density, double limit) {
+    g_density_refusal = true;
     char buf[320];
     snprintf(buf, sizeof buf, "images are %.1f %% signal pixels, above this sparse library's density limit of %.1f %%: the dense-layout scan "
              "(cds_library + cds_search) is faster there -- keep them in a cds_library, or raise the limit with cds_sparse_library_set_density_limit",
@@ -2578,7 +2680,7 @@ static int sparse_append_locked(cds_sparse_library *sl, const cds_library *src, 
         sl->d_tmp = nullptr;
         sl->tmp_images = 0;
         const int64_t n = std::min(count, max_batch);
-        CDS_HIP(hipMalloc(&sl->d_tmp, (size_t)n * sizeof(uint32_t) + sizeof(uint64_t)));
+        CDS_HIP(dev_malloc(&sl->d_tmp, (size_t)n * sizeof(uint32_t) + sizeof(uint64_t)));
         sl->tmp_images = n;
     }
     for (int64_t done = 0; done < count;) {
@@ -2608,6 +2710,11 @@ static int sparse_append_locked(cds_sparse_library *sl, const cds_library *src, 
             const double floor_density = tally.records / ((double)std::max(tally.images_total, tally.images) * sl->W * sl->H);
             if (floor_density > sl->density_limit) return density_refused(tally.records / ((double)tally.images * sl->W * sl->H), sl->density_limit);
         }
+        if (sl->n_px + (int64_t)total > sl->cap_px && sl->growable) {
+            const int rcg = sparse_grow(sl, 0, sl->n_px + (int64_t)total);
+            if (rcg) return rcg;
+            p.px = sl->d_px;   // (the fill below writes into the new arena)
+        }
         if (sl->n_px + (int64_t)total > sl->cap_px) {
             char buf[200];
             snprintf(buf, sizeof buf, "sparse library is full: %lld records held, %lld more needed, capacity %lld", (long long)sl->n_px,
@@ -2635,8 +2742,12 @@ int cds_sparse_library_append(cds_sparse_library *sl, const cds_library *src, in
     if (src->ctx != sl->ctx) return fail(CDS_ERR_INVALID_ARGUMENT, "libraries belong to different contexts");
     if (count == 0) return CDS_OK;
     std::lock_guard<std::mutex> lk(sl->mu);
-    if (sl->n_images + count > sl->cap_images) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (images)");
     CDS_HIP(hipSetDevice(sl->ctx->device));
+    if (sl->n_images + count > sl->cap_images && sl->growable) {
+        const int rcg = sparse_grow(sl, sl->n_images + count, 0);
+        if (rcg) return rcg;
+    }
+    if (sl->n_images + count > sl->cap_images) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (images)");
     AppendTally tally;
     append_begin(sl, count, tally);
     return append_end(sl, tally, sparse_append_locked(sl, src, first, count, tally));
@@ -2648,8 +2759,12 @@ int cds_sparse_library_append_host(cds_sparse_library *sl, int64_t count, const 
     if (count == 0) return CDS_OK;
     if (!rgb) return fail(CDS_ERR_INVALID_ARGUMENT, "rgb is NULL");
     std::lock_guard<std::mutex> lk(sl->mu);
-    if (sl->n_images + count > sl->cap_images) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (images)");
     CDS_HIP(hipSetDevice(sl->ctx->device));
+    if (sl->n_images + count > sl->cap_images && sl->growable) {
+        const int rcg = sparse_grow(sl, sl->n_images + count, 0);
+        if (rcg) return rcg;
+    }
+    if (sl->n_images + count > sl->cap_images) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (images)");
     const int64_t stage_n = 64;  // dense staging slots (132 MB at 1210 x 566)
     if (!sl->stage) {
         int rc = cds_library_create(sl->ctx, sl->W, sl->H, stage_n, &sl->stage);
@@ -2768,8 +2883,13 @@ int cds_sparse_library_import(cds_sparse_library *sl, int64_t count, const uint6
     if (!image_offsets || !cell_offsets || !records) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n_strips != sl->nstrips || strip_width != sl->strip_w) return fail(CDS_ERR_INVALID_ARGUMENT, "record layout (strips) differs from this library's");
     std::lock_guard<std::mutex> lk(sl->mu);
-    if (sl->n_images + count > sl->cap_images) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (images)");
     const uint64_t n_rec = image_offsets[count] - image_offsets[0];
+    if (sl->growable && (sl->n_images + count > sl->cap_images || sl->n_px + (int64_t)n_rec > sl->cap_px)) {
+        CDS_HIP(hipSetDevice(sl->ctx->device));
+        const int rcg = sparse_grow(sl, sl->n_images + count, sl->n_px + (int64_t)n_rec);
+        if (rcg) return rcg;
+    }
+    if (sl->n_images + count > sl->cap_images) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (images)");
     if (sl->n_px + (int64_t)n_rec > sl->cap_px) return fail(CDS_ERR_OUT_OF_MEMORY, "sparse library is full (records)");
     // consistency of the untrusted tables: monotone image offsets, every image's last cell offset == its record count
     const size_t cells = (size_t)sl->nstrips * (sl->H + 1);
@@ -2797,7 +2917,7 @@ int cds_sparse_library_import(cds_sparse_library *sl, int64_t count, const uint6
     if (n_rec) CDS_HIP(hipMemcpyAsync(sl->d_px + sl->n_px, records + image_offsets[0], (size_t)n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     {   // the records themselves, on the device (nothing is committed before they pass)
         unsigned long long *d_err = nullptr, err[2] = {0, 0};
-        CDS_HIP(hipMalloc(&d_err, sizeof err));
+        CDS_HIP(dev_malloc(&d_err, sizeof err));
         hipError_t e = hipMemsetAsync(d_err, 0, sizeof err, st);
         ValidateParams vp{sl->d_px, sl->d_img_off, sl->d_rowptr, sl->n_images, count, sl->W, sl->H, sl->nstrips, sl->strip_w, d_err};
         const int64_t n_cells = count * sl->nstrips * sl->H;
@@ -2840,9 +2960,9 @@ static int sparse_search_host(const cds_maskset *ms, const cds_sparse_library *s
     CDS_HIP(hipSetDevice(ms->ctx->device));
     const size_t n = (size_t)ms->n_masks * count;
     int32_t *d_scores = nullptr, *d_counts = nullptr;
-    CDS_HIP(hipMalloc(&d_scores, n * sizeof(int32_t)));
+    CDS_HIP(dev_malloc(&d_scores, n * sizeof(int32_t)));
     if (counts) {
-        hipError_t e = hipMalloc(&d_counts, n * CDS_N_TRANSFORMS * sizeof(int32_t));
+        hipError_t e = dev_malloc(&d_counts, n * CDS_N_TRANSFORMS * sizeof(int32_t));
         if (e != hipSuccess) {
             hipFree(d_scores);
             return hip_fail(e, "hipMalloc(counts)");
@@ -3063,45 +3183,71 @@ int cds_match_list_fetch_columns(const cds_match_list *ml, int64_t first, int64_
     if (ratio && (!query_sizes || n_masks <= 0)) return fail(CDS_ERR_INVALID_ARGUMENT, "ratio wanted without the query sizes");
     if (count == 0) return CDS_OK;
     CDS_HIP(hipSetDevice(ml->ctx->device));
-    // the rows come down in pieces of 4 M (48 MB) and are split into the columns by a few host threads while the next piece is copied
+    // the rows come down in pieces of 4 M (48 MB) and are split into the columns by a few host threads while the next piece is copied.
+    // No C++ exception may cross the C ABI (ctypes, JNI), and none may escape a std::thread (std::terminate): the buffers' bad_alloc is
+    // caught here, a refused thread (std::system_error under a container's thread limit) falls back to the calling thread, and the
+    // splitter is joined by a scope guard on every way out.
     const int64_t piece = (int64_t)4 << 20;
-    std::vector<cds_match> buf[2];
     std::atomic<int> bad{0};
-    auto split = [&](const cds_match *src, int64_t at, int64_t n) {
+    auto work = [&](const cds_match *src, int64_t at, int64_t n, int k, int nt) {
+        const int64_t a = n * k / nt, b = n * (k + 1) / nt;
+        for (int64_t i = a; i < b; i++) {
+            const cds_match r = src[i];
+            const int32_t sc = r.score & 0x7fffffff;
+            if (mask) mask[at + i] = r.mask + mask_offset;
+            if (target) target[at + i] = r.target;
+            if (score) score[at + i] = sc;
+            if (mirrored) mirrored[at + i] = (uint8_t)((uint32_t)r.score >> 31);
+            if (ratio) {
+                if (r.mask < 0 || r.mask >= n_masks) { bad.store(1); continue; }
+                ratio[at + i] = (float)((double)sc / std::max((double)query_sizes[r.mask], 1.0));
+            }
+        }
+    };
+    auto split = [&](const cds_match *src, int64_t at, int64_t n) noexcept {   // (nothing in here throws past its own catch)
         const unsigned hc = std::thread::hardware_concurrency();
         const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hc ? hc : 1u, 8u), n / 65536 + 1));
-        auto work = [&](int k) {
-            const int64_t a = n * k / nt, b = n * (k + 1) / nt;
-            for (int64_t i = a; i < b; i++) {
-                const cds_match r = src[i];
-                const int32_t sc = r.score & 0x7fffffff;
-                if (mask) mask[at + i] = r.mask + mask_offset;
-                if (target) target[at + i] = r.target;
-                if (score) score[at + i] = sc;
-                if (mirrored) mirrored[at + i] = (uint8_t)((uint32_t)r.score >> 31);
-                if (ratio) {
-                    if (r.mask < 0 || r.mask >= n_masks) { bad.store(1); continue; }
-                    ratio[at + i] = (float)((double)sc / std::max((double)query_sizes[r.mask], 1.0));
-                }
-            }
-        };
         std::vector<std::thread> pool;
-        for (int k = 1; k < nt; k++) pool.emplace_back(work, k);
-        work(0);
+        int started = 1;   // share 0 is the calling thread's
+        try {
+            pool.reserve((size_t)nt);
+            for (; started < nt; started++) pool.emplace_back(work, src, at, n, started, nt);
+        } catch (...) {   // no more threads (or no memory for the handle): the shares not handed out are done here
+        }
+        work(src, at, n, 0, nt);
+        for (int k = started; k < nt; k++) work(src, at, n, k, nt);
         for (auto &t : pool) t.join();
     };
-    std::thread splitter;
-    int which = 0;
-    hipError_t e = hipSuccess;
-    for (int64_t at = 0; at < count && e == hipSuccess; at += piece, which ^= 1) {
-        const int64_t n = std::min(piece, count - at);
-        buf[which].resize((size_t)n);
-        e = hipMemcpy(buf[which].data(), ml->d + first + at, (size_t)n * sizeof(cds_match), hipMemcpyDeviceToHost);
-        if (splitter.joinable()) splitter.join();   // (the other buffer is free again before the next copy goes into it)
-        if (e == hipSuccess) splitter = std::thread(split, buf[which].data(), at, n);
+    std::vector<cds_match> buf[2];   // (declared before the splitter: destroyed after it has been joined, on every way out)
+    struct Joiner {
+        std::thread t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } splitter;
+    try {
+        int which = 0;
+        hipError_t e = hipSuccess;
+        for (int64_t at = 0; at < count && e == hipSuccess; at += piece, which ^= 1) {
+            const int64_t n = std::min(piece, count - at);
+            buf[which].resize((size_t)n);
+            e = hipMemcpy(buf[which].data(), ml->d + first + at, (size_t)n * sizeof(cds_match), hipMemcpyDeviceToHost);
+            if (splitter.t.joinable()) splitter.t.join();   // (the other buffer is free again before the next copy goes into it)
+            if (e != hipSuccess) break;
+            const cds_match *src = buf[which].data();
+            try {
+                splitter.t = std::thread(split, src, at, n);
+            } catch (const std::system_error &) {
+                split(src, at, n);   // no thread to be had: split this piece before the next copy
+            }
+        }
+        if (splitter.t.joinable()) splitter.t.join();
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpy(match list)");
+    } catch (const std::bad_alloc &) {
+        if (splitter.t.joinable()) splitter.t.join();
+        return fail(CDS_ERR_OUT_OF_MEMORY, "out of host memory for the match list's staging buffers");
+    } catch (const std::exception &ex) {
+        if (splitter.t.joinable()) splitter.t.join();
+        return fail(CDS_ERR_HIP, std::string("cds_match_list_fetch_columns: ") + ex.what());
     }
-    if (splitter.joinable()) splitter.join();
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(match list)");
     if (bad.load()) return fail(CDS_ERR_INVALID_ARGUMENT, "the match list names a mask beyond n_masks: query_sizes of another mask set?");
     return CDS_OK;
 }
@@ -3156,9 +3302,9 @@ int cds_scores_topk(const cds_maskset *ms, const int32_t *d_scores, int64_t coun
             return cds::hip_fail(_e, #call); \
         }                                    \
     } while (0)
-    TK_HIP(hipMalloc(&d_q, (size_t)ms->n_masks * sizeof(int32_t)));
-    TK_HIP(hipMalloc(&d_t, n_out * sizeof(int32_t)));
-    TK_HIP(hipMalloc(&d_s, n_out * sizeof(int32_t)));
+    TK_HIP(dev_malloc(&d_q, (size_t)ms->n_masks * sizeof(int32_t)));
+    TK_HIP(dev_malloc(&d_t, n_out * sizeof(int32_t)));
+    TK_HIP(dev_malloc(&d_s, n_out * sizeof(int32_t)));
     TK_HIP(hipMemcpyAsync(d_q, ms->sizes.data(), (size_t)ms->n_masks * sizeof(int32_t), hipMemcpyHostToDevice, st));
     TopkParams p{};
     p.scores = d_scores; p.qsize = d_q; p.count = count; p.k = k; p.kp = 1;
@@ -3220,10 +3366,10 @@ int cds_search_sparse_topk(const cds_maskset *ms, const cds_sparse_library *sl, 
             return cds::hip_fail(_e, #call); \
         }                                    \
     } while (0)
-    TK_HIP(hipMalloc(&d_scores, (size_t)widest * count * sizeof(int32_t)));
-    TK_HIP(hipMalloc(&d_q, (size_t)ms->n_masks * sizeof(int32_t)));
-    TK_HIP(hipMalloc(&d_t, n_out * sizeof(int32_t)));
-    TK_HIP(hipMalloc(&d_s, n_out * sizeof(int32_t)));
+    TK_HIP(dev_malloc(&d_scores, (size_t)widest * count * sizeof(int32_t)));
+    TK_HIP(dev_malloc(&d_q, (size_t)ms->n_masks * sizeof(int32_t)));
+    TK_HIP(dev_malloc(&d_t, n_out * sizeof(int32_t)));
+    TK_HIP(dev_malloc(&d_s, n_out * sizeof(int32_t)));
     TK_HIP(hipMemcpyAsync(d_q, ms->sizes.data(), (size_t)ms->n_masks * sizeof(int32_t), hipMemcpyHostToDevice, st));
     int kp = 1;
     while (kp < k) kp <<= 1;

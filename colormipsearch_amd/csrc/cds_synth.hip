@@ -198,7 +198,7 @@ static int generate_impl(cds_library *lib, uint64_t seed, int64_t first_index, c
     }
     int64_t *d_idx = nullptr;
     if (indices) {
-        CDS_HIP(hipMalloc(&d_idx, (size_t)count * sizeof(int64_t)));
+        CDS_HIP(dev_malloc(&d_idx, (size_t)count * sizeof(int64_t)));
         const hipError_t e = hipMemcpy(d_idx, indices, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             hipFree(d_idx);

@@ -80,6 +80,13 @@ void cds_context_destroy(cds_context *ctx);
 int cds_context_set_stream(cds_context *ctx, void *hip_stream);
 int cds_context_reset_stream(cds_context *ctx);
 int cds_context_synchronize(cds_context *ctx);
+/* The idle blocks of the context's cache go back to the driver now (after the device has finished the work enqueued so far);
+ * *freed_bytes (may be NULL) = what was returned.  cds_context_set_cache_limit caps what the cache may keep idle (bytes; 0 = keep
+ * nothing: every release is a hipFree; default 6 GB, or CDS_CACHE_LIMIT_MB at context creation) and trims down to it.  Every device
+ * allocation of the library that meets hipErrorOutOfMemory drops the caches of that device's contexts and tries once more, so the
+ * retained memory is never the reason a library or mask set cannot be created. */
+int cds_context_trim(cds_context *ctx, uint64_t *freed_bytes);
+int cds_context_set_cache_limit(cds_context *ctx, uint64_t bytes);
 
 /* ---- target library (replaces the host-side MIP cache, tools cmd/CachedMIPsUtils.java:60-100) -- */
 /* Device bytes for `capacity` targets of W x H (padded row pitch, see DESIGN.md "data layout"). */
@@ -157,6 +164,15 @@ int cds_is_match(int32_t score, int32_t query_size, double pct_positive_pixels);
 int cds_sparse_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t capacity_images, int64_t capacity_pixels,
                               cds_sparse_library **out);
 void cds_sparse_library_destroy(cds_sparse_library *slib);
+/* A GROWABLE library enlarges its arrays (by half, or to what the append needs) when an append or import finds a capacity lacking --
+ * the reference's MIP cache sizes itself with use (tools cmd/CachedMIPsUtils.java:60-100), so a host that does not know its
+ * library's size creates a small one and lets it grow (a growth step copies what is held device to device: transiently twice the
+ * memory of the grown array).  cds_sparse_library_reserve grows to explicit capacities at once (never shrinks).  The derived 16-bit
+ * stage-1 stream follows while records + stream stay under CDS_SPARSE_STREAM16_MAX_FRACTION (default 0.6) of the device's memory
+ * and is dropped otherwise (searches then read the 4-byte records; results are the same). */
+int cds_sparse_library_set_growable(cds_sparse_library *slib, int32_t on);
+int cds_sparse_library_reserve(cds_sparse_library *slib, int64_t capacity_images, int64_t capacity_pixels);
+int cds_sparse_library_capacity(const cds_sparse_library *slib, int64_t *capacity_images, int64_t *capacity_pixels, int32_t *has_stream16);
 int cds_sparse_library_dims(const cds_sparse_library *slib, int32_t *W, int32_t *H);
 /* Append slots [first, first+count) of a resident dense library (device -> device); the images get the next
  * indices size() .. size()+count-1.  An append call is a transaction: when it fails -- CDS_ERR_OUT_OF_MEMORY (a capacity

@@ -61,6 +61,8 @@ public:
     cds_context *handle() const { return h_; }
     void setStream(void *hipStream) { check(cds_context_set_stream(h_, hipStream)); }
     void synchronize() { check(cds_context_synchronize(h_)); }
+    uint64_t trim() { uint64_t freed = 0; check(cds_context_trim(h_, &freed)); return freed; }
+    void setCacheLimit(uint64_t bytes) { check(cds_context_set_cache_limit(h_, bytes)); }
 private:
     cds_context *h_ = nullptr;
 };

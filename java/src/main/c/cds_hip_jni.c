@@ -83,6 +83,16 @@ JNIEXPORT void JNICALL CLS(contextSynchronize)(JNIEnv *env, jclass c, jlong ctx)
     int rc = cds_context_synchronize(P(cds_context, ctx));
     if (rc) throw_for(env, rc);
 }
+JNIEXPORT jlong JNICALL CLS(contextTrim)(JNIEnv *env, jclass c, jlong ctx) {
+    uint64_t freed = 0;
+    int rc = cds_context_trim(P(cds_context, ctx), &freed);
+    if (rc) { throw_for(env, rc); return 0; }
+    return (jlong)freed;
+}
+JNIEXPORT void JNICALL CLS(contextSetCacheLimit)(JNIEnv *env, jclass c, jlong ctx, jlong bytes) {
+    int rc = cds_context_set_cache_limit(P(cds_context, ctx), bytes < 0 ? 0 : (uint64_t)bytes);
+    if (rc) throw_for(env, rc);
+}
 
 /* ---- pixel-match mask sets ---- */
 JNIEXPORT jlong JNICALL CLS(masksetCreate)(JNIEnv *env, jclass c, jlong ctx, jint nMasks, jbyteArray masksRgb, jint w, jint h, jint maskThr,
@@ -177,6 +187,14 @@ JNIEXPORT jlong JNICALL CLS(sparseLibraryCreate)(JNIEnv *env, jclass c, jlong ct
     return (jlong)(intptr_t)sl;
 }
 JNIEXPORT void JNICALL CLS(sparseLibraryDestroy)(JNIEnv *env, jclass c, jlong sl) { cds_sparse_library_destroy(P(cds_sparse_library, sl)); }
+JNIEXPORT void JNICALL CLS(sparseLibrarySetGrowable)(JNIEnv *env, jclass c, jlong sl, jboolean on) {
+    int rc = cds_sparse_library_set_growable(P(cds_sparse_library, sl), on ? 1 : 0);
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT void JNICALL CLS(sparseLibraryReserve)(JNIEnv *env, jclass c, jlong sl, jlong capImages, jlong capPixels) {
+    int rc = cds_sparse_library_reserve(P(cds_sparse_library, sl), capImages, capPixels);
+    if (rc) throw_for(env, rc);
+}
 JNIEXPORT void JNICALL CLS(sparseLibrarySetDensityLimit)(JNIEnv *env, jclass c, jlong sl, jdouble limit) {
     int rc = cds_sparse_library_set_density_limit(P(cds_sparse_library, sl), limit);
     if (rc) throw_for(env, rc);

@@ -20,6 +20,9 @@ final class CdsHip {
     static native long contextCreate(int device);
     static native void contextDestroy(long ctx);
     static native void contextSynchronize(long ctx);
+    /** Idle device blocks of the cache of the context go back to the driver; returns the bytes freed. */
+    static native long contextTrim(long ctx);
+    static native void contextSetCacheLimit(long ctx, long bytes);
 
     // ---- pixel-match mask sets (n x PixelMatchColorDepthSearchAlgorithm) ----
     /** masksRgb: nMasks x 3*w*h bytes; rectsXYXY: x0,y0,x1,y1 per excluded rectangle (at most 8). */
@@ -43,6 +46,9 @@ final class CdsHip {
     // ---- sparse resident library (signal-pixel records: the pixel-match scan's layout) ----
     static native long sparseLibraryCreate(long ctx, int w, int h, long capacityImages, long capacityPixels);
     static native void sparseLibraryDestroy(long slib);
+    /** appends enlarge the library when a capacity is lacking (the reference's MIP cache sizes itself with use). */
+    static native void sparseLibrarySetGrowable(long slib, boolean on);
+    static native void sparseLibraryReserve(long slib, long capacityImages, long capacityPixels);
     static native void sparseLibrarySetDensityLimit(long slib, double maxSignalFraction);
     static native void sparseLibrarySetMinThreshold(long slib, int minDataThreshold);
     static native void sparseLibraryAppend(long slib, long count, ByteBuffer directRgb);

@@ -13,8 +13,10 @@ import org.janelia.colormipsearch.imageprocessing.ImageRegionDefinition;
  * on the device (cds_search_sparse_matches).  Parameters come from ColorMIPSearch.getCDSParameters() (cds/ColorMIPSearch.java:26-31:
  * mirrorMask, dataThreshold, pixColorFluctuation, xyShift, pctPositivePixels, defaultMaskThreshold).
  *
- * With several devices the library is cut into one shard per GPU (targets dealt round-robin; library index = the shard's offset +
- * the index inside the shard), the mask set is replicated, every GPU filters and compacts its own matches and the lists come back
+ * With several devices the library is cut into one shard per GPU -- shard r holds a contiguous range of library indices (library
+ * index = the shard's offset + the index inside the shard, DESIGN.md 7); when the number of targets is known (expectTargets) the
+ * arriving targets fill shard after shard in equal parts, otherwise they are dealt round-robin so that the shards stay balanced --,
+ * the mask set is replicated, every GPU filters and compacts its own matches and the lists come back
  * merged by mask and library index (cds_search_sparse_sharded_matches) -- the counterpart of the reference's partitions of targets
  * whose results are collect()-ed (cdsprocess/SparkColorMIPSearchProcessor.java:50-73).
  */
@@ -37,6 +39,8 @@ public final class GpuBatchSearch<K> implements AutoCloseable {
     private final List<GpuTargetLibrary<K>> shards = new ArrayList<>();
     private long[] offsets = new long[]{0};   // library index of every shard's first target (set by targetsComplete)
     private int dealt;
+    private long expectedTargets = -1;        // expectTargets(): the first guess of the library's size
+    private int width = -1, height = -1;      // setImageSize(): the masks' size, which every target must have
 
     public GpuBatchSearch(int device, Map<String, Object> cdsParameters, ImageRegionDefinition excludedRegions) {
         this(new int[]{device}, cdsParameters, excludedRegions);
@@ -73,17 +77,67 @@ public final class GpuBatchSearch<K> implements AutoCloseable {
         return v == null ? def : Double.parseDouble(v.toString());
     }
 
+    /** how many targets the caller is going to add: the library's first capacity (it grows when the guess was short). */
+    public synchronized void expectTargets(long n) {
+        expectedTargets = n;
+    }
+
+    /**
+     * The image size of the run -- the masks' (PixelMatchColorDepthSearchAlgorithm.java:171-175 compares every target with the
+     * query's size).  Without it the first target decides.
+     */
+    public synchronized void setImageSize(int width, int height) {
+        if (shards.isEmpty()) {
+            this.width = width;
+            this.height = height;
+        }
+    }
+
+    /**
+     * @throws IllegalArgumentException when the image's size is not the run's: the reference's per-pair
+     *         "Invalid image size" error -- the caller logs it and goes on with the next target
+     *         (cmd/cdsprocess/AbstractColorMIPSearchProcessor.java:80-83)
+     */
     public synchronized void addTarget(K key, ImageArray<?> image) {
-        if (shards.isEmpty()) {   // sized for a million 1210 x 566 MIPs of a few percent signal; -Dcds.gpu.library.* override
-            long images = Long.getLong("cds.gpu.library.images", 1L << 20) / ctxs.length + 1;
-            long records = Long.getLong("cds.gpu.library.records", 40_000L * images);
+        if (width < 0) {
+            width = image.getWidth();
+            height = image.getHeight();
+        }
+        if (image.getWidth() != width || image.getHeight() != height) {
+            throw new IllegalArgumentException(String.format(
+                    "Invalid image size - target's image size (%d, %d) must match query's image size: (%d, %d)",
+                    image.getWidth(), image.getHeight(), width, height));
+        }
+        if (shards.isEmpty()) {
+            // first capacities: the announced number of targets (else 4,096 per shard) at 20,000 records each -- real LM MIPs carry
+            // ~36,000, synthetic ones ~18,000 --; the library is growable, so a short guess costs a copy, not the run.
+            // -Dcds.gpu.library.images / .records override.  (Round 4 asked for 2^20 images x 40,000 records for ANY run: 168 GB.)
+            long perShard = expectedTargets > 0 ? (expectedTargets + ctxs.length - 1) / ctxs.length : 4096;
+            long images = Long.getLong("cds.gpu.library.images", perShard);
+            long records = Long.getLong("cds.gpu.library.records", (20_000L + 4L * height) * images);
             for (long ctx : ctxs) {
-                GpuTargetLibrary<K> shard = new GpuTargetLibrary<>(ctx, image.getWidth(), image.getHeight(), images, records, 64);
+                GpuTargetLibrary<K> shard = new GpuTargetLibrary<>(ctx, width, height, images, records, 64);
                 shard.setMinDataThreshold(dataThreshold);   // the library lives for this run's searches: pixels the scan never looks at stay out
                 shards.add(shard);
             }
         }
-        shards.get(dealt++ % shards.size()).add(key, image);
+        int r;
+        if (expectedTargets > 0) {   // contiguous ranges of the arrival order, equal parts (the last shard takes any surplus)
+            long per = (expectedTargets + shards.size() - 1) / shards.size();
+            r = (int) Math.min(shards.size() - 1, dealt / per);
+        } else {
+            r = dealt % shards.size();
+        }
+        dealt++;
+        shards.get(r).add(key, image);
+    }
+
+    public int getWidth() {
+        return width;
+    }
+
+    public int getHeight() {
+        return height;
     }
 
     public synchronized void targetsComplete() {

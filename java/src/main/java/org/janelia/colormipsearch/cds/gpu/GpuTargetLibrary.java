@@ -26,6 +26,8 @@ public final class GpuTargetLibrary<K> implements AutoCloseable {
         this.height = height;
         this.stagingImages = Math.max(1, stagingImages);
         this.handle = CdsHip.sparseLibraryCreate(ctx, width, height, capacityImages, capacityRecords);
+        CdsHip.sparseLibrarySetGrowable(handle, true);   // the capacities are a first guess: like the reference's MIP cache
+                                                         // (cmd/CachedMIPsUtils.java:60-100) the library sizes itself with use
         this.staging = ByteBuffer.allocateDirect(this.stagingImages * 3 * width * height);
     }
 
@@ -44,6 +46,14 @@ public final class GpuTargetLibrary<K> implements AutoCloseable {
 
     public int size() {
         return keys.size();
+    }
+
+    public int getWidth() {
+        return width;
+    }
+
+    public int getHeight() {
+        return height;
     }
 
     public K key(int index) {

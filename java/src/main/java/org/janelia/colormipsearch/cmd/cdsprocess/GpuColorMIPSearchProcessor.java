@@ -71,14 +71,36 @@ public class GpuColorMIPSearchProcessor<M extends AbstractNeuronEntity, T extend
         Map<String, Object> params = colorMIPSearch.getCDSParameters();
         List<CDMatchEntity<M, T>> results = new ArrayList<>();
         try (GpuBatchSearch<T> search = new GpuBatchSearch<>(devices, params, excludedRegions)) {
-            // 1. the targets, resident once for all masks; partitions bound the host memory held at a time
+            // 0. the run's image size is the masks' (the reference compares every target with the QUERY's size,
+            //    PixelMatchColorDepthSearchAlgorithm.java:171-175): the first mask that has an image decides
+            for (M queryMIP : queryMIPs) {
+                NeuronMIP<M> queryImage = NeuronMIPUtils.loadComputeFile(queryMIP, ComputeFileType.InputColorDepthImage);
+                if (queryImage != null && !queryImage.hasNoImageArray()) {
+                    search.setImageSize(queryImage.getImageArray().getWidth(), queryImage.getImageArray().getHeight());
+                    break;
+                }
+            }
+            search.expectTargets(targetMIPs.size());
+            // 1. the targets, resident once for all masks; partitions bound the host memory held at a time.  A target that cannot be
+            //    compared -- another image size, an unreadable file -- is the reference's per-pair error: logged, dropped, and the
+            //    run goes on (AbstractColorMIPSearchProcessor.java:68-83: catch Throwable, setErrors; LocalColorMIPSearchProcessor
+            //    .java:102-107: filter hasNoErrors)
+            int targetErrors = 0;
             for (int p0 = 0; p0 < targetMIPs.size(); p0 += localProcessingPartitionSize) {
                 for (T targetMIP : targetMIPs.subList(p0, Math.min(targetMIPs.size(), p0 + localProcessingPartitionSize))) {
-                    NeuronMIP<T> targetImage = CachedMIPsUtils.loadMIP(targetMIP, ComputeFileType.InputColorDepthImage);
-                    if (NeuronMIPUtils.hasImageArray(targetImage)) {
-                        search.addTarget(targetMIP, NeuronMIPUtils.getImageArray(targetImage));
+                    try {
+                        NeuronMIP<T> targetImage = CachedMIPsUtils.loadMIP(targetMIP, ComputeFileType.InputColorDepthImage);
+                        if (NeuronMIPUtils.hasImageArray(targetImage)) {
+                            search.addTarget(targetMIP, NeuronMIPUtils.getImageArray(targetImage));
+                        }
+                    } catch (Throwable e) {
+                        targetErrors++;
+                        LOG.warn("Error comparing the masks with {}", targetMIP, e);
                     }
                 }
+            }
+            if (targetErrors > 0) {
+                LOG.warn("{} of {} targets were dropped with errors", targetErrors, targetMIPs.size());
             }
             search.targetsComplete();
             LOG.info("{} of {} targets resident after {}s", search.targetCount(), targetMIPs.size(), (System.currentTimeMillis() - startTime) / 1000.);
@@ -93,8 +115,15 @@ public class GpuColorMIPSearchProcessor<M extends AbstractNeuronEntity, T extend
                         LOG.error("No input color depth image found for mask {}", queryMIP);
                         continue;
                     }
+                    ImageArray<?> qi_image = queryImage.getImageArray();
+                    if (search.targetCount() > 0 && (qi_image.getWidth() != search.getWidth() || qi_image.getHeight() != search.getHeight())) {
+                        // every pair of THIS mask is the reference's "Invalid image size" error; the other masks of the set are not touched
+                        LOG.warn("Error comparing mask {} with the resident targets: Invalid image size - target's image size ({}, {}) must match query's image size: ({}, {})",
+                                queryMIP, search.getWidth(), search.getHeight(), qi_image.getWidth(), qi_image.getHeight());
+                        continue;
+                    }
                     setMIPs.add(queryMIP);
-                    setImages.add(queryImage.getImageArray());
+                    setImages.add(qi_image);
                 }
                 if (setMIPs.size() == MASKS_PER_SET || (qi == queryMIPs.size() && !setMIPs.isEmpty())) {
                     collectMatches(search, setMIPs, setImages, results);
@@ -113,8 +142,17 @@ public class GpuColorMIPSearchProcessor<M extends AbstractNeuronEntity, T extend
         GpuBatchSearch.Matches found;
         try {
             found = search.findMatches(maskImages);     // masks whose query size is 0 yield nothing ("No computation created ... because it is empty")
-        } catch (IllegalArgumentException e) {            // e.g. a mask whose size differs from the library's: every pair of the set is in error
-            LOG.warn("Error comparing masks {} with the resident targets", maskMIPs, e);
+        } catch (RuntimeException e) {
+            // (sizes were checked mask by mask before the set was built: what arrives here is a failure of the set's search itself.
+            // One mask at a time then, so that a mask the library cannot prepare costs only its own pairs)
+            if (maskMIPs.size() == 1) {
+                LOG.warn("Error comparing mask {} with the resident targets", maskMIPs.get(0), e);
+                return;
+            }
+            LOG.warn("Error searching a set of {} masks; retrying them one by one", maskMIPs.size(), e);
+            for (int i = 0; i < maskMIPs.size(); i++) {
+                collectMatches(search, maskMIPs.subList(i, i + 1), maskImages.subList(i, i + 1), results);
+            }
             return;
         }
         for (int i = 0; i < found.count; i++) {

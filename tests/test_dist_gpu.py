@@ -112,6 +112,78 @@ def test_native_sharded_search_through_the_c_abi(oracle):
     assert want_s.max() > 0 and len(rows) > 0
 
 
+def _build_rccl_stub():
+    """tests/rccl_stub/rccl_stub.cpp -> librccl_stub.so (host code over the HIP runtime API; g++ is enough)."""
+    import shutil
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_stub")
+    src, out = os.path.join(here, "rccl_stub.cpp"), os.path.join(here, "librccl_stub.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        cxx = shutil.which("g++") or os.path.join(rocm, "bin", "amdclang++")
+        subprocess.check_call([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), src, "-o", out,
+                               "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath," + os.path.join(rocm, "lib")],
+                              stderr=subprocess.DEVNULL)
+    return out
+
+
+def test_the_rccl_branch_of_the_sharded_search_over_three_ranks_on_one_gpu(oracle, monkeypatch):
+    """the code that will run on 8 GPUs had never executed with more than one rank.  With CDS_RCCL_LIBRARY pointing at
+    the stand-in of tests/rccl_stub (ncclCommInitAll / GroupStart / Gather / GroupEnd / CommDestroy over hipMemcpyAsync on the callers'
+    streams; it accepts duplicate devices and REJECTS what a real gather would hang or fault on) and CDS_COMM_FORCE_RCCL=1,
+    cds_search_sparse_sharded takes its n > 1 RCCL branch over three contexts of the one GPU: communicator init over three ranks, one
+    grouped gather with NULL receive buffers on the non-roots, the root's read-back behind the root's stream, the peers' streams
+    synchronised afterwards, buffers reused by a second call and regrown by a larger one.  Scores equal the oracle's."""
+    import ctypes
+    from colormipsearch_amd import cds
+    stub = _build_rccl_stub()
+    monkeypatch.setenv("CDS_RCCL_LIBRARY", stub)
+    monkeypatch.setenv("CDS_COMM_FORCE_RCCL", "1")
+    probe = ctypes.CDLL(stub)
+    probe.rccl_stub_gathers.restype = probe.rccl_stub_inits.restype = ctypes.c_ulong
+    rects = cds.label_regions(W)
+    n = 37
+    masks = np.stack([oracle.synth_image(0xBADC0DE, i, 2) for i in range(2)])
+    targets = np.stack([oracle.synth_image(0xC0FFEE, 1200 + i, 0) for i in range(n - 2)] + [masks[0], np.fliplr(masks[1]).copy()])
+    want_s, want_m = [], []
+    for m in range(2):
+        ws, wm = oracle.PixelMatchQuery(masks[m], 20, 20, 0.01, 2, True, rects).scan(targets, n_threads=8)
+        want_s.append(ws), want_m.append(wm.astype(bool))
+    want_s, want_m = np.stack(want_s), np.stack(want_m)
+
+    def shard_of(ctx, imgs):
+        sl = cds.SparseLibrary(W, H, max(1, len(imgs)), int((imgs.max(axis=3) > 0).sum()) + 4 * H * len(imgs) + 64, context=ctx)
+        if len(imgs):
+            sl.append(imgs)
+        return sl
+
+    g0, i0 = probe.rccl_stub_gathers(), probe.rccl_stub_inits()
+    calls = 0
+    for bounds in ([0, 9, 20, n], [0, 30, 30, n], [0, 1, 2, n]):      # uneven shards; an empty one in the middle; the largest shard last
+        ctxs = [cds.Context(0) for _ in range(3)]
+        comm = cds.Comm(ctxs)
+        assert len(comm) == 3 and comm.uses_rccl
+        algs = [cds.PixelMatchColorDepthSearchAlgorithm(masks, 20, True, None, 0, False, 20, 0.01, 2, rects, context=c) for c in ctxs]
+        libs = [shard_of(ctxs[r], targets[bounds[r]:bounds[r + 1]]) for r in range(3)]
+        for _ in range(2):                                             # (the second call reuses the communicator's buffers)
+            s, mir, offs = comm.searchSparseLibrarySharded(algs, libs)
+            calls += 1
+            assert offs.tolist() == bounds
+            assert np.array_equal(s, want_s) and np.array_equal(mir, want_m), bounds
+        # a larger search through the same communicator: send / receive buffers grow
+        big = [shard_of(ctxs[r], np.concatenate([targets[bounds[r]:bounds[r + 1]]] * 2)) for r in range(3)]
+        s, mir, offs = comm.searchSparseLibrarySharded(algs, big)
+        calls += 1
+        for r in range(3):
+            a, b = bounds[r], bounds[r + 1]
+            lo = int(offs[r])
+            for rep in range(2):
+                assert np.array_equal(s[:, lo + rep * (b - a): lo + (rep + 1) * (b - a)], want_s[:, a:b]), (bounds, r, rep)
+        comm.close()
+    assert probe.rccl_stub_gathers() - g0 == calls and probe.rccl_stub_inits() - i0 == 3    # the stand-in really carried every gather
+    assert want_s.max() > 0
+
+
 def _variant_shard(cds, ctx, seed, first, count):
     lib = cds.Library(W, H, max(1, count), context=ctx)
     if count:

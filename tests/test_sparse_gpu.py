@@ -1022,6 +1022,63 @@ def test_stage1_stream_is_derived_from_the_records_and_optional(cds, oracle, mon
     assert np.array_equal(alg.searchSparseLibraryCounts(lib), alg.searchSparseLibraryCounts(without))
 
 
+def test_the_record_behind_an_odd_run_is_not_scanned(cds, oracle, scan_kernel):
+    """The geometry of round 4's one GPU-side abort (tree afdb1a9, case 13 of the seeded sweep: gpurun_out/r04e_tests.log).
+    The stream kernel reads two records per lane, so a run of odd length also reads the record BEHIND it -- the first record of the
+    next row, strip or image.  The first stream kernel let that record through as a pixel of row R + 4 (R = the slab's rows), counting on
+    an empty map cell row there; for R mod 4 != 0 that row shares its cells with the halo rows R + 1 .. R + 3, the record passed the band
+    map, and its evaluation read the plane's row R + 8, one past the plane (rows 0 .. R + 7): band-map bytes taken for a 16-bit interval
+    index, and -- with more than 2,048 interval records the table lives in global memory -- a load up to 1 MB past a < 100 KB
+    allocation: the fault.  Here: a mask of 22 rows (R mod 4 = 2) with > 2,048 interval records, xyShift 2; targets whose run over the
+    mask's row window is odd and whose next row starts, in the same cell, with the colour of the mask's last row; and a second mask whose
+    window ends with the image, so that the record behind the run is the next image's first one, or the sentinel behind the arena's last
+    record.  All 18 counts against the oracle."""
+    w, h = 200, 64
+    rng = np.random.default_rng(5)
+
+    def colours(n):   # distinct hue ratios by the thousand: maximum 200..255 in a random channel, the other two below it
+        c = np.zeros((n, 3), dtype=np.uint8)
+        mx = rng.integers(200, 256, n)
+        ch = rng.integers(0, 3, n)
+        for k in range(3):
+            c[:, k] = np.where(ch == k, mx, rng.integers(1, 200, n))
+        return c
+
+    def mask_at(y0):
+        m = np.zeros((h, w, 3), dtype=np.uint8)
+        m[y0:y0 + 22, 20:160] = colours(22 * 140).reshape(22, 140, 3)
+        return m
+
+    top, bottom = mask_at(10), mask_at(40)       # bottom: rows 40 .. 61, its window [38, 64) ends with the image
+    targets = []
+    for extra in (0, 1, 2):                       # 0 / 1 / 2 more records in the window: the run's length is odd for one parity at least
+        t = top.copy()
+        t[34, 20:160] = top[31, 20:160]           # the row behind the window [8, 34) starts where -- and as -- the mask's last row does
+        if extra >= 1:
+            t[9, 50] = top[12, 50]
+        if extra >= 2:
+            t[9, 90] = top[12, 90]
+        t[40:62, 20:160] = bottom[40:62, 20:160]  # (and the second mask's pixels: its run ends with the image's last record)
+        if extra >= 1:
+            t[39, 60] = bottom[41, 60]
+        if extra >= 2:
+            t[39, 61] = bottom[41, 61]
+        targets.append(t)
+    targets = np.stack(targets)
+    sl = sparse_of(cds, targets)
+    for name, mask in (("top", top), ("bottom", bottom)):
+        for mirror in (False, True):
+            alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, mirror, None, 0, False, 20, 0.01, 2, [])
+            assert alg.sparseLayout(0)["interval_records"] > 2048, "the case needs the interval table in global memory"
+            counts = alg.searchSparseLibraryCounts(sl)
+            if scan_kernel == "stream16":
+                assert alg.lastScanKernel()[0] == 1
+            q = oracle.PixelMatchQuery(mask, 20, 20, 0.01, 2, mirror, [])
+            for t in range(len(targets)):
+                assert np.array_equal(counts[0, t], q.score(targets[t])[2]), (name, mirror, t)
+            assert counts[0, :, 4].min() >= 22 * 140 * 0.9, name      # (the unshifted transform finds the mask in every target)
+
+
 def test_the_pilot_picks_the_scan_kernel_per_mask_and_library(cds, oracle, fixtures, monkeypatch, scan_kernel):
     """Without a forced kernel the first search of >= 16,384 targets measures, on its first 4,096 targets, the share of visited records
     that reach an evaluation round, and scans the rest (and every later search of that library) through the 16-bit stream when the
