@@ -16,7 +16,8 @@ dense slots), the (host) top-N selection over the few survivors, one `cds_gradsc
 records here; `colormipsearch_amd/results.py` turns them into the reference's JSON result files (Mongo stays out of scope).
 """
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence
+import threading
+from typing import List, Optional, Sequence, Tuple
 
 import time
 
@@ -333,6 +334,58 @@ class GpuColorMIPSearchProcessor:
         self.dense_slots = None if dense_slots is None else np.asarray(dense_slots, dtype=np.int64)
         self._targets = targets            # (default metadata -- one line and one sample per target -- is made on first use:
         assert targets is None or len(targets) == self.count   # a million-target library does not need a million records to be scanned)
+        # The reference catches Throwable per (mask, target) pair, keeps the message in CDMatchEntity.errors and drops that pair only
+        # (AbstractColorMIPSearchProcessor.java:68-83, LocalColorMIPSearchProcessor.java:102-107).  Here an image of the wrong size
+        # spoils all pairs of its mask / its target and nothing else: one entry ("mask" | "target", index in the caller's list, message).
+        self.errors: List[Tuple[str, int, str]] = []
+        self._pools = None
+        self._timing_lock = threading.Lock()
+
+    # ---- lifecycle: the pipeline's worker threads live as long as the processor ------------------------
+    def close(self):
+        """Shut the pipeline's worker pools down (waits for running tasks).  The processor is a context manager."""
+        pools, self._pools = self._pools, None
+        if pools:
+            for p in pools:
+                p.shutdown(wait=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _library_size(self):
+        lib = self.sparse_library if self.sparse_library is not None else self.library
+        return int(lib.height), int(lib.width)
+
+    def _usable_masks(self, masks):
+        """(uint8[k,H,W,3] of the masks that have the library's image size, their indices in the caller's list).  A mask of another
+        size is the reference's 'Invalid image size' error for every one of its pairs (PixelMatchColorDepthSearchAlgorithm.java:171-175):
+        recorded in `errors`, dropped, and the other masks are searched."""
+        if isinstance(masks, np.ndarray) and masks.ndim in (3, 4):
+            m = cds.capi.rgb_images(masks)
+            if tuple(m.shape[1:3]) == self._library_size():
+                return m, np.arange(m.shape[0], dtype=np.int32)
+            masks = list(m)
+        H, W = self._library_size()
+        keep, idx = [], []
+        for i, m in enumerate(masks):
+            a = np.asarray(m)
+            if a.ndim == 3 and a.shape == (H, W, 3):
+                keep.append(np.ascontiguousarray(a, dtype=np.uint8)), idx.append(i)
+            else:
+                shape = tuple(a.shape[:2][::-1]) if a.ndim >= 2 else tuple(a.shape)
+                self.errors.append(("mask", i, f"Invalid image size - target's image size ({W}, {H}) must match query's image size: {shape}"))
+        stacked = np.stack(keep) if keep else np.zeros((0, H, W, 3), dtype=np.uint8)
+        return stacked, np.asarray(idx, dtype=np.int32)
 
     @property
     def targets(self):
@@ -368,8 +421,7 @@ class GpuColorMIPSearchProcessor:
         long as its scan) on one thread, and two search workers taking the prepared sets in turn, so that the list download and the
         host-side columns of set i are made while set i + 1 is scanned (ctypes releases the GIL; the mask sets are independent
         objects and the context's stream orders their launches).  At most three prepared sets exist at a time."""
-        import threading
-        from concurrent.futures import ThreadPoolExecutor
+        from concurrent.futures import ThreadPoolExecutor, wait
         masks = cds.capi.rgb_images(masks)
         n = masks.shape[0]
         make = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold
@@ -387,7 +439,8 @@ class GpuColorMIPSearchProcessor:
                 ahead.release()
                 raise
             finally:
-                self.last_pipeline["prepare_s"] += time.perf_counter() - t0
+                with self._timing_lock:
+                    self.last_pipeline["prepare_s"] += time.perf_counter() - t0
 
         def search(m0, prepared):
             alg = prepared.result()
@@ -397,7 +450,8 @@ class GpuColorMIPSearchProcessor:
             finally:
                 alg.close()
                 ahead.release()
-            self.last_pipeline["search_s"] += time.perf_counter() - t0
+            with self._timing_lock:     # (two search workers)
+                self.last_pipeline["search_s"] += time.perf_counter() - t0
             return t
 
         # (the device idles while the FIRST set is prepared: that one is a quarter of the size -- a multiple of the kernel's group of 8; a
@@ -416,11 +470,30 @@ class GpuColorMIPSearchProcessor:
         ends = starts[1:] + [n]
         # (the pools live as long as the processor: a host thread that has used the GPU runtime is slow to exit -- ~100 ms for the three
         # of them after every call, measured --, and a processor runs many searches)
-        if getattr(self, "_pools", None) is None:
+        if self._pools is None:
             self._pools = (ThreadPoolExecutor(max_workers=1, thread_name_prefix="cds-prepare"), ThreadPoolExecutor(max_workers=2, thread_name_prefix="cds-search"))
         prep_pool, search_pool = self._pools
         prepared = [prep_pool.submit(prepare, m0, m1) for m0, m1 in zip(starts, ends)]
-        parts = [f.result() for f in [search_pool.submit(search, m0, pf) for m0, pf in zip(starts, prepared)]]
+        searches = [search_pool.submit(search, m0, pf) for m0, pf in zip(starts, prepared)]
+        try:
+            parts = [f.result() for f in searches]
+        except BaseException:
+            # nothing of this call may still touch the library once the error is handed to the caller (who may close it next):
+            # what has not started is cancelled, what runs is waited for, prepared sets nobody will search are closed
+            for f in searches + prepared:
+                f.cancel()
+            closed = set()
+            while True:
+                for i, (sf, pf) in enumerate(zip(searches, prepared)):   # (their permits let a preparation that is already running finish)
+                    if i not in closed and sf.cancelled() and pf.done() and not pf.cancelled() and pf.exception() is None:
+                        closed.add(i)
+                        pf.result().close()
+                        ahead.release()
+                running = [f for f in searches + prepared if not f.done()]
+                if not running:
+                    break
+                wait(running, timeout=0.05)
+            raise
         t0 = time.perf_counter()
         rows = sum(len(t) for t in parts)
         out = MatchTable(np.empty(rows, np.int32), np.empty(rows, np.int64), np.empty(rows, np.int32), np.empty(rows, np.float32), np.empty(rows, bool))
@@ -435,9 +508,15 @@ class GpuColorMIPSearchProcessor:
         return out
 
     def findAllColorDepthMatches(self, masks) -> List[CDMatch]:
+        masks, orig = self._usable_masks(masks)
+        if masks.shape[0] == 0:
+            return []
         alg = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold(masks)
         if self.sparse_library is not None:
-            return self._device_match_table(alg).to_matches()
+            out = self._device_match_table(alg).to_matches()
+            for r in out:
+                r.maskIndex = int(orig[r.maskIndex])
+            return out
         scores, mirrored = self._scan(alg)
         sizes = alg.getQuerySizes()
         out = []
@@ -447,15 +526,22 @@ class GpuColorMIPSearchProcessor:
             keep = self.colorMIPSearch.isMatchArray(scores[m], int(sizes[m]))
             ratio = (scores[m].astype(np.float64) / float(sizes[m])).astype(np.float32)
             for t in np.flatnonzero(keep):
-                out.append(CDMatch(m, int(t), int(scores[m, t]), float(ratio[t]), bool(mirrored[m, t])))
+                out.append(CDMatch(int(orig[m]), int(t), int(scores[m, t]), float(ratio[t]), bool(mirrored[m, t])))
         return out
 
     def findAllColorDepthMatchesTable(self, masks, mask_set_size=128, first_set_size=None) -> MatchTable:
         """findAllColorDepthMatches in columnar form (same rows, same order).  Over a sparse library the masks go in sets of
         `mask_set_size` whose preparation overlaps the previous set's scan; the first set is smaller (`first_set_size`, default a
         quarter of a set when there are at least three sets) so that the device starts early."""
+        masks, orig = self._usable_masks(masks)
+        if masks.shape[0] == 0:
+            return MatchTable(np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32), np.zeros(0, bool))
+        renumber = not np.array_equal(orig, np.arange(len(orig)))
         if self.sparse_library is not None:
-            return self._pipelined_match_table(masks, max(8, int(mask_set_size) // 8 * 8), first_set_size)
+            t = self._pipelined_match_table(masks, max(8, int(mask_set_size) // 8 * 8), first_set_size)
+            if renumber:
+                t.maskIndex = orig[t.maskIndex]
+            return t
         alg = self.colorMIPSearch.createQueryColorDepthSearchWithDefaultThreshold(masks)
         scores, mirrored = self._scan(alg)
         sizes = np.asarray(alg.getQuerySizes())
@@ -464,10 +550,69 @@ class GpuColorMIPSearchProcessor:
             if sizes[m] == 0:
                 continue
             t = np.flatnonzero(self.colorMIPSearch.isMatchArray(scores[m], int(sizes[m])))
-            mi.append(np.full(len(t), m, dtype=np.int32)); ti.append(t.astype(np.int64)); sc.append(scores[m, t].astype(np.int32))
+            mi.append(np.full(len(t), orig[m], dtype=np.int32)); ti.append(t.astype(np.int64)); sc.append(scores[m, t].astype(np.int32))
             ra.append((scores[m, t].astype(np.float64) / float(sizes[m])).astype(np.float32)); mr.append(mirrored[m, t].astype(bool))
         cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dtype=dt)
         return MatchTable(cat(mi, np.int32), cat(ti, np.int64), cat(sc, np.int32), cat(ra, np.float32), cat(mr, bool))
+
+    # ---- a library larger than the resident capacity: pass after pass over resident chunks ---------------
+    def _append_usable_targets(self, images, first_index):
+        """Append the images of a chunk that have the library's size to the sparse library; the others (another size, None: a file that
+        could not be read) are their targets' errors -- the reference's per-pair catch (AbstractColorMIPSearchProcessor.java:68-83) --
+        and are left out.  Returns the caller-side index of every appended image."""
+        H, W = self._library_size()
+        if isinstance(images, np.ndarray) and images.ndim == 4 and tuple(images.shape[1:]) == (H, W, 3):
+            self.sparse_library.append(images)
+            return first_index + np.arange(images.shape[0], dtype=np.int64)
+        keep, idx = [], []
+        for i, img in enumerate(images):
+            a = None if img is None else np.asarray(img)
+            if a is not None and a.shape == (H, W, 3):
+                keep.append(np.ascontiguousarray(a, dtype=np.uint8)), idx.append(first_index + i)
+            elif a is None:
+                self.errors.append(("target", first_index + i, "no image"))
+            else:
+                shape = tuple(a.shape[:2][::-1]) if a.ndim >= 2 else tuple(a.shape)
+                self.errors.append(("target", first_index + i, f"Invalid image size - target's image size {shape} must match query's image size: ({W}, {H})"))
+        if keep:
+            self.sparse_library.append(np.stack(keep))
+        return np.asarray(idx, dtype=np.int64)
+
+    def findAllColorDepthMatchesOverChunksTable(self, masks, n_targets, load_chunk, chunk_targets, mask_set_size=128) -> MatchTable:
+        """colorDepthSearch over a library that does not fit the resident capacity.  The reference walks a library of any size in
+        partitions through its MIP cache (LocalColorMIPSearchProcessor.java:93-97, CachedMIPsUtils.java:60-100); here the sparse
+        library is the resident window: chunk k = targets [k * chunk_targets, ...) is made resident (`load_chunk(first, count)` ->
+        uint8[count,H,W,3], or a list of `count` images in which an entry of another size / None is that target's error), ALL mask
+        sets scan it (the pipelined search above), the next chunk replaces it, and the match lists are merged into the order one
+        resident library would give: by mask, then target index.  A real LM MIP costs ~150 KB as records (~220 KB with the 16-bit
+        stream), so one MI355X holds about 1.2-1.8 M of them; beyond that, or for a deliberately small window, this is the loop."""
+        if self.sparse_library is None:
+            raise ValueError("the chunked search keeps its resident window in a sparse library")
+        n_targets, chunk_targets = int(n_targets), max(1, int(chunk_targets))
+        masks, orig = self._usable_masks(masks)      # (once: a mask of another size is one error, not one per chunk)
+        parts, first0, count0 = [], self.first, self.count
+        self.last_chunks = []
+        try:
+            for c0 in range(0, n_targets, chunk_targets):
+                cn = min(chunk_targets, n_targets - c0)
+                t0 = time.perf_counter()
+                self.sparse_library.clear()
+                ids = self._append_usable_targets(load_chunk(c0, cn), c0)
+                t1 = time.perf_counter()
+                self.first, self.count = 0, len(ids)
+                if len(ids) and masks.shape[0]:
+                    t = self.findAllColorDepthMatchesTable(masks, mask_set_size=mask_set_size)
+                    t.targetIndex = ids[t.targetIndex]
+                    t.maskIndex = orig[t.maskIndex]
+                    parts.append(t)
+                self.last_chunks.append({"first": c0, "targets": cn, "resident": int(len(ids)), "load_s": t1 - t0, "search_s": time.perf_counter() - t1})
+        finally:
+            self.first, self.count = first0, count0
+        cat = lambda f, dt: np.concatenate([getattr(p, f) for p in parts]) if parts else np.zeros(0, dtype=dt)
+        out = MatchTable(cat("maskIndex", np.int32), cat("targetIndex", np.int64), cat("matchingPixels", np.int32),
+                         cat("matchingPixelsRatio", np.float32), cat("mirrored", bool))
+        # every chunk's rows are ordered by mask, then target, and the chunks ascend: a STABLE sort by mask gives (mask, target)
+        return out.take(np.argsort(out.maskIndex, kind="stable"))
 
     def selectBestMatchesTable(self, table: MatchTable, topLineMatches, topSamplesPerLine, topMatchesPerSample) -> MatchTable:
         """selectBestMatches in columnar form, all masks at once: per mask top lines -> top samples per line -> top matches per

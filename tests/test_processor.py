@@ -222,6 +222,95 @@ def test_mask_sets_prepared_while_the_previous_one_is_scanned(oracle):
 
 
 @pytest.mark.gpu
+def test_a_wrong_size_mask_or_target_costs_only_its_own_pairs(oracle):
+    """The reference catches Throwable per (mask, target) pair, keeps the message and drops that pair
+    (AbstractColorMIPSearchProcessor.java:68-83, LocalColorMIPSearchProcessor.java:102-107): a target or a mask of another image size
+    ('Invalid image size', PixelMatchColorDepthSearchAlgorithm.java:171-175) loses its own pairs and nothing else.  One wrong-size
+    mask among 11 and one wrong-size target (and one unreadable one) among 90, over a growable window of 32 resident targets: the rows
+    equal those of the search without the bad images, with the caller's indices, and `errors` names the three."""
+    from colormipsearch_amd import cds
+    n_masks, n_t = 10, 88
+    mlib = cds.Library(W, H, n_masks)
+    mlib.generate_synthetic(0xBADC0DE, 0, 0, n_masks, kind=2)
+    good_masks = mlib.download(0, n_masks)
+    lib = cds.Library(W, H, n_t)
+    lib.generate_synthetic(0xC0FFEE, 7000, 0, n_t, kind=0)
+    lib.upload(3, good_masks[[1, 8]])
+    good_targets = lib.download(0, n_t)
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(True, 20, 1, 2, cds.label_regions)
+    search = cds.ColorMIPSearch(0.01, 20, provider)
+    whole = cds.SparseLibrary(W, H, n_t, 40000 * n_t)
+    whole.append(good_targets)
+    with P.GpuColorMIPSearchProcessor(search, None, None, sparse_library=whole) as ref:
+        want = ref.findAllColorDepthMatchesTable(good_masks, mask_set_size=8)
+        assert ref.errors == []
+    # the caller's lists: mask 4 and targets 20 and 61 are bad
+    masks = list(good_masks[:4]) + [np.zeros((H // 2, W, 3), np.uint8)] + list(good_masks[4:])
+    targets = list(good_targets[:20]) + [np.zeros((H, W - 10, 3), np.uint8)] + list(good_targets[20:60]) + [None] + list(good_targets[60:])
+    mask_of = np.array([0, 1, 2, 3, 5, 6, 7, 8, 9, 10])
+    target_of = np.array([i for i in range(len(targets)) if i not in (20, 61)])
+    window = cds.SparseLibrary(W, H)                                    # growable, starts small
+    assert window.capacity_images == 1024
+    with P.GpuColorMIPSearchProcessor(search, None, None, sparse_library=window) as proc:
+        got = proc.findAllColorDepthMatchesOverChunksTable(masks, len(targets), lambda a, n: targets[a:a + n], 32, mask_set_size=8)
+        assert [c["resident"] for c in proc.last_chunks] == [31, 31, 26]
+        kinds = sorted((k, i) for k, i, _ in proc.errors)
+        assert kinds == [("mask", 4), ("target", 20), ("target", 61)], proc.errors
+        assert all("Invalid image size" in m or m == "no image" for _, _, m in proc.errors)
+    assert np.array_equal(got.maskIndex, mask_of[want.maskIndex]) and np.array_equal(got.targetIndex, target_of[want.targetIndex])
+    for f in ("matchingPixels", "matchingPixelsRatio", "mirrored"):
+        assert np.array_equal(getattr(got, f), getattr(want, f)), f
+    assert len(want) > 10 and {1, 8} <= set(want.maskIndex.tolist())
+    # the list form reports the caller's mask indices too
+    with P.GpuColorMIPSearchProcessor(search, None, None, sparse_library=whole) as proc:
+        rows = proc.findAllColorDepthMatches(masks)
+        assert [(r.maskIndex, r.targetIndex, r.matchingPixels) for r in rows] == list(zip(mask_of[want.maskIndex].tolist(), want.targetIndex.tolist(), want.matchingPixels.tolist()))
+        assert [e[:2] for e in proc.errors] == [("mask", 4)]
+
+
+@pytest.mark.gpu
+def test_a_failing_mask_set_leaves_no_worker_behind(oracle):
+    """when one task of the pipelined search raises, the call must not return while other tasks still scan the library
+    (the caller may close it next).  A mask set whose preparation fails -- xyShift 4, which the library refuses as the reference's
+    table overrun -- in the middle of four sets: the error arrives, no task of the call is still running, the pools still work."""
+    from colormipsearch_amd import cds
+    n_masks, n_t = 32, 64
+    mlib = cds.Library(W, H, n_masks)
+    mlib.generate_synthetic(0xBADC0DE, 0, 0, n_masks, kind=2)
+    masks = mlib.download(0, n_masks)
+    slib = cds.SparseLibrary(W, H)
+    lib = cds.Library(W, H, n_t)
+    lib.generate_synthetic(0xC0FFEE, 100, 0, n_t, kind=0)
+    slib.append_from(lib)
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(True, 20, 1, 2, cds.label_regions)
+    search = cds.ColorMIPSearch(0.01, 20, provider)
+    with P.GpuColorMIPSearchProcessor(search, None, None, sparse_library=slib) as proc:
+        good = proc.findAllColorDepthMatchesTable(masks, mask_set_size=8)
+        make, calls = search.createQueryColorDepthSearchWithDefaultThreshold, []
+
+        def failing(m):
+            calls.append(len(m))
+            if len(calls) == 3:
+                raise cds.CdsError(cds.capi.CDS_ERR_UNSUPPORTED, "injected failure of the third set")
+            return make(m)
+
+        search.createQueryColorDepthSearchWithDefaultThreshold = failing
+        try:
+            with pytest.raises(cds.CdsError, match="injected"):
+                proc.findAllColorDepthMatchesTable(masks, mask_set_size=8)
+        finally:
+            search.createQueryColorDepthSearchWithDefaultThreshold = make
+        import threading
+        busy = [t.name for t in threading.enumerate() if t.name.startswith("cds-")]
+        # (the pool threads exist, idle: a second search through the same pools gives the same rows)
+        again = proc.findAllColorDepthMatchesTable(masks, mask_set_size=8)
+        for f in ("maskIndex", "targetIndex", "matchingPixels", "mirrored"):
+            assert np.array_equal(getattr(again, f), getattr(good, f)), f
+        assert busy
+    assert not [t.name for t in threading.enumerate() if t.name.startswith("cds-")]          # close() joined them
+
+
+@pytest.mark.gpu
 def test_sharded_processor_equals_single_library(oracle):
     """ShardedGpuColorMIPSearchProcessor (one process, cds.Comm over three contexts of the one GPU: uneven shards) == the processor
     over one sparse library holding all targets: same match rows, same order."""

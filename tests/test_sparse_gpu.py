@@ -1022,6 +1022,58 @@ def test_stage1_stream_is_derived_from_the_records_and_optional(cds, oracle, mon
     assert np.array_equal(alg.searchSparseLibraryCounts(lib), alg.searchSparseLibraryCounts(without))
 
 
+def test_a_growable_library_sizes_itself_and_the_cache_can_be_trimmed(cds, oracle, monkeypatch, scan_kernel):
+    """cds_sparse_library_set_growable / _reserve / _capacity (the reference's MIP cache sizes itself with use, CachedMIPsUtils.java:60-100):
+    a library created for 2 images and 1,000 records takes 23 images in four appends -- arrays regrown, records, row pointers and the
+    16-bit stream copied -- and scans like one created at full size; a non-growable one still refuses; the stream is left out by
+    policy when records + stream would exceed the configured share of the device's memory; cds_context_trim hands the context's
+    idle blocks back."""
+    rects = cds.label_regions(W)
+    imgs = np.stack([oracle.synth_image(0xC0FFEE, 1500 + i, 0) for i in range(23)])
+    mask = oracle.synth_image(0xBADC0DE, 5, 2)
+    imgs[7] = mask
+    full = sparse_of(cds, imgs)
+    small = cds.SparseLibrary(W, H, 2, 1000)
+    with pytest.raises(cds.CdsError, match="full"):
+        small.append(imgs[:3])
+    assert len(small) == 0
+    small.set_growable(True)
+    for a, b in ((0, 3), (3, 4), (4, 15), (15, 23)):
+        small.append(imgs[a:b])
+    assert len(small) == 23 and small.pixels == full.pixels
+    assert small.capacity_images >= 23 and small.capacity_pixels >= small.pixels and small.has_stream16 == full.has_stream16
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, 20, True, None, 0, False, 20, 0.01, 2, rects)
+    want = alg.searchSparseLibraryCounts(full)
+    assert np.array_equal(alg.searchSparseLibraryCounts(small), want) and want[0, 7].max() > 5000
+    small.reserve(100, 10_000_000)                       # explicit growth keeps the contents
+    assert small.capacity_images >= 100 and small.capacity_pixels >= 10_000_000
+    assert np.array_equal(alg.searchSparseLibraryCounts(small), want)
+    # default construction: growable from 1,024 images
+    auto = cds.SparseLibrary(W, H)
+    auto.append(imgs)
+    assert np.array_equal(alg.searchSparseLibraryCounts(auto), want)
+    # policy: no stream when records + stream would take more than the allowed share of the device
+    monkeypatch.setenv("CDS_SPARSE_STREAM16_MAX_FRACTION", "1e-9")
+    lean = sparse_of(cds, imgs)
+    monkeypatch.delenv("CDS_SPARSE_STREAM16_MAX_FRACTION")
+    assert not lean.has_stream16
+    if scan_kernel == "stream16":
+        monkeypatch.delenv("CDS_SPARSE_SCAN16")            # (nothing to force: the library has no stream)
+    assert np.array_equal(alg.searchSparseLibraryCounts(lean), want)
+    # the context's block cache: released mask-set blocks sit idle until trimmed
+    ctx = cds.default_context()
+    alg2 = cds.PixelMatchColorDepthSearchAlgorithm(np.stack([mask, imgs[3]]), 20, True, None, 0, False, 20, 0.01, 2, rects)
+    alg2.searchSparseLibrary(full)
+    alg2.close()
+    assert ctx.trim() > 0 and ctx.trim() == 0
+    ctx.set_cache_limit(0)                                 # keep nothing
+    alg3 = cds.PixelMatchColorDepthSearchAlgorithm(np.stack([mask, imgs[3]]), 20, True, None, 0, False, 20, 0.01, 2, rects)
+    alg3.searchSparseLibrary(full)
+    alg3.close()
+    assert ctx.trim() == 0
+    ctx.set_cache_limit(6 << 30)
+
+
 def test_the_record_behind_an_odd_run_is_not_scanned(cds, oracle, scan_kernel):
     """The geometry of round 4's one GPU-side abort (tree afdb1a9, case 13 of the seeded sweep: gpurun_out/r04e_tests.log).
     The stream kernel reads two records per lane, so a run of odd length also reads the record BEHIND it -- the first record of the
