@@ -44,7 +44,6 @@
 
 namespace cds {
 
-constexpr int SP16_MAXG = 8;                         // targets per grab of the stream kernel (their 18 counters each live in the wave's LDS block)
 constexpr int SP_QCAP = 128;                          // queue entries per wave and orientation (appends <= 64, drained at >= 64)
 constexpr int SP_QBYTES = 2 * SP_QCAP * 8;            // two queues of (u32 record, u32 plane offset): one 8-byte LDS access per entry
 constexpr int SP_MAX_IV_LDS = 2048;                   // interval records kept in LDS (32 KB); larger tables are read from L2
@@ -702,7 +701,7 @@ __device__ __forceinline__ uint32_t pk_shr2_mad_u16(uint32_t a, uint32_t b, uint
 template <bool XY2, bool MIRROR, bool IVLDS, bool P8, int WPE, bool LO = false, bool PG = false>
 __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanParams p) {
     extern __shared__ uint4 lds4[];
-    constexpr int NS = XY2 ? 9 : 1, NSX = XY2 ? 3 : 1;
+    constexpr int NS = XY2 ? 9 : 1, NSX = XY2 ? 3 : 1, NO = MIRROR ? 2 : 1, NC = NS * NO;
     constexpr int HALO = XY2 ? 2 : 0;
 #ifndef SP16_NB
 #define SP16_NB 4
@@ -718,13 +717,10 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
     uint4 *ivt = reinterpret_cast<uint4 *>(lds + p.map64_bytes);
     uint8_t *slab = lds + p.map64_bytes + (IVLDS ? (size_t)p.n_iv * 16 : 0);
     const plane_t *plane = reinterpret_cast<const plane_t *>(slab);   // (PG: set per slab, below)
-    // per wave: ONE queue for both orientations and all targets of a grab (round 5), and the grab's match counters
     uint8_t *qb = slab + (PG ? 0 : p.near_off) + (size_t)wave * SP_QBYTES;
-    uint2 *q = reinterpret_cast<uint2 *>(qb);
-    int *cnt = reinterpret_cast<int *>(qb + SP_QCAP * 8);   // [target of the grab][18 transforms]
+    uint2 *q0 = reinterpret_cast<uint2 *>(qb), *q1 = q0 + SP_QCAP;
     if (IVLDS)
         for (int i = threadIdx.x; i < p.n_iv; i += blockDim.x) ivt[i] = p.iv[i];
-    for (int i = lane; i < SP16_MAXG * CDS_N_TRANSFORMS; i += 64) cnt[i] = 0;
     const int safe_off = SP_PAD * p.pitch + SP_PAD;  // an in-range plane offset for idle lanes
 
     for (int si = 0; si < p.n_slabs; si++) {
@@ -812,39 +808,52 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                 uint64_t off;
                 uint32_t a, b;
                 header(0, off, a, b);
-                // The records of a grab's targets are consecutive in the arena: ONE descriptor, based at the first target's records, serves
-                // the rounds' gathers of the whole grab, and a queue entry names its record by a 32-bit index relative to that base.
-                const uint64_t off0 = off;
                 uint32_t cur[NB], nxt[NB];
                 load_blocks(off, a, b, cur);
-                int qh = 0, qt = 0;   // queue head / tail (monotonic, wave-uniform)
-                int ql = 64;          // head + 64: a full round is due when the tail reaches it
-                int kin = 0;          // strip of the current run, relative to ks0
+                int c[NC];
+#pragma unroll
+                for (int k = 0; k < NC; k++) c[k] = 0;
+                int qh0 = 0, qt0 = 0, qh1 = 0, qt1 = 0;  // queue heads / tails (monotonic over the grab, wave-uniform)
+                int ql0 = 64, ql1 = 64;                  // head + 64: a full round is due when the tail reaches it
+                int kin = 0;                             // strip of the current run, relative to ks0
+                // Round 5: an evaluation round is cut in two.  ISSUE takes up to 64 entries out of the queue and REQUESTS their records (one
+                // gather through the image's descriptor) -- nothing waits; EVAL, later, does the round's work on the records that have arrived
+                // meanwhile.  Between the two the wave goes on with stage 1 of the following blocks, whose stream loads were requested before
+                // the gather (vmcnt retires in order: waiting for those blocks waits for the gather too, so it costs no wait of its own).
+                // A full queue evaluates the round issued at the previous trigger and issues the next; a target's LAST (partial) rounds are
+                // issued at its end and evaluated one step into the next target of the grab (`tail_t`), or at the end of the grab.  Round 4
+                // evaluated every round where it was issued: 0.3-0.45 ms of a 1 M-target launch went into waiting for dependent gathers.
+                uint32_t pr0 = 0, py0 = 0, pr1 = 0, py1 = 0;   // the issued round of each orientation: gathered records, entries' row | column
+                int pn0 = 0, pn1 = 0;                          // its entries (0: none issued)
+                uint32_t tail_t = 0;                           // the target whose last rounds are issued but not evaluated ...
+                bool have_tail = false;                        // ... if any
 
-                // Evaluate up to 64 queued pixels: every lane busy.  Round 5: the queue is shared by BOTH orientations and ALL targets of the
-                // grab -- an entry carries its orientation (bit 31) and its counter set (bits 26..29: target-in-grab * 2 + orientation) --, so a
-                // round is due once per 64 entries of the grab instead of at least once per target and orientation (the synthetic library queues
-                // ~50 entries per target and orientation: two rounds three quarters full per target before, ~1.5 full ones now).  Matches
-                // go to the wave's LDS counters of (target, transform) by an atomic add behind a wave-uniform branch: where this kernel is
-                // chosen (few visited records reach a round) most probes of a round match nothing and cost one scalar test.
-                auto round = [&]() {
+                auto issue = [&](const uint2 *q, int &qh, int &ql, const int qt, uint32_t &pr, uint32_t &py, int &pn) {
                     const int n = min(qt - qh, 64);
-#if SP16_EXP == 1   // (timing only: no evaluation rounds)
-                    qh += n; ql = qh + 64; return;
-#endif
                     __builtin_amdgcn_wave_barrier();
-                    bool valid = lane < n;
                     const uint2 ent = q[(qh + lane) & (SP_QCAP - 1)];
 #if SP16_EXP == 2   // (timing only: rounds without the gather of the records)
-                    const uint32_t r = ent.x * 2654435761u | 0x00050001u;
+                    pr = ent.x * 2654435761u | 0x00050001u;
 #else
-                    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.px + off0), 0, (int)0x7ffffffc, 0x00020000);
-                    const uint32_t r = __builtin_amdgcn_raw_buffer_load_b32(ri, valid ? (int)(ent.x * 4u) : 0, 0, 0);
+                    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.px + off), 0, (int)0x7ffffffc, 0x00020000);
+                    pr = __builtin_amdgcn_raw_buffer_load_b32(ri, lane < n ? (int)(ent.x * 4u) : 0, 0, 0);
 #endif
+                    py = ent.y;
+                    pn = n;
+                    qh += n;
+                    ql = qh + 64;
+                };
+                // evaluate an issued round: up to 64 queued pixels of one orientation, every lane busy; the data threshold is applied here
+                auto eval = [&](const uint32_t r, const uint32_t y, int &pn, int *cc, const bool mirrored) {
+                    const int n = pn;
+                    pn = 0;
+#if SP16_EXP == 1   // (timing only: no evaluation rounds)
+                    cc[0] += n; return;
+#endif
+                    bool valid = lane < n;
                     uint32_t po;   // plane offset of the pixel: (row + 2) * pitch + 2 + window column
-                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(po) : "v"(__builtin_amdgcn_ubfe(ent.y, 16u, 10u)), "v"(v_pitch), "v"(poff));
-                    const uint32_t u = ent.y & 0xffffu;
-                    const uint32_t col = MIRROR && (int)ent.y < 0 ? v_km - u : u - v_kp;
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(po) : "v"(y >> 16), "v"(v_pitch), "v"(poff));
+                    const uint32_t col = mirrored ? v_km - (y & 0xffffu) : (y & 0xffffu) - v_kp;
                     valid = valid && col <= v_colmax;   // (outside the window nothing can match: all nine probes miss the mask)
                     const int poffs = valid ? (int)(po + col) : safe_off;
                     valid = valid && (r & 255u) > v_thr;
@@ -883,59 +892,74 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                         for (int k = 0; k < GS && k0 + k < NS; k++) iv[k] = IVLDS ? ivt[idx[k0 + k]] : p.iv[idx[k0 + k]];
 #pragma unroll
                         for (int k = 0; k < GS && k0 + k < NS; k++) {
-                            const bool hit = (code - iv[k].x) <= iv[k].y || (code - iv[k].z) <= iv[k].w;
-                            if (__ballot(hit)) {   // wave-uniform
-                                // (target-in-grab * 2 + orientation) * 9 + shift: the 18-entry layout of the ABI per target.  The entry's tag is
-                                // read AGAIN from the queue here: keeping it in a register across the probes costs the 64-VGPR variants three
-                                // spills, and this path is the rare one
-                                if (hit) {
-                                    const uint32_t y2 = reinterpret_cast<const volatile uint32_t *>(q)[2 * ((qh + lane) & (SP_QCAP - 1)) + 1];
-                                    atomicAdd(cnt + (int)(__builtin_amdgcn_ubfe(y2, 26u, 4u) * (uint32_t)9 + (uint32_t)(k0 + k)), 1);
-                                }
-                            }
+                            const unsigned long long mb = __ballot((code - iv[k].x) <= iv[k].y) | __ballot((code - iv[k].z) <= iv[k].w);
+                            cc[k0 + k] += __popcll(mb);
                         }
                     }
-                    qh += n;
-                    ql = qh + 64;
                 };
-                auto append = [&](const unsigned long long hb, const bool hit, const uint32_t idx, const uint32_t po) {
+                // the score of a target whose every round has been evaluated (or this slab's per-transform counts); the counters start over
+                auto write_target = [&](const uint32_t t) {
+                    if (p.partial) {  // per-transform counts of this slab: lane k holds transform k (the 18-entry layout of the ABI)
+                        int v = 0;
+#pragma unroll
+                        for (int k = 0; k < NS; k++) {
+                            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[k])), "n"(k));
+                            if (MIRROR) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(c[NS + k])), "n"(9 + k));
+                        }
+                        if (lane < CDS_N_TRANSFORMS) p.partial[((size_t)s * p.count + t) * CDS_N_TRANSFORMS + lane] = v;
+                    } else {
+                        int best = 0, bm = 0;
+#pragma unroll
+                        for (int k = 0; k < NS; k++) best = max(best, c[k]);
+                        if (MIRROR) {
+#pragma unroll
+                            for (int k = 0; k < NS; k++) bm = max(bm, c[NS + k]);
+                        }
+                        int32_t packed = best;
+                        if (MIRROR && bm > best) packed = (int32_t)((uint32_t)bm | 0x80000000u);
+                        if (lane == 0) p.out[t] = packed;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NC; k++) c[k] = 0;
+                };
+                // the previous target's issued last rounds: evaluate them, the target is complete
+                auto finalize_tail = [&]() {
+                    if (pn0) eval(pr0, py0, pn0, c, false);
+                    if (MIRROR && pn1) eval(pr1, py1, pn1, c + NS, true);
+                    write_target(tail_t);
+                    have_tail = false;
+                };
+                // a queue holds 64 entries: the round issued before (if any) is evaluated, the next one issued.  (Entries of the CURRENT target
+                // may only be counted once the previous target is complete: its tail goes first.)
+                auto full0 = [&]() {
+                    if (have_tail) finalize_tail();
+                    if (pn0) eval(pr0, py0, pn0, c, false);
+                    issue(q0, qh0, ql0, qt0, pr0, py0, pn0);
+                };
+                auto full1 = [&]() {
+                    if (have_tail) finalize_tail();
+                    if (pn1) eval(pr1, py1, pn1, c + NS, true);
+                    issue(q1, qh1, ql1, qt1, pr1, py1, pn1);
+                };
+                auto append = [&](uint2 *q, int &qt, const unsigned long long hb, const bool hit, const uint32_t idx, const uint32_t po) {
 #if SP16_EXP == 3   // (timing only: nothing queued)
-                    qh += 0; return;
+                    c[0] += __popcll(hb); return;
 #endif
                     if (hit) {
                         const int slot = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0))) & (SP_QCAP - 1);
                         q[slot] = make_uint2(idx, po);
                     }
                     qt += __popcll(hb);
-                    if (qt >= ql) round();
                 };
-                // end of a grab: the rest of the queue, then every target's score (or this slab's per-transform counts)
-                auto finish_grab = [&]() {
-                    while (qt > qh) round();
-                    __builtin_amdgcn_wave_barrier();
-                    for (int g = 0; g < ng; g++) {   // wave-uniform
-                        const uint32_t t = t0 + (uint32_t)g;
-                        const int *cg = cnt + g * CDS_N_TRANSFORMS;
-                        if (p.partial) {  // per-transform counts of this slab: lane k holds transform k (the 18-entry layout of the ABI)
-                            if (lane < CDS_N_TRANSFORMS) p.partial[((size_t)s * p.count + t) * CDS_N_TRANSFORMS + lane] = cg[lane];
-                        } else {
-                            int best = 0, bm = 0;   // (every lane reads the same words: broadcasts)
-#pragma unroll
-                            for (int k = 0; k < NS; k++) best = max(best, cg[k]);
-                            if (MIRROR) {
-#pragma unroll
-                                for (int k = 0; k < NS; k++) bm = max(bm, cg[9 + k]);
-                            }
-                            int32_t packed = best;
-                            if (MIRROR && bm > best) packed = (int32_t)((uint32_t)bm | 0x80000000u);
-                            if (lane == 0) p.out[t] = packed;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    for (int i = lane; i < ng * CDS_N_TRANSFORMS; i += 64) cnt[i] = 0;
-                    if (p.stat) st_queued += (uint32_t)qt;
-                    qh = qt = 0;
-                    ql = 64;
+                // end of a target's records: what its queues still hold (< 64 entries each) is issued; `tail_t` is evaluated later
+                auto end_target = [&](const uint32_t t) {
+                    if (have_tail) finalize_tail();   // (a target of one step: the previous tail has not been taken yet)
+                    if (pn0) eval(pr0, py0, pn0, c, false);
+                    if (MIRROR && pn1) eval(pr1, py1, pn1, c + NS, true);
+                    if (qt0 > qh0) issue(q0, qh0, ql0, qt0, pr0, py0, pn0);
+                    if (MIRROR && qt1 > qh1) issue(q1, qh1, ql1, qt1, pr1, py1, pn1);
+                    tail_t = t;
+                    have_tail = true;
                 };
                 for (int r = 0; r < nruns; r++) {  // wave-uniform
                     int yrel = ra - 1 - ry0;  // (rows started before the current block) - 1, relative to the band map
@@ -946,10 +970,6 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                         const uint32_t sbase = (uint32_t)(ks0 + kin) * (uint32_t)p.strip_w;
                         asm volatile("v_mov_b32 %0, %1" : "=v"(v_ux0pk) : "s"(((ux0 - sbase) & 0xffffu) * 0x10001u));
                     }
-                    // what an entry of this run carries besides its row and column: the counter set (bits 26..29) and the orientation (bit 31)
-                    const uint32_t g_in_grab = (uint32_t)(r / nsv);
-                    const uint32_t tag_p = (g_in_grab * 2u) << 26, tag_m = ((g_in_grab * 2u + 1u) << 26) | 0x80000000u;
-                    const uint32_t relbase = (uint32_t)(off - off0);   // this image's first record, relative to the grab's
                     for (uint32_t i = a; i < b; i += 128 * NB) {  // wave-uniform
                         const uint32_t rem = b - i;  // records of this run from block 0 of this iteration on
                         {   // the next NB blocks -- of this run, or the first ones of the grab's next run -- are in flight while these are examined
@@ -963,7 +983,7 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                             uint32_t acc = 0;
 #pragma unroll
                             for (int j = 0; j < NB; j++) acc ^= cur[j];
-                            if (__ballot(acc == 0x12345u)) atomicAdd(cnt, 1);
+                            c[0] += __popcll(__ballot(acc == 0x12345u));
                         } else {
 #pragma unroll
                             for (int j = 0; j < NB; j++) {
@@ -1000,35 +1020,51 @@ __global__ __launch_bounds__(1024, WPE) void sparse_scan16_kernel(SparseScanPara
                                 const uint32_t upk = pk_sub_min_u16(xpk, v_ux0pk, v_wnearpk);
                                 const uint32_t offpk = pk_shr2_mad_u16(rypk, v_rowbpk, upk & 0xFFF8FFF8u);
                                 const uint32_t bh = rec >> 16;                             // the high record alone (v_bfe takes the band mod 32 from the low bits)
-                                const uint32_t idl = relbase + i + 128u * j + 2u * (uint32_t)lane;   // index of the low record, relative to the grab's first record
+                                const uint32_t idl = i + 128u * j + 2u * (uint32_t)lane;   // index of the low record in the image
                                 // one 8-byte cell per record: .x = the bands the plain mask accepts around here, .y = the mirrored mask's
                                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                                 typedef __attribute__((address_space(3))) const u32x2 lds_u64;
                                 const uint32_t al = offpk & 0xffffu, ah = offpk >> 16;   // (the map starts at LDS address 0: checked by the host, launch_sparse_one)
                                 const u32x2 wl = *reinterpret_cast<lds_u64 *>((uintptr_t)al), wh = *reinterpret_cast<lds_u64 *>((uintptr_t)ah);
-                                // (an entry carries row << 16 | map column, one v_perm, + the run's tag; the round turns it into the plane offset: the
-                                // vector pipe is the kernel's bottleneck, and two multiply-adds per block here cost more than one per round there)
+                                // (an entry carries row << 16 | map column, one v_perm; the round turns it into the plane offset: the vector pipe is
+                                // the kernel's bottleneck, and two multiply-adds per block here cost more than one per round there)
                                 {
                                     const bool hl = (int)(wl.x << (rec & 31u)) < 0, hh = (int)(wh.x << (bh & 31u)) < 0;   // (bit 31 - field: see the map)
                                     const unsigned long long hbl = __ballot(hl), hbh = __ballot(hh);
-                                    if (hbl) append(hbl, hl, idl, __builtin_amdgcn_perm(rypk, upk, 0x05040100u) | tag_p);
-                                    if (hbh) append(hbh, hh, idl + 1u, __builtin_amdgcn_perm(rypk, upk, 0x07060302u) | tag_p);
+                                    if (hbl) {
+                                        append(q0, qt0, hbl, hl, idl, __builtin_amdgcn_perm(rypk, upk, 0x05040100u));
+                                        if (qt0 >= ql0) full0();
+                                    }
+                                    if (hbh) {
+                                        append(q0, qt0, hbh, hh, idl + 1u, __builtin_amdgcn_perm(rypk, upk, 0x07060302u));
+                                        if (qt0 >= ql0) full0();
+                                    }
                                 }
                                 if (MIRROR) {
                                     const bool hl = (int)(wl.y << (rec & 31u)) < 0, hh = (int)(wh.y << (bh & 31u)) < 0;
                                     const unsigned long long hbl = __ballot(hl), hbh = __ballot(hh);
-                                    if (hbl) append(hbl, hl, idl, __builtin_amdgcn_perm(rypk, upk, 0x05040100u) | tag_m);
-                                    if (hbh) append(hbh, hh, idl + 1u, __builtin_amdgcn_perm(rypk, upk, 0x07060302u) | tag_m);
+                                    if (hbl) {
+                                        append(q1, qt1, hbl, hl, idl, __builtin_amdgcn_perm(rypk, upk, 0x05040100u));
+                                        if (qt1 >= ql1) full1();
+                                    }
+                                    if (hbh) {
+                                        append(q1, qt1, hbh, hh, idl + 1u, __builtin_amdgcn_perm(rypk, upk, 0x07060302u));
+                                        if (qt1 >= ql1) full1();
+                                    }
                                 }
                             }
                         }
+                        if (have_tail) finalize_tail();   // (one step into the next target: the tail's records have arrived behind this step's blocks)
 #pragma unroll
                         for (int j = 0; j < NB; j++) cur[j] = nxt[j];
                     }
+                    // the target's last rounds gather from ITS image: issued before the header of the next run replaces `off`
+                    if (kin + 1 == nsv) end_target(t0 + (uint32_t)(r / nsv));
                     if (r + 1 < nruns) header(r + 1, off, a, b);
                     kin = kin + 1 == nsv ? 0 : kin + 1;
                 }
-                finish_grab();
+                if (have_tail) finalize_tail();   // the grab's last target
+                if (p.stat) st_queued += (uint32_t)(qt0 + qt1);
             }
         }
         if (p.stat && lane == 0 && (st_visited | st_queued)) {   // (pilot launches: this wave's share of the statistics)
@@ -2095,7 +2131,6 @@ static int sparse_search_impl(const cds_maskset *ms, const cds_sparse_library *s
             p.psize = (uint32_t)((p.count + nparts - 1) / nparts);
         }
         p.use16 = use16;
-        if (use16) p.group = std::min(p.group, SP16_MAXG);   // (a grab's counters live in the wave's LDS block)
         p.stat = nullptr;
         ms->last_scan_kernel = use16;
         size_t lds_launch = pl.lds_bytes;

@@ -29,10 +29,27 @@ run trace_headline32 300 --kernel-trace --stats --output-format csv -d $OUT/trac
 run pmc_headline32_fetch 300 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_headline32_fetch -- python3 $H_ARGS
 run pmc_headline32_sq 300 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_headline32_sq -- python3 $H_ARGS
 unset CDS_SPARSE_SCAN32
+# the overlapping regime: the reference's LM test MIPs against an EM mask that overlaps them (records32, the pilot's choice there),
+# and bench.py's overlapping-synthetic library -- classes real_images_em_12191 / overlapping_synthetic, each with its counters
+SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU"
+SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA"
+R_ARGS="$R/tools/real_image_rate.py --copies 8192 --reps 3 --sparse-only --mask em_12191"
+O_ARGS="$R/tools/overlap_rate.py --targets 131072 --no-cpu-baseline"
+for cmd in real overlap; do
+    [ $cmd = real ] && A="$R_ARGS" || A="$O_ARGS"
+    run trace_$cmd 300 --kernel-trace --stats --output-format csv -d $OUT/trace_$cmd -- python3 $A
+    run pmc_${cmd}_fetch 300 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_${cmd}_fetch -- python3 $A
+    run pmc_${cmd}_sq 300 --pmc $SQ1 --output-format csv -d $OUT/pmc_${cmd}_sq -- python3 $A
+    run pmc_${cmd}_sq2 300 --pmc $SQ2 --output-format csv -d $OUT/pmc_${cmd}_sq2 -- python3 $A
+done
 if [ -n "$FULL" ]; then
     run trace_full 500 --kernel-trace --stats --output-format csv -d $OUT/trace_full -- python3 $F_ARGS
     run pmc_full_fetch 500 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_full_fetch -- python3 $F_ARGS
-    run pmc_full_sq 500 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_full_sq -- python3 $F_ARGS
+    run pmc_full_sq 500 --pmc $SQ1 --output-format csv -d $OUT/pmc_full_sq -- python3 $F_ARGS
+    # (where do the multi-mask kernel's gathers hit, and what do its waves wait for)
+    run pmc_full_sq2 500 --pmc $SQ2 --output-format csv -d $OUT/pmc_full_sq2 -- python3 $F_ARGS
+    run pmc_full_mem 500 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/pmc_full_mem -- python3 $F_ARGS
+    run pmc_full_tcp 500 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum --output-format csv -d $OUT/pmc_full_tcp -- python3 $F_ARGS
 fi
 # (the full command scans the 1,024-mask set three times: aux.mask_batch and its end-to-end leg through the processor, which runs twice)
 cd $R && python3 tools/summarize_profile.py $OUT --tag $TAG --extra-multi 2147483648 --write-json $OUT/scan_pmc.json

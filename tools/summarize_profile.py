@@ -154,6 +154,12 @@ def main():
     add_class("sparse_scan_records32", "sparse_scan_kernel", "headline32", "targets", a.targets, last=a.steps,
               desc=f"the same {a.steps} scans with CDS_SPARSE_SCAN32=1: cds::sparse_scan_kernel over the 4-byte records (round 3's headline kernel)")
     add_class("dense_scan", "cds::scan_kernel", "headline", "targets", a.stage, desc="the dense-layout kernel over the verification windows")
+    # the overlapping regime: every dispatch of the 4-byte-record kernel in the two commands (1 warm-up + 3 timed scans of 32,768 targets;
+    # the overlapping-synthetic tool: pilot rest + 3 timed + 4 forced + 1 final scans of 131,072 targets)
+    add_class("real_images_em_12191", "sparse_scan_kernel", "real", "targets", 32768,
+              desc="tools/real_image_rate.py --mask em_12191: the reference's 4 LM test MIPs x 8,192 copies against the EM mask that overlaps them (cds::sparse_scan_kernel, the pilot's choice)")
+    add_class("overlapping_synthetic", "sparse_scan_kernel", "overlap", "targets", 131072,
+              desc="tools/overlap_rate.py (= bench.py aux.overlapping_synthetic at 131,072 targets): synthetic targets that overlap the benchmark mask, 38 % of the visited records reach a round (cds::sparse_scan_kernel)")
     add_class("sparse_multi", "sparse_multi_kernel", "full", "comparisons", None, units_total=a.multi_masks * a.targets + a.extra_multi,
               desc=f"aux.mask_batch + the scans aux.gradient_scores' selection needs: every multi-mask launch of the command ({a.multi_masks} masks x {a.targets} targets)")
     add_class("gradscore_list", "gradscore_list_kernel<true>", "full", "pairs", None, units_total=a.pairs or (a.multi_masks * 500 + 1),
