@@ -367,7 +367,7 @@ def main():
                     "frac_of_stream_read_in_this_run": None},
                 "dense_layout_bytes_per_target": dense_bytes_per_target,
                 "note": "bound = hbm by the task's convention: frac = measured HBM traffic of the launch (PMC counters of profiles/scan_pmc.json, "
-                        "2 x FETCH_SIZE per target, keyed by the kernel sources' hash) / kernel time of this run / the 8 TB/s spec.  The kernel "
+                        "per target, keyed by the kernel sources' hash; see traffic_source for how FETCH_SIZE becomes bytes) / kernel time of this run / the 8 TB/s spec.  The kernel "
                         "reads a record library (signal pixels only), not packed-RGB rows: SURVEY 8(d)'s byte model "
                         "(dense_layout_bytes_per_target) describes aux.dense_layout, not this kernel.  Round 4 halved the streamed bytes (the "
                         "16-bit stage-1 stream), so the fraction of the HBM peak FELL while `value` rose: the stream kernel is bound by "
@@ -377,6 +377,13 @@ def main():
         if cls and {"SQ_INSTS_VALU", "hbm_bytes"} <= set(cls.get("per_target", {})):
             pt = cls["per_target"]
             roof["traffic"] = pt["hbm_bytes"] * n
+            # (round 5, tools/fetchcal: FETCH_SIZE counts 64 B per request; the stream's coalesced loads are 128-B requests -> x 2, the rounds'
+            # gathered records are 64-B requests -> x 1.  Round 4 doubled everything and reported 10,455 B per target = 0.50 of the peak.)
+            roof["traffic_source"] = {"hbm_correction": pt.get("hbm_correction", "x2 (profile older than round 5)"),
+                                      "bytes_per_target": pt["hbm_bytes"], "face_value": pt.get("hbm_bytes_face_value"), "doubled": pt.get("hbm_bytes_doubled"),
+                                      "what": "FETCH_SIZE x 1024 B counts 64 B per TCC request (profiles/r05_fetch_size_calibration.txt): 128-B requests of "
+                                              "coalesced streaming loads count half, scattered 64-B requests in full.  `twin` = FETCH_SIZE + the loads-only twin's "
+                                              "FETCH_SIZE: the stream doubled, the rounds' gathers at face value; `doubled` is round 4's figure"}
             roof["achieved"] = roof["traffic"] / (kern_ms * 1e-3) / 1e9
             roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
             roof["frac_of_measured_copy_rate"] = roof["achieved"] / HBM_COPY_GBS
@@ -950,7 +957,9 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
                               "distinct_targets": int(gs["distinct_targets"]), "normalized_scores_positive": int((table.normalizedScore > 0).sum()),
                               "roofline": {"bound": "hbm", "achieved": (g_traffic / (gms * 1e-3) / 1e9) if g_traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": (g_traffic / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS) if g_traffic else None, "traffic": g_traffic,
-                                           "traffic_source": (f"profiles/scan_pmc.json (tag {pmc.get('tag')}), 2 x FETCH_SIZE per pair; stale sources: {pmc.get('stale_sources')}") if gcls else None,
+                                           "traffic_source": (f"profiles/scan_pmc.json (tag {pmc.get('tag')}), correction {gcls['per_pair'].get('hbm_correction', 'x2 (profile older than round 5)')}: "
+                                                              f"the scorer's loads are 12-byte groups at scattered pixels = 64-B requests, which FETCH_SIZE counts in full (tools/fetchcal); "
+                                                              f"doubled (round 4's figure) it would be {gcls['per_pair'].get('hbm_bytes_doubled')} B per pair; stale sources: {pmc.get('stale_sources')}") if gcls else None,
                                            "survey_8d_bytes_per_pair": 2081200, "survey_8d_GBps": g_alg,
                                            "note": "the list kernel reads only the groups the mask's lists select, fewer bytes than SURVEY 8(d) counts; frac is by measured traffic"},
                               "pairs_checked_against_oracle": n_checked, "sampled_pairs_equal_oracle": bool(ok_g)}

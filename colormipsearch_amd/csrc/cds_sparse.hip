@@ -284,6 +284,9 @@ __global__ __launch_bounds__(256) void sparse_validate_kernel(ValidateParams p) 
 #ifndef SP_NB
 #define SP_NB 4
 #endif
+#ifndef SM_TMAP_BINROWS
+#define SM_TMAP_BINROWS 1  // the multi-mask kernel's fine map as [cell row][hue bin][cell column] (1) or [cell][hue bin] (0, round 3)
+#endif
 #ifndef SP16_EXP
 #define SP16_EXP 0  // (timing experiments of sparse_scan16_kernel only: 1 = no rounds, 2 = rounds without the record gather, 3 = nothing queued)
 #endif
@@ -1297,6 +1300,9 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                     // lines the ACTIVE lanes touch; (C), after the next record blocks have been requested, the set bits become
                     // queue entries.  One LDS wait and one L2 wait per NB blocks.
                     uint32_t wp4[NB], wm4[NB], prow4[NB], cellp4[NB], cellm4[NB], up4[NB], um4[NB];
+#if SM_TMAP_BINROWS
+                    uint32_t rowq4[NB];
+#endif
 #pragma unroll
                     for (int j = 0; j < NB; j++) {
                         const uint32_t rec = cur[j];  // (lanes and whole blocks beyond the run were loaded as 0: no flag, below every threshold)
@@ -1314,6 +1320,10 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                             up4[j] = umap[cellp4[j]];
                             um4[j] = MIRROR ? umap[cellm4[j]] : 0u;
                         }
+#if SM_TMAP_BINROWS
+                        rowq4[j] = ry >> 2;
+                        cellp4[j] = cxp >> 3, cellm4[j] = cxm >> 3;   // (from here on: the cell COLUMNS; the fine map is [cell row][bin][cell column])
+#endif
                     }
 #pragma unroll
                     for (int j = 0; j < NB; j++) {
@@ -1337,10 +1347,22 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
 #else
                         // (unconditional loads: a lane that did not pass reads byte 0 of the map -- cell 0, class 0: never set -- together
                         // with every other such lane, ONE line; a branch around the load would make hipcc wait for it at the join)
+#if SM_TMAP_BINROWS
+                        // fine map laid out [cell row][bin][cell column]: the records of one row that share a hue bin -- the pixels of one
+                        // stroke, and of its neighbours in depth -- read neighbouring BYTES, so the active lanes of a gather touch a handful
+                        // of lines instead of one per cell (this kernel waits for the number of distinct lines its gathers touch)
+                        const uint32_t rowbin = __umul24(rowq4[j], 7u * kSparseGroupBins) + bin;
+                        const uint32_t offp = passp ? __umul24(rowbin, nwpr) + cellp4[j] : 0u;
+#else
                         const uint32_t offp = passp ? __umul24(cellp4[j], 7u * kSparseGroupBins) + bin : 0u;
+#endif
                         wp4[j] = __builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)offp, 0, 0);
                         if (MIRROR) {
+#if SM_TMAP_BINROWS
+                            const uint32_t offm = passm ? __umul24(rowbin, nwpr) + cellm4[j] : 0u;
+#else
                             const uint32_t offm = passm ? __umul24(cellm4[j], 7u * kSparseGroupBins) + bin : 0u;
+#endif
                             wm4[j] = __builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)offm, 0, 0);
                         }
 #endif
@@ -1619,8 +1641,13 @@ static int build_group_plans(cds_maskset *ms, const std::vector<std::vector<Mask
             std::sort(cells.begin(), cells.end());
             cells.erase(std::unique(cells.begin(), cells.end()), cells.end());
             for (const uint32_t cr : cells) {
+#if SM_TMAP_BINROWS
+                const size_t crow = (size_t)(cr >> 12) / (size_t)gp.nwpr, ccol = (size_t)(cr >> 12) % (size_t)gp.nwpr;
+                for (const uint16_t b : tab_bins[cr & 4095u]) tmap[(crow * 7 * kSparseGroupBins + b) * (size_t)gp.nwpr + ccol] |= (uint8_t)(1u << j);
+#else
                 uint8_t *cell = tmap.data() + (size_t)(cr >> 12) * 7 * kSparseGroupBins;
                 for (const uint16_t b : tab_bins[cr & 4095u]) cell[b] |= (uint8_t)(1u << j);
+#endif
                 umap[cr >> 12] |= tab_bits[cr & 4095u];
             }
         }

@@ -10,6 +10,10 @@ FULL=${2:-}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
+# (gpurun kills a command that writes nothing for 7 minutes; a profiled bench.py prints at its end only)
+( while true; do date +%T >> $OUT/heartbeat.txt; sleep 45; done ) &
+HB=$!
+trap "kill $HB 2>/dev/null" EXIT
 cd /tmp && export TMPDIR=/tmp
 H_ARGS="$R/bench.py --no-aux --no-cpu-baseline --verify-windows 3"
 F_ARGS="$R/bench.py --no-cpu-baseline --verify-windows 3 --steps 3 --warmup 1"
@@ -17,6 +21,9 @@ run() {  # name, seconds, rocprofv3 options..., then the python args
     local name=$1 secs=$2; shift 2
     timeout -k 10 $secs rocprofv3 "$@" > $OUT/$name.log 2>&1; echo "pass $name done: $?"
 }
+# FULL = "" (headline, headline32, real, overlap), "full" (those + the full command), "fullonly" (the full command alone: a second
+# gpurun call of <= 20 minutes; merge the two scan_pmc.json files with tools/merge_pmc.py)
+if [ "$FULL" != "fullonly" ]; then
 timeout -k 10 300 python3 $H_ARGS > $OUT/bench_headline.json 2> $OUT/bench_headline.err; echo "bench headline: $?"
 run trace_headline 300 --kernel-trace --stats --output-format csv -d $OUT/trace_headline -- python3 $H_ARGS
 run pmc_headline_fetch 300 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_headline_fetch -- python3 $H_ARGS
@@ -35,21 +42,24 @@ SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_
 SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA"
 R_ARGS="$R/tools/real_image_rate.py --copies 8192 --reps 3 --sparse-only --mask em_12191"
 O_ARGS="$R/tools/overlap_rate.py --targets 131072 --no-cpu-baseline"
-for cmd in real overlap; do
-    [ $cmd = real ] && A="$R_ARGS" || A="$O_ARGS"
+M_ARGS="$R/tools/bench_sparse.py --masks 64 --targets 262144 --reps 2 --warmup 1 --check 0"
+for cmd in real overlap multi; do
+    A="$R_ARGS"; [ $cmd = overlap ] && A="$O_ARGS"; [ $cmd = multi ] && A="$M_ARGS"
     run trace_$cmd 300 --kernel-trace --stats --output-format csv -d $OUT/trace_$cmd -- python3 $A
     run pmc_${cmd}_fetch 300 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_${cmd}_fetch -- python3 $A
     run pmc_${cmd}_sq 300 --pmc $SQ1 --output-format csv -d $OUT/pmc_${cmd}_sq -- python3 $A
     run pmc_${cmd}_sq2 300 --pmc $SQ2 --output-format csv -d $OUT/pmc_${cmd}_sq2 -- python3 $A
+    # request sizes at the memory side of L2: FETCH_SIZE counts 64 B per request whatever its size (tools/fetchcal); these give the bytes
+    run pmc_${cmd}_req 300 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $OUT/pmc_${cmd}_req -- python3 $A
+    [ $cmd = multi ] && run pmc_${cmd}_l2 300 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OUT/pmc_${cmd}_l2 -- python3 $A
 done
-if [ -n "$FULL" ]; then
-    run trace_full 500 --kernel-trace --stats --output-format csv -d $OUT/trace_full -- python3 $F_ARGS
-    run pmc_full_fetch 500 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_full_fetch -- python3 $F_ARGS
-    run pmc_full_sq 500 --pmc $SQ1 --output-format csv -d $OUT/pmc_full_sq -- python3 $F_ARGS
-    # (where do the multi-mask kernel's gathers hit, and what do its waves wait for)
-    run pmc_full_sq2 500 --pmc $SQ2 --output-format csv -d $OUT/pmc_full_sq2 -- python3 $F_ARGS
-    run pmc_full_mem 500 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/pmc_full_mem -- python3 $F_ARGS
-    run pmc_full_tcp 500 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum --output-format csv -d $OUT/pmc_full_tcp -- python3 $F_ARGS
+run pmc_headline_req 300 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $OUT/pmc_headline_req -- python3 $H_ARGS
+fi
+SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU"
+SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA"
+if [ -n "$FULL" ]; then   # (each pass of the full command takes 4-7 minutes under the profiler: two passes per gpurun call)
+    run trace_full 560 --kernel-trace --stats --output-format csv -d $OUT/trace_full -- python3 $F_ARGS
+    run pmc_full_fetch 560 --pmc FETCH_SIZE GRBM_GUI_ACTIVE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $OUT/pmc_full_fetch -- python3 $F_ARGS
 fi
 # (the full command scans the 1,024-mask set three times: aux.mask_batch and its end-to-end leg through the processor, which runs twice)
 cd $R && python3 tools/summarize_profile.py $OUT --tag $TAG --extra-multi 2147483648 --write-json $OUT/scan_pmc.json

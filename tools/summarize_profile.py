@@ -11,8 +11,15 @@ A launch class = the dispatches of one kernel in one profiled command whose work
   sparse_multi          `bench.py --no-cpu-baseline --verify-windows 3`: cds::sparse_multi_kernel dispatches (aux.mask_batch:
                         one per mask group over TARGETS targets); per (mask, target) comparison
   gradscore_list        same command: cds::gradscore_list_kernel dispatches of PAIRS pairs (aux.gradient_scores)
-HBM bytes = 2 x FETCH_SIZE (KB x 1024): on gfx950 FETCH_SIZE reports half the bytes of a streaming read
-(MI355X_MICROARCH.md, HBM / rocprofv3 section).
+HBM bytes from FETCH_SIZE (KB).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced streaming read
+(128-B requests tallied at 64 B) -> x 2.  tools/fetchcal (profiles/r05_fetch_size_calibration.txt, round 5) measured the other case:
+SCATTERED loads -- 4-, 8- or 12-byte loads whose lanes fall into different 64-B sectors -- are issued as 64-B requests and counted at
+face value (FETCH_SIZE x 1024 = the bytes of the touched sectors; TCC_EA0_RDREQ x 64 B in both cases).  So the factor is per class:
+  CORRECTION[class] = "x2"     every byte comes from coalesced streaming loads (loads-only twins, the dense scan, the record streams)
+                      "x1"     the kernel's traffic is scattered groups (the GradientAreaGap list scorer: 12-byte groups at mask pixels)
+                      "twin"   stream + gathers (the stream scan): the stream's share is the twin class's FETCH_SIZE (x 2), the rest -- the
+                               rounds' gathered records -- counts once
+and every class also lists the face-value and the doubled figure.
 """
 import argparse
 import collections
@@ -87,6 +94,39 @@ def main():
     o = a.out_dir
     lines = []
     classes = {}
+    CORRECTION = {"sparse_scan_headline": "twin", "gradscore_list": "x1", "gradscore_list_zslice_plane": "x1"}   # default "x2"
+
+    def hbm(key, per, units, ms_total, unit_name):
+        """per-unit HBM bytes of a class from its FETCH_SIZE, by the class's correction (see the module docstring)"""
+        face = per["FETCH_SIZE"] * 1024.0
+        how = CORRECTION.get(key, "x2")
+        if {"TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum"} <= set(per):
+            # the memory-side requests of L2 by size: the bytes themselves (FETCH_SIZE = 64 B x all of them, whatever their size)
+            n, n128 = per["TCC_EA0_RDREQ_sum"], per["TCC_EA0_RDREQ_128B_sum"]
+            n32, n64 = per.get("TCC_EA0_RDREQ_32B_sum", 0.0), per.get("TCC_EA0_RDREQ_64B_sum")
+            if n64 is None:
+                n64 = max(n - n128 - n32, 0.0)
+            per["hbm_bytes"] = 32.0 * n32 + 64.0 * n64 + 128.0 * n128 + 64.0 * max(n - n32 - n64 - n128, 0.0)
+            per["hbm_bytes_face_value"], per["hbm_bytes_doubled"], per["hbm_correction"] = face, 2.0 * face, "request sizes"
+            gbs = per["hbm_bytes"] * units / (ms_total * 1e-3) / 1e9
+            lines.append(f"   HBM traffic = 32 B x TCC_EA0_RDREQ_32B + 64 B x _64B + 128 B x _128B = {per['hbm_bytes']:.1f} B per {unit_name[:-1]} "
+                         f"({n128 / max(n, 1e-30):.2f} of the requests are 128 B wide) = {gbs:.0f} GB/s at the traced duration = {gbs / 8000:.3f} of the 8 TB/s peak"
+                         f"   [FETCH_SIZE at face value {face:.1f} B = {gbs * face / per['hbm_bytes'] / 8000:.3f}; doubled {2 * face:.1f} B = {gbs * 2 * face / per['hbm_bytes'] / 8000:.3f}]")
+            return
+        twin = classes.get("sparse_scan_load_only", {}).get("per_target", {}).get("FETCH_SIZE")
+        if how == "twin" and twin is not None:
+            per["hbm_bytes"] = face + min(face, twin * 1024.0)     # the stream's requests are 128 B wide (counted half), the gathers' 64 B
+            note = f"FETCH_SIZE + the loads-only twin's FETCH_SIZE (the stream's 128-B requests count half; the rounds' gathers are 64-B requests at face value)"
+        elif how == "x1":
+            per["hbm_bytes"] = face
+            note = "FETCH_SIZE at face value (scattered 12-byte groups: 64-B requests, tools/fetchcal)"
+        else:
+            per["hbm_bytes"] = 2.0 * face
+            note = "2 x FETCH_SIZE (coalesced streaming loads: 128-B requests tallied at 64 B)"
+        per["hbm_bytes_face_value"], per["hbm_bytes_doubled"], per["hbm_correction"] = face, 2.0 * face, how
+        gbs = per["hbm_bytes"] * units / (ms_total * 1e-3) / 1e9
+        lines.append(f"   HBM traffic = {note} = {per['hbm_bytes']:.1f} B per {unit_name[:-1]} = {gbs:.0f} GB/s at the traced duration = {gbs / 8000:.3f} of the 8 TB/s peak"
+                     f"   [face value {face:.1f} B = {gbs * face / per['hbm_bytes'] / 8000:.3f}; doubled {2 * face:.1f} B = {gbs * 2 * face / per['hbm_bytes'] / 8000:.3f}]")
 
     def add_class(key, kernel, cmd_tag, unit_name, units_per_dispatch, last=None, desc="", units_total=None):
         """units_total: the class is ALL dispatches of the kernel in the command, which together process that many units
@@ -113,9 +153,9 @@ def main():
                 per[c] = tot / units_total
                 lines.append(f"   {c:24s} sum over {len(sq):5d} dispatches {tot:20.1f}   per {unit_name[:-1]} {tot / units_total:12.4f}")
             if "FETCH_SIZE" in per:
-                per["hbm_bytes"] = 2.0 * per["FETCH_SIZE"] * 1024.0
-                gbs = per["hbm_bytes"] * units_total / (tot_ms * 1e-3) / 1e9
-                lines.append(f"   HBM traffic = 2 x FETCH_SIZE = {per['hbm_bytes']:.2f} B per {unit_name[:-1]} = {gbs:.0f} GB/s at the traced duration = {gbs / 8000:.3f} of the 8 TB/s peak")
+                hbm(key, per, units_total, tot_ms, unit_name)
+            if "TCC_HIT_sum" in per and "TCC_MISS_sum" in per:
+                lines.append(f"   L2: {per['TCC_HIT_sum'] / max(per['TCC_HIT_sum'] + per['TCC_MISS_sum'], 1e-30):.3f} of the requests hit")
             classes[key] = cls
             return
         ms = [x[2] for x in sel]
@@ -135,18 +175,22 @@ def main():
             lines.append(f"   {c:24s} mean per dispatch {mean:18.1f}  (n={len(s)})   per {unit_name[:-1]} {mean / units_per_dispatch:12.3f}")
         per = cls["per_" + unit_name[:-1]]
         if "FETCH_SIZE" in per:
-            per["hbm_bytes"] = 2.0 * per["FETCH_SIZE"] * 1024.0
-            gbs = per["hbm_bytes"] * units_per_dispatch / (cls["mean_ms"] * 1e-3) / 1e9
-            lines.append(f"   HBM traffic = 2 x FETCH_SIZE = {per['hbm_bytes']:.1f} B per {unit_name[:-1]} = {gbs:.0f} GB/s at the traced duration = {gbs / 8000:.3f} of the 8 TB/s peak")
+            hbm(key, per, units_per_dispatch, cls["mean_ms"], unit_name)
+        if "GRBM_GUI_ACTIVE" in per and "SQ_ACTIVE_INST_VALU" in per:   # busy shares of the two pipes this round argues with (256 CUs, 8 XCDs)
+            cyc_cu = per["GRBM_GUI_ACTIVE"] / 8.0 * 256.0          # cycles one CU spends per unit (every CU works on its own units)
+            s_ = f"   per {unit_name[:-1]} and CU: {cyc_cu:.0f} cycles; vector pipes active {per['SQ_ACTIVE_INST_VALU'] * 4.0 / (4.0 * cyc_cu):.2f}"
+            if "SQ_LDS_IDX_ACTIVE" in per:
+                s_ += f", LDS active {per['SQ_LDS_IDX_ACTIVE'] / cyc_cu:.2f} (bank conflicts {per.get('SQ_LDS_BANK_CONFLICT', 0.0) / max(per['SQ_LDS_IDX_ACTIVE'], 1e-30):.2f} of that)"
+            lines.append(s_)
         classes[key] = cls
 
     # the headline kernel: the 16-bit-stream scan when the run's pilot chose it (round 4), else the 4-byte-record scan
+    add_class("sparse_scan_load_only", "sparse_scan16_kernel&" + LOAD_ONLY16, "headline", "targets", a.targets, last=5,
+              desc="the loads-only twin of the stream kernel (bench.py roofline.load_only): same grabs, headers, stream loads, no examination")
     add_class("sparse_scan_headline", "sparse_scan16_kernel", "headline", "targets", a.targets, last=a.steps,
               desc=f"the {a.steps} timed 1-mask scans of the resident library (bench.py `value`): cds::sparse_scan16_kernel over the 16-bit stage-1 stream")
-    if "sparse_scan_headline" in classes:
-        add_class("sparse_scan_load_only", "sparse_scan16_kernel&" + LOAD_ONLY16, "headline", "targets", a.targets, last=5,
-                  desc="the loads-only twin of the stream kernel (bench.py roofline.load_only): same grabs, headers, stream loads, no examination")
-    else:
+    if "sparse_scan_headline" not in classes:
+        classes.pop("sparse_scan_load_only", None)
         add_class("sparse_scan_headline", "sparse_scan_kernel", "headline", "targets", a.targets, last=a.steps,
                   desc=f"the {a.steps} timed 1-mask scans of the resident library (bench.py `value`)")
         add_class("sparse_scan_load_only", "sparse_scan_kernel&" + LOAD_ONLY, "headline", "targets", a.targets, last=5,
@@ -160,7 +204,10 @@ def main():
               desc="tools/real_image_rate.py --mask em_12191: the reference's 4 LM test MIPs x 8,192 copies against the EM mask that overlaps them (cds::sparse_scan_kernel, the pilot's choice)")
     add_class("overlapping_synthetic", "sparse_scan_kernel", "overlap", "targets", 131072,
               desc="tools/overlap_rate.py (= bench.py aux.overlapping_synthetic at 131,072 targets): synthetic targets that overlap the benchmark mask, 38 % of the visited records reach a round (cds::sparse_scan_kernel)")
-    add_class("sparse_multi", "sparse_multi_kernel", "full", "comparisons", None, units_total=a.multi_masks * a.targets + a.extra_multi,
+    add_class("sparse_multi", "sparse_multi_kernel", "multi", "comparisons", 8 * 262144,
+              desc="tools/bench_sparse.py --masks 64 --targets 262144: every launch of cds::sparse_multi_kernel (one group of 8 masks over 262,144 targets each) -- the "
+                   "kernel of BASELINE configs[2] at a size whose counter passes fit one gpurun call; per (mask, target) comparison")
+    add_class("sparse_multi_full" if "sparse_multi" in classes else "sparse_multi", "sparse_multi_kernel", "full", "comparisons", None, units_total=a.multi_masks * a.targets + a.extra_multi,
               desc=f"aux.mask_batch + the scans aux.gradient_scores' selection needs: every multi-mask launch of the command ({a.multi_masks} masks x {a.targets} targets)")
     add_class("gradscore_list", "gradscore_list_kernel<true>", "full", "pairs", None, units_total=a.pairs or (a.multi_masks * 500 + 1),
               desc="aux.gradient_scores, the default path at 2.2 pairs per target: the scorer reads the zgap bytes itself, no conversion pass (one launch per batch of selected targets) + the one fixture pair")
@@ -180,9 +227,10 @@ def main():
     text = "\n".join(lines) + "\n"
     open(os.path.join(o, "summary.txt"), "w").write(text)
     print(text)
-    if a.write_json and "sparse_scan_headline" in classes:
+    if a.write_json and classes:
         j = {"tag": a.tag, "command": "python3 bench.py --no-aux --no-cpu-baseline --verify-windows 3 (class *_headline) / --no-cpu-baseline --verify-windows 3 (others)",
-             "hbm_bytes": "2 x FETCH_SIZE x 1024 (gfx950 correction, MI355X_MICROARCH.md)",
+             "hbm_bytes": "per class: 2 x FETCH_SIZE x 1024 for coalesced streams (MI355X_MICROARCH.md), FETCH_SIZE x 1024 for scattered 64-B requests, "
+                          "stream + gathers for the stream scan (tools/fetchcal, profiles/r05_fetch_size_calibration.txt); hbm_bytes_face_value / _doubled beside it",
              "sources": {s: hashlib.sha256(open(os.path.join(ROOT, s), "rb").read()).hexdigest() for s in SOURCES},
              "classes": classes}
         json.dump(j, open(a.write_json, "w"), indent=1)
