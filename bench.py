@@ -377,13 +377,14 @@ def main():
         if cls and {"SQ_INSTS_VALU", "hbm_bytes"} <= set(cls.get("per_target", {})):
             pt = cls["per_target"]
             roof["traffic"] = pt["hbm_bytes"] * n
-            # (round 5, tools/fetchcal: FETCH_SIZE counts 64 B per request; the stream's coalesced loads are 128-B requests -> x 2, the rounds'
-            # gathered records are 64-B requests -> x 1.  Round 4 doubled everything and reported 10,455 B per target = 0.50 of the peak.)
+            # (round 5, VERDICT r4 #7: FETCH_SIZE counts 64 B per request whatever its size; the profile now carries the request-size counters,
+            # and every read request of this kernel -- the stream's AND the rounds' gathers -- is 128 B wide: the doubled figure is the exact one)
             roof["traffic_source"] = {"hbm_correction": pt.get("hbm_correction", "x2 (profile older than round 5)"),
                                       "bytes_per_target": pt["hbm_bytes"], "face_value": pt.get("hbm_bytes_face_value"), "doubled": pt.get("hbm_bytes_doubled"),
-                                      "what": "FETCH_SIZE x 1024 B counts 64 B per TCC request (profiles/r05_fetch_size_calibration.txt): 128-B requests of "
-                                              "coalesced streaming loads count half, scattered 64-B requests in full.  `twin` = FETCH_SIZE + the loads-only twin's "
-                                              "FETCH_SIZE: the stream doubled, the rounds' gathers at face value; `doubled` is round 4's figure"}
+                                      "what": "`request sizes` = 32 B x TCC_EA0_RDREQ_32B + 64 B x _64B + 128 B x _128B per target, measured in separate --pmc passes "
+                                              "(FETCH_SIZE x 1024 B = 64 B per request: half the bytes when the requests are 128 B wide -- which all of this kernel's "
+                                              "are, gathers included: default-policy loads make L2 fetch whole 128-B lines; tools/fetchcal, "
+                                              "profiles/r05_fetch_size_calibration.txt)"}
             roof["achieved"] = roof["traffic"] / (kern_ms * 1e-3) / 1e9
             roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
             roof["frac_of_measured_copy_rate"] = roof["achieved"] / HBM_COPY_GBS
@@ -958,8 +959,9 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
                               "roofline": {"bound": "hbm", "achieved": (g_traffic / (gms * 1e-3) / 1e9) if g_traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": (g_traffic / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS) if g_traffic else None, "traffic": g_traffic,
                                            "traffic_source": (f"profiles/scan_pmc.json (tag {pmc.get('tag')}), correction {gcls['per_pair'].get('hbm_correction', 'x2 (profile older than round 5)')}: "
-                                                              f"the scorer's loads are 12-byte groups at scattered pixels = 64-B requests, which FETCH_SIZE counts in full (tools/fetchcal); "
-                                                              f"doubled (round 4's figure) it would be {gcls['per_pair'].get('hbm_bytes_doubled')} B per pair; stale sources: {pmc.get('stale_sources')}") if gcls else None,
+                                                              f"the scorer's 12-byte groups at scattered pixels are default-policy loads = 128-B line fetches (tools/fetchcal: only non-temporal "
+                                                              f"scattered loads go out as 64-B requests), so 2 x FETCH_SIZE = {gcls['per_pair'].get('hbm_bytes_doubled')} B per pair is the figure unless the "
+                                                              f"class carries the request-size counters; stale sources: {pmc.get('stale_sources')}") if gcls else None,
                                            "survey_8d_bytes_per_pair": 2081200, "survey_8d_GBps": g_alg,
                                            "note": "the list kernel reads only the groups the mask's lists select, fewer bytes than SURVEY 8(d) counts; frac is by measured traffic"},
                               "pairs_checked_against_oracle": n_checked, "sampled_pairs_equal_oracle": bool(ok_g)}

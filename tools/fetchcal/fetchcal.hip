@@ -10,6 +10,8 @@
 //   mode 2  gather12 : 12 B per lane at a 12-byte-aligned offset inside a 64-B sector of its own (the scorer's target / zgap groups)
 //   mode 3  gather4x4: four lanes share a 64-B sector (4-byte loads 16 B apart: a round's gather at ~25 % survivors)
 //   mode 4  gather8  : 8 B per lane (the stream kernel's plane rows from L2 / the scorer's zslice + gradient pairs), own sector
+//   mode 5 / 6       : modes 1 / 2 WITHOUT the non-temporal hint -- the cache policy of this repository's kernels' gathers: L2 allocates
+//                      the whole 128-B line, so the request is 128 B wide although the lane wants 4 or 12 bytes
 // For every mode the tool prints the bytes REQUESTED (lanes x width), the bytes in the 32-B / 64-B / 128-B granules touched, and the
 // kernel time; run under `rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum` (tools/fetchcal/run.sh) the summary
 // divides the granule bytes by FETCH_SIZE x 1024.
@@ -35,13 +37,15 @@ __global__ __launch_bounds__(256) void cal(const uint8_t *buf, uint64_t n_granul
     const uint64_t mask = n_granules - 1;   // power of two
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_granules; i += (uint64_t)gridDim.x * 256) {
         uint64_t g = i;
-        if (MODE == 1 || MODE == 2 || MODE == 4) g = (i * 0x9E3779B97F4A7C15ull) & mask;            // own sector, scattered
+        if (MODE == 1 || MODE == 2 || MODE == 4 || MODE == 5 || MODE == 6) g = (i * 0x9E3779B97F4A7C15ull) & mask;   // own sector, scattered
         if (MODE == 3) g = ((((i >> 2) * 0x9E3779B97F4A7C15ull) & (mask >> 2)) << 2) | (i & 3);      // 4 neighbours share a 64-B sector
         const uint8_t *p = buf + g * STRIDE;
         if (MODE == 0) { const u32x4 v = __builtin_nontemporal_load((const u32x4 *)p); acc ^= v.x ^ v.y ^ v.z ^ v.w; }
         if (MODE == 1 || MODE == 3) acc ^= __builtin_nontemporal_load((const uint32_t *)(p + 4 * (g % 3)));
         if (MODE == 2) { const u32x3 v = __builtin_nontemporal_load((const u32x3 *)(p + 12 * (g & 3))); acc ^= v.x ^ v.y ^ v.z; }
         if (MODE == 4) { const u32x2 v = __builtin_nontemporal_load((const u32x2 *)(p + 8 * (g & 7))); acc ^= v.x ^ v.y; }
+        if (MODE == 5) acc ^= *(const uint32_t *)(p + 4 * (g % 3));
+        if (MODE == 6) { const u32x3 v = *(const u32x3 *)(p + 12 * (g & 3)); acc ^= v.x ^ v.y ^ v.z; }
     }
     if (acc == 0x12345678u) out[0] = acc;
 }
@@ -85,6 +89,8 @@ int main(int argc, char **argv) {
     run<2>("gather12", buf, bytes, 12, 64, out);
     run<3>("gather4x4", buf, bytes, 4, 16, out);
     run<4>("gather8", buf, bytes, 8, 64, out);
+    run<5>("gather4_default_policy", buf, bytes, 4, 64, out);
+    run<6>("gather12_default_policy", buf, bytes, 12, 64, out);
     CHECK(hipDeviceSynchronize());
     return 0;
 }

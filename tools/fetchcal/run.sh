@@ -10,7 +10,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 G=${1:-6}
 $OUT/fetchcal $G > $OUT/plain.jsonl || exit 1
-for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_REQ_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCC_HIT_sum"; do
+for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_REQ_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCC_HIT_sum"; do
     tag=$(echo $set | cut -d' ' -f1)
     timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$tag -- $OUT/fetchcal $G > $OUT/pmc_$tag.log 2>&1 || echo "pass $tag failed"
 done
@@ -33,7 +33,12 @@ for m in modes:
         line += f" | FETCH_SIZE {fb/1e9:7.2f} GB -> sectors/FETCH = {m['bytes_64B_sectors']/fb:5.2f}, lines/FETCH = {m['bytes_128B_lines']/fb:5.2f}, requested/FETCH = {m['bytes_requested']/fb:5.2f}"
     if "TCC_EA0_RDREQ_sum" in c:
         rd, rd32 = c["TCC_EA0_RDREQ_sum"], c.get("TCC_EA0_RDREQ_32B_sum", 0.0)
-        line += f" | EA RDREQ {rd/1e6:8.1f} M ({rd32/1e6:8.1f} M of them 32 B) -> bytes if the rest are 64 B = {(rd32*32 + (rd-rd32)*64)/1e9:7.2f} GB"
+        rd64, rd128 = c.get("TCC_EA0_RDREQ_64B_sum"), c.get("TCC_EA0_RDREQ_128B_sum")
+        if rd128 is not None:
+            rd64 = rd64 if rd64 is not None else rd - rd32 - rd128
+            line += f" | EA RDREQ {rd/1e6:8.1f} M = {rd32/1e6:.1f} M x 32 B + {rd64/1e6:.1f} M x 64 B + {rd128/1e6:.1f} M x 128 B = {(rd32*32 + rd64*64 + rd128*128)/1e9:7.2f} GB"
+        else:
+            line += f" | EA RDREQ {rd/1e6:8.1f} M ({rd32/1e6:8.1f} M of them 32 B) -> bytes if the rest are 64 B = {(rd32*32 + (rd-rd32)*64)/1e9:7.2f} GB"
     for k in ("TCC_REQ_sum", "TCC_MISS_sum", "TCC_HIT_sum", "TCP_TCC_READ_REQ_sum"):
         if k in c:
             line += f" | {k} {c[k]/1e6:8.1f} M"

@@ -13,13 +13,13 @@ A launch class = the dispatches of one kernel in one profiled command whose work
   gradscore_list        same command: cds::gradscore_list_kernel dispatches of PAIRS pairs (aux.gradient_scores)
 HBM bytes from FETCH_SIZE (KB).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced streaming read
 (128-B requests tallied at 64 B) -> x 2.  tools/fetchcal (profiles/r05_fetch_size_calibration.txt, round 5) measured the other case:
-SCATTERED loads -- 4-, 8- or 12-byte loads whose lanes fall into different 64-B sectors -- are issued as 64-B requests and counted at
-face value (FETCH_SIZE x 1024 = the bytes of the touched sectors; TCC_EA0_RDREQ x 64 B in both cases).  So the factor is per class:
-  CORRECTION[class] = "x2"     every byte comes from coalesced streaming loads (loads-only twins, the dense scan, the record streams)
-                      "x1"     the kernel's traffic is scattered groups (the GradientAreaGap list scorer: 12-byte groups at mask pixels)
-                      "twin"   stream + gathers (the stream scan): the stream's share is the twin class's FETCH_SIZE (x 2), the rest -- the
-                               rounds' gathered records -- counts once
-and every class also lists the face-value and the doubled figure.
+FETCH_SIZE = 64 B x TCC_EA0_RDREQ whatever the request's size; the REQUEST SIZE depends on the load's cache policy, not on its shape:
+scattered 4- / 8- / 12-byte loads with the non-temporal hint go out as 64-B requests (face value is right), the same loads with the default
+policy -- what every gather of this repository's kernels uses -- make L2 fetch the whole 128-B line (x 2 is right, as for streams).
+So a class's bytes are taken from the request-size counters when its passes hold them (TCC_EA0_RDREQ_32B / _64B / _128B: the bytes
+themselves -- in round 5's profiles every product kernel shows 1.00 of its requests at 128 B), and from 2 x FETCH_SIZE otherwise
+(CORRECTION[class] could name another rule: "x1" face value, "twin" stream doubled + the rest once); every class also lists the
+face-value and the doubled figure.
 """
 import argparse
 import collections
@@ -94,7 +94,7 @@ def main():
     o = a.out_dir
     lines = []
     classes = {}
-    CORRECTION = {"sparse_scan_headline": "twin", "gradscore_list": "x1", "gradscore_list_zslice_plane": "x1"}   # default "x2"
+    CORRECTION = {}   # default "x2" (see the module docstring: every gather of the product kernels uses the default cache policy)
 
     def hbm(key, per, units, ms_total, unit_name):
         """per-unit HBM bytes of a class from its FETCH_SIZE, by the class's correction (see the module docstring)"""
@@ -229,8 +229,9 @@ def main():
     print(text)
     if a.write_json and classes:
         j = {"tag": a.tag, "command": "python3 bench.py --no-aux --no-cpu-baseline --verify-windows 3 (class *_headline) / --no-cpu-baseline --verify-windows 3 (others)",
-             "hbm_bytes": "per class: 2 x FETCH_SIZE x 1024 for coalesced streams (MI355X_MICROARCH.md), FETCH_SIZE x 1024 for scattered 64-B requests, "
-                          "stream + gathers for the stream scan (tools/fetchcal, profiles/r05_fetch_size_calibration.txt); hbm_bytes_face_value / _doubled beside it",
+             "hbm_bytes": "per class: from the request-size counters (32 B x TCC_EA0_RDREQ_32B + 64 B x _64B + 128 B x _128B) when the class has them, else "
+                          "2 x FETCH_SIZE x 1024 (FETCH_SIZE counts 64 B per request; default-policy loads, streams and gathers alike, are 128-B requests: "
+                          "tools/fetchcal, profiles/r05_fetch_size_calibration.txt); hbm_bytes_face_value / _doubled beside it",
              "sources": {s: hashlib.sha256(open(os.path.join(ROOT, s), "rb").read()).hexdigest() for s in SOURCES},
              "classes": classes}
         json.dump(j, open(a.write_json, "w"), indent=1)
