@@ -722,6 +722,42 @@ def overlapping_leg(args, cds, ctx, dev, stream, mask, rects, failed, n_o=262144
             "targets_equal_oracle": bool(ok_or) if checked else None}
 
 
+def config0_leg(args, cds, ctx, dev, stream, dense, mask, rects, failed, n0=100):
+    """BASELINE configs[0]: 1 mask x 100 synthetic targets, xyShift 0, no mirror -- the reference's own CPU-runnable case (plumbing).  The C
+    restatement of the reference's per-pair loop on ONE host thread (the per-pair call the reference's worker threads make), the same
+    pairs through the dense and the sparse resident layout on the GPU, scores and mirrored flags equal."""
+    dense.generate_synthetic(LIB_SEED, 0, 0, n0, kind=0)
+    alg = cds.PixelMatchColorDepthSearchAlgorithm(mask, MASK_THR, False, None, 0, False, DATA_THR, ZTOL, 0, rects, context=ctx)
+    sc_d = torch.empty(n0, dtype=torch.int32, device=dev)
+    alg.searchLibraryDevice(dense, 0, n0, sc_d.data_ptr())
+    t_dense = timed(stream, lambda: alg.searchLibraryDevice(dense, 0, n0, sc_d.data_ptr()), 5)
+    sl = cds.SparseLibrary(W, H, n0, 40000 * n0, context=ctx)
+    sl.append_from(dense, 0, n0)
+    sc_s = torch.empty(n0, dtype=torch.int32, device=dev)
+    alg.searchSparseLibraryDevice(sl, 0, n0, sc_s.data_ptr())
+    t_sparse = timed(stream, lambda: alg.searchSparseLibraryDevice(sl, 0, n0, sc_s.data_ptr()), 5)
+    same = bool(torch.equal(sc_d, sc_s))
+    out = {"workload": f"1 mask x {n0} synthetic 1210x566 RGB targets, xyShift 0, no mirror (BASELINE configs[0])",
+           "gpu_ms_per_pass": {"dense_layout": t_dense, "sparse_layout": t_sparse}, "dense_and_sparse_scores_equal": same}
+    if not same:
+        failed.append("configs[0]: dense and sparse scans disagree")
+    if not args.no_cpu_baseline:
+        from oracle import cds_oracle as O
+        imgs = dense.download(0, n0)
+        q = O.PixelMatchQuery(mask, MASK_THR, DATA_THR, ZTOL, 0, False, rects)
+        q.scan(imgs[:4], n_threads=1)
+        t0 = time.perf_counter()
+        ws, wm = q.scan(imgs, n_threads=1)
+        dt = time.perf_counter() - t0
+        hs = sc_d.cpu().numpy()
+        ok = bool(np.array_equal(ws, hs & 0x7FFFFFFF) and not wm.any() and not (hs < 0).any())
+        out["cpu"] = {"comparisons_per_s": n0 / dt, "threads": 1, "kind": "port", "what": "the C restatement of the reference's per-pair loop (one transform), one host thread",
+                      "scores_equal_gpu": ok}
+        if not ok:
+            failed.append("configs[0]: GPU scores differ from the CPU oracle's")
+    return out
+
+
 def timed(stream, fn, reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
@@ -1058,6 +1094,7 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
             failed.append("sparse and dense scans disagree on the reference's images")
         if not ok_f:
             failed.append("reference fixture pairs do not give the reference's JUnit values")
+    aux["config0"] = config0_leg(args, cds, ctx, dev, stream, dense, mask, rects, failed)
     return aux
 
 

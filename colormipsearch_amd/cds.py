@@ -303,6 +303,14 @@ class Library:
     def upload_variants(self, first, gradients=None, zgaps=None):
         n = None
         gp = zp = None
+        if gradients is not None and np.asarray(gradients).dtype == np.uint8:
+            # a GRAY8 gradient (the reference accepts GRAY8 and GRAY16 through ImageArray.get): widened by the library
+            g8 = np.ascontiguousarray(gradients)
+            if g8.ndim == 2:
+                g8 = g8[None]
+            capi.check(self._lib.cds_library_upload_gradient_u8(self._h, int(first), g8.shape[0], capi.as_u8p(g8)))
+            n = g8.shape[0]
+            gradients = None
         if gradients is not None:
             gradients = np.ascontiguousarray(gradients, dtype=np.uint16)
             if gradients.ndim == 2:
@@ -313,7 +321,7 @@ class Library:
             zgaps = capi.rgb_images(zgaps, n)
             n = zgaps.shape[0]
             zp = capi.as_u8p(zgaps)
-        if n is None:
+        if n is None or (gp is None and zp is None):
             return
         capi.check(self._lib.cds_library_upload_variants(self._h, int(first), n, gp, zp))
 

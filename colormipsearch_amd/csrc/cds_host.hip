@@ -661,6 +661,30 @@ int cds_library_upload_variants(cds_library *lib, int64_t first, int64_t count, 
     return CDS_OK;
 }
 
+int cds_library_upload_gradient_u8(cds_library *lib, int64_t first, int64_t count, const uint8_t *grad8) {
+    int rc = check_range(lib, first, count);
+    if (rc) return rc;
+    if (count == 0) return CDS_OK;
+    if (!grad8) return fail(CDS_ERR_INVALID_ARGUMENT, "grad8 is NULL");
+    // widened on the host, a batch of images at a time (the upload path of the 16-bit plane is reused; a GRAY8 gradient is the rare case)
+    const size_t px = (size_t)lib->W * lib->H;
+    const int64_t batch = std::max<int64_t>(1, (int64_t)(((size_t)64 << 20) / (2 * px)));
+    try {
+        std::vector<uint16_t> wide;
+        for (int64_t done = 0; done < count; done += batch) {
+            const int64_t n = std::min(batch, count - done);
+            wide.resize((size_t)n * px);
+            const uint8_t *src = grad8 + (size_t)done * px;
+            for (size_t i = 0; i < (size_t)n * px; i++) wide[i] = src[i];
+            rc = cds_library_upload_variants(lib, first + done, n, wide.data(), nullptr);
+            if (rc) return rc;
+        }
+    } catch (const std::bad_alloc &) {
+        return fail(CDS_ERR_OUT_OF_MEMORY, "out of host memory widening the gradient images");
+    }
+    return CDS_OK;
+}
+
 int cds_library_download_variants(cds_library *lib, int64_t first, int64_t count, uint16_t *grad, uint8_t *zgap_rgb) {
     int rc = check_range(lib, first, count);
     if (rc) return rc;

@@ -107,6 +107,10 @@ int cds_library_download(cds_library *lib, int64_t first, int64_t count, uint8_t
 int cds_library_upload_variants(cds_library *lib, int64_t first, int64_t count, const uint16_t *grad,
                                 const uint8_t *zgap_rgb);
 int cds_library_download_variants(cds_library *lib, int64_t first, int64_t count, uint16_t *grad, uint8_t *zgap_rgb);
+/* The reference's shape scorer takes a GRAY8 or a GRAY16 gradient image through ImageArray.get
+ * (API/imageprocessing/ByteImageArray.java:3-16, ShortImageArray.java): an 8-bit gradient (pitch W) is widened into the u16
+ * plane the scorer reads -- same values, same scores. */
+int cds_library_upload_gradient_u8(cds_library *lib, int64_t first, int64_t count, const uint8_t *grad8);
 /* Fill slots [first_slot, first_slot+count) on the device with synthetic images number
  * first_index.. of the stream `seed` (DESIGN.md "synthetic library").  kind: 0 sparse-lut target,
  * 1 dense-uniform target, 2 arbor mask.  with_variants != 0 also generates gradient + zgap (kind 0). */

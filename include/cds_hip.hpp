@@ -82,6 +82,9 @@ public:
     void uploadVariants(int64_t first, int64_t count, const uint16_t *grad, const uint8_t *zgap) {
         check(cds_library_upload_variants(lib_, first, count, grad, zgap));
     }
+    void uploadGradientU8(int64_t first, int64_t count, const uint8_t *grad8) {   // a GRAY8 gradient image (ByteImageArray.java:3-16)
+        check(cds_library_upload_gradient_u8(lib_, first, count, grad8));
+    }
     void generateSynthetic(uint64_t seed, int64_t firstIndex, int64_t firstSlot, int64_t count, int kind, bool variants = false) {
         check(cds_library_generate_synthetic(lib_, seed, firstIndex, firstSlot, count, kind, variants ? 1 : 0));
     }
@@ -108,6 +111,12 @@ public:
     void clear() { check(cds_sparse_library_clear(lib_)); }
     // pixels at or below the searches' data threshold need not be resident (searches below it are refused)
     void setMinDataThreshold(int targetThreshold) { check(cds_sparse_library_set_min_threshold(lib_, targetThreshold)); }
+    // appends enlarge the library when a capacity is lacking (the reference's MIP cache sizes itself with use, CachedMIPsUtils.java:60-100)
+    void setGrowable(bool on = true) { check(cds_sparse_library_set_growable(lib_, on ? 1 : 0)); }
+    void reserve(int64_t capacityImages, int64_t capacityPixels) { check(cds_sparse_library_reserve(lib_, capacityImages, capacityPixels)); }
+    int64_t capacityImages() const { int64_t v = 0; check(cds_sparse_library_capacity(lib_, &v, nullptr, nullptr)); return v; }
+    int64_t capacityPixels() const { int64_t v = 0; check(cds_sparse_library_capacity(lib_, nullptr, &v, nullptr)); return v; }
+    bool hasStream16() const { int32_t v = 0; check(cds_sparse_library_capacity(lib_, nullptr, nullptr, &v)); return v != 0; }
 private:
     cds_sparse_library *lib_ = nullptr;
 };

@@ -156,6 +156,12 @@ JNIEXPORT void JNICALL CLS(libraryUploadVariants)(JNIEnv *env, jclass c, jlong l
     int rc = cds_library_upload_variants(P(cds_library, lib), first, count, g, z);
     if (rc) throw_for(env, rc);
 }
+JNIEXPORT void JNICALL CLS(libraryUploadGradientU8)(JNIEnv *env, jclass c, jlong lib, jlong first, jlong count, jobject directGrad8) {
+    const uint8_t *g = (const uint8_t *)direct_bytes(env, directGrad8, library_bytes(lib, count, 1), "directGrad8 is not a direct buffer of count * w * h bytes");
+    if (!g) return;
+    int rc = cds_library_upload_gradient_u8(P(cds_library, lib), first, count, g);
+    if (rc) throw_for(env, rc);
+}
 JNIEXPORT void JNICALL CLS(libraryMakeZgapVariants)(JNIEnv *env, jclass c, jlong lib, jlong first, jlong count, jint threshold, jdouble radius,
                                                     jintArray rects) {
     cds_rect r[CDS_MAX_RECTS];

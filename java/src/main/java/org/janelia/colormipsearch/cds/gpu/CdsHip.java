@@ -40,6 +40,8 @@ final class CdsHip {
     static native void libraryUpload(long lib, long first, long count, ByteBuffer directRgb);
     /** directGrad (count x w*h unsigned shorts, native order) and directZgapRgb may each be null. */
     static native void libraryUploadVariants(long lib, long first, long count, ByteBuffer directGrad, ByteBuffer directZgapRgb);
+    /** a GRAY8 gradient image (imageprocessing/ByteImageArray): widened into the 16-bit plane the scorer reads. */
+    static native void libraryUploadGradientU8(long lib, long first, long count, ByteBuffer directGrad8);
     static native void libraryMakeZgapVariants(long lib, long first, long count, int threshold, double radius, int[] rectsXYXY);
     static native void search(long maskset, long lib, long first, long count, int[] scores, byte[] mirrored);
 

@@ -55,6 +55,21 @@ int main() {
         std::vector<int32_t> tk, sk;
         pm->searchLibraryTopK(slib, 0, 4, 2, tk, sk);
         if (tk[0] != 0 || tk[1] != 3 || (sk[0] & 0x7fffffff) != scores[0]) return 9;
+        // a growable library started far too small holds the same targets and scans the same (round 5: the reference's MIP cache sizes itself
+        // with use); the context's block cache can be trimmed and capped
+        {
+            cds::SparseLibrary tiny(ctx, W, H, 1, 1000);
+            tiny.setGrowable();
+            tiny.appendFrom(lib, 0, 3);
+            tiny.append(1, flipped.rgb.data());
+            if (tiny.size() != 4 || tiny.pixels() != slib.pixels() || tiny.capacityImages() < 4 || tiny.capacityPixels() < tiny.pixels()) return 19;
+            std::vector<int32_t> gs;
+            std::vector<uint8_t> gm;
+            pm->searchLibrary(tiny, 0, 4, gs, gm);
+            if (gs != scores || gm != mirrored) return 20;
+            (void)ctx.trim();
+            ctx.setCacheLimit((uint64_t)6 << 30);
+        }
 
         // the same library cut into two shards over two contexts (of the one GPU: the rehearsal path of cds_comm)
         {

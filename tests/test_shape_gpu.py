@@ -107,6 +107,31 @@ def test_synthetic_pairs_parity(cds, oracle):
     assert (gap[0], high[0], mir[0]) == (-1, -1, False) and gap[1] >= 0
 
 
+def test_gray8_gradient_images(cds, fixtures, oracle):
+    """The reference's scorer reads the gradient through ImageArray.get, so a GRAY8 gradient (ByteImageArray.java:3-16) is as good as a GRAY16
+    one; the C ABI widens it (cds_library_upload_gradient_u8).  The reference's own gradient fixtures clipped to 8 bits, two slots, against the
+    oracle fed the same values, and against the 16-bit upload of the same clipped image."""
+    keys = ("lm_VT033614", "lm_BJD")
+    g8 = np.stack([np.minimum(fixtures["grad_VT033614"], 255).astype(np.uint8), np.minimum(fixtures["grad_BJD"], 255).astype(np.uint8)])
+    targets = np.stack([fixtures[k] for k in keys])
+    lib8, lib16 = cds.Library(W, H, 2), cds.Library(W, H, 2)
+    for lib, g in ((lib8, g8), (lib16, g8.astype(np.uint16))):
+        lib.upload(0, targets)
+        lib.upload_variants(0, gradients=g)
+        lib.make_zgap_variants(0, 2, 20, 10, cds.label_regions)
+    grads, zgaps = lib8.download_variants(0, 2)
+    assert grads.dtype == np.uint16 and np.array_equal(grads, g8)
+    alg = cds.Shape2DMatchColorDepthSearchAlgorithm(fixtures["em_12191"], 20, True, None, cds.label_regions)
+    got8, got16 = alg.scoreLibraryPairs(lib8, [0, 0], [0, 1]), alg.scoreLibraryPairs(lib16, [0, 0], [0, 1])
+    for a, b in zip(got8, got16):
+        assert np.array_equal(a, b)
+    sq = oracle.ShapeQuery(fixtures["em_12191"], 20, True, E.STD_RECTS, None)
+    for t in range(2):
+        want = sq.score(targets[t], grads[t], zgaps[t])
+        assert (int(got8[0][t]), int(got8[1][t]), bool(got8[2][t])) == (want[0], want[1], want[3]), t
+    assert int(got8[0][0]) > 0
+
+
 def test_device_side_zgap_variants(cds, fixtures, oracle):
     """ZGapImage variants generated on the device from resident targets equal the reference's CPU construction, and
     scoring through them reproduces the goldens (12191 x VT033614 -> 21365 / 731, Shape2DMatch...Test.java:86-94)."""
