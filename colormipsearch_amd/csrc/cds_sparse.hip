@@ -1334,12 +1334,17 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                         const uint32_t band = (rec >> kRecBandShift) & kRecBandMask;
                         const bool bright = (rec & 255u) > thr;
                         uint32_t bin = ((__umul24(band, 13u) >> 6) << kSparseGroupBinsLog2) + (uint32_t)(hf * (float)kSparseGroupBins);
-                        bin = bright ? bin : 0u;
+                        if (!PF) bin = bright ? bin : 0u;   // (with the union map a dim pixel fails the map test below and reads byte 0 anyway)
                         bool passp = true, passm = MIRROR;
+                        uint32_t bitp = 1u, bitm = MIRROR ? 1u : 0u;   // the union map's verdict as 0 / 1 (round 5: the offsets are MULTIPLIED by it --
+                                                                      // hipcc turned the select into an exec-mask region per gather: a vector ->
+                                                                      // scalar -> vector hop four times per block)
                         if (PF) {
                             const uint32_t cband = bright ? band : 3u;  // bit 3 is never set (v_bfe takes the band mod 32)
-                            passp = __builtin_amdgcn_ubfe(up4[j], cband, 1u) != 0;
-                            if (MIRROR) passm = __builtin_amdgcn_ubfe(um4[j], cband, 1u) != 0;
+                            bitp = __builtin_amdgcn_ubfe(up4[j], cband, 1u);
+                            if (MIRROR) bitm = __builtin_amdgcn_ubfe(um4[j], cband, 1u);
+                            passp = bitp != 0, passm = bitm != 0;
+                            (void)passp, (void)passm;
                         }
                         wp4[j] = 0, wm4[j] = 0;
 #if defined(SM_EXP) && SM_EXP == 2   // (timing experiment: no map loads at all -- the floor of stage 1)
@@ -1352,14 +1357,14 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                         // stroke, and of its neighbours in depth -- read neighbouring BYTES, so the active lanes of a gather touch a handful
                         // of lines instead of one per cell (this kernel waits for the number of distinct lines its gathers touch)
                         const uint32_t rowbin = __umul24(rowq4[j], 7u * kSparseGroupBins) + bin;
-                        const uint32_t offp = passp ? __umul24(rowbin, nwpr) + cellp4[j] : 0u;
+                        const uint32_t offp = __umul24(__umul24(rowbin, nwpr) + cellp4[j], bitp);   // (< 2^24: the map is a few MB)
 #else
                         const uint32_t offp = passp ? __umul24(cellp4[j], 7u * kSparseGroupBins) + bin : 0u;
 #endif
                         wp4[j] = __builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)offp, 0, 0);
                         if (MIRROR) {
 #if SM_TMAP_BINROWS
-                            const uint32_t offm = passm ? __umul24(rowbin, nwpr) + cellm4[j] : 0u;
+                            const uint32_t offm = __umul24(__umul24(rowbin, nwpr) + cellm4[j], bitm);
 #else
                             const uint32_t offm = passm ? __umul24(cellm4[j], 7u * kSparseGroupBins) + bin : 0u;
 #endif
