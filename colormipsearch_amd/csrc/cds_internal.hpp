@@ -311,7 +311,7 @@ struct SparseScanParams {
 // can matter to.
 constexpr int kSparseGroupMasks = 8;
 #ifndef SP_BINS_LOG2
-#define SP_BINS_LOG2 6
+#define SP_BINS_LOG2 7
 #endif
 constexpr int kSparseGroupBinsLog2 = SP_BINS_LOG2;
 constexpr int kSparseGroupBins = 1 << kSparseGroupBinsLog2;   // hue bins per class in the group's map (7 x 64 bytes per cell; class 0 is never set)

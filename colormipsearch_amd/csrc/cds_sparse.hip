@@ -1339,6 +1339,7 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                         uint32_t bitp = 1u, bitm = MIRROR ? 1u : 0u;   // the union map's verdict as 0 / 1 (round 5: the offsets are MULTIPLIED by it --
                                                                       // hipcc turned the select into an exec-mask region per gather: a vector ->
                                                                       // scalar -> vector hop four times per block)
+
                         if (PF) {
                             const uint32_t cband = bright ? band : 3u;  // bit 3 is never set (v_bfe takes the band mod 32)
                             bitp = __builtin_amdgcn_ubfe(up4[j], cband, 1u);
@@ -1357,14 +1358,14 @@ __global__ __launch_bounds__(1024, 8) void sparse_multi_kernel(SparseMultiParams
                         // stroke, and of its neighbours in depth -- read neighbouring BYTES, so the active lanes of a gather touch a handful
                         // of lines instead of one per cell (this kernel waits for the number of distinct lines its gathers touch)
                         const uint32_t rowbin = __umul24(rowq4[j], 7u * kSparseGroupBins) + bin;
-                        const uint32_t offp = __umul24(__umul24(rowbin, nwpr) + cellp4[j], bitp);   // (< 2^24: the map is a few MB)
+                        const uint32_t offp = (__umul24(rowbin, nwpr) + cellp4[j]) & (0u - bitp);   // (an AND, not a 24-bit multiply: a full-frame mask's map exceeds 2^24 bytes)
 #else
                         const uint32_t offp = passp ? __umul24(cellp4[j], 7u * kSparseGroupBins) + bin : 0u;
 #endif
                         wp4[j] = __builtin_amdgcn_raw_buffer_load_b8(tmap_rs, (int)offp, 0, 0);
                         if (MIRROR) {
 #if SM_TMAP_BINROWS
-                            const uint32_t offm = __umul24(__umul24(rowbin, nwpr) + cellm4[j], bitm);
+                            const uint32_t offm = (__umul24(rowbin, nwpr) + cellm4[j]) & (0u - bitm);
 #else
                             const uint32_t offm = passm ? __umul24(cellm4[j], 7u * kSparseGroupBins) + bin : 0u;
 #endif
