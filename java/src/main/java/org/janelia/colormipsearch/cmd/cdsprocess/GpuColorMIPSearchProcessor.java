@@ -115,15 +115,15 @@ public class GpuColorMIPSearchProcessor<M extends AbstractNeuronEntity, T extend
                         LOG.error("No input color depth image found for mask {}", queryMIP);
                         continue;
                     }
-                    ImageArray<?> qi_image = queryImage.getImageArray();
-                    if (search.targetCount() > 0 && (qi_image.getWidth() != search.getWidth() || qi_image.getHeight() != search.getHeight())) {
+                    ImageArray<?> queryArray = queryImage.getImageArray();
+                    if (search.targetCount() > 0 && (queryArray.getWidth() != search.getWidth() || queryArray.getHeight() != search.getHeight())) {
                         // every pair of THIS mask is the reference's "Invalid image size" error; the other masks of the set are not touched
                         LOG.warn("Error comparing mask {} with the resident targets: Invalid image size - target's image size ({}, {}) must match query's image size: ({}, {})",
-                                queryMIP, search.getWidth(), search.getHeight(), qi_image.getWidth(), qi_image.getHeight());
+                                queryMIP, search.getWidth(), search.getHeight(), queryArray.getWidth(), queryArray.getHeight());
                         continue;
                     }
                     setMIPs.add(queryMIP);
-                    setImages.add(qi_image);
+                    setImages.add(queryArray);
                 }
                 if (setMIPs.size() == MASKS_PER_SET || (qi == queryMIPs.size() && !setMIPs.isEmpty())) {
                     collectMatches(search, setMIPs, setImages, results);
