@@ -473,6 +473,53 @@ int cds_sparse_library_append_files(cds_sparse_library *sl, const char *const *p
     CDS_NOEXCEPT_END
 }
 
+// ---- the records of a decoded image, built on the HOST (round 5) -------------------------------------------------------------------
+// cds_sparse_library_append_files used to send every decoded frame (2 MB) to the device and convert it there: both compressed formats
+// then waited for the upload.  The decode threads now build the image's records themselves -- the format of
+// cds_internal.hpp / sparse_rows_kernel: strip by strip, row by row, x ascending; (x - strip start) << 22 | band << 16 | second << 8 |
+// max, bit 31 on the first record of its (strip, row) cell, one filler per empty cell -- and ~80 KB per image cross PCIe through the
+// import path, whose device-side validation (sparse_validate_kernel) checks every cell like any other imported shard.  The band is
+// made with the DEVICE's reciprocal table (cds_context::rcp: v_rcp_f32 of 0..255 as this GPU computes it) and the same single-precision
+// multiplies and truncation as px_record in cds_sparse.hip, so the records are bit-identical to the device-built ones (tests).
+struct HostRecords {
+    std::vector<uint32_t> rec;       // the image's records
+    std::vector<uint32_t> cells;     // [nstrips][H + 1] offsets of the (strip, row) cells
+};
+static void host_records_of_image(const uint8_t *rgb, int W, int H, int nstrips, int strip_w, uint32_t min_thr, const float *rcp, HostRecords &out) {
+    out.rec.clear();
+    out.cells.assign((size_t)nstrips * (H + 1), 0u);
+    for (int k = 0; k < nstrips; k++) {
+        const int x0 = k * strip_w, x1 = std::min(W, (k + 1) * strip_w);
+        for (int y = 0; y < H; y++) {
+            out.cells[(size_t)k * (H + 1) + y] = (uint32_t)out.rec.size();
+            const uint8_t *row = rgb + ((size_t)y * W + x0) * 3;
+            const size_t at = out.rec.size();
+            for (int x = x0; x < x1;) {
+                if (x + 8 <= x1) {   // eight black pixels at a time (a MIP is a few percent signal)
+                    uint64_t a, b, c;
+                    memcpy(&a, row, 8), memcpy(&b, row + 8, 8), memcpy(&c, row + 16, 8);
+                    if ((a | b | c) == 0) { x += 8, row += 24; continue; }
+                }
+                const uint32_t r = row[0], g = row[1], bl = row[2];
+                row += 3;
+                const uint32_t mx = std::max(r, std::max(g, bl)), mn = std::min(r, std::min(g, bl)), md = r + g + bl - mx - mn;
+                if (mx > md && mx > min_thr) {
+                    const uint32_t idx = (r > g ? 4u : 0u) | (g > bl ? 8u : 0u) | (bl > r ? 16u : 0u);
+                    const uint32_t cls = (0x03125460u >> idx) & 7u;
+                    volatile float hf = (float)md * rcp[mx];       // one IEEE single multiply, as the device's v_mul_f32
+                    volatile float h5 = hf * 5.0f;
+                    const uint32_t band = cls * 5u + (uint32_t)h5;
+                    out.rec.push_back((band << kRecBandShift) | (md << 8) | mx | ((uint32_t)(x - x0) << kRecXShift));
+                }
+                x++;
+            }
+            if (out.rec.size() == at) out.rec.push_back(kRecRowFlag);   // the filler of an empty cell
+            else out.rec[at] |= kRecRowFlag;
+        }
+        out.cells[(size_t)k * (H + 1) + H] = (uint32_t)out.rec.size();
+    }
+}
+
 static int append_files_impl(cds_sparse_library *sl, const char *const *paths, int64_t count, int32_t threads) {
     if (!sl || (count > 0 && !paths)) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (count < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "count is negative");
@@ -481,6 +528,92 @@ static int append_files_impl(cds_sparse_library *sl, const char *const *paths, i
     const int nthreads = std::max(1, std::min(threads > 0 ? threads : (int)std::thread::hardware_concurrency(), 64));
     const int64_t batch = 64;  // = the dense staging slots of cds_sparse_library_append_host
     const size_t img_bytes = (size_t)3 * sl->W * sl->H;
+    static const bool dense_upload = getenv("CDS_INGEST_DENSE_UPLOAD") != nullptr;   // (A/B: round 2's path -- decoded frames to the device, records made there)
+    if (!dense_upload) {
+        // ---- records built by the decode threads: two batches in flight (decode + build || upload + validate) ----
+        const int nstrips = sl->nstrips, strip_w = sl->strip_w, W = sl->W, H = sl->H;
+        const uint32_t min_thr = (uint32_t)sl->min_threshold;
+        const float *rcp = sl->ctx->rcp;
+        struct Batch {
+            std::vector<HostRecords> img;
+            std::vector<uint64_t> off;
+            std::vector<uint32_t> cells, rec;
+        } bt[2];
+        std::string first_err;
+        std::mutex err_mu;
+        auto decode_batch = [&](int64_t b0, int64_t nb, Batch &B) {
+            B.img.resize((size_t)nb);
+            std::atomic<int64_t> next{0};
+            auto worker = [&]() {
+                std::vector<uint8_t> file, frame;
+                for (int64_t i = next.fetch_add(1); i < nb; i = next.fetch_add(1)) {
+                    std::string err;
+                    ImgInfo info;
+                    bool ok = false;
+                    try {
+                        frame.resize(img_bytes);
+                        ok = read_file(paths[b0 + i], file, err) && image_probe(file.data(), file.size(), info, err);
+                        if (ok && (info.W != W || info.H != H || info.channels != 3 || info.bits != 8)) {
+                            err = "is not an 8-bit RGB image of the library's size";
+                            ok = false;
+                        }
+                        if (ok) ok = image_decode(file.data(), file.size(), info, frame.data(), err);
+                        if (ok) host_records_of_image(frame.data(), W, H, nstrips, strip_w, min_thr, rcp, B.img[(size_t)i]);
+                    } catch (const std::exception &e) {   // (an exception must not leave a worker thread)
+                        err = e.what();
+                        ok = false;
+                    }
+                    if (!ok) {
+                        std::lock_guard<std::mutex> lk(err_mu);
+                        if (first_err.empty()) first_err = std::string(paths[b0 + i]) + ": " + err;
+                    }
+                }
+            };
+            std::vector<std::thread> pool;
+            try {
+                for (int t = 1; t < std::min<int64_t>(nthreads, nb); t++) pool.emplace_back(worker);
+            } catch (const std::exception &) {   // (fewer threads than asked for: the ones that started do the work)
+            }
+            worker();
+            for (auto &th : pool) th.join();
+            if (!first_err.empty()) return;
+            // the batch as ONE import: image offsets, cell offsets, records back to back
+            const size_t cells = (size_t)nstrips * (H + 1);
+            B.off.assign((size_t)nb + 1, 0);
+            for (int64_t i = 0; i < nb; i++) B.off[(size_t)i + 1] = B.off[(size_t)i] + B.img[(size_t)i].rec.size();
+            B.cells.resize((size_t)nb * cells);
+            B.rec.resize((size_t)B.off[(size_t)nb]);
+            for (int64_t i = 0; i < nb; i++) {
+                memcpy(B.cells.data() + (size_t)i * cells, B.img[(size_t)i].cells.data(), cells * sizeof(uint32_t));
+                memcpy(B.rec.data() + B.off[(size_t)i], B.img[(size_t)i].rec.data(), B.img[(size_t)i].rec.size() * sizeof(uint32_t));
+            }
+        };
+        int rc_gpu = CDS_OK;
+        std::string gpu_err;
+        std::thread gpu;
+        struct Joiner {
+            std::thread &t;
+            ~Joiner() { if (t.joinable()) t.join(); }
+        } joiner{gpu};
+        static const bool decode_only = getenv("CDS_INGEST_DECODE_ONLY") != nullptr;   // (measurement: host decode + record building alone)
+        for (int64_t b0 = 0, k = 0; b0 < count; b0 += batch, k++) {
+            const int64_t nb = std::min(batch, count - b0);
+            // (batch k decodes into the buffers of batch k - 2, whose import was joined before batch k - 1's was started)
+            Batch &B = bt[k & 1];
+            decode_batch(b0, nb, B);
+            if (gpu.joinable()) gpu.join();
+            if (!first_err.empty()) return fail(CDS_ERR_INVALID_ARGUMENT, first_err);
+            if (rc_gpu) return fail(rc_gpu, gpu_err);
+            if (decode_only) continue;
+            gpu = std::thread([sl, nb, &B, nstrips, strip_w, &rc_gpu, &gpu_err]() {
+                rc_gpu = cds_sparse_library_import(sl, nb, B.off.data(), B.cells.data(), B.rec.data(), nstrips, strip_w, sl->min_threshold);
+                if (rc_gpu) gpu_err = cds_last_error();   // (the message is thread-local: carry it over)
+            });
+        }
+        if (gpu.joinable()) gpu.join();
+        if (rc_gpu) return fail(rc_gpu, gpu_err);
+        return CDS_OK;
+    }
     // the decoded batches live in pinned host memory: the upload is then one DMA at PCIe rate (pageable memory: 17 GB/s)
     struct Pinned {
         uint8_t *p = nullptr;

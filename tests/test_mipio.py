@@ -198,6 +198,26 @@ def test_append_files_to_sparse_library(tmp_path, fixtures):
     for i in range(150):
         if i % 4 in want:
             assert (int(scores[0, i]), bool(mir[0, i])) == want[i % 4], i
+    # round 5: the decode threads build the records on the host (the device's reciprocal table, the device's arithmetic); they are
+    # bit-identical to the records the device makes from the same frames, here on the reference's four LM images and on dense-uniform
+    # noise (every hue class, ties, thresholds) at a minimum data threshold
+    dev = cds.SparseLibrary(1210, 566, 8, 8 * 700000, density_limit=2.0, min_threshold=7)
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 256, size=(2, 566, 1210, 3), dtype=np.uint8)
+    noise[0, ::3] = 0
+    frames = np.concatenate([np.stack([fixtures[k] for k in keys]), noise])
+    dev.append(frames)
+    npaths = []
+    for i in range(len(frames)):
+        p = tmp_path / f"cmp{i}.tif"
+        PIL.fromarray(frames[i], "RGB").save(p, compression="packbits")
+        npaths.append(str(p))
+    host = cds.SparseLibrary(1210, 566, 8, 8 * 700000, density_limit=2.0, min_threshold=7)
+    host.append_files(npaths, threads=3)
+    assert len(host) == len(dev) == 6 and host.pixels == dev.pixels
+    for i in range(6):
+        (ra, ca), (rb, cb) = host.image_records(i), dev.image_records(i)
+        assert np.array_equal(ra, rb) and np.array_equal(ca, cb), i
     bad = tmp_path / "bad.tif"
     bad.write_bytes(open(paths[0], "rb").read()[:5000])
     with pytest.raises(cds.CdsError, match="bad.tif"):
