@@ -75,6 +75,7 @@ SIGNATURES = {
     "cds_library_download": (_i, [_vp, _i64, _i64, _u8p]),
     "cds_library_upload_variants": (_i, [_vp, _i64, _i64, _u16p, _u8p]),
     "cds_library_upload_gradient_u8": (_i, [_vp, _i64, _i64, _u8p]),
+    "cds_library_load_files": (_i, [_vp, _i64, _i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p), _i32]),
     "cds_library_download_variants": (_i, [_vp, _i64, _i64, _u16p, _u8p]),
     "cds_library_generate_synthetic": (_i, [_vp, ctypes.c_uint64, _i64, _i64, _i64, _i32, _i32]),
     "cds_library_generate_synthetic_list": (_i, [_vp, ctypes.c_uint64, _i64p, _i64, _i64, _i32, _i32]),

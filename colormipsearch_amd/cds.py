@@ -325,6 +325,21 @@ class Library:
             return
         capi.check(self._lib.cds_library_upload_variants(self._h, int(first), n, gp, zp))
 
+    def load_files(self, first, target_paths, gradient_paths=None, zgap_paths=None, threads=0):
+        """Slots first.. straight from files: the targets (8-bit RGB), their GradientImage (8- / 16-bit gray; None entry = none: the slot's
+        pairs score (-1, -1)) and ZGapImage files (8-bit RGB; None entry = none), decoded natively on `threads` host threads while the
+        previous 64 slots are uploaded (cds_library_load_files)."""
+        n = len(target_paths)
+
+        def arr(paths):
+            if paths is None:
+                return None
+            if len(paths) != n:
+                raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "one path (or None) per target")
+            return (ctypes.c_char_p * max(1, n))(*[None if p is None else os.fsencode(p) for p in paths])
+
+        capi.check(self._lib.cds_library_load_files(self._h, int(first), n, arr(target_paths), arr(gradient_paths), arr(zgap_paths), int(threads)))
+
     def download_variants(self, first, count):
         g = np.empty((int(count), self.height, self.width), dtype=np.uint16)
         z = np.empty((int(count), self.height, self.width, 3), dtype=np.uint8)

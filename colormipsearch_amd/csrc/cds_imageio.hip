@@ -685,4 +685,120 @@ static int append_files_impl(cds_sparse_library *sl, const char *const *paths, i
     return CDS_OK;
 }
 
+int cds_library_load_files(cds_library *lib, int64_t first, int64_t count, const char *const *target_paths,
+                           const char *const *gradient_paths, const char *const *zgap_paths, int32_t threads) {
+    CDS_NOEXCEPT_BEGIN
+    if (!lib || (count > 0 && !target_paths)) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (first < 0 || count < 0 || first + count > lib->capacity) return fail(CDS_ERR_INVALID_ARGUMENT, "slot range outside the library");
+    if (count == 0) return CDS_OK;
+    const int W = lib->W, H = lib->H;
+    const size_t px = (size_t)W * H, rgb_bytes = 3 * px, grad_bytes = 2 * px;
+    const int nthreads = std::max(1, std::min(threads > 0 ? threads : (int)std::thread::hardware_concurrency(), 64));
+    const int64_t batch = 64;
+    const bool any_grad = gradient_paths != nullptr, any_zgap = zgap_paths != nullptr;
+    struct Pinned {
+        uint8_t *p = nullptr;
+        ~Pinned() { if (p) hipHostFree(p); }
+    } tb[2], gb[2], zb[2];
+    CDS_HIP(hipSetDevice(lib->ctx->device));
+    for (int k = 0; k < (count > batch ? 2 : 1); k++) {
+        const size_t n = (size_t)std::min(batch, count);
+        CDS_HIP(hipHostMalloc((void **)&tb[k].p, n * rgb_bytes, hipHostMallocDefault));
+        if (any_grad) CDS_HIP(hipHostMalloc((void **)&gb[k].p, n * grad_bytes, hipHostMallocDefault));
+        if (any_zgap) CDS_HIP(hipHostMalloc((void **)&zb[k].p, n * rgb_bytes, hipHostMallocDefault));
+    }
+    std::string first_err;
+    std::mutex err_mu;
+    // one work item = one FILE (three per slot): the pool is busy even when a batch holds fewer slots than threads
+    auto decode_batch = [&](int64_t b0, int64_t nb, int k) {
+        std::atomic<int64_t> next{0};
+        auto worker = [&]() {
+            std::vector<uint8_t> file, tmp8;
+            for (int64_t w = next.fetch_add(1); w < 3 * nb; w = next.fetch_add(1)) {
+                const int64_t i = w / 3;
+                const int kind = (int)(w % 3);   // 0 target, 1 gradient, 2 zgap
+                const char *path = kind == 0 ? target_paths[b0 + i] : kind == 1 ? (any_grad ? gradient_paths[b0 + i] : nullptr) : (any_zgap ? zgap_paths[b0 + i] : nullptr);
+                if (!path) {
+                    if (kind == 0) {
+                        std::lock_guard<std::mutex> lk(err_mu);
+                        if (first_err.empty()) first_err = "a target path is NULL";
+                    } else if (kind == 1 && any_grad) memset(gb[k].p + (size_t)i * grad_bytes, 0, grad_bytes);
+                    else if (kind == 2 && any_zgap) memset(zb[k].p + (size_t)i * rgb_bytes, 0, rgb_bytes);
+                    continue;
+                }
+                std::string err;
+                ImgInfo info;
+                bool ok = false;
+                try {
+                    ok = read_file(path, file, err) && image_probe(file.data(), file.size(), info, err);
+                    if (ok && (info.W != W || info.H != H)) {
+                        err = "image size differs from the library's";
+                        ok = false;
+                    }
+                    if (ok && kind != 1) {
+                        if (info.channels != 3 || info.bits != 8) { err = "is not an 8-bit RGB image"; ok = false; }
+                        else ok = image_decode(file.data(), file.size(), info, (kind == 0 ? tb[k].p : zb[k].p) + (size_t)i * rgb_bytes, err);
+                    } else if (ok) {
+                        uint16_t *dst = reinterpret_cast<uint16_t *>(gb[k].p + (size_t)i * grad_bytes);
+                        if (info.channels != 1) { err = "gradient image must be grayscale"; ok = false; }
+                        else if (info.bits == 16) ok = image_decode(file.data(), file.size(), info, dst, err);
+                        else if (info.bits == 8) {   // GRAY8: widened (ImageArray.get semantics, ByteImageArray.java:3-16)
+                            tmp8.resize(px);
+                            ok = image_decode(file.data(), file.size(), info, tmp8.data(), err);
+                            if (ok) for (size_t q = 0; q < px; q++) dst[q] = tmp8[q];
+                        } else { err = "gradient image must be 8- or 16-bit"; ok = false; }
+                    }
+                } catch (const std::exception &e) {   // (an exception must not leave a worker thread)
+                    err = e.what();
+                    ok = false;
+                }
+                if (!ok) {
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    if (first_err.empty()) first_err = std::string(path) + ": " + err;
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        try {
+            for (int t = 1; t < std::min<int64_t>(nthreads, 3 * nb); t++) pool.emplace_back(worker);
+        } catch (const std::exception &) {
+        }
+        worker();
+        for (auto &th : pool) th.join();
+    };
+    int rc_gpu = CDS_OK;
+    std::string gpu_err;
+    std::thread gpu;
+    struct Joiner {
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{gpu};
+    for (int64_t b0 = 0, k = 0; b0 < count; b0 += batch, k++) {
+        const int64_t nb = std::min(batch, count - b0);
+        const int kk = (int)(k & 1);
+        decode_batch(b0, nb, kk);   // (into the buffers of batch k - 2, whose upload was joined before batch k - 1's was started)
+        if (gpu.joinable()) gpu.join();
+        if (!first_err.empty()) return fail(CDS_ERR_INVALID_ARGUMENT, first_err);
+        if (rc_gpu) return fail(rc_gpu, gpu_err);
+        gpu = std::thread([&, b0, nb, kk]() {
+            int rc = cds_library_upload(lib, first + b0, nb, tb[kk].p);
+            if (rc == CDS_OK && (any_grad || any_zgap))
+                rc = cds_library_upload_variants(lib, first + b0, nb, any_grad ? reinterpret_cast<const uint16_t *>(gb[kk].p) : nullptr, any_zgap ? zb[kk].p : nullptr);
+            if (rc == CDS_OK) {   // a slot whose variant file was not given has none (the upload marked the whole range)
+                std::lock_guard<std::mutex> lk(lib->mu);
+                for (int64_t i = 0; i < nb; i++) {
+                    if (any_grad && !gradient_paths[b0 + i]) lib->has_grad[(size_t)(first + b0 + i)] = 0;
+                    if (any_zgap && !zgap_paths[b0 + i]) lib->has_zgap[(size_t)(first + b0 + i)] = 0;
+                }
+            }
+            rc_gpu = rc;
+            if (rc) gpu_err = cds_last_error();
+        });
+    }
+    if (gpu.joinable()) gpu.join();
+    if (rc_gpu) return fail(rc_gpu, gpu_err);
+    return CDS_OK;
+    CDS_NOEXCEPT_END
+}
+
 }  // extern "C"

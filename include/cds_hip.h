@@ -241,6 +241,16 @@ int cds_image_decode(const uint8_t *data, size_t size, void *out, size_t out_byt
  * cannot be read / decoded (its path is in cds_last_error()); batches appended before it stay.  A density refusal
  * (CDS_ERR_UNSUPPORTED, tested per batch of 64 files) removes everything the call had appended. */
 int cds_sparse_library_append_files(cds_sparse_library *slib, const char *const *paths, int64_t count, int32_t threads);
+/* Kernel 2's inputs straight from files into resident dense slots [first, first + count): slot first + i gets the target image
+ * target_paths[i] (8-bit RGB), its GradientImage gradient_paths[i] (8- or 16-bit gray; a NULL entry, or gradient_paths == NULL, leaves the
+ * slot without a gradient: its pairs score (-1, -1), Shape2DMatchColorDepthSearchAlgorithm.java:155-158) and its ZGapImage zgap_paths[i]
+ * (8-bit RGB; NULL: the slot has no zgap -- the caller may make one on the device, cds_library_make_zgap_variants, as the reference's
+ * tests do).  What CalculateGradientScoresCmd does per match through NeuronMIPUtils.loadComputeFile (tools cmd/CalculateGradientScoresCmd
+ * .java:541-586, API/mips/NeuronMIPUtils.java:36-103), for a whole batch: the files are decoded on `threads` host threads (<= 0: all
+ * cores) into pinned memory, 64 slots at a time, while the previous 64 are uploaded.  Fails at the first file that cannot be read or
+ * has another size (its path is in cds_last_error()); slots loaded before it stay. */
+int cds_library_load_files(cds_library *lib, int64_t first, int64_t count, const char *const *target_paths,
+                           const char *const *gradient_paths, const char *const *zgap_paths, int32_t threads);
 
 /* The scan over images [first, first+count) of a sparse library: same outputs as cds_search / cds_search_device /
  * cds_search_counts. */
