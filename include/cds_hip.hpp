@@ -82,6 +82,12 @@ public:
     void uploadVariants(int64_t first, int64_t count, const uint16_t *grad, const uint8_t *zgap) {
         check(cds_library_upload_variants(lib_, first, count, grad, zgap));
     }
+    // targets + their GradientImage / ZGapImage files (either vector may be empty, single entries NULL) decoded natively into the slots
+    void loadFiles(int64_t first, const std::vector<const char *> &targets, const std::vector<const char *> &gradients,
+                   const std::vector<const char *> &zgaps, int threads = 0) {
+        check(cds_library_load_files(lib_, first, (int64_t)targets.size(), targets.data(), gradients.empty() ? nullptr : gradients.data(),
+                                     zgaps.empty() ? nullptr : zgaps.data(), threads));
+    }
     void uploadGradientU8(int64_t first, int64_t count, const uint8_t *grad8) {   // a GRAY8 gradient image (ByteImageArray.java:3-16)
         check(cds_library_upload_gradient_u8(lib_, first, count, grad8));
     }

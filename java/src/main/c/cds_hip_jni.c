@@ -217,6 +217,51 @@ JNIEXPORT void JNICALL CLS(sparseLibraryAppend)(JNIEnv *env, jclass c, jlong sl,
     int rc = cds_sparse_library_append_host(P(cds_sparse_library, sl), count, px);
     if (rc) throw_for(env, rc);
 }
+/* a String[] as a malloc'ed array of strdup'ed UTF-8 paths (NULL elements stay NULL when allow_null); every local reference is dropped
+ * inside the loop: a library has millions of files and the local-reference table holds a few hundred entries.  NULL on failure. */
+static const char **copy_paths(JNIEnv *env, jobjectArray paths, jsize n, int allow_null) {
+    const char **cp = (const char **)calloc((size_t)n + 1, sizeof(char *));
+    if (!cp) return NULL;
+    for (jsize i = 0; i < n; i++) {
+        jstring str = (jstring)(*env)->GetObjectArrayElement(env, paths, i);
+        const char *u = str ? (*env)->GetStringUTFChars(env, str, NULL) : NULL;
+        if (u) {
+            cp[i] = strdup(u);
+            (*env)->ReleaseStringUTFChars(env, str, u);
+        }
+        if (str) (*env)->DeleteLocalRef(env, str);
+        if (!cp[i] && !(allow_null && !str)) {
+            for (jsize k = 0; k < i; k++) free((void *)cp[k]);
+            free(cp);
+            return NULL;
+        }
+    }
+    return cp;
+}
+static void free_paths(const char **cp, jsize n) {
+    if (!cp) return;
+    for (jsize i = 0; i < n; i++) free((void *)cp[i]);
+    free(cp);
+}
+/* cds_library_load_files: slots first.. from the targets' files and their GradientImage / ZGapImage files (either array, or single
+ * elements, may be null: no such variant) */
+JNIEXPORT void JNICALL CLS(libraryLoadFiles)(JNIEnv *env, jclass c, jlong lib, jlong first, jobjectArray targets, jobjectArray gradients, jobjectArray zgaps, jint threads) {
+    if (!targets) { throw_iae(env, "targets is null"); return; }
+    jsize n = (*env)->GetArrayLength(env, targets);
+    if ((gradients && (*env)->GetArrayLength(env, gradients) != n) || (zgaps && (*env)->GetArrayLength(env, zgaps) != n)) {
+        throw_iae(env, "gradients / zgaps must have one entry (or null) per target");
+        return;
+    }
+    const char **tp = copy_paths(env, targets, n, 0);
+    const char **gp = gradients ? copy_paths(env, gradients, n, 1) : NULL;
+    const char **zp = zgaps ? copy_paths(env, zgaps, n, 1) : NULL;
+    int rc = (!tp || (gradients && !gp) || (zgaps && !zp)) ? CDS_ERR_INVALID_ARGUMENT : cds_library_load_files(P(cds_library, lib), first, n, tp, gp, zp, threads);
+    free_paths(tp, n);
+    free_paths(gp, n);
+    free_paths(zp, n);
+    if (rc == CDS_ERR_INVALID_ARGUMENT && (!tp || (gradients && !gp) || (zgaps && !zp))) { throw_iae(env, "a path is null or not a valid string"); return; }
+    if (rc) throw_for(env, rc);
+}
 JNIEXPORT void JNICALL CLS(sparseLibraryAppendFiles)(JNIEnv *env, jclass c, jlong sl, jobjectArray paths, jint threads) {
     if (!paths) { throw_iae(env, "paths is null"); return; }
     jsize n = (*env)->GetArrayLength(env, paths);

@@ -42,6 +42,12 @@ final class CdsHip {
     static native void libraryUploadVariants(long lib, long first, long count, ByteBuffer directGrad, ByteBuffer directZgapRgb);
     /** a GRAY8 gradient image (imageprocessing/ByteImageArray): widened into the 16-bit plane the scorer reads. */
     static native void libraryUploadGradientU8(long lib, long first, long count, ByteBuffer directGrad8);
+    /**
+     * Slots first.. straight from files: the targets, their GradientImage and ZGapImage files (arrays or single entries may be null: the
+     * slot has no such variant), decoded on native threads while the previous 64 slots are uploaded -- the batch form of the per-match
+     * NeuronMIPUtils.loadComputeFile calls of cmd/CalculateGradientScoresCmd.java:541-586.
+     */
+    static native void libraryLoadFiles(long lib, long first, String[] targets, String[] gradients, String[] zgaps, int threads);
     static native void libraryMakeZgapVariants(long lib, long first, long count, int threshold, double radius, int[] rectsXYXY);
     static native void search(long maskset, long lib, long first, long count, int[] scores, byte[] mirrored);
 
