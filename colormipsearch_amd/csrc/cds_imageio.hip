@@ -8,6 +8,7 @@
 // RGBA 8, palette 8).  Everything else is refused with a message (no silent fallback).
 // cds_sparse_library_append_files decodes on `threads` host threads, two batches in flight: one being decoded while the
 // previous one is uploaded and turned into signal-pixel records on the GPU.
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -18,7 +19,9 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "cds_internal.hpp"
@@ -26,6 +29,90 @@
 namespace cds {
 
 constexpr uint32_t kMaxImageSide = 16384;  // (a header is untrusted input: bounds the buffers a file can make us allocate)
+
+// Pinned host buffers of the file loaders, kept between calls: pinning memory costs the driver ~0.15 ms per MB (a call of
+// cds_library_load_files over 64-slot batches pins ~700 MB: 100 ms, as long as decoding its files), so a released buffer waits here for
+// the next call that fits it (up to 2 GB idle; process lifetime).
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<uint8_t *, size_t>> idle;
+    size_t idle_bytes = 0;
+    uint8_t *get(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t best = SIZE_MAX, at = 0;
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].second >= bytes && idle[i].second < best) best = idle[i].second, at = i;
+            if (best != SIZE_MAX && best <= 2 * bytes + ((size_t)1 << 20)) {
+                uint8_t *p = idle[at].first;
+                sizes_[p] = best;
+                idle.erase(idle.begin() + (std::ptrdiff_t)at);
+                idle_bytes -= best;
+                return p;
+            }
+        }
+        uint8_t *p = nullptr;
+        if (hipHostMalloc((void **)&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+        std::lock_guard<std::mutex> lk(mu);
+        sizes_[p] = bytes;
+        return p;
+    }
+    void put(uint8_t *p) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = sizes_.find(p);
+            const size_t b = it == sizes_.end() ? 0 : it->second;
+            if (it != sizes_.end()) sizes_.erase(it);
+            if (b && idle_bytes + b <= ((size_t)2 << 30)) {
+                idle.push_back({p, b});
+                idle_bytes += b;
+                return;
+            }
+        }
+        hipHostFree(p);
+    }
+    std::unordered_map<uint8_t *, size_t> sizes_;
+};
+static PinnedPool g_pinned;
+
+// One-shot zlib-stream decompression into a buffer of known size (a PNG's filtered scanlines, a Deflate TIFF strip).  libdeflate -- present
+// in the image as libdeflate.so.0, no headers: bound by dlopen, three functions of its stable C API -- inflates 2-3x as fast as zlib, and a
+// 16-bit gradient PNG is 1.4 MB behind zlib: the whole cost of loading kernel 2's inputs from files.  zlib's uncompress stays
+// the fallback (no libdeflate, CDS_IMAGEIO_ZLIB=1, or libdeflate refusing a stream that zlib may still read).
+struct Deflater {
+    void *(*alloc)() = nullptr;
+    int (*zlib_decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    Deflater() {
+        if (getenv("CDS_IMAGEIO_ZLIB")) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (decltype(alloc))dlsym(h, "libdeflate_alloc_decompressor");
+        zlib_decompress = (decltype(zlib_decompress))dlsym(h, "libdeflate_zlib_decompress");
+        release = (decltype(release))dlsym(h, "libdeflate_free_decompressor");
+        if (!alloc || !zlib_decompress || !release) alloc = nullptr;
+    }
+};
+static bool zlib_inflate_exact(const uint8_t *src, size_t len, uint8_t *dst, size_t want) {
+    static const Deflater lib;
+    if (lib.alloc) {
+        struct Holder {   // one decompressor per thread, freed with the thread
+            void *d = nullptr;
+            void (*release)(void *) = nullptr;
+            ~Holder() { if (d && release) release(d); }
+        };
+        thread_local Holder hd;
+        if (!hd.d) hd.d = lib.alloc(), hd.release = lib.release;
+        if (hd.d) {
+            size_t got = 0;
+            if (lib.zlib_decompress(hd.d, src, len, dst, want, &got) == 0 && got == want) return true;   // (LIBDEFLATE_SUCCESS == 0)
+        }
+    }
+    uLongf got = (uLongf)want;
+    return uncompress(dst, &got, src, (uLong)len) == Z_OK && got == want;
+}
 
 struct ImgInfo {
     int W = 0, H = 0, channels = 0, bits = 0;  // channels of the DECODED image (alpha dropped, palette expanded)
@@ -256,10 +343,7 @@ static bool tiff_decode(const uint8_t *data, size_t n, const ImgInfo &info, void
             case 1: ok = len >= want; if (ok) memcpy(strip.data(), src, want); break;
             case 32773: ok = packbits_decode(src, len, strip.data(), want); break;
             case 5: ok = lzw_decode(src, len, strip.data(), want); break;
-            default: {
-                uLongf got = (uLongf)want;
-                ok = uncompress(strip.data(), &got, src, (uLong)len) == Z_OK && got == want;
-            }
+            default: ok = zlib_inflate_exact(src, len, strip.data(), want);
         }
         if (!ok) { err = "TIFF strip " + std::to_string(s) + " is truncated or corrupt"; return false; }
         for (size_t yy = 0; yy < rows; yy++) {
@@ -319,6 +403,50 @@ static bool png_head(const uint8_t *data, size_t n, PngHead &h, std::string &err
     return true;
 }
 
+// One scanline of a PNG, unfiltered.  One loop per filter type, and the left / up-left neighbours of the BPP byte lanes of a pixel are kept
+// in REGISTERS: read back from the row just written, every byte of a Sub / Average / Paeth row waits for a store-to-load forward (round 5:
+// 4.7 ms per 16-bit gradient image, more than twice its inflate).  The first pixel of a row has no left neighbour (a = c = 0).
+template <int BPP>
+static bool png_unfilter_row(int ft, const uint8_t *s, const uint8_t *pv, uint8_t *cu, size_t stride) {
+    uint8_t a[BPP], c[BPP];
+    for (int k = 0; k < BPP; k++) a[k] = c[k] = 0;
+    const size_t whole = stride / BPP * BPP;
+    switch (ft) {
+        case 0: memcpy(cu, s, stride); return true;
+        case 2:
+            for (size_t i = 0; i < stride; i++) cu[i] = (uint8_t)(s[i] + pv[i]);
+            return true;
+        case 1:
+            for (size_t i = 0; i < whole; i += BPP)
+                for (int k = 0; k < BPP; k++) cu[i + k] = a[k] = (uint8_t)(s[i + k] + a[k]);
+            return true;
+        case 3:
+            for (size_t i = 0; i < whole; i += BPP)
+                for (int k = 0; k < BPP; k++) cu[i + k] = a[k] = (uint8_t)(s[i + k] + ((a[k] + pv[i + k]) >> 1));
+            return true;
+        case 4:
+            // Paeth: the predictor is whichever of a (left), b (up), c (up-left) is nearest to a + b - c, ties in that order; written with the
+            // differences (pa = |b - c|, pb = |a - c|, pc = |a + b - 2c|) so that it compiles to compares and conditional moves
+            for (size_t i = 0; i < whole; i += BPP)
+                for (int k = 0; k < BPP; k++) {
+                    const int av = a[k], b = pv[i + k], cv = c[k];
+                    const int db = b - cv, da = av - cv, dc = db + da;
+                    const int pa = (db ^ (db >> 31)) - (db >> 31), pb = (da ^ (da >> 31)) - (da >> 31), pc = (dc ^ (dc >> 31)) - (dc >> 31);
+                    // selects as masks (hipcc's host compiler made BRANCHES of the conditional form: on a noisy ramp they mispredict every
+                    // other byte, 5.8 ns per byte): pred = pb < pa ? b : a, then pc < min(pa, pb) ? c : pred
+                    const int m1 = -(int)(pb < pa);
+                    const int best = (pa & ~m1) | (pb & m1);
+                    int pred = (av & ~m1) | (b & m1);
+                    const int m2 = -(int)(pc < best);
+                    pred = (pred & ~m2) | (cv & m2);
+                    cu[i + k] = a[k] = (uint8_t)(s[i + k] + pred);
+                    c[k] = (uint8_t)b;
+                }
+            return true;
+        default: return false;
+    }
+}
+
 static bool png_decode(const uint8_t *data, size_t n, const ImgInfo &info, void *outv, std::string &err) {
     PngHead h;
     if (!png_head(data, n, h, err)) return false;
@@ -335,8 +463,7 @@ static bool png_decode(const uint8_t *data, size_t n, const ImgInfo &info, void 
     const int src_ch = h.ctype == 0 || h.ctype == 3 ? 1 : h.ctype == 2 ? 3 : 4;
     const size_t bpp = (size_t)src_ch * h.depth / 8, stride = (size_t)h.W * bpp;
     std::vector<uint8_t> raw((stride + 1) * h.H);
-    uLongf got = (uLongf)raw.size();
-    if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size()) { err = "PNG data is truncated or corrupt"; return false; }
+    if (!zlib_inflate_exact(idat.data(), idat.size(), raw.data(), raw.size())) { err = "PNG data is truncated or corrupt"; return false; }
     if (h.ctype == 3 && plte.size() < 3) { err = "palette PNG without PLTE"; return false; }
     std::vector<uint8_t> prev(stride, 0), cur(stride);
     uint8_t *out = static_cast<uint8_t *>(outv);
@@ -344,22 +471,10 @@ static bool png_decode(const uint8_t *data, size_t n, const ImgInfo &info, void 
         const uint8_t *line = raw.data() + y * (stride + 1);
         const int ft = line[0];
         const uint8_t *s = line + 1;
-        for (size_t i = 0; i < stride; i++) {
-            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-            int v = s[i];
-            switch (ft) {
-                case 0: break;
-                case 1: v += a; break;
-                case 2: v += b; break;
-                case 3: v += (a + b) >> 1; break;
-                case 4: {
-                    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-                    v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                    break;
-                }
-                default: err = "PNG filter type out of range"; return false;
-            }
-            cur[i] = (uint8_t)v;
+        if (!(bpp == 1 ? png_unfilter_row<1>(ft, s, prev.data(), cur.data(), stride) : bpp == 2 ? png_unfilter_row<2>(ft, s, prev.data(), cur.data(), stride)
+              : bpp == 3 ? png_unfilter_row<3>(ft, s, prev.data(), cur.data(), stride) : png_unfilter_row<4>(ft, s, prev.data(), cur.data(), stride))) {
+            err = "PNG filter type out of range";
+            return false;
         }
         if (h.ctype == 0 && h.depth == 16) {
             uint16_t *o16 = reinterpret_cast<uint16_t *>(out) + y * h.W;
@@ -696,16 +811,17 @@ int cds_library_load_files(cds_library *lib, int64_t first, int64_t count, const
     const int nthreads = std::max(1, std::min(threads > 0 ? threads : (int)std::thread::hardware_concurrency(), 64));
     const int64_t batch = 64;
     const bool any_grad = gradient_paths != nullptr, any_zgap = zgap_paths != nullptr;
-    struct Pinned {
+    struct Pinned {   // (from the pool above: pinning ~700 MB per call would cost as much as decoding the call's files)
         uint8_t *p = nullptr;
-        ~Pinned() { if (p) hipHostFree(p); }
+        ~Pinned() { g_pinned.put(p); }
     } tb[2], gb[2], zb[2];
     CDS_HIP(hipSetDevice(lib->ctx->device));
     for (int k = 0; k < (count > batch ? 2 : 1); k++) {
         const size_t n = (size_t)std::min(batch, count);
-        CDS_HIP(hipHostMalloc((void **)&tb[k].p, n * rgb_bytes, hipHostMallocDefault));
-        if (any_grad) CDS_HIP(hipHostMalloc((void **)&gb[k].p, n * grad_bytes, hipHostMallocDefault));
-        if (any_zgap) CDS_HIP(hipHostMalloc((void **)&zb[k].p, n * rgb_bytes, hipHostMallocDefault));
+        bool ok = (tb[k].p = g_pinned.get(n * rgb_bytes)) != nullptr;
+        if (ok && any_grad) ok = (gb[k].p = g_pinned.get(n * grad_bytes)) != nullptr;
+        if (ok && any_zgap) ok = (zb[k].p = g_pinned.get(n * rgb_bytes)) != nullptr;
+        if (!ok) return fail(CDS_ERR_OUT_OF_MEMORY, "no pinned host memory for the decoded images");
     }
     std::string first_err;
     std::mutex err_mu;
@@ -773,11 +889,18 @@ int cds_library_load_files(cds_library *lib, int64_t first, int64_t count, const
         std::thread &t;
         ~Joiner() { if (t.joinable()) t.join(); }
     } joiner{gpu};
+    static const bool timed = getenv("CDS_TIME_LOAD") != nullptr;   // (diagnostic: decode / wait-for-upload seconds of the call on stderr)
+    double t_dec = 0, t_wait = 0;
+    const auto t_call = std::chrono::steady_clock::now();
     for (int64_t b0 = 0, k = 0; b0 < count; b0 += batch, k++) {
         const int64_t nb = std::min(batch, count - b0);
         const int kk = (int)(k & 1);
+        const auto t0 = std::chrono::steady_clock::now();
         decode_batch(b0, nb, kk);   // (into the buffers of batch k - 2, whose upload was joined before batch k - 1's was started)
+        const auto t1 = std::chrono::steady_clock::now();
         if (gpu.joinable()) gpu.join();
+        t_dec += std::chrono::duration<double>(t1 - t0).count();
+        t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
         if (!first_err.empty()) return fail(CDS_ERR_INVALID_ARGUMENT, first_err);
         if (rc_gpu) return fail(rc_gpu, gpu_err);
         gpu = std::thread([&, b0, nb, kk]() {
@@ -796,6 +919,9 @@ int cds_library_load_files(cds_library *lib, int64_t first, int64_t count, const
         });
     }
     if (gpu.joinable()) gpu.join();
+    if (timed)
+        fprintf(stderr, "[cds load_files] %lld slots: %.3f s (decode %.3f s, waiting for uploads %.3f s, %d threads)\n", (long long)count,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count(), t_dec, t_wait, nthreads);
     if (rc_gpu) return fail(rc_gpu, gpu_err);
     return CDS_OK;
     CDS_NOEXCEPT_END

@@ -797,11 +797,12 @@ class GpuColorMIPSearchProcessor:
         is_path = lambda x: x is None or isinstance(x, (str, bytes, os.PathLike))
         # Round 5: plain files go through the library's own batch loader (cds_library_load_files: the three files of every target decoded on
         # native threads straight into pinned memory, 64 slots in flight behind the decode) and batch i + 1 is loaded into a second dense
-        # library while batch i is scored -- 0.70 K targets/s became 1.16 K (tools/gradscore_files_rate.py: 4,096 targets, 16 cores); what is left
-        # is zlib inflating the 16-bit gradient PNGs (1.4 MB of pixels each at ~250 MB/s per core).  Anything else (zip entries,
+        # library while batch i is scored -- 0.70 K targets/s became 4.5 K (tools/gradscore_files_rate.py: 4,096 targets, 16 cores); what is left
+        # is inflating the 16-bit gradient PNGs (1.4 MB of pixels each), and it scales with the cores.  Anything else (zip entries,
         # bytes, file objects: mipio.read_mip takes them) keeps the per-item path.
         native = all(is_path(target_files[int(t)]) and is_path(gradient_files[int(t)]) and (zgap_files is None or is_path(zgap_files[int(t)])) for t in distinct)
         n_libs = 2 if native and len(distinct) > cap else 1
+        self.last_from_files = {"native_loader": bool(native), "dense_libraries": n_libs, "batch": cap, "distinct_targets": int(len(distinct))}
         libs = [cds.Library(W, H, cap, context=ctx) for _ in range(n_libs)]
 
         def load_native(lib, chunk):
@@ -862,160 +863,6 @@ class GpuColorMIPSearchProcessor:
             else:
                 for c0, c1 in chunks:
                     score(libs[0], c0, c1, load_items(libs[0], distinct[c0:c1], pool))
-        return normalizeTable(table)                             # CalculateGradientScoresCmd.normalizeScores (:616-645)
-
-    def calculateGradientScoresBatchedTable(self, masks, table: MatchTable, load_range, queryThreshold, mirrorMask=True, roiMask=None,
-                                            excludedRegions=cds.label_regions, batch=8192, library=None) -> MatchTable:
-        """calculateGradientScoresTable for a library far larger than the dense slots the shape scorer reads (BASELINE configs[4]:
-        1,024 masks x top-500 of a 1 M-target library resident as signal-pixel records): the table's pairs are visited in windows
-        of `batch` consecutive target indices (the table's targetIndex is relative to `self.first`, like every table this class
-        makes); `load_range(lib, first_target, count)` makes LIBRARY targets first_target..+count-1 (absolute: self.first is
-        added here) resident WITH their gradient / zgap variants in slots 0..count-1 of `lib` (regenerated on the device for a synthetic
-        library: `lambda lib, f, c: lib.generate_synthetic(seed, f, 0, c, kind=0, with_variants=True)`; ingested from a shard
-        or from files otherwise), one `cds_gradscore` launch per window, per-mask normalisation on the host
-        (CalculateGradientScoresCmd.java:541-586, 616-645).  The kernel time of the launches is left in
-        `self.last_gradscore = {kernel_ms, launches, pairs, mask_preparation_s, load_range_s, score_calls_s}` (host seconds of the
-        shape-mask preparation, of the `load_range` callbacks and of the scoring calls)."""
-        n = len(table)
-        table.gradientAreaGap = np.full(n, -1, dtype=np.int64)
-        table.highExpressionArea = np.full(n, -1, dtype=np.int64)
-        table.normalizedScore = np.zeros(n, dtype=np.float32)
-        self.last_gradscore = {"kernel_ms": 0.0, "launches": 0, "pairs": 0, "mask_preparation_s": 0.0, "load_range_s": 0.0, "score_calls_s": 0.0}
-        if n == 0:
-            return table
-        ctx = library.ctx if library is not None else (self.library.ctx if self.library is not None else self.sparse_library.ctx)
-        t0 = time.perf_counter()
-        alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, queryThreshold, mirrorMask, roiMask, excludedRegions, context=ctx)
-        self.last_gradscore["mask_preparation_s"] = time.perf_counter() - t0
-        lib = library if library is not None else cds.Library(alg.width, alg.height, int(batch), context=ctx)
-        batch = min(int(batch), lib.capacity)
-        order = np.argsort(table.targetIndex, kind="stable")
-        tsorted = table.targetIndex[order]
-        limit = self.count                      # (relative, like targetIndex and the windows below)
-        w0 = (int(tsorted[0]) // batch) * batch
-        while w0 <= int(tsorted[-1]):
-            lo, hi = np.searchsorted(tsorted, w0), np.searchsorted(tsorted, w0 + batch)
-            if hi > lo:
-                rows = order[lo:hi]
-                t0 = time.perf_counter()
-                load_range(lib, self.first + w0, min(batch, limit - w0))
-                ctx.synchronize()
-                t1 = time.perf_counter()
-                gap, high, _ = alg.scoreLibraryPairs(lib, table.maskIndex[rows].astype(np.int32), table.targetIndex[rows] - w0)
-                self.last_gradscore["load_range_s"] += t1 - t0
-                self.last_gradscore["score_calls_s"] += time.perf_counter() - t1
-                table.gradientAreaGap[rows] = gap
-                table.highExpressionArea[rows] = high
-                ms, launches = alg.lastKernelMs()
-                self.last_gradscore["kernel_ms"] += ms * launches
-                self.last_gradscore["launches"] += launches
-                self.last_gradscore["pairs"] += len(rows)
-            w0 += batch
-        return normalizeTable(table)
-
-    def calculateGradientScoresSelectedTable(self, masks, table: MatchTable, load_targets, queryThreshold, mirrorMask=True, roiMask=None,
-                                             excludedRegions=cds.label_regions, batch=8192, library=None) -> MatchTable:
-        """The gradient-score step when only the SELECTED targets are made resident (what the reference does: it opens the variant files
-        of the matches it scores, CalculateGradientScoresCmd.java:541-586): the distinct targets of the table's pairs are visited
-        `batch` at a time; `load_targets(lib, library_indices)` (int64 array, absolute: self.first added) fills slots 0..k-1 of `lib` with
-        those targets AND their gradient / zgap variants; one `cds_gradscore` launch per batch; per-mask normalisation on the host.
-        Against calculateGradientScoresBatchedTable (whole index windows): for BASELINE configs[4] 230 K distinct targets are loaded
-        instead of 1 M.  `self.last_gradscore` = {kernel_ms, launches, pairs, distinct_targets, mask_preparation_s, load_s, score_calls_s,
-        conversion_ms, converted_slots, launches_on_zslice_plane}."""
-        n = len(table)
-        table.gradientAreaGap = np.full(n, -1, dtype=np.int64)
-        table.highExpressionArea = np.full(n, -1, dtype=np.int64)
-        table.normalizedScore = np.zeros(n, dtype=np.float32)
-        st = {"kernel_ms": 0.0, "launches": 0, "pairs": 0, "distinct_targets": 0, "mask_preparation_s": 0.0, "load_s": 0.0, "score_calls_s": 0.0,
-              "conversion_ms": 0.0, "converted_slots": 0, "launches_on_zslice_plane": 0}
-        self.last_gradscore = st
-        if n == 0:
-            return table
-        ctx = library.ctx if library is not None else (self.library.ctx if self.library is not None else self.sparse_library.ctx)
-        t0 = time.perf_counter()
-        alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, queryThreshold, mirrorMask, roiMask, excludedRegions, context=ctx)
-        st["mask_preparation_s"] = time.perf_counter() - t0
-        lib = library if library is not None else cds.Library(alg.width, alg.height, int(batch), context=ctx)
-        batch = min(int(batch), lib.capacity)
-        distinct, inv = np.unique(table.targetIndex, return_inverse=True)
-        st["distinct_targets"] = int(len(distinct))
-        order = np.argsort(inv, kind="stable")
-        isorted = inv[order]
-        for b0 in range(0, len(distinct), batch):
-            idx = distinct[b0:b0 + batch]
-            lo, hi = np.searchsorted(isorted, b0), np.searchsorted(isorted, b0 + len(idx))
-            rows = order[lo:hi]
-            t0 = time.perf_counter()
-            load_targets(lib, self.first + idx.astype(np.int64))
-            ctx.synchronize()
-            t1 = time.perf_counter()
-            gap, high, _ = alg.scoreLibraryPairs(lib, table.maskIndex[rows].astype(np.int32), (inv[rows] - b0).astype(np.int64))
-            st["load_s"] += t1 - t0
-            st["score_calls_s"] += time.perf_counter() - t1
-            table.gradientAreaGap[rows] = gap
-            table.highExpressionArea[rows] = high
-            ms, launches = alg.lastKernelMs()
-            plane, conv, cms = alg.lastCallInfo()
-            st["kernel_ms"] += ms * launches
-            st["launches"] += launches
-            st["pairs"] += len(rows)
-            st["conversion_ms"] += cms
-            st["converted_slots"] += conv
-            st["launches_on_zslice_plane"] += int(plane)
-        return normalizeTable(table)
-
-    def calculateGradientScoresFromFilesTable(self, masks, table: MatchTable, target_files, gradient_files, zgap_files, queryThreshold,
-                                              mirrorMask=True, roiMask=None, excludedRegions=cds.label_regions, batch=256, threads=8,
-                                              zgap_radius=10) -> MatchTable:
-        """calculateGradientScoresTable for a library that is resident only as a sparse library: the targets the table names are
-        read from files the way CalculateGradientScoresCmd does it through its variant suppliers (:541-586) -- `target_files[t]`,
-        `gradient_files[t]`, `zgap_files[t]` (file_data as mipio.read_mip takes it; a missing gradient (None) leaves the pair at
-        (-1, -1) like Shape2DMatch...Algorithm.java:155-158; a missing zgap is synthesised on the device from the target as the
-        reference's tests do, Shape2DMatch...Test.java:171-174).  `batch` distinct targets at a time are decoded natively on a
-        thread pool, uploaded into a dense library of `batch` slots and scored with one launch."""
-        from concurrent.futures import ThreadPoolExecutor
-        from . import mipio
-        n = len(table)
-        table.gradientAreaGap = np.full(n, -1, dtype=np.int64)
-        table.highExpressionArea = np.full(n, -1, dtype=np.int64)
-        table.normalizedScore = np.zeros(n, dtype=np.float32)
-        if n == 0:
-            return table
-        ctx = self.library.ctx if self.library is not None else self.sparse_library.ctx
-        alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, queryThreshold, mirrorMask, roiMask, excludedRegions, context=ctx)
-        W, H = alg.width, alg.height
-        distinct = np.unique(table.targetIndex)
-        lib = cds.Library(W, H, min(int(batch), len(distinct)), context=ctx)
-        regions = cds._resolve_regions(excludedRegions, W)
-
-        def load(t):
-            g = gradient_files[t]
-            if g is None:
-                return None
-            z = zgap_files[t] if zgap_files is not None else None
-            return mipio.read_mip(target_files[t]), mipio.read_gradient(g), (None if z is None else mipio.read_mip(z))
-
-        with ThreadPoolExecutor(max_workers=max(1, int(threads))) as pool:
-            for b0 in range(0, len(distinct), lib.capacity):
-                chunk = distinct[b0:b0 + lib.capacity]
-                loaded = list(pool.map(load, [int(t) for t in chunk]))     # (the native decoder releases the GIL)
-                slot_of = {}
-                for t, item in zip(chunk, loaded):
-                    if item is None:
-                        continue
-                    k = len(slot_of)
-                    slot_of[int(t)] = k
-                    lib.upload(k, item[0][None])
-                    lib.upload_variants(k, gradients=item[1][None], zgaps=None if item[2] is None else item[2][None])
-                    if item[2] is None:
-                        lib.make_zgap_variants(k, 1, queryThreshold, zgap_radius, regions)
-                rows = np.flatnonzero(np.isin(table.targetIndex, chunk) & np.array([int(t) in slot_of for t in table.targetIndex]))
-                if len(rows) == 0:
-                    continue
-                slots = np.array([slot_of[int(t)] for t in table.targetIndex[rows]], dtype=np.int64)
-                gap, high, _ = alg.scoreLibraryPairs(lib, table.maskIndex[rows].astype(np.int32), slots)
-                table.gradientAreaGap[rows] = gap
-                table.highExpressionArea[rows] = high
         return normalizeTable(table)                             # CalculateGradientScoresCmd.normalizeScores (:616-645)
 
     # ---- gradientScores ---------------------------------------------------------------------------

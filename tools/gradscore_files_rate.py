@@ -50,7 +50,10 @@ with tempfile.TemporaryDirectory() as d:
     t0 = time.perf_counter()
     out = proc.calculateGradientScoresFromFilesTable(masks, table, tf, gf, zf, 20, batch=a.batch, threads=a.threads)
     t = time.perf_counter() - t0
+    # the same pairs scored from the variants as they sit in memory (file i holds the variants of resident target i % n_files)
+    ref = proc.calculateGradientScoresTable(masks, P.MatchTable(table.maskIndex, table.targetIndex % n_files, table.matchingPixels, table.matchingPixelsRatio, table.mirrored), 20)
+    same = bool((ref.gradientAreaGap == out.gradientAreaGap).all() and (ref.highExpressionArea == out.highExpressionArea).all())
     bytes_files = sum(os.path.getsize(p) for p in tf[:n_files] + gf[:n_files] + zf[:n_files]) / n_files
     print(json.dumps({"distinct_targets": a.targets, "pairs": n_pairs, "masks": a.masks, "threads": a.threads, "batch": a.batch, "seconds": round(t, 3),
                       "targets_per_s": round(a.targets / t), "files_per_s": round(3 * a.targets / t), "pairs_per_s": round(n_pairs / t),
-                      "file_bytes_per_target": round(bytes_files), "scored": int((out.gradientAreaGap >= 0).sum())}))
+                      "file_bytes_per_target": round(bytes_files), "scored": int((out.gradientAreaGap >= 0).sum()), "equal_to_in_memory_scores": same, "path": proc.last_from_files}))
