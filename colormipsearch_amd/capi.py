@@ -76,6 +76,15 @@ SIGNATURES = {
     "cds_library_upload_variants": (_i, [_vp, _i64, _i64, _u16p, _u8p]),
     "cds_library_upload_gradient_u8": (_i, [_vp, _i64, _i64, _u8p]),
     "cds_library_load_files": (_i, [_vp, _i64, _i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p), _i32]),
+    "cds_variant_shard_create": (_i, [ctypes.c_char_p, _i32, _i32, ctypes.POINTER(_vp)]),
+    "cds_variant_shard_append": (_i, [_vp, _i64, _u8p, _u16p, _u8p, _i32]),
+    "cds_variant_shard_append_files": (_i, [_vp, _i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p), _i32]),
+    "cds_variant_shard_finish": (_i, [_vp]),
+    "cds_variant_shard_open": (_i, [ctypes.c_char_p, ctypes.POINTER(_vp)]),
+    "cds_variant_shard_info": (_i, [_vp, _i32p, _i32p, _i64p, _i64p]),
+    "cds_variant_shard_target_info": (_i, [_vp, _i64, _i64, _u32p, _u32p]),
+    "cds_variant_shard_close": (None, [_vp]),
+    "cds_library_load_variants": (_i, [_vp, _i64, _vp, _i64p, _i64, _i32]),
     "cds_library_download_variants": (_i, [_vp, _i64, _i64, _u16p, _u8p]),
     "cds_library_generate_synthetic": (_i, [_vp, ctypes.c_uint64, _i64, _i64, _i64, _i32, _i32]),
     "cds_library_generate_synthetic_list": (_i, [_vp, ctypes.c_uint64, _i64p, _i64, _i64, _i32, _i32]),

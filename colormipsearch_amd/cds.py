@@ -340,6 +340,14 @@ class Library:
 
         capi.check(self._lib.cds_library_load_files(self._h, int(first), n, arr(target_paths), arr(gradient_paths), arr(zgap_paths), int(threads)))
 
+    def load_variants(self, first, shard, targets, threads=0):
+        """Slots first.. <- the targets `targets` of a VariantShard: image, gradient and zgap as stored, decoded on the device
+        (cds_library_load_variants).  Returns the targets' flags (VariantShard.HAS_GRADIENT / HAS_ZGAP bits) so that the caller knows
+        which slots came without a gradient or a zgap."""
+        idx = np.ascontiguousarray(targets, dtype=np.int64)
+        capi.check(self._lib.cds_library_load_variants(self._h, int(first), shard._h, capi.as_i64p(idx), len(idx), int(threads)))
+        return shard.flags[idx]
+
     def download_variants(self, first, count):
         g = np.empty((int(count), self.height, self.width), dtype=np.uint16)
         z = np.empty((int(count), self.height, self.width, 3), dtype=np.uint8)
@@ -360,6 +368,109 @@ class Library:
         idx = np.ascontiguousarray(indices, dtype=np.int64)
         capi.check(self._lib.cds_library_generate_synthetic_list(self._h, ctypes.c_uint64(seed), capi.as_i64p(idx), int(first_slot), len(idx),
                                                                  int(kind), int(bool(with_variants))))
+
+
+def _path_array(paths, n):
+    if paths is None:
+        return None
+    if len(paths) != n:
+        raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "one path (or None) per target")
+    return (ctypes.c_char_p * max(1, n))(*[None if p is None else os.fsencode(p) for p in paths])
+
+
+class VariantShardWriter:
+    """Writes a variant shard (cds_variant_shard_create / _append / _append_files / _finish): kernel 2's inputs of a library -- every
+    target's MIP, GradientImage and ZGapImage -- losslessly in one file that Library.load_variants decodes on the GPU.  No GPU is needed
+    to write one.  Use as a context manager, or call finish()."""
+
+    def __init__(self, path, width, height):
+        self._lib = capi.load()
+        self.width, self.height = int(width), int(height)
+        self.count = 0
+        self._h = None
+        h = ctypes.c_void_p()
+        capi.check(self._lib.cds_variant_shard_create(os.fsencode(path), self.width, self.height, ctypes.byref(h)))
+        self._h = h
+
+    def append(self, images, gradients=None, zgaps=None, threads=0):
+        images = capi.rgb_images(images)
+        n = images.shape[0]
+        gp = zp = None
+        if gradients is not None:
+            gradients = np.ascontiguousarray(gradients, dtype=np.uint16).reshape(n, self.height, self.width)
+            gp = capi.as_u16p(gradients)
+        if zgaps is not None:
+            zgaps = capi.rgb_images(zgaps, n)
+            zp = capi.as_u8p(zgaps)
+        if images.shape[1:3] != (self.height, self.width):
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "image size differs from the shard's")
+        capi.check(self._lib.cds_variant_shard_append(self._h, n, capi.as_u8p(images), gp, zp, int(threads)))
+        self.count += n
+
+    def append_files(self, target_paths, gradient_paths=None, zgap_paths=None, threads=0):
+        n = len(target_paths)
+        capi.check(self._lib.cds_variant_shard_append_files(self._h, n, _path_array(target_paths, n), _path_array(gradient_paths, n),
+                                                            _path_array(zgap_paths, n), int(threads)))
+        self.count += n
+
+    def finish(self):
+        if self._h is not None:
+            h, self._h = self._h, None
+            capi.check(self._lib.cds_variant_shard_finish(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.finish()
+        return False
+
+    def __del__(self):
+        try:
+            self.finish()
+        except Exception:
+            pass
+
+
+class VariantShard:
+    """A variant shard opened for reading (cds_variant_shard_open)."""
+    HAS_GRADIENT, GRADIENT_DELTA2, HAS_ZGAP = 1, 2, 4
+
+    def __init__(self, path):
+        self._lib = capi.load()
+        self._h = None
+        h = ctypes.c_void_p()
+        capi.check(self._lib.cds_variant_shard_open(os.fsencode(path), ctypes.byref(h)))
+        self._h = h
+        w, hh, n, b = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+        capi.check(self._lib.cds_variant_shard_info(h, ctypes.byref(w), ctypes.byref(hh), ctypes.byref(n), ctypes.byref(b)))
+        self.width, self.height, self.count, self.file_bytes = w.value, hh.value, n.value, b.value
+        self.flags = np.zeros(self.count, dtype=np.uint32)
+        self.packed_bytes = np.zeros(self.count, dtype=np.uint32)
+        if self.count:
+            capi.check(self._lib.cds_variant_shard_target_info(h, 0, self.count, self.flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                                               self.packed_bytes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+
+    def __len__(self):
+        return self.count
+
+    def close(self):
+        if self._h is not None:
+            h, self._h = self._h, None
+            self._lib.cds_variant_shard_close(h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class SparseLibrary:

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "cds_internal.hpp"
+#include "cds_imageio.hpp"
 
 namespace cds {
 
@@ -75,6 +76,8 @@ struct PinnedPool {
     std::unordered_map<uint8_t *, size_t> sizes_;
 };
 static PinnedPool g_pinned;
+uint8_t *pinned_get(size_t bytes) { return g_pinned.get(bytes); }
+void pinned_put(uint8_t *p) { g_pinned.put(p); }
 
 // One-shot zlib-stream decompression into a buffer of known size (a PNG's filtered scanlines, a Deflate TIFF strip).  libdeflate -- present
 // in the image as libdeflate.so.0, no headers: bound by dlopen, three functions of its stable C API -- inflates 2-3x as fast as zlib, and a
@@ -533,6 +536,31 @@ static bool read_file(const char *path, std::vector<uint8_t> &buf, std::string &
     return true;
 }
 
+bool decode_file_into(const char *path, int W, int H, int kind, void *dst, std::string &err) {
+    thread_local std::vector<uint8_t> file, tmp8;
+    const size_t px = (size_t)W * H;
+    ImgInfo info;
+    try {
+        if (!read_file(path, file, err) || !image_probe(file.data(), file.size(), info, err)) return false;
+        if (info.W != W || info.H != H) { err = "image size differs from the library's"; return false; }
+        if (kind == 0) {
+            if (info.channels != 3 || info.bits != 8) { err = "is not an 8-bit RGB image"; return false; }
+            return image_decode(file.data(), file.size(), info, dst, err);
+        }
+        uint16_t *d16 = static_cast<uint16_t *>(dst);
+        if (info.channels != 1) { err = "gradient image must be grayscale"; return false; }
+        if (info.bits == 16) return image_decode(file.data(), file.size(), info, d16, err);
+        if (info.bits != 8) { err = "gradient image must be 8- or 16-bit"; return false; }
+        tmp8.resize(px);   // GRAY8: widened (ImageArray.get semantics, ByteImageArray.java:3-16)
+        if (!image_decode(file.data(), file.size(), info, tmp8.data(), err)) return false;
+        for (size_t q = 0; q < px; q++) d16[q] = tmp8[q];
+        return true;
+    } catch (const std::exception &e) {   // (an exception must not leave a worker thread)
+        err = e.what();
+        return false;
+    }
+}
+
 }  // namespace cds
 
 using namespace cds;
@@ -829,7 +857,6 @@ int cds_library_load_files(cds_library *lib, int64_t first, int64_t count, const
     auto decode_batch = [&](int64_t b0, int64_t nb, int k) {
         std::atomic<int64_t> next{0};
         auto worker = [&]() {
-            std::vector<uint8_t> file, tmp8;
             for (int64_t w = next.fetch_add(1); w < 3 * nb; w = next.fetch_add(1)) {
                 const int64_t i = w / 3;
                 const int kind = (int)(w % 3);   // 0 target, 1 gradient, 2 zgap
@@ -843,31 +870,8 @@ int cds_library_load_files(cds_library *lib, int64_t first, int64_t count, const
                     continue;
                 }
                 std::string err;
-                ImgInfo info;
-                bool ok = false;
-                try {
-                    ok = read_file(path, file, err) && image_probe(file.data(), file.size(), info, err);
-                    if (ok && (info.W != W || info.H != H)) {
-                        err = "image size differs from the library's";
-                        ok = false;
-                    }
-                    if (ok && kind != 1) {
-                        if (info.channels != 3 || info.bits != 8) { err = "is not an 8-bit RGB image"; ok = false; }
-                        else ok = image_decode(file.data(), file.size(), info, (kind == 0 ? tb[k].p : zb[k].p) + (size_t)i * rgb_bytes, err);
-                    } else if (ok) {
-                        uint16_t *dst = reinterpret_cast<uint16_t *>(gb[k].p + (size_t)i * grad_bytes);
-                        if (info.channels != 1) { err = "gradient image must be grayscale"; ok = false; }
-                        else if (info.bits == 16) ok = image_decode(file.data(), file.size(), info, dst, err);
-                        else if (info.bits == 8) {   // GRAY8: widened (ImageArray.get semantics, ByteImageArray.java:3-16)
-                            tmp8.resize(px);
-                            ok = image_decode(file.data(), file.size(), info, tmp8.data(), err);
-                            if (ok) for (size_t q = 0; q < px; q++) dst[q] = tmp8[q];
-                        } else { err = "gradient image must be 8- or 16-bit"; ok = false; }
-                    }
-                } catch (const std::exception &e) {   // (an exception must not leave a worker thread)
-                    err = e.what();
-                    ok = false;
-                }
+                void *dst = kind == 0 ? (void *)(tb[k].p + (size_t)i * rgb_bytes) : kind == 1 ? (void *)(gb[k].p + (size_t)i * grad_bytes) : (void *)(zb[k].p + (size_t)i * rgb_bytes);
+                const bool ok = decode_file_into(path, W, H, kind == 1 ? 1 : 0, dst, err);
                 if (!ok) {
                     std::lock_guard<std::mutex> lk(err_mu);
                     if (first_err.empty()) first_err = std::string(path) + ": " + err;

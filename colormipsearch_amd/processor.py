@@ -787,13 +787,8 @@ class GpuColorMIPSearchProcessor:
         ctx = self.library.ctx if self.library is not None else self.sparse_library.ctx
         alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, queryThreshold, mirrorMask, roiMask, excludedRegions, context=ctx)
         W, H = alg.width, alg.height
-        # the table's rows grouped by target, once (a chunk's rows are then a slice of `order`)
-        order = np.argsort(table.targetIndex, kind="stable")
-        sorted_t = table.targetIndex[order]
-        distinct, starts = np.unique(sorted_t, return_index=True)
-        ends = np.append(starts[1:], len(sorted_t))
-        cap = min(int(batch), len(distinct))
         regions = cds._resolve_regions(excludedRegions, W)
+        distinct = np.unique(table.targetIndex)
         is_path = lambda x: x is None or isinstance(x, (str, bytes, os.PathLike))
         # Round 5: plain files go through the library's own batch loader (cds_library_load_files: the three files of every target decoded on
         # native threads straight into pinned memory, 64 slots in flight behind the decode) and batch i + 1 is loaded into a second dense
@@ -801,9 +796,6 @@ class GpuColorMIPSearchProcessor:
         # is inflating the 16-bit gradient PNGs (1.4 MB of pixels each), and it scales with the cores.  Anything else (zip entries,
         # bytes, file objects: mipio.read_mip takes them) keeps the per-item path.
         native = all(is_path(target_files[int(t)]) and is_path(gradient_files[int(t)]) and (zgap_files is None or is_path(zgap_files[int(t)])) for t in distinct)
-        n_libs = 2 if native and len(distinct) > cap else 1
-        self.last_from_files = {"native_loader": bool(native), "dense_libraries": n_libs, "batch": cap, "distinct_targets": int(len(distinct))}
-        libs = [cds.Library(W, H, cap, context=ctx) for _ in range(n_libs)]
 
         def load_native(lib, chunk):
             """chunk's targets that have a gradient -> slots 0.. of `lib`; returns their slot numbers (-1: not loaded)"""
@@ -839,6 +831,61 @@ class GpuColorMIPSearchProcessor:
                 k += 1
             return slot
 
+        with ThreadPoolExecutor(max_workers=max(1, int(threads))) as pool:
+            load = load_native if native else (lambda lib, chunk: load_items(lib, chunk, pool))
+            info = self._score_in_batches(alg, table, ctx, batch, load, overlap=native)
+        self.last_from_files = dict(info, native_loader=bool(native))
+        return normalizeTable(table)                             # CalculateGradientScoresCmd.normalizeScores (:616-645)
+
+    def calculateGradientScoresFromShardTable(self, masks, table: MatchTable, shard, queryThreshold, mirrorMask=True, roiMask=None,
+                                              excludedRegions=cds.label_regions, batch=512, threads=8, zgap_radius=10,
+                                              shard_targets=None) -> MatchTable:
+        """calculateGradientScoresFromFilesTable with the library's variants in a variant shard (cds.VariantShard: every target's MIP,
+        GradientImage and ZGapImage in one file, written once from the same files -- cds.VariantShardWriter.append_files): the selected
+        targets' blobs are read into pinned memory and decoded on the GPU instead of being inflated on host cores.  Target t of the
+        table is target `shard_targets[t]` of the shard (default: t).  A target stored without a gradient leaves its pairs at (-1, -1); one
+        stored without a zgap gets it from the device as in the file path.  Same scores as from the files (tests/test_processor.py)."""
+        n = len(table)
+        table.gradientAreaGap = np.full(n, -1, dtype=np.int64)
+        table.highExpressionArea = np.full(n, -1, dtype=np.int64)
+        table.normalizedScore = np.zeros(n, dtype=np.float32)
+        if n == 0:
+            return table
+        ctx = self.library.ctx if self.library is not None else self.sparse_library.ctx
+        alg = cds.Shape2DMatchColorDepthSearchAlgorithm(masks, queryThreshold, mirrorMask, roiMask, excludedRegions, context=ctx)
+        if (alg.width, alg.height) != (shard.width, shard.height):
+            raise cds.CdsInvalidArgument(cds.capi.CDS_ERR_INVALID_ARGUMENT, "the shard's image size differs from the masks'")
+        regions = cds._resolve_regions(excludedRegions, alg.width)
+        where = None if shard_targets is None else np.asarray(shard_targets, dtype=np.int64)
+
+        def load_shard(lib, chunk):
+            in_shard = chunk if where is None else where[chunk]
+            has_g = (shard.flags[in_shard] & shard.HAS_GRADIENT) != 0
+            slot = np.full(len(chunk), -1, dtype=np.int64)
+            slot[has_g] = np.arange(int(has_g.sum()))
+            if has_g.any():
+                flags = lib.load_variants(0, shard, in_shard[has_g], threads=threads)
+                for r0, r1 in _runs((flags & shard.HAS_ZGAP) == 0):
+                    lib.make_zgap_variants(r0, r1 - r0, queryThreshold, zgap_radius, regions)
+            return slot
+
+        self.last_from_files = dict(self._score_in_batches(alg, table, ctx, batch, load_shard, overlap=True), variant_shard=True)
+        return normalizeTable(table)
+
+    def _score_in_batches(self, alg, table, ctx, batch, load, overlap):
+        """The table's pairs scored `batch` distinct targets at a time: `load(lib, targets)` fills slots 0.. of a dense library of `batch`
+        slots with the targets it can load and returns each target's slot (-1: none); with `overlap` batch i + 1 is loaded into a second
+        library on a loader thread while batch i is scored."""
+        from concurrent.futures import ThreadPoolExecutor
+        # the table's rows grouped by target, once (a chunk's rows are then a slice of `order`)
+        order = np.argsort(table.targetIndex, kind="stable")
+        sorted_t = table.targetIndex[order]
+        distinct, starts = np.unique(sorted_t, return_index=True)
+        ends = np.append(starts[1:], len(sorted_t))
+        cap = min(int(batch), len(distinct))
+        n_libs = 2 if overlap and len(distinct) > cap else 1
+        libs = [cds.Library(alg.width, alg.height, cap, context=ctx) for _ in range(n_libs)]
+
         def score(lib, c0, c1, slot):
             rows_sorted = np.arange(starts[c0], ends[c1 - 1])                      # positions in `order` of the chunk's rows
             slots = np.repeat(slot, ends[c0:c1] - starts[c0:c1])
@@ -851,19 +898,19 @@ class GpuColorMIPSearchProcessor:
             table.highExpressionArea[rows] = high
 
         chunks = [(c0, min(c0 + cap, len(distinct))) for c0 in range(0, len(distinct), cap)]
-        with ThreadPoolExecutor(max_workers=max(1, int(threads))) as pool, ThreadPoolExecutor(max_workers=1) as loader:
-            if native:
-                pending = loader.submit(load_native, libs[0], distinct[chunks[0][0]:chunks[0][1]])
+        if n_libs == 2:
+            with ThreadPoolExecutor(max_workers=1) as loader:
+                pending = loader.submit(load, libs[0], distinct[chunks[0][0]:chunks[0][1]])
                 for i, (c0, c1) in enumerate(chunks):
                     slot = pending.result()
                     if i + 1 < len(chunks):                                           # the next batch loads while this one is scored
                         n0, n1 = chunks[i + 1]
-                        pending = loader.submit(load_native, libs[(i + 1) % n_libs], distinct[n0:n1])
-                    score(libs[i % n_libs], c0, c1, slot)
-            else:
-                for c0, c1 in chunks:
-                    score(libs[0], c0, c1, load_items(libs[0], distinct[c0:c1], pool))
-        return normalizeTable(table)                             # CalculateGradientScoresCmd.normalizeScores (:616-645)
+                        pending = loader.submit(load, libs[(i + 1) % 2], distinct[n0:n1])
+                    score(libs[i % 2], c0, c1, slot)
+        else:
+            for c0, c1 in chunks:
+                score(libs[0], c0, c1, load(libs[0], distinct[c0:c1]))
+        return {"dense_libraries": n_libs, "batch": cap, "distinct_targets": int(len(distinct))}
 
     # ---- gradientScores ---------------------------------------------------------------------------
     def selectBestMatches(self, matches: List[CDMatch], topLineMatches, topSamplesPerLine, topMatchesPerSample) -> List[CDMatch]:

@@ -252,6 +252,41 @@ int cds_sparse_library_append_files(cds_sparse_library *slib, const char *const 
 int cds_library_load_files(cds_library *lib, int64_t first, int64_t count, const char *const *target_paths,
                            const char *const *gradient_paths, const char *const *zgap_paths, int32_t threads);
 
+/* ---- The variant shard: kernel 2's inputs of a library in one file, decoded on the GPU ---------------
+ * CalculateGradientScoresCmd reads three image files per selected target through its variant suppliers (tools cmd/
+ * CalculateGradientScoresCmd.java:541-586; NeuronMIPUtils.loadComputeFile, API/mips/NeuronMIPUtils.java:36-103) and inflates them on
+ * host cores.  A shard holds the same three images of every target -- the MIP, its GradientImage, its ZGapImage -- LOSSLESSLY in codes a
+ * wavefront expands (run lengths for the two RGB images, two bits per pixel for a gradient that is a distance ramp, raw 16-bit otherwise):
+ * written once per library, then any subset of its targets is read into pinned memory and decoded into dense slots by two kernels.  The
+ * slots are bit-equal to what cds_library_load_files makes of the files.  Layout: colormipsearch_amd/csrc/cds_variants.hip. */
+typedef struct cds_variant_writer cds_variant_writer;
+typedef struct cds_variant_shard cds_variant_shard;
+#define CDS_VARIANT_HAS_GRADIENT 1u     /* per-target flags (cds_variant_shard_target_info) */
+#define CDS_VARIANT_GRADIENT_DELTA2 2u  /* the gradient is stored as two bits per pixel (else raw) */
+#define CDS_VARIANT_HAS_ZGAP 4u
+int cds_variant_shard_create(const char *path, int32_t width, int32_t height, cds_variant_writer **out);
+/* `n` targets from host memory: rgb [n][H][W][3]; gradients [n][H][W] u16 or NULL (none of them has one); zgaps like rgb or NULL.
+ * Packed on `threads` host threads (<= 0: all cores), written in order: target numbers in the shard count up from 0 across calls. */
+int cds_variant_shard_append(cds_variant_writer *w, int64_t n, const uint8_t *rgb, const uint16_t *gradients, const uint8_t *zgaps, int32_t threads);
+/* The same from image files (formats of cds_image_decode; a NULL gradient / zgap entry, or a NULL array: that target has none).
+ * Fails at the first file that cannot be read or has another size (its path is in cds_last_error()); nothing of the call is kept then. */
+int cds_variant_shard_append_files(cds_variant_writer *w, int64_t n, const char *const *target_paths, const char *const *gradient_paths,
+                                   const char *const *zgap_paths, int32_t threads);
+/* Writes the index and the header, closes the file and releases `w` (also when it returns an error).  A file that was not finished
+ * does not open. */
+int cds_variant_shard_finish(cds_variant_writer *w);
+int cds_variant_shard_open(const char *path, cds_variant_shard **out);
+int cds_variant_shard_info(const cds_variant_shard *s, int32_t *width, int32_t *height, int64_t *n_targets, int64_t *file_bytes);
+/* flags (CDS_VARIANT_*) and packed size of targets [first, first + count); either array may be NULL */
+int cds_variant_shard_target_info(const cds_variant_shard *s, int64_t first, int64_t count, uint32_t *flags, uint32_t *bytes);
+void cds_variant_shard_close(cds_variant_shard *s);
+/* Dense slots [first_slot, first_slot + n) <- the shard's targets `targets[0..n)` (any order, repeats allowed): image, gradient and zgap
+ * as stored; a target stored without a gradient / zgap leaves its slot without one (its pairs score (-1, -1) / the caller may make the
+ * zgap on the device, as with cds_library_load_files).  Blobs are read on `threads` host threads (<= 0: all cores) into pinned memory, up
+ * to 64 MB at a time, while the previous batch is copied and decoded.  Safe to call while another thread scores OTHER slots or another
+ * library of the same context. */
+int cds_library_load_variants(cds_library *lib, int64_t first_slot, const cds_variant_shard *s, const int64_t *targets, int64_t n, int32_t threads);
+
 /* The scan over images [first, first+count) of a sparse library: same outputs as cds_search / cds_search_device /
  * cds_search_counts. */
 int cds_search_sparse(const cds_maskset *ms, const cds_sparse_library *slib, int64_t first, int64_t count,

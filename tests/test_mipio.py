@@ -160,6 +160,121 @@ def test_match_records_per_mask(tmp_path):
     assert [os.path.relpath(p, tmp_path / "out2") for p in paths] == ["m.json"]
 
 
+def _variant_cases(fixtures):
+    """(image, gradient | None, zgap | None): the reference's images and the shapes that stress the two codes -- a gradient that is
+    no distance ramp (kept raw), runs longer than 255 pixels, a row of pixels that all differ, a frame without any run of black"""
+    rng = np.random.default_rng(5)
+    H, W = fixtures["lm_BJD"].shape[:2]
+    noise16 = rng.integers(0, 65536, (H, W)).astype(np.uint16)
+    noise8 = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+    flat = np.full((H, W, 3), 7, np.uint8)
+    steps = (np.arange(W)[None, :] // 3 + np.arange(H)[:, None]).astype(np.uint16)      # a ramp with its first pixel far from 0
+    return [(fixtures["lm_BJD"], fixtures["grad_BJD"], fixtures["zgap_BJD"]),
+            (fixtures["lm_VT016795"], fixtures["grad_VT016795"], np.ascontiguousarray(fixtures["zgap_BJD"][::-1])),
+            (fixtures["lm_VT033614"], noise16, None),
+            (fixtures["lm_GMR"], None, None),
+            (noise8, steps + 40000, flat),
+            (flat, None, noise8)]
+
+
+def test_variant_shard_codes_on_the_host(tmp_path, fixtures):
+    """The packer of the variant shard (csrc/cds_variants.hip; needs no GPU) against a numpy reading of the file format
+    (tests/variant_shard_ref.py): every image comes back bit for bit, from arrays and from files; the reference's gradients take the
+    two-bit code; a file that was not finished, is cut short or has another size does not open."""
+    PIL = pytest.importorskip("PIL.Image")
+    from colormipsearch_amd import cds
+    from tests.variant_shard_ref import read_shard
+    cases = _variant_cases(fixtures)
+    H, W = cases[0][0].shape[:2]
+    path = tmp_path / "lib.cdsv"
+    with cds.VariantShardWriter(path, W, H) as w:
+        w.append(np.stack([c[0] for c in cases[:2]]), np.stack([c[1] for c in cases[:2]]), np.stack([c[2] for c in cases[:2]]), threads=2)
+        for img, g, z in cases[2:]:
+            w.append(img, None if g is None else g[None], None if z is None else z[None])
+        tf, gf = tmp_path / "t.tif", tmp_path / "g.png"
+        PIL.fromarray(cases[0][0], "RGB").save(tf, compression="packbits")
+        PIL.fromarray(cases[0][1]).save(gf)
+        w.append_files([str(tf), str(tf)], [str(gf), None], None, threads=2)
+        with pytest.raises(cds.CdsError, match="nope"):
+            w.append_files([str(tf), str(tmp_path / "nope.tif")])
+        assert w.count == len(cases) + 2
+    shard = cds.VariantShard(path)
+    assert (shard.width, shard.height, len(shard)) == (W, H, len(cases) + 2) and shard.file_bytes == os.path.getsize(path)
+    assert shard.flags.tolist() == [7, 7, 1, 0, 7, 4, 3, 0]               # has gradient | two-bit code | has zgap
+    assert shard.packed_bytes[0] < 450_000                                # (the reference's target: 3.4 MB + 1.4 MB raw)
+    w2, h2, got = read_shard(path)
+    assert (w2, h2) == (W, H)
+    for (flags, rgb, g, z), (ergb, eg, ez) in zip(got, cases + [(cases[0][0], cases[0][1], None), (cases[0][0], None, None)]):
+        assert np.array_equal(rgb, ergb)
+        assert (g is None) == (eg is None) and (eg is None or np.array_equal(g, eg))
+        assert (z is None) == (ez is None) and (ez is None or np.array_equal(z, ez))
+    shard.close()
+    raw = path.read_bytes()
+    cut = tmp_path / "cut.cdsv"
+    cut.write_bytes(raw[:len(raw) - 40])
+    with pytest.raises(ValueError, match="not a variant shard"):
+        cds.VariantShard(cut)
+    unfinished = tmp_path / "unfinished.cdsv"
+    unfinished.write_bytes(b"\0" * 64 + raw[64:])
+    with pytest.raises(ValueError, match="magic"):
+        cds.VariantShard(unfinished)
+    with pytest.raises(cds.CdsError, match="image size"):
+        cds.VariantShardWriter(tmp_path / "x.cdsv", 4, 4)
+    empty = tmp_path / "empty.cdsv"
+    cds.VariantShardWriter(empty, W, H).finish()
+    assert len(cds.VariantShard(empty)) == 0
+
+
+@pytest.mark.gpu
+def test_variant_shard_slots_equal_the_images(tmp_path, fixtures):
+    """cds_library_load_variants: targets of a shard decoded ON THE DEVICE into dense slots -- any order, repeats, into a library
+    whose slots held other images -- are the images, gradients and zgaps that were packed, bit for bit; the slots' variant flags
+    follow the shard's; a damaged blob is refused."""
+    from colormipsearch_amd import cds
+    cases = _variant_cases(fixtures)
+    H, W = cases[0][0].shape[:2]
+    path = tmp_path / "lib.cdsv"
+    with cds.VariantShardWriter(path, W, H) as w:
+        for img, g, z in cases:
+            w.append(img, None if g is None else g[None], None if z is None else z[None])
+    shard = cds.VariantShard(path)
+    lib = cds.Library(W, H, 12)
+    lib.generate_synthetic(0xC0FFEE, 0, 0, 12, kind=0, with_variants=True)           # every slot holds something else first
+    order = [5, 0, 3, 2, 0, 4, 1, 1, 2]
+    flags = lib.load_variants(2, shard, order, threads=3)
+    assert flags.tolist() == [int(shard.flags[t]) for t in order]
+    imgs = lib.download(2, len(order))
+    grads, zgaps = lib.download_variants(2, len(order))
+    for k, t in enumerate(order):
+        img, g, z = cases[t]
+        assert np.array_equal(imgs[k], img), (k, t)
+        if g is not None:
+            assert np.array_equal(grads[k], g), (k, t)
+        if z is not None:
+            assert np.array_equal(zgaps[k], z), (k, t)
+    # a slot loaded without a gradient scores (-1, -1); with one, the same as the uploaded images
+    alg = cds.Shape2DMatchColorDepthSearchAlgorithm(fixtures["em_12191"][None], 20, True, None, cds.label_regions)
+    ref = cds.Library(W, H, 2)
+    ref.upload(0, np.stack([cases[0][0], cases[1][0]]))
+    ref.upload_variants(0, gradients=np.stack([cases[0][1], cases[1][1]]), zgaps=np.stack([cases[0][2], cases[1][2]]))
+    g_ref, h_ref, _ = alg.scoreLibraryPairs(ref, np.zeros(2, np.int32), np.array([0, 1]))
+    g_got, h_got, _ = alg.scoreLibraryPairs(lib, np.zeros(3, np.int32), np.array([3, 8, 4]))   # targets 0, 1 and 3 (no gradient)
+    assert (g_got[:2].tolist(), h_got[:2].tolist()) == (g_ref.tolist(), h_ref.tolist()) and (g_got[2], h_got[2]) == (-1, -1)
+    with pytest.raises(ValueError):
+        lib.load_variants(0, shard, [len(cases)])
+    with pytest.raises(ValueError):
+        lib.load_variants(8, shard, order)                                         # does not fit
+    shard.close()
+    raw = bytearray(path.read_bytes())
+    index_off = int(np.frombuffer(raw, "<u8", 1, 24)[0])
+    off0 = int(np.frombuffer(raw, "<u8", 1, index_off)[0])
+    raw[off0 + 16 + 4 * 300 + 2] ^= 0xFF                                           # a row offset of target 0's image, far off
+    bad = tmp_path / "bad.cdsv"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(ValueError, match="damaged"):
+        lib.load_variants(0, cds.VariantShard(bad), [0])
+
+
 @pytest.mark.gpu
 def test_shard_upload_and_search(tmp_path, fixtures, oracle):
     from colormipsearch_amd import cds

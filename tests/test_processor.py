@@ -456,3 +456,20 @@ def test_gradient_scores_from_files(tmp_path, fixtures):
             assert got[(mk[mask], target)] == (gap, high), (mask, target)
     assert all(v == (-1, -1) for (m, t), v in got.items() if t == "lm_GMR")
     assert (scored.normalizedScore > 0).any()
+    # the same library as a variant shard (written from the same files, no GPU involved; decoded on the device): the same scores
+    shard_path = tmp_path / "variants.cdsv"
+    with cds.VariantShardWriter(shard_path, W, H) as w:
+        w.append_files(tfiles, gfiles, zfiles, threads=2)
+    shard = cds.VariantShard(shard_path)
+    assert (shard.flags & shard.HAS_GRADIENT).tolist() == [1, 1, 1, 0] and (shard.flags & shard.GRADIENT_DELTA2).tolist() == [2, 2, 2, 0]
+    again = proc.calculateGradientScoresFromShardTable(masks, table.take(np.arange(len(table))), shard, 20, batch=2, threads=3)
+    assert proc.last_from_files["variant_shard"] and proc.last_from_files["dense_libraries"] == 2
+    assert np.array_equal(again.gradientAreaGap, scored.gradientAreaGap) and np.array_equal(again.highExpressionArea, scored.highExpressionArea)
+    assert np.array_equal(again.normalizedScore, scored.normalizedScore)
+    # ... and with the shard's targets in another order than the library's
+    back = cds.VariantShardWriter(tmp_path / "reversed.cdsv", W, H)
+    back.append_files(tfiles[::-1], gfiles[::-1], None)
+    back.finish()
+    third = proc.calculateGradientScoresFromShardTable(masks, table.take(np.arange(len(table))), cds.VariantShard(tmp_path / "reversed.cdsv"), 20,
+                                                       batch=8, shard_targets=[3, 2, 1, 0])
+    assert np.array_equal(third.gradientAreaGap, scored.gradientAreaGap) and np.array_equal(third.highExpressionArea, scored.highExpressionArea)

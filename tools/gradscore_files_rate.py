@@ -17,10 +17,20 @@ ap.add_argument("--masks", type=int, default=16)
 ap.add_argument("--pairs-per-target", type=float, default=2.2)
 ap.add_argument("--threads", type=int, default=16)
 ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--shard", action="store_true", help="also: the same targets through a variant shard written from the files (decoded on the GPU)")
+ap.add_argument("--real", action="store_true", help="the reference's three LM test targets with their gradient / zgap images instead of synthetic variants")
 a = ap.parse_args()
 n_files = min(a.targets, 256)
 lib = cds.Library(W, H, n_files)
-lib.generate_synthetic(0xC0FFEE, 0, 0, n_files, kind=0, with_variants=True)
+if a.real:   # (tests/golden: the images of the reference's own JUnit cases; the zgap of the two targets without a ZGapImage file is made on the device)
+    fx = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "cds_fixtures.npz"))
+    n_files = 3
+    lib = cds.Library(W, H, n_files)
+    lib.upload(0, np.stack([fx["lm_BJD"], fx["lm_VT016795"], fx["lm_VT033614"]]))
+    lib.upload_variants(0, gradients=np.stack([fx["grad_BJD"], fx["grad_VT016795"], fx["grad_VT033614"]]))
+    lib.make_zgap_variants(0, 3, 20, 10, cds.label_regions)
+else:
+    lib.generate_synthetic(0xC0FFEE, 0, 0, n_files, kind=0, with_variants=True)
 imgs = lib.download(0, n_files)
 grads, zgaps = lib.download_variants(0, n_files)
 mlib = cds.Library(W, H, a.masks)
@@ -57,3 +67,21 @@ with tempfile.TemporaryDirectory() as d:
     print(json.dumps({"distinct_targets": a.targets, "pairs": n_pairs, "masks": a.masks, "threads": a.threads, "batch": a.batch, "seconds": round(t, 3),
                       "targets_per_s": round(a.targets / t), "files_per_s": round(3 * a.targets / t), "pairs_per_s": round(n_pairs / t),
                       "file_bytes_per_target": round(bytes_files), "scored": int((out.gradientAreaGap >= 0).sum()), "equal_to_in_memory_scores": same, "path": proc.last_from_files}))
+    if a.shard:
+        sp = os.path.join(d, "variants.cdsv")
+        t0 = time.perf_counter()
+        with cds.VariantShardWriter(sp, W, H) as w:
+            w.append_files(tf, gf, zf, threads=a.threads)
+        t_write = time.perf_counter() - t0
+        shard = cds.VariantShard(sp)
+        fresh = lambda: P.MatchTable(table.maskIndex, table.targetIndex, table.matchingPixels, table.matchingPixelsRatio, table.mirrored)
+        proc.calculateGradientScoresFromShardTable(masks, fresh().take(np.arange(min(n_pairs, 64))), shard, 20, batch=a.batch, threads=a.threads)   # warm-up
+        t0 = time.perf_counter()
+        out2 = proc.calculateGradientScoresFromShardTable(masks, fresh(), shard, 20, batch=a.batch, threads=a.threads)
+        t2 = time.perf_counter() - t0
+        same2 = bool((ref.gradientAreaGap == out2.gradientAreaGap).all() and (ref.highExpressionArea == out2.highExpressionArea).all())
+        print(json.dumps({"variant_shard": True, "distinct_targets": a.targets, "pairs": n_pairs, "threads": a.threads, "batch": a.batch, "seconds": round(t2, 3),
+                          "targets_per_s": round(a.targets / t2), "shard_bytes_per_target": round(shard.file_bytes / a.targets),
+                          "shard_read_GB_per_s": round(shard.file_bytes / t2 / 1e9, 2), "two_bit_gradients": int((shard.flags & 2 != 0).sum()),
+                          "write_seconds": round(t_write, 2), "write_targets_per_s": round(a.targets / t_write),
+                          "equal_to_in_memory_scores": same2, "path": proc.last_from_files}))
