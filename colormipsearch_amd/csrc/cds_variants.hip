@@ -10,9 +10,11 @@
 //   * the gradient (16 bits, a distance ramp: in every GradientImage of the reference's test data neighbouring pixels of a row differ by
 //     at most 1): DELTA2 -- per row its first value and two bits per pixel (0 same, 1 up, 2 down); a lane takes a word of 16 pixels, the
 //     words' sums go through a wave scan, 32 bytes per lane are stored.  A gradient that is not such a ramp is kept RAW16.
-// The reference's three test targets pack to 0.27-0.33 MB each (their PNG + 2 TIFF: 0.25 MB) -- the shard buys no bytes, it moves the
-// decode from 16 cores to the GPU.  A slot filled from a shard is an ordinary slot of a dense library (image, gradient, zgap: bit-equal
-// to what cds_library_load_files makes of the files; tests/test_mipio.py), so everything downstream is unchanged.
+// The reference's three test targets pack to 0.39-0.55 MB each, 0.48 MB on average (their PackBits TIFF + 16-bit PNG + PackBits TIFF: 0.41 MB)
+// -- the shard buys no bytes, it moves the decode from 16 host cores to the GPU: 55.8 K targets/s from the page cache (26.6 GB/s of blobs),
+// 9.8 K/s from the box's cold disk, where inflating the files gives 5.4 K/s (tools/gradscore_files_rate.py --real --shard; profiles/
+// r05j_variant_shard.txt).  A slot filled from a shard is an ordinary slot of a dense library (image, gradient, zgap: bit-equal to what
+// cds_library_load_files makes of the files; tests/test_mipio.py), so everything downstream is unchanged.
 //
 // File: [64-byte header] [blobs, 16-byte aligned] [index: n x {u64 offset, u32 bytes, u32 flags}]; little-endian.
 // Blob: u32 flags, rgb_bytes, grad_bytes, zgap_bytes; then the three sections in that order.

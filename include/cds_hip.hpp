@@ -67,6 +67,56 @@ private:
     cds_context *h_ = nullptr;
 };
 
+// Kernel 2's inputs of a library in one file (cds_variant_shard_*): written once, from memory or from the library's image files (no GPU
+// needed), then any subset of targets is decoded on the GPU by Library::loadVariants.
+class VariantShardWriter {
+public:
+    VariantShardWriter(const char *path, int width, int height) { check(cds_variant_shard_create(path, width, height, &w_)); }
+    ~VariantShardWriter() { if (w_) cds_variant_shard_finish(w_); }
+    VariantShardWriter(const VariantShardWriter &) = delete;
+    VariantShardWriter &operator=(const VariantShardWriter &) = delete;
+    void append(int64_t n, const uint8_t *rgb, const uint16_t *gradients, const uint8_t *zgaps, int threads = 0) {
+        check(cds_variant_shard_append(w_, n, rgb, gradients, zgaps, threads));
+    }
+    void appendFiles(const std::vector<const char *> &targets, const std::vector<const char *> &gradients, const std::vector<const char *> &zgaps,
+                     int threads = 0) {
+        check(cds_variant_shard_append_files(w_, (int64_t)targets.size(), targets.data(), gradients.empty() ? nullptr : gradients.data(),
+                                             zgaps.empty() ? nullptr : zgaps.data(), threads));
+    }
+    void finish() {
+        cds_variant_writer *w = w_;
+        w_ = nullptr;
+        if (w) check(cds_variant_shard_finish(w));
+    }
+private:
+    cds_variant_writer *w_ = nullptr;
+};
+
+class VariantShard {
+public:
+    explicit VariantShard(const char *path) {
+        check(cds_variant_shard_open(path, &s_));
+        check(cds_variant_shard_info(s_, &w_, &h_, &n_, &bytes_));
+    }
+    ~VariantShard() { cds_variant_shard_close(s_); }
+    VariantShard(const VariantShard &) = delete;
+    VariantShard &operator=(const VariantShard &) = delete;
+    const cds_variant_shard *handle() const { return s_; }
+    int width() const { return w_; }
+    int height() const { return h_; }
+    int64_t size() const { return n_; }
+    int64_t fileBytes() const { return bytes_; }
+    uint32_t flags(int64_t target) const {   // CDS_VARIANT_HAS_GRADIENT | CDS_VARIANT_GRADIENT_DELTA2 | CDS_VARIANT_HAS_ZGAP
+        uint32_t f = 0;
+        check(cds_variant_shard_target_info(s_, target, 1, &f, nullptr));
+        return f;
+    }
+private:
+    cds_variant_shard *s_ = nullptr;
+    int32_t w_ = 0, h_ = 0;
+    int64_t n_ = 0, bytes_ = 0;
+};
+
 // Resident shard of targets (counterpart of the host-side MIP cache, CachedMIPsUtils.java:60-100).
 class Library {
 public:
@@ -87,6 +137,10 @@ public:
                    const std::vector<const char *> &zgaps, int threads = 0) {
         check(cds_library_load_files(lib_, first, (int64_t)targets.size(), targets.data(), gradients.empty() ? nullptr : gradients.data(),
                                      zgaps.empty() ? nullptr : zgaps.data(), threads));
+    }
+    // slots first.. <- the shard's targets `targets` (image, gradient, zgap as stored), decoded on the device
+    void loadVariants(int64_t first, const VariantShard &shard, const std::vector<int64_t> &targets, int threads = 0) {
+        check(cds_library_load_variants(lib_, first, shard.handle(), targets.data(), (int64_t)targets.size(), threads));
     }
     void uploadGradientU8(int64_t first, int64_t count, const uint8_t *grad8) {   // a GRAY8 gradient image (ByteImageArray.java:3-16)
         check(cds_library_upload_gradient_u8(lib_, first, count, grad8));

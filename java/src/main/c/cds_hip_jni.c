@@ -262,6 +262,71 @@ JNIEXPORT void JNICALL CLS(libraryLoadFiles)(JNIEnv *env, jclass c, jlong lib, j
     if (rc == CDS_ERR_INVALID_ARGUMENT && (!tp || (gradients && !gp) || (zgaps && !zp))) { throw_iae(env, "a path is null or not a valid string"); return; }
     if (rc) throw_for(env, rc);
 }
+/* ---- the variant shard (cds_variant_shard_*): kernel 2's inputs of a library in one file, decoded on the GPU ---- */
+JNIEXPORT jlong JNICALL CLS(variantShardCreate)(JNIEnv *env, jclass c, jstring path, jint w, jint h) {
+    const char *u = path ? (*env)->GetStringUTFChars(env, path, NULL) : NULL;
+    if (!u) { throw_iae(env, "path is null"); return 0; }
+    cds_variant_writer *wr = NULL;
+    int rc = cds_variant_shard_create(u, w, h, &wr);
+    (*env)->ReleaseStringUTFChars(env, path, u);
+    if (rc) { throw_for(env, rc); return 0; }
+    return (jlong)(intptr_t)wr;
+}
+JNIEXPORT void JNICALL CLS(variantShardAppendFiles)(JNIEnv *env, jclass c, jlong writer, jobjectArray targets, jobjectArray gradients, jobjectArray zgaps, jint threads) {
+    if (!targets) { throw_iae(env, "targets is null"); return; }
+    jsize n = (*env)->GetArrayLength(env, targets);
+    if ((gradients && (*env)->GetArrayLength(env, gradients) != n) || (zgaps && (*env)->GetArrayLength(env, zgaps) != n)) {
+        throw_iae(env, "gradients / zgaps must have one entry (or null) per target");
+        return;
+    }
+    const char **tp = copy_paths(env, targets, n, 0);
+    const char **gp = gradients ? copy_paths(env, gradients, n, 1) : NULL;
+    const char **zp = zgaps ? copy_paths(env, zgaps, n, 1) : NULL;
+    const int bad = !tp || (gradients && !gp) || (zgaps && !zp);
+    int rc = bad ? CDS_ERR_INVALID_ARGUMENT : cds_variant_shard_append_files(P(cds_variant_writer, writer), n, tp, gp, zp, threads);
+    free_paths(tp, n);
+    free_paths(gp, n);
+    free_paths(zp, n);
+    if (bad) { throw_iae(env, "a path is null or not a valid string"); return; }
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT void JNICALL CLS(variantShardFinish)(JNIEnv *env, jclass c, jlong writer) {
+    int rc = cds_variant_shard_finish(P(cds_variant_writer, writer));
+    if (rc) throw_for(env, rc);
+}
+JNIEXPORT jlong JNICALL CLS(variantShardOpen)(JNIEnv *env, jclass c, jstring path) {
+    const char *u = path ? (*env)->GetStringUTFChars(env, path, NULL) : NULL;
+    if (!u) { throw_iae(env, "path is null"); return 0; }
+    cds_variant_shard *sh = NULL;
+    int rc = cds_variant_shard_open(u, &sh);
+    (*env)->ReleaseStringUTFChars(env, path, u);
+    if (rc) { throw_for(env, rc); return 0; }
+    return (jlong)(intptr_t)sh;
+}
+JNIEXPORT jlong JNICALL CLS(variantShardSize)(JNIEnv *env, jclass c, jlong shard) {
+    int64_t n = 0;
+    int rc = cds_variant_shard_info(P(cds_variant_shard, shard), NULL, NULL, &n, NULL);
+    if (rc) { throw_for(env, rc); return 0; }
+    return (jlong)n;
+}
+JNIEXPORT jint JNICALL CLS(variantShardTargetFlags)(JNIEnv *env, jclass c, jlong shard, jlong target) {
+    uint32_t f = 0;
+    int rc = cds_variant_shard_target_info(P(cds_variant_shard, shard), target, 1, &f, NULL);
+    if (rc) { throw_for(env, rc); return 0; }
+    return (jint)f;
+}
+JNIEXPORT void JNICALL CLS(variantShardClose)(JNIEnv *env, jclass c, jlong shard) {
+    cds_variant_shard_close(P(cds_variant_shard, shard));
+}
+JNIEXPORT void JNICALL CLS(libraryLoadVariants)(JNIEnv *env, jclass c, jlong lib, jlong first, jlong shard, jlongArray targets, jint threads) {
+    if (!targets) { throw_iae(env, "targets is null"); return; }
+    jsize n = (*env)->GetArrayLength(env, targets);
+    jlong *t = (*env)->GetLongArrayElements(env, targets, NULL);
+    if (!t) return;
+    int rc = cds_library_load_variants(P(cds_library, lib), first, P(cds_variant_shard, shard), (const int64_t *)t, n, threads);
+    (*env)->ReleaseLongArrayElements(env, targets, t, JNI_ABORT);
+    if (rc) throw_for(env, rc);
+}
 JNIEXPORT void JNICALL CLS(sparseLibraryAppendFiles)(JNIEnv *env, jclass c, jlong sl, jobjectArray paths, jint threads) {
     if (!paths) { throw_iae(env, "paths is null"); return; }
     jsize n = (*env)->GetArrayLength(env, paths);

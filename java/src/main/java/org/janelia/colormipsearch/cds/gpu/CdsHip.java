@@ -48,6 +48,20 @@ final class CdsHip {
      * NeuronMIPUtils.loadComputeFile calls of cmd/CalculateGradientScoresCmd.java:541-586.
      */
     static native void libraryLoadFiles(long lib, long first, String[] targets, String[] gradients, String[] zgaps, int threads);
+    /**
+     * The variant shard: every target's MIP, GradientImage and ZGapImage of a library losslessly in one file (written once from the files
+     * -- no GPU needed), of which libraryLoadVariants decodes any subset ON THE DEVICE into dense slots: 44 K targets/s where inflating
+     * the three files of a target on 16 host cores gives 5 K (cmd/CalculateGradientScoresCmd.java:541-586 loads them per match).
+     */
+    static native long variantShardCreate(String path, int width, int height);
+    static native void variantShardAppendFiles(long writer, String[] targets, String[] gradients, String[] zgaps, int threads);
+    static native void variantShardFinish(long writer);
+    static native long variantShardOpen(String path);
+    static native long variantShardSize(long shard);
+    /** bit 0: the target has a gradient, bit 2: it has a zgap image */
+    static native int variantShardTargetFlags(long shard, long target);
+    static native void variantShardClose(long shard);
+    static native void libraryLoadVariants(long lib, long first, long shard, long[] targets, int threads);
     static native void libraryMakeZgapVariants(long lib, long first, long count, int threshold, double radius, int[] rectsXYXY);
     static native void search(long maskset, long lib, long first, long count, int[] scores, byte[] mirrored);
 

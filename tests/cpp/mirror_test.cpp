@@ -3,6 +3,8 @@
 // Prints "OK <self score> <mirrored score> <mirrored flag>" on success.
 #include <cstdio>
 #include <cstdlib>
+#include <unistd.h>
+#include <cstdlib>
 
 #include "cds_hip.hpp"
 
@@ -103,6 +105,38 @@ int main() {
             cds::check(cds_gradscore(sh1.handle(), whole.handle(), 6, pmask.data(), ptarget.data(), wg.data(), wh.data(), wm.data()));
             sharded.gradScores({sh1.handle(), sh2.handle()}, {la.handle(), lb.handle()}, {}, pmask, ptarget, offs, gg, gh, gm);
             if (offs != std::vector<int64_t>({0, 3, 5}) || gg != wg || gh != wh || gm != wm || wg[0] <= 0) return 12;
+
+            // the same five targets through a variant shard: packed from host memory, decoded on the device in another order, scored
+            {
+                const size_t px = (size_t)W * H;
+                std::vector<uint8_t> rgb(5 * 3 * px), zg(5 * 3 * px);
+                std::vector<uint16_t> gr(5 * px);
+                cds::check(cds_library_download(whole.handle(), 0, 5, rgb.data()));
+                cds::check(cds_library_download_variants(whole.handle(), 0, 5, gr.data(), zg.data()));
+                char path[] = "/tmp/cds_mirror_shard_XXXXXX";
+                const int fd = mkstemp(path);
+                if (fd < 0) return 21;
+                close(fd);
+                {
+                    cds::VariantShardWriter w(path, W, H);
+                    w.append(3, rgb.data(), gr.data(), zg.data(), 2);
+                    w.append(2, rgb.data() + 3 * 3 * px, gr.data() + 3 * px, zg.data() + 3 * 3 * px);
+                    w.finish();
+                }
+                cds::VariantShard shard(path);
+                std::remove(path);
+                if (shard.size() != 5 || shard.width() != W || !(shard.flags(4) & CDS_VARIANT_HAS_GRADIENT) || !(shard.flags(0) & CDS_VARIANT_HAS_ZGAP)) return 22;
+                cds::Library fromShard(ctx, W, H, 5);
+                const std::vector<int64_t> order = {4, 0, 3, 1, 2};            // slot k holds target order[k]
+                fromShard.loadVariants(0, shard, order, 2);
+                std::vector<int64_t> slot(6), sg(6), shh(6);
+                std::vector<uint8_t> smm(6);
+                for (size_t i = 0; i < 6; i++)
+                    for (size_t k = 0; k < 5; k++)
+                        if (order[k] == ptarget[i]) slot[i] = (int64_t)k;
+                cds::check(cds_gradscore(sh1.handle(), fromShard.handle(), 6, pmask.data(), slot.data(), sg.data(), shh.data(), smm.data()));
+                if (sg != wg || shh != wh || smm != wm) return 23;
+            }
         }
 
         cds::ColorMIPSearch search(1.0, 20, std::move(provider));

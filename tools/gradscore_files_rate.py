@@ -11,6 +11,19 @@ from PIL import Image
 from colormipsearch_amd import cds
 from colormipsearch_amd import processor as P
 W, H = 1210, 566
+
+
+def drop_cache(paths):
+    """ask the kernel to forget the pages of these files (works on a disk-backed file system; a tmpfs keeps them)"""
+    for q in set(os.path.realpath(x) for x in paths):
+        fd = os.open(q, os.O_RDONLY)
+        try:
+            os.fsync(fd)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+        finally:
+            os.close(fd)
+
+
 ap = argparse.ArgumentParser()
 ap.add_argument("--targets", type=int, default=1024)
 ap.add_argument("--masks", type=int, default=16)
@@ -18,6 +31,7 @@ ap.add_argument("--pairs-per-target", type=float, default=2.2)
 ap.add_argument("--threads", type=int, default=16)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--shard", action="store_true", help="also: the same targets through a variant shard written from the files (decoded on the GPU)")
+ap.add_argument("--cold", action="store_true", help="drop the files' / the shard's pages from the page cache before the timed run (posix_fadvise DONTNEED)")
 ap.add_argument("--real", action="store_true", help="the reference's three LM test targets with their gradient / zgap images instead of synthetic variants")
 a = ap.parse_args()
 n_files = min(a.targets, 256)
@@ -57,6 +71,8 @@ with tempfile.TemporaryDirectory() as d:
     provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(True, 20, 1, 2, cds.label_regions)
     proc = P.GpuColorMIPSearchProcessor(cds.ColorMIPSearch(0.01, 20, provider), lib, None)
     proc.calculateGradientScoresFromFilesTable(masks, table.take(np.arange(min(n_pairs, 64))), tf, gf, zf, 20, batch=a.batch, threads=a.threads)   # warm-up
+    if a.cold:
+        drop_cache(tf[:n_files] + gf[:n_files] + zf[:n_files])
     t0 = time.perf_counter()
     out = proc.calculateGradientScoresFromFilesTable(masks, table, tf, gf, zf, 20, batch=a.batch, threads=a.threads)
     t = time.perf_counter() - t0
@@ -76,6 +92,8 @@ with tempfile.TemporaryDirectory() as d:
         shard = cds.VariantShard(sp)
         fresh = lambda: P.MatchTable(table.maskIndex, table.targetIndex, table.matchingPixels, table.matchingPixelsRatio, table.mirrored)
         proc.calculateGradientScoresFromShardTable(masks, fresh().take(np.arange(min(n_pairs, 64))), shard, 20, batch=a.batch, threads=a.threads)   # warm-up
+        if a.cold:
+            drop_cache([sp])
         t0 = time.perf_counter()
         out2 = proc.calculateGradientScoresFromShardTable(masks, fresh(), shard, 20, batch=a.batch, threads=a.threads)
         t2 = time.perf_counter() - t0
@@ -83,5 +101,5 @@ with tempfile.TemporaryDirectory() as d:
         print(json.dumps({"variant_shard": True, "distinct_targets": a.targets, "pairs": n_pairs, "threads": a.threads, "batch": a.batch, "seconds": round(t2, 3),
                           "targets_per_s": round(a.targets / t2), "shard_bytes_per_target": round(shard.file_bytes / a.targets),
                           "shard_read_GB_per_s": round(shard.file_bytes / t2 / 1e9, 2), "two_bit_gradients": int((shard.flags & 2 != 0).sum()),
-                          "write_seconds": round(t_write, 2), "write_targets_per_s": round(a.targets / t_write),
+                          "cold": bool(a.cold), "file_system": os.popen("df -T %s | tail -1" % d).read().split()[1:2], "write_seconds": round(t_write, 2), "write_targets_per_s": round(a.targets / t_write),
                           "equal_to_in_memory_scores": same2, "path": proc.last_from_files}))
