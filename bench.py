@@ -722,6 +722,60 @@ def overlapping_leg(args, cds, ctx, dev, stream, mask, rects, failed, n_o=262144
             "targets_equal_oracle": bool(ok_or) if checked else None}
 
 
+def variant_shard_leg(cds, ctx, fx, rects, failed, n_t=2048, pairs_per_target=2.2):
+    """Kernel 2 over a library whose variants sit in a variant shard (round 5): the reference's three LM test targets with
+    their GradientImage and a device-made zgap, packed under n_t names, the selected targets' blobs read back and DECODED ON THE GPU batch
+    by batch while the previous batch is scored (processor.calculateGradientScoresFromShardTable) -- every score compared with the same
+    pairs scored from memory."""
+    import tempfile
+    from colormipsearch_amd import processor as P
+    keys = [("lm_BJD", "grad_BJD"), ("lm_VT016795", "grad_VT016795"), ("lm_VT033614", "grad_VT033614")]
+    H, W = fx[keys[0][0]].shape[:2]
+    lib = cds.Library(W, H, len(keys), context=ctx)
+    lib.upload(0, np.stack([fx[t] for t, _ in keys]))
+    lib.upload_variants(0, gradients=np.stack([fx[g] for _, g in keys]))
+    lib.make_zgap_variants(0, len(keys), 20, 10, rects)
+    imgs = lib.download(0, len(keys))
+    grads, zgaps = lib.download_variants(0, len(keys))
+    masks = np.stack([fx[k] for k in sorted(k for k in fx if k.startswith("em_"))])
+    rng = np.random.default_rng(7)
+    n_pairs = int(n_t * pairs_per_target)
+    t_idx = np.concatenate([np.arange(n_t), rng.integers(0, n_t, n_pairs - n_t)]).astype(np.int64)
+    m_idx = rng.integers(0, len(masks), n_pairs).astype(np.int32)
+    order = np.lexsort((t_idx, m_idx))
+    table = lambda ti: P.MatchTable(m_idx[order], ti, np.full(n_pairs, 100, np.int32), np.full(n_pairs, 0.01, np.float32), np.zeros(n_pairs, bool))
+    provider = cds.ColorDepthSearchAlgorithmProviderFactory.createPixMatchCDSAlgorithmProvider(True, 20, 1, 2, rects)
+    proc = P.GpuColorMIPSearchProcessor(cds.ColorMIPSearch(0.01, 20, provider), lib, None)
+    ref = proc.calculateGradientScoresTable(masks, table(t_idx[order] % len(keys)), 20, excludedRegions=rects)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "variants.cdsv")
+        rep = 16
+        t0 = time.perf_counter()
+        with cds.VariantShardWriter(path, W, H) as w:   # target i of the shard = fixture i % 3
+            block = (np.concatenate([imgs] * rep), np.concatenate([grads] * rep), np.concatenate([zgaps] * rep))
+            for first in range(0, n_t, len(keys) * rep):
+                k = min(len(keys) * rep, n_t - first)
+                w.append(block[0][:k], block[1][:k], block[2][:k], threads=usable_cores())
+        t_write = time.perf_counter() - t0
+        shard = cds.VariantShard(path)
+        proc.calculateGradientScoresFromShardTable(masks, table(t_idx[order]).take(np.arange(64)), shard, 20, excludedRegions=rects, batch=512, threads=usable_cores())
+        t0 = time.perf_counter()
+        out = proc.calculateGradientScoresFromShardTable(masks, table(t_idx[order]), shard, 20, excludedRegions=rects, batch=512, threads=usable_cores())
+        t = time.perf_counter() - t0
+        same = bool(np.array_equal(out.gradientAreaGap, ref.gradientAreaGap) and np.array_equal(out.highExpressionArea, ref.highExpressionArea))
+        res = {"workload": f"{n_t} distinct targets (the reference's 3 LM test targets + GradientImage + device-made zgap under {n_t} names) x {n_pairs} pairs of "
+                           f"{len(masks)} EM masks, variants read from a variant shard and decoded on the GPU (page cache warm)",
+               "targets_per_s": n_t / t, "pairs_per_s": n_pairs / t, "seconds": t, "shard_bytes_per_target": shard.file_bytes / n_t,
+               "blob_bytes_read_per_s": shard.file_bytes / t, "gradients_stored_as_two_bits_per_pixel": int((shard.flags & shard.GRADIENT_DELTA2 != 0).sum()),
+               "write_targets_per_s_from_memory": n_t / t_write, "host_threads": usable_cores(), "scores_equal_to_in_memory_path": same,
+               "path": proc.last_from_files}
+        shard.close()
+    proc.close()
+    if not same:
+        failed.append("gradient scores through the variant shard differ from the in-memory path's")
+    return res
+
+
 def config0_leg(args, cds, ctx, dev, stream, dense, mask, rects, failed, n0=100):
     """BASELINE configs[0]: 1 mask x 100 synthetic targets, xyShift 0, no mirror -- the reference's own CPU-runnable case (plumbing).  The C
     restatement of the reference's per-pair loop on ONE host thread (the per-pair call the reference's worker threads make), the same
@@ -1090,6 +1144,7 @@ def aux_legs(args, cds, ctx, dev, stream, dense, slib, alg, mask, rects, scores,
         del rs100, rs
         aux["real_images"] = real
         aux["overlapping_synthetic"] = overlapping_leg(args, cds, ctx, dev, stream, mask, rects, failed)
+        aux["variant_shard"] = variant_shard_leg(cds, ctx, fx, E.STD_RECTS, failed, n_t=2048 if n >= (1 << 20) else 256)
         if not ok_r:
             failed.append("sparse and dense scans disagree on the reference's images")
         if not ok_f:
