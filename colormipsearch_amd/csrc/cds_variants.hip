@@ -523,19 +523,21 @@ int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant
     for (int64_t i = 0; i < n; i++) biggest = std::max<size_t>(biggest, s->idx[(size_t)targets[i]].bytes);
     const size_t table = (size_t)kMaxBatch * 8;
     const size_t stage_bytes = std::max<size_t>((size_t)64 << 20, table + biggest + 16);
-    struct Buffers {
-        uint8_t *h[2] = {nullptr, nullptr}, *d[2] = {nullptr, nullptr};
+    struct Buffers {   // (device blocks from the context's cache: hipFree would wait for the scoring another thread has in flight)
+        cds_context *ctx;
+        uint8_t *h[2] = {nullptr, nullptr};
+        void *d[2] = {nullptr, nullptr};
         hipEvent_t ev[2] = {nullptr, nullptr};
         bool busy[2] = {false, false};
         ~Buffers() {
             for (int k = 0; k < 2; k++) {
                 if (busy[k]) hipEventSynchronize(ev[k]);
                 pinned_put(h[k]);
-                if (d[k]) hipFree(d[k]);
+                if (d[k]) cache_free(ctx, d[k]);
                 if (ev[k]) hipEventDestroy(ev[k]);
             }
         }
-    } B;
+    } B{ctx};
     const bool two = [&]() {   // (a call that fits one batch needs one pair of buffers)
         size_t used = table;
         for (int64_t i = 0; i < n; i++) {
@@ -546,7 +548,7 @@ int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant
     }();
     for (int k = 0; k < (two ? 2 : 1); k++) {
         if (!(B.h[k] = pinned_get(stage_bytes))) return fail(CDS_ERR_OUT_OF_MEMORY, "no pinned host memory for the shard's blobs");
-        CDS_HIP(dev_malloc(&B.d[k], stage_bytes));
+        CDS_HIP(cache_alloc(ctx, &B.d[k], stage_bytes));
         CDS_HIP(hipEventCreateWithFlags(&B.ev[k], hipEventDisableTiming));
     }
     static const bool timed = getenv("CDS_TIME_LOAD") != nullptr;
@@ -595,7 +597,7 @@ int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant
         CDS_HIP(hipMemsetAsync(lib->d_rgb + (size_t)slot0 * lib->img_stride, 0, (size_t)nb * lib->img_stride, st));
         if (any_zgap) CDS_HIP(hipMemsetAsync(lib->d_zgap + (size_t)slot0 * lib->img_stride, 0, (size_t)nb * lib->img_stride, st));
         VarDecodeParams p{};
-        p.stage = B.d[kk];
+        p.stage = static_cast<const uint8_t *>(B.d[kk]);
         p.nb = nb, p.W = lib->W, p.H = lib->H;
         p.rgb = lib->d_rgb + (size_t)slot0 * lib->img_stride;
         p.zgap = lib->d_zgap + (size_t)slot0 * lib->img_stride;
