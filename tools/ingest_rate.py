@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--files", type=int, default=2048)
 ap.add_argument("--compression", default="packbits")
 ap.add_argument("--threads", type=int, default=0)
+ap.add_argument("--variant-shard", action="store_true", help="also: the same target files packed into a variant shard (no gradient / zgap) and loaded into dense slots through the GPU decoders")
 a = ap.parse_args()
 lib = cds.Library(W, H, 256)
 lib.generate_synthetic(0xC0FFEE, 0, 0, 256, kind=0)
@@ -35,6 +36,23 @@ with tempfile.TemporaryDirectory() as d:
     for p in paths[:64]:
         mipio.read_mip(p, native=False)
     tp = (time.perf_counter() - t0) / 64
-    print(json.dumps({"files": a.files, "compression": a.compression, "mean_file_bytes": round(nbytes / a.files), "threads": a.threads or os.cpu_count(),
+    extra = {}
+    if a.variant_shard:   # kernel 2's loader on the same files: write once, then decode on the device (tools/gradscore_files_rate.py --shard adds the variants)
+        sp = os.path.join(d, "targets.cdsv")
+        t0 = time.perf_counter()
+        with cds.VariantShardWriter(sp, W, H) as w:
+            w.append_files(paths, threads=a.threads)
+        tw = time.perf_counter() - t0
+        shard = cds.VariantShard(sp)
+        dl = cds.Library(W, H, min(a.files, 1024))
+        dl.load_variants(0, shard, np.arange(min(a.files, 64)), threads=a.threads)          # warm-up
+        t0 = time.perf_counter()
+        for first in range(0, a.files, dl.capacity):
+            dl.load_variants(0, shard, np.arange(first, min(first + dl.capacity, a.files)), threads=a.threads)
+        tl = time.perf_counter() - t0
+        same = bool(np.array_equal(dl.download(0, 4), np.stack([mipio.read_mip(q) for q in paths[(a.files - 1) // dl.capacity * dl.capacity:][:4]])))
+        extra = {"variant_shard": {"write_images_per_s": round(a.files / tw), "load_images_per_s": round(a.files / tl), "bytes_per_image": round(shard.file_bytes / a.files),
+                                   "read_GBps": round(shard.file_bytes / tl / 1e9, 2), "last_batch_equals_the_files": same}}
+    print(json.dumps({**extra, "files": a.files, "compression": a.compression, "mean_file_bytes": round(nbytes / a.files), "threads": a.threads or os.cpu_count(),
                       "append_files_s": round(t, 3), "images_per_s": round(a.files / t), "decoded_GBps": round(a.files * 3 * W * H / t / 1e9, 2),
                       "pillow_decode_ms_per_image_single_thread": round(tp * 1e3, 2), "records": sl.pixels}))
