@@ -225,6 +225,77 @@ def test_variant_shard_codes_on_the_host(tmp_path, fixtures):
     assert len(cds.VariantShard(empty)) == 0
 
 
+def _random_variant_images(rng, W, H, n):
+    """n (image, gradient | None, zgap | None) of W x H: sparse strokes, runs of every length, ramps and non-ramps"""
+    out = []
+    for i in range(n):
+        img = np.zeros((H, W, 3), np.uint8)
+        for _ in range(rng.integers(0, 6)):
+            y0, x0 = rng.integers(0, H), rng.integers(0, W)
+            h, w = rng.integers(1, H + 1), rng.integers(1, min(W, 300) + 1)
+            img[y0:y0 + h, x0:x0 + w] = rng.integers(0, 256, 3) if rng.random() < 0.5 else rng.integers(0, 256, (min(h, H - y0), min(w, W - x0), 3))
+        kind = i % 4
+        if kind == 0:
+            grad = None
+        elif kind == 1:       # a ramp: steps of -1 / 0 / +1 from a random start, never leaving 0 .. 65535
+            steps = rng.integers(-1, 2, (H, W))
+            steps[:, 0] = 0
+            grad = np.clip(rng.integers(0, 65536, (H, 1)) + np.cumsum(steps, axis=1), 0, 65535).astype(np.uint16)   # (clipping keeps the steps within 1)
+        elif kind == 2:       # no ramp
+            grad = rng.integers(0, 65536, (H, W)).astype(np.uint16)
+        else:                 # flat, at the top of the range
+            grad = np.full((H, W), 65535, np.uint16)
+        zgap = None if i % 3 == 0 else np.roll(img, 1, axis=1)
+        out.append((img, grad, zgap))
+    return out
+
+
+@pytest.mark.parametrize("W,H", [(8, 1), (9, 3), (16, 2), (17, 5), (33, 4), (255, 3), (256, 2), (257, 2), (511, 1), (1210, 3), (2000, 2)])
+def test_variant_shard_codes_at_other_image_sizes(tmp_path, W, H):
+    """the packer at the sizes where its words end unevenly (W not a multiple of 16, of 2; one row; the widest image) against the numpy reading"""
+    from colormipsearch_amd import cds
+    from tests.variant_shard_ref import read_shard
+    cases = _random_variant_images(np.random.default_rng(W * 1000 + H), W, H, 8)
+    path = tmp_path / "s.cdsv"
+    with cds.VariantShardWriter(path, W, H) as w:
+        for img, g, z in cases:
+            w.append(img, None if g is None else g[None], None if z is None else z[None], threads=1)
+    w2, h2, got = read_shard(path)
+    assert (w2, h2, len(got)) == (W, H, len(cases))
+    for (flags, rgb, g, z), (eimg, eg, ez) in zip(got, cases):
+        assert np.array_equal(rgb, eimg)
+        assert (g is None) == (eg is None) and (eg is None or np.array_equal(g, eg))
+        assert (z is None) == (ez is None) and (ez is None or np.array_equal(z, ez))
+    ramps = [bool(f & 2) for f, _, _, _ in got]
+    assert ramps[1] and ramps[3] and not ramps[2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H", [(8, 1), (9, 3), (16, 2), (17, 5), (33, 4), (255, 3), (257, 2), (511, 1), (1023, 2), (2000, 3)])
+def test_variant_shard_device_decoders_at_other_image_sizes(tmp_path, W, H):
+    """the device decoders where a row's last word, the row pitch and the 16-byte stores end unevenly: slots equal the packed images"""
+    from colormipsearch_amd import cds
+    cases = _random_variant_images(np.random.default_rng(W * 1000 + H), W, H, 12)
+    path = tmp_path / "s.cdsv"
+    with cds.VariantShardWriter(path, W, H) as w:
+        for img, g, z in cases:
+            w.append(img, None if g is None else g[None], None if z is None else z[None], threads=1)
+    shard = cds.VariantShard(path)
+    lib = cds.Library(W, H, len(cases) + 1)
+    lib.upload(0, np.full((len(cases) + 1, H, W, 3), 200, np.uint8))                                  # stale content everywhere first
+    lib.upload_variants(0, gradients=np.full((len(cases) + 1, H, W), 77, np.uint16), zgaps=np.full((len(cases) + 1, H, W, 3), 9, np.uint8))
+    lib.load_variants(1, shard, np.arange(len(cases)))
+    imgs = lib.download(0, len(cases) + 1)
+    grads, zgaps = lib.download_variants(0, len(cases) + 1)
+    assert (imgs[0] == 200).all() and (grads[0] == 77).all() and (zgaps[0] == 9).all()               # the slot in front is untouched
+    for k, (img, g, z) in enumerate(cases):
+        assert np.array_equal(imgs[k + 1], img), k
+        if g is not None:
+            assert np.array_equal(grads[k + 1], g), k
+        if z is not None:
+            assert np.array_equal(zgaps[k + 1], z), k
+
+
 @pytest.mark.gpu
 def test_variant_shard_slots_equal_the_images(tmp_path, fixtures):
     """cds_library_load_variants: targets of a shard decoded ON THE DEVICE into dense slots -- any order, repeats, into a library
