@@ -766,7 +766,7 @@ def variant_shard_leg(cds, ctx, fx, rects, failed, n_t=2048, pairs_per_target=2.
         res = {"workload": f"{n_t} distinct targets (the reference's 3 LM test targets + GradientImage + device-made zgap under {n_t} names) x {n_pairs} pairs of "
                            f"{len(masks)} EM masks, variants read from a variant shard and decoded on the GPU (page cache warm)",
                "targets_per_s": n_t / t, "pairs_per_s": n_pairs / t, "seconds": t, "shard_bytes_per_target": shard.file_bytes / n_t,
-               "blob_bytes_read_per_s": shard.file_bytes / t, "gradients_stored_as_two_bits_per_pixel": int((shard.flags & shard.GRADIENT_DELTA2 != 0).sum()),
+               "blob_bytes_read_per_s": shard.file_bytes / t, "gradients_stored_as_second_differences": int((shard.flags & shard.GRADIENT_DIFF2 != 0).sum()),
                "write_targets_per_s_from_memory": n_t / t_write, "host_threads": usable_cores(), "scores_equal_to_in_memory_path": same,
                "path": proc.last_from_files}
         shard.close()

@@ -434,7 +434,7 @@ class VariantShardWriter:
 
 class VariantShard:
     """A variant shard opened for reading (cds_variant_shard_open)."""
-    HAS_GRADIENT, GRADIENT_DELTA2, HAS_ZGAP = 1, 2, 4
+    HAS_GRADIENT, GRADIENT_DELTA2, HAS_ZGAP, GRADIENT_DIFF2 = 1, 2, 4, 8
 
     def __init__(self, path):
         self._lib = capi.load()

@@ -10,9 +10,10 @@
 //   * the gradient (16 bits, a distance ramp: in every GradientImage of the reference's test data neighbouring pixels of a row differ by
 //     at most 1): DELTA2 -- per row its first value and two bits per pixel (0 same, 1 up, 2 down); a lane takes a word of 16 pixels, the
 //     words' sums go through a wave scan, 32 bytes per lane are stored.  A gradient that is not such a ramp is kept RAW16.
-// The reference's three test targets pack to 0.39-0.55 MB each, 0.48 MB on average (their PackBits TIFF + 16-bit PNG + PackBits TIFF: 0.41 MB)
-// -- the shard buys no bytes, it moves the decode from 16 host cores to the GPU: 55.8 K targets/s from the page cache (26.6 GB/s of blobs),
-// 9.8 K/s from the box's cold disk, where inflating the files gives 5.4 K/s (tools/gradscore_files_rate.py --real --shard; profiles/
+//     (Superseded as the first choice by DIFF2, the non-zero second differences: see grad_encode.)
+// The reference's three test targets pack to 0.22-0.39 MB each, 0.32 MB on average (their PackBits TIFF + 16-bit PNG + PackBits TIFF: 0.41 MB)
+// and the decode moves from 16 host cores to the GPU: 74.3 K targets/s from the page cache (23.4 GB/s of blobs),
+// 14.1 K/s from the box's cold disk, where inflating the files gives 5.5 K/s (tools/gradscore_files_rate.py --real --shard; profiles/
 // r05j_variant_shard.txt).  A slot filled from a shard is an ordinary slot of a dense library (image, gradient, zgap: bit-equal to what
 // cds_library_load_files makes of the files; tests/test_mipio.py), so everything downstream is unchanged.
 //
@@ -39,7 +40,7 @@
 namespace cds {
 namespace {
 
-constexpr uint32_t kVarGrad = CDS_VARIANT_HAS_GRADIENT, kVarDelta2 = CDS_VARIANT_GRADIENT_DELTA2, kVarZgap = CDS_VARIANT_HAS_ZGAP;
+constexpr uint32_t kVarGrad = CDS_VARIANT_HAS_GRADIENT, kVarDelta2 = CDS_VARIANT_GRADIENT_DELTA2, kVarZgap = CDS_VARIANT_HAS_ZGAP, kVarDiff2 = CDS_VARIANT_GRADIENT_DIFF2;
 constexpr char kShardMagic[8] = {'C', 'D', 'S', 'V', 'A', 'R', '0', '1'};
 
 struct ShardHeader {
@@ -79,7 +80,13 @@ void rle4_encode(const uint8_t *rgb, int W, int H, std::vector<uint32_t> &blob) 
     blob[base + (size_t)H] = nruns;
 }
 
-// returns the flag bits of the gradient section it appended
+// returns the flag bits of the gradient section it appended: the smallest of the three codes
+//   DIFF2   the second mixed difference e = g[y][x] - g[y-1][x] - g[y][x-1] + g[y-1][x-1] (mod 2^16, outside the image = 0) where it is not 0:
+//           per row a list of `x | e << 16`, found through a table of H + 1 list indices.  A distance ramp is piecewise linear: in the reference's
+//           GradientImages 99.7-99.9 % of the pixels have e = 0 (a few thousand exceptions: the image's first row and column, the ridges) --
+//           the device gets the image back as the 2-D prefix sum of the exceptions, a row pass and a column pass;
+//   DELTA2  two bits per pixel, for a ramp whose exceptions are many;
+//   RAW16   anything else.
 uint32_t grad_encode(const uint16_t *g, int W, int H, std::vector<uint32_t> &blob) {
     bool ramp = true;
     for (int y = 0; y < H && ramp; y++) {
@@ -88,6 +95,30 @@ uint32_t grad_encode(const uint16_t *g, int W, int H, std::vector<uint32_t> &blo
             const int d = (int)r[x] - (int)r[x - 1];
             if (d > 1 || d < -1) { ramp = false; break; }
         }
+    }
+    const size_t other_words = (size_t)H * (ramp ? delta2_row_words(W) : raw16_row_words(W));
+    {   // DIFF2, given up as soon as it is longer than the alternative
+        const size_t base = blob.size();
+        blob.resize(base + (size_t)H + 1);
+        uint32_t n = 0;
+        bool fits = true;
+        for (int y = 0; y < H && fits; y++) {
+            blob[base + (size_t)y] = n;
+            const uint16_t *r = g + (size_t)y * W, *u = y ? r - W : nullptr;
+            for (int x = 0; x < W; x++) {
+                const uint32_t e = ((uint32_t)r[x] - (u ? u[x] : 0u) - (x ? r[x - 1] : 0u) + ((u && x) ? u[x - 1] : 0u)) & 0xffffu;
+                if (e) {
+                    blob.push_back((uint32_t)x | e << 16);
+                    n++;
+                }
+            }
+            fits = (size_t)H + 1 + n < other_words;
+        }
+        if (fits) {
+            blob[base + (size_t)H] = n;
+            return kVarGrad | kVarDiff2;
+        }
+        blob.resize(base);
     }
     if (ramp) {
         const uint32_t rw = delta2_row_words(W);
@@ -148,10 +179,13 @@ bool blob_ok(const uint32_t *blob, size_t bytes, uint32_t flags_in_index, int W,
         return true;
     };
     if (!rle_ok(blob + 4, rb)) return false;
-    if (flags & kVarGrad) {
+    if ((flags & kVarDelta2) && (flags & kVarDiff2)) return false;
+    if ((flags & kVarGrad) && (flags & kVarDiff2)) {
+        if (!rle_ok(blob + 4 + rb / 4, gb)) return false;   // (the same shape: a table of H + 1 list indices, then the lists)
+    } else if (flags & kVarGrad) {
         const uint64_t want = (uint64_t)H * ((flags & kVarDelta2) ? delta2_row_words(W) : raw16_row_words(W)) * 4;
         if (gb != want) return false;
-    } else if (gb != 0 || (flags & kVarDelta2)) return false;
+    } else if (gb != 0 || (flags & (kVarDelta2 | kVarDiff2))) return false;
     if (flags & kVarZgap) {
         if (!rle_ok(blob + 4 + rb / 4 + gb / 4, zb)) return false;
     } else if (zb != 0) return false;
@@ -244,8 +278,10 @@ __global__ __launch_bounds__(256) void var_rle4_kernel(VarDecodeParams p) {
     }
 }
 
-// DELTA2 / RAW16 rows -> pitched 16-bit rows.  One wave per (target, row).
+// DELTA2 / RAW16 rows -> pitched 16-bit rows; DIFF2 rows -> the ROW prefix sums of their exceptions (var_colsum_kernel finishes them).
+// One wave per (target, row).
 __global__ __launch_bounds__(256) void var_grad_kernel(VarDecodeParams p) {
+    __shared__ uint16_t rowbuf[4][2048];   // DIFF2: a wave's row of exceptions (W <= 2000)
     const int lane = threadIdx.x & 63;
     const int64_t items = p.nb * p.H;
     const uint64_t *offs = reinterpret_cast<const uint64_t *>(p.stage);
@@ -257,7 +293,39 @@ __global__ __launch_bounds__(256) void var_grad_kernel(VarDecodeParams p) {
         if (!(flags & kVarGrad)) continue;
         const uint32_t *sec = blob + 4 + blob[1] / 4;
         uint8_t *dst = reinterpret_cast<uint8_t *>(p.grad) + (size_t)i * p.grad_stride + (size_t)y * p.gpitch;
-        if (flags & kVarDelta2) {
+        if (flags & kVarDiff2) {
+            // the row's exceptions scattered into LDS, then an inclusive scan along the row (mod 2^16), two pixels per lane and step
+            uint16_t *rb = rowbuf[threadIdx.x >> 6];
+            const int wpad = p.gpitch / 2;   // pixels per pitched row (even, >= W): the padding is written as 0
+            for (int x = lane * 2; x < wpad; x += 128) *reinterpret_cast<uint32_t *>(rb + x) = 0u;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t e0 = sec[y], e1 = sec[y + 1];
+            const uint32_t *ex = sec + p.H + 1;
+            for (uint32_t e = e0 + (uint32_t)lane; e < e1; e += 64) {
+                const uint32_t v = ex[e];
+                if ((int)(v & 0xffffu) < p.W) rb[v & 0xffffu] = (uint16_t)(v >> 16);
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t carry = 0;
+            for (int x0 = 0; x0 < wpad; x0 += 128) {
+                const int x = x0 + 2 * lane;
+                const uint32_t pr = x < wpad ? *reinterpret_cast<const uint32_t *>(rb + x) : 0u;
+                const uint32_t a = pr & 0xffffu, b2 = pr >> 16;
+                uint32_t incl = a + b2;   // (sums may exceed 16 bits on the way: only their low halves are kept)
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                const uint32_t before = carry + incl - (a + b2);
+                uint32_t lo = (before + a) & 0xffffu, hi = (before + a + b2) & 0xffffu;
+                if (x >= p.W) lo = 0;
+                if (x + 1 >= p.W) hi = 0;
+                if (x < wpad) *reinterpret_cast<uint32_t *>(dst + (size_t)x * 2) = lo | hi << 16;
+                carry += (uint32_t)__shfl((int)incl, 63, 64);
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else if (flags & kVarDelta2) {
             const int nw = (p.W + 15) / 16;
             const uint32_t *rowp = sec + (size_t)y * (1 + nw);
             int carry = (int)(rowp[0] & 0xffffu);   // the value in front of the step's first word
@@ -297,6 +365,36 @@ __global__ __launch_bounds__(256) void var_grad_kernel(VarDecodeParams p) {
                 uint32_t word = rowp[j];
                 if (2 * j + 1 >= p.W) word &= 0xffffu;
                 reinterpret_cast<uint32_t *>(dst)[j] = word;
+            }
+        }
+    }
+}
+
+// DIFF2, second pass: prefix sums down the columns (mod 2^16), in place.  One wave per (target, 128 columns): two pixels per lane, the
+// rows' loads do not depend on the sums, so they run ahead of the adds.
+__global__ __launch_bounds__(256) void var_colsum_kernel(VarDecodeParams p) {
+    const int lane = threadIdx.x & 63;
+    const int chunks = (p.W + 127) / 128;
+    const int64_t items = p.nb * chunks;
+    const uint64_t *offs = reinterpret_cast<const uint64_t *>(p.stage);
+    for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += (int64_t)gridDim.x * 4) {   // wave-uniform
+        const int64_t i = it / chunks;
+        const int x = (int)(it % chunks) * 128 + 2 * lane;
+        const uint32_t flags = *reinterpret_cast<const uint32_t *>(p.stage + offs[i]);
+        if ((flags & (kVarGrad | kVarDiff2)) != (kVarGrad | kVarDiff2) || x >= p.W) continue;
+        uint8_t *col = reinterpret_cast<uint8_t *>(p.grad) + (size_t)i * p.grad_stride + (size_t)x * 2;
+        uint32_t lo = 0, hi = 0;
+        constexpr int U = 8;
+        for (int y0 = 0; y0 < p.H; y0 += U) {
+            uint32_t v[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) v[k] = y0 + k < p.H ? *reinterpret_cast<const uint32_t *>(col + (size_t)(y0 + k) * p.gpitch) : 0u;
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                if (y0 + k >= p.H) break;
+                lo = (lo + (v[k] & 0xffffu)) & 0xffffu;
+                hi = (hi + (v[k] >> 16)) & 0xffffu;
+                *reinterpret_cast<uint32_t *>(col + (size_t)(y0 + k) * p.gpitch) = lo | hi << 16;
             }
         }
     }
@@ -587,11 +685,11 @@ int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant
         t_wait += std::chrono::duration<double>(t1 - t0).count();
         t_read += std::chrono::duration<double>(t2 - t1).count();
         const int64_t slot0 = first + b0;
-        bool any_grad = false, any_zgap = false;
+        bool any_grad = false, any_zgap = false, any_diff2 = false;
         for (int64_t i = 0; i < nb; i++) {
             const uint32_t f = s->idx[(size_t)targets[b0 + i]].flags;
             slot_flags[(size_t)(b0 + i)] = (uint8_t)f;
-            any_grad |= (f & kVarGrad) != 0, any_zgap |= (f & kVarZgap) != 0;
+            any_grad |= (f & kVarGrad) != 0, any_zgap |= (f & kVarZgap) != 0, any_diff2 |= (f & kVarDiff2) != 0;
         }
         CDS_HIP(hipMemcpyAsync(B.d[kk], B.h[kk], used, hipMemcpyHostToDevice, st));
         CDS_HIP(hipMemsetAsync(lib->d_rgb + (size_t)slot0 * lib->img_stride, 0, (size_t)nb * lib->img_stride, st));
@@ -606,6 +704,7 @@ int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant
         const int64_t cap_grid = (int64_t)ctx->n_cus * 32;
         hipLaunchKernelGGL(var_rle4_kernel, dim3((unsigned)std::min<int64_t>((nb * lib->H * 2 + 3) / 4, cap_grid)), dim3(256), 0, st, p);
         if (any_grad) hipLaunchKernelGGL(var_grad_kernel, dim3((unsigned)std::min<int64_t>((nb * lib->H + 3) / 4, cap_grid)), dim3(256), 0, st, p);
+        if (any_diff2) hipLaunchKernelGGL(var_colsum_kernel, dim3((unsigned)std::min<int64_t>((nb * ((lib->W + 127) / 128) + 3) / 4, cap_grid)), dim3(256), 0, st, p);
         CDS_HIP(hipGetLastError());
         CDS_HIP(hipEventRecord(B.ev[kk], st));
         B.busy[kk] = true;

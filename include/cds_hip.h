@@ -256,14 +256,16 @@ int cds_library_load_files(cds_library *lib, int64_t first, int64_t count, const
  * CalculateGradientScoresCmd reads three image files per selected target through its variant suppliers (tools cmd/
  * CalculateGradientScoresCmd.java:541-586; NeuronMIPUtils.loadComputeFile, API/mips/NeuronMIPUtils.java:36-103) and inflates them on
  * host cores.  A shard holds the same three images of every target -- the MIP, its GradientImage, its ZGapImage -- LOSSLESSLY in codes a
- * wavefront expands (run lengths for the two RGB images, two bits per pixel for a gradient that is a distance ramp, raw 16-bit otherwise):
+ * wavefront expands (run lengths for the two RGB images; for the gradient, a distance ramp, its few non-zero second differences -- the image is
+ * their 2-D prefix sum -- or two bits per pixel, raw 16-bit otherwise):
  * written once per library, then any subset of its targets is read into pinned memory and decoded into dense slots by two kernels.  The
  * slots are bit-equal to what cds_library_load_files makes of the files.  Layout: colormipsearch_amd/csrc/cds_variants.hip. */
 typedef struct cds_variant_writer cds_variant_writer;
 typedef struct cds_variant_shard cds_variant_shard;
 #define CDS_VARIANT_HAS_GRADIENT 1u     /* per-target flags (cds_variant_shard_target_info) */
-#define CDS_VARIANT_GRADIENT_DELTA2 2u  /* the gradient is stored as two bits per pixel (else raw) */
+#define CDS_VARIANT_GRADIENT_DELTA2 2u  /* the gradient is stored as two bits per pixel (neither this nor DIFF2: raw) */
 #define CDS_VARIANT_HAS_ZGAP 4u
+#define CDS_VARIANT_GRADIENT_DIFF2 8u   /* the gradient is stored as the non-zero second mixed differences (a distance ramp has few) */
 int cds_variant_shard_create(const char *path, int32_t width, int32_t height, cds_variant_writer **out);
 /* `n` targets from host memory: rgb [n][H][W][3]; gradients [n][H][W] u16 or NULL (none of them has one); zgaps like rgb or NULL.
  * Packed on `threads` host threads (<= 0: all cores), written in order: target numbers in the shard count up from 0 across calls. */

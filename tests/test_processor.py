@@ -461,7 +461,7 @@ def test_gradient_scores_from_files(tmp_path, fixtures):
     with cds.VariantShardWriter(shard_path, W, H) as w:
         w.append_files(tfiles, gfiles, zfiles, threads=2)
     shard = cds.VariantShard(shard_path)
-    assert (shard.flags & shard.HAS_GRADIENT).tolist() == [1, 1, 1, 0] and (shard.flags & shard.GRADIENT_DELTA2).tolist() == [2, 2, 2, 0]
+    assert (shard.flags & shard.HAS_GRADIENT).tolist() == [1, 1, 1, 0] and (shard.flags & shard.GRADIENT_DIFF2).tolist() == [8, 8, 8, 0]
     again = proc.calculateGradientScoresFromShardTable(masks, table.take(np.arange(len(table))), shard, 20, batch=2, threads=3)
     assert proc.last_from_files["variant_shard"] and proc.last_from_files["dense_libraries"] == 2
     assert np.array_equal(again.gradientAreaGap, scored.gradientAreaGap) and np.array_equal(again.highExpressionArea, scored.highExpressionArea)

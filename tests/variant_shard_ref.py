@@ -33,7 +33,15 @@ def read_shard(path):
         grad = None
         if flags & 1:
             sec = blob[4 + rb // 4:4 + (rb + gb) // 4]
-            if flags & 2:   # two bits per pixel: 0 same, 1 up, 2 down, relative to the pixel on its left; word 0 of a row = its first value
+            if flags & 8:   # the non-zero second mixed differences, per row `x | e << 16`: the image is their 2-D prefix sum (mod 2^16)
+                rows, ex = sec[:H + 1], sec[H + 1:]
+                e = np.zeros((H, W), np.int64)
+                for y in range(H):
+                    r = ex[rows[y]:rows[y + 1]]
+                    assert ((r & 0xffff) < W).all() and ((r >> 16) != 0).all() and (np.diff((r & 0xffff).astype(np.int64)) > 0).all()
+                    e[y, r & 0xffff] = r >> 16
+                grad = (np.cumsum(np.cumsum(e, axis=1), axis=0) & 0xffff).astype(np.uint16)
+            elif flags & 2:   # two bits per pixel: 0 same, 1 up, 2 down, relative to the pixel on its left; word 0 of a row = its first value
                 sec = sec.reshape(H, 1 + (W + 15) // 16)
                 codes = ((sec[:, 1:, None] >> (2 * np.arange(16, dtype=np.uint32))) & 3).reshape(H, -1)[:, :W].astype(np.int64)
                 grad = ((sec[:, 0:1] & 0xffff).astype(np.int64) + np.cumsum((codes == 1).astype(np.int64) - (codes == 2), axis=1)).astype(np.uint16)

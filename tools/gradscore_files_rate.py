@@ -100,6 +100,6 @@ with tempfile.TemporaryDirectory() as d:
         same2 = bool((ref.gradientAreaGap == out2.gradientAreaGap).all() and (ref.highExpressionArea == out2.highExpressionArea).all())
         print(json.dumps({"variant_shard": True, "distinct_targets": a.targets, "pairs": n_pairs, "threads": a.threads, "batch": a.batch, "seconds": round(t2, 3),
                           "targets_per_s": round(a.targets / t2), "shard_bytes_per_target": round(shard.file_bytes / a.targets),
-                          "shard_read_GB_per_s": round(shard.file_bytes / t2 / 1e9, 2), "two_bit_gradients": int((shard.flags & 2 != 0).sum()),
+                          "shard_read_GB_per_s": round(shard.file_bytes / t2 / 1e9, 2), "gradient_codes": {"second_differences": int((shard.flags & 8 != 0).sum()), "two_bits_per_pixel": int((shard.flags & 2 != 0).sum())},
                           "cold": bool(a.cold), "file_system": os.popen("df -T %s | tail -1" % d).read().split()[1:2], "write_seconds": round(t_write, 2), "write_targets_per_s": round(a.targets / t_write),
                           "equal_to_in_memory_scores": same2, "path": proc.last_from_files}))
