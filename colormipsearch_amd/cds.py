@@ -328,17 +328,10 @@ class Library:
     def load_files(self, first, target_paths, gradient_paths=None, zgap_paths=None, threads=0):
         """Slots first.. straight from files: the targets (8-bit RGB), their GradientImage (8- / 16-bit gray; None entry = none: the slot's
         pairs score (-1, -1)) and ZGapImage files (8-bit RGB; None entry = none), decoded natively on `threads` host threads while the
-        previous 64 slots are uploaded (cds_library_load_files)."""
+        previous 64 slots are uploaded (cds_library_load_files).  A path may be a pair (archive.zip, entry name)."""
         n = len(target_paths)
-
-        def arr(paths):
-            if paths is None:
-                return None
-            if len(paths) != n:
-                raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "one path (or None) per target")
-            return (ctypes.c_char_p * max(1, n))(*[None if p is None else os.fsencode(p) for p in paths])
-
-        capi.check(self._lib.cds_library_load_files(self._h, int(first), n, arr(target_paths), arr(gradient_paths), arr(zgap_paths), int(threads)))
+        capi.check(self._lib.cds_library_load_files(self._h, int(first), n, _path_array(target_paths, n), _path_array(gradient_paths, n),
+                                                    _path_array(zgap_paths, n), int(threads)))
 
     def load_variants(self, first, shard, targets, threads=0):
         """Slots first.. <- the targets `targets` of a VariantShard: image, gradient and zgap as stored, decoded on the device
@@ -370,12 +363,36 @@ class Library:
                                                                  int(kind), int(bool(with_variants))))
 
 
+def native_path(file_data):
+    """A MIP's file_data as the native loaders take it: a path, or -- the reference's FileData of type zipEntry (API/model/FileData.java) --
+    a pair (archive.zip, entry name), handed over as `archive.zip!entry`.  None stays None; anything else (bytes of an image, a file
+    object, an archive that is not a .zip) is not a native path: ValueError."""
+    if file_data is None:
+        return None
+    if isinstance(file_data, (tuple, list)) and len(file_data) == 2 and all(isinstance(x, (str, os.PathLike)) for x in file_data) \
+            and os.fspath(file_data[0]).lower().endswith(".zip"):
+        return os.fsencode(os.fspath(file_data[0]) + "!" + os.fspath(file_data[1]))
+    if isinstance(file_data, (str, os.PathLike)):
+        return os.fsencode(file_data)
+    if isinstance(file_data, bytes) and b"\0" not in file_data and len(file_data) < 4096:
+        return file_data
+    raise ValueError("not a file path or (zip archive, entry) pair")
+
+
+def is_native_path(file_data):
+    try:
+        native_path(file_data)
+        return True
+    except ValueError:
+        return False
+
+
 def _path_array(paths, n):
     if paths is None:
         return None
     if len(paths) != n:
         raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "one path (or None) per target")
-    return (ctypes.c_char_p * max(1, n))(*[None if p is None else os.fsencode(p) for p in paths])
+    return (ctypes.c_char_p * max(1, n))(*[native_path(p) for p in paths])
 
 
 class VariantShardWriter:
@@ -586,10 +603,8 @@ class SparseLibrary:
 
     def append_files(self, paths, threads=0):
         """Append 8-bit RGB image files (TIFF / PNG, the library's size): decoded natively on `threads` host threads
-        (0 = all cores), two batches in flight (decode || upload + conversion)."""
-        paths = [os.fsencode(p) for p in paths]
-        arr = (ctypes.c_char_p * max(1, len(paths)))(*paths)
-        capi.check(self._lib.cds_sparse_library_append_files(self._h, arr, len(paths), int(threads)))
+        (0 = all cores), two batches in flight (decode || upload + conversion).  A path may be a pair (archive.zip, entry name)."""
+        capi.check(self._lib.cds_sparse_library_append_files(self._h, _path_array(paths, len(paths)), len(paths), int(threads)))
 
     def export(self, first=0, count=None):
         """(image_offsets uint64[count+1], cell_offsets uint32[count, n_strips, H+1], records uint32[n]) of images

@@ -9,6 +9,10 @@
 // cds_sparse_library_append_files decodes on `threads` host threads, two batches in flight: one being decoded while the
 // previous one is uploaded and turned into signal-pixel records on the GPU.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <strings.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -19,6 +23,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -86,6 +91,7 @@ void pinned_put(uint8_t *p) { g_pinned.put(p); }
 struct Deflater {
     void *(*alloc)() = nullptr;
     int (*zlib_decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    int (*deflate_decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;   // a raw deflate stream (zip entries)
     void (*release)(void *) = nullptr;
     Deflater() {
         if (getenv("CDS_IMAGEIO_ZLIB")) return;
@@ -94,13 +100,14 @@ struct Deflater {
         if (!h) return;
         alloc = (decltype(alloc))dlsym(h, "libdeflate_alloc_decompressor");
         zlib_decompress = (decltype(zlib_decompress))dlsym(h, "libdeflate_zlib_decompress");
+        deflate_decompress = (decltype(deflate_decompress))dlsym(h, "libdeflate_deflate_decompress");
         release = (decltype(release))dlsym(h, "libdeflate_free_decompressor");
         if (!alloc || !zlib_decompress || !release) alloc = nullptr;
     }
 };
-static bool zlib_inflate_exact(const uint8_t *src, size_t len, uint8_t *dst, size_t want) {
+static bool zlib_inflate_exact(const uint8_t *src, size_t len, uint8_t *dst, size_t want, bool raw = false) {
     static const Deflater lib;
-    if (lib.alloc) {
+    if (lib.alloc && (!raw || lib.deflate_decompress)) {
         struct Holder {   // one decompressor per thread, freed with the thread
             void *d = nullptr;
             void (*release)(void *) = nullptr;
@@ -110,8 +117,19 @@ static bool zlib_inflate_exact(const uint8_t *src, size_t len, uint8_t *dst, siz
         if (!hd.d) hd.d = lib.alloc(), hd.release = lib.release;
         if (hd.d) {
             size_t got = 0;
-            if (lib.zlib_decompress(hd.d, src, len, dst, want, &got) == 0 && got == want) return true;   // (LIBDEFLATE_SUCCESS == 0)
+            if ((raw ? lib.deflate_decompress : lib.zlib_decompress)(hd.d, src, len, dst, want, &got) == 0 && got == want) return true;   // (LIBDEFLATE_SUCCESS == 0)
         }
+    }
+    if (raw) {   // zlib, windowBits < 0: no zlib header, no checksum
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -MAX_WBITS) != Z_OK) return false;
+        zs.next_in = const_cast<Bytef *>(src), zs.avail_in = (uInt)len;
+        zs.next_out = dst, zs.avail_out = (uInt)want;
+        const int rc = inflate(&zs, Z_FINISH);
+        const bool ok = rc == Z_STREAM_END && zs.total_out == want;
+        inflateEnd(&zs);
+        return ok;
     }
     uLongf got = (uLongf)want;
     return uncompress(dst, &got, src, (uLong)len) == Z_OK && got == want;
@@ -522,7 +540,159 @@ static bool image_decode(const uint8_t *data, size_t n, const ImgInfo &info, voi
     return tiff_decode(data, n, info, out, err);
 }
 
+// ---- zip archives: the reference's FileData of type zipEntry (API/model/FileData.java:22-26; NeuronMIPUtils.openInputStream, API/mips/
+// NeuronMIPUtils.java:177-199: the MIPs of a library packed into one archive) --------------------------------------------------------
+// A path of the form `<archive>.zip!<entry>` (or `...zip!/<entry>`) names an entry of a zip archive.  Stored and deflated entries, zip64
+// (a library has more than 65,535 MIPs and more than 4 GB), CRC checked.  An entry that is not found by its full name is looked up by
+// its file name alone, as the reference does ("slightly longer test", NeuronMIPUtils.java:163-170).  The central directory of an
+// archive is parsed once and kept (the 8 most recent archives; a changed size or modification time re-reads it).
+struct ZipEntry {
+    uint64_t local_off = 0, csize = 0, usize = 0;
+    uint32_t crc = 0;
+    uint16_t method = 0, flags = 0;
+};
+struct ZipArchive {
+    int fd = -1;
+    uint64_t size = 0;
+    int64_t mtime_ns = 0;
+    std::unordered_map<std::string, ZipEntry> by_name, by_base;
+    ~ZipArchive() { if (fd >= 0) close(fd); }
+};
+static uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | p[1] << 8); }
+static uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+static uint64_t le64(const uint8_t *p) { return (uint64_t)le32(p) | (uint64_t)le32(p + 4) << 32; }
+static bool pread_all(int fd, void *dst, size_t n, uint64_t at) {
+    uint8_t *q = static_cast<uint8_t *>(dst);
+    while (n) {
+        const ssize_t r = pread(fd, q, n, (off_t)at);
+        if (r <= 0) return false;
+        q += r, n -= (size_t)r, at += (uint64_t)r;
+    }
+    return true;
+}
+static std::shared_ptr<ZipArchive> zip_parse(const std::string &path, std::string &err) {
+    auto za = std::make_shared<ZipArchive>();
+    za->fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    struct stat sb;
+    if (za->fd < 0 || fstat(za->fd, &sb) != 0) { err = "cannot open " + path; return nullptr; }
+    za->size = (uint64_t)sb.st_size;
+    za->mtime_ns = (int64_t)sb.st_mtim.tv_sec * 1000000000ll + sb.st_mtim.tv_nsec;
+    // end of central directory: the last 22 .. 22 + 65535 bytes
+    const size_t tail = (size_t)std::min<uint64_t>(za->size, 22 + 65535);
+    std::vector<uint8_t> t(tail);
+    if (tail < 22 || !pread_all(za->fd, t.data(), tail, za->size - tail)) { err = path + " is not a zip archive"; return nullptr; }
+    ptrdiff_t e = -1;
+    for (ptrdiff_t i = (ptrdiff_t)tail - 22; i >= 0; i--)
+        if (le32(&t[(size_t)i]) == 0x06054b50u && (size_t)i + 22 + le16(&t[(size_t)i + 20]) <= tail) { e = i; break; }
+    if (e < 0) { err = path + " is not a zip archive (no end-of-central-directory record)"; return nullptr; }
+    uint64_t n = le16(&t[(size_t)e + 10]), cd_size = le32(&t[(size_t)e + 12]), cd_off = le32(&t[(size_t)e + 16]);
+    if (n == 0xffffu || cd_size == 0xffffffffu || cd_off == 0xffffffffu) {   // zip64: the locator sits in front of this record
+        const uint64_t eocd_at = za->size - tail + (uint64_t)e;
+        uint8_t loc[20], rec[56];
+        if (eocd_at < 20 || !pread_all(za->fd, loc, 20, eocd_at - 20) || le32(loc) != 0x07064b50u) { err = path + ": zip64 locator missing"; return nullptr; }
+        const uint64_t rec_at = le64(loc + 8);
+        if (rec_at + 56 > za->size || !pread_all(za->fd, rec, 56, rec_at) || le32(rec) != 0x06064b50u) { err = path + ": zip64 end record missing"; return nullptr; }
+        n = le64(rec + 32), cd_size = le64(rec + 40), cd_off = le64(rec + 48);
+    }
+    if (cd_off > za->size || cd_size > za->size - cd_off || n > cd_size / 46) { err = path + ": central directory outside the file"; return nullptr; }
+    std::vector<uint8_t> cd((size_t)cd_size);
+    if (cd_size && !pread_all(za->fd, cd.data(), (size_t)cd_size, cd_off)) { err = path + ": cannot read the central directory"; return nullptr; }
+    size_t at = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (at + 46 > cd.size() || le32(&cd[at]) != 0x02014b50u) { err = path + ": damaged central directory"; return nullptr; }
+        ZipEntry ze;
+        ze.flags = le16(&cd[at + 8]), ze.method = le16(&cd[at + 10]), ze.crc = le32(&cd[at + 16]);
+        ze.csize = le32(&cd[at + 20]), ze.usize = le32(&cd[at + 24]), ze.local_off = le32(&cd[at + 42]);
+        const size_t nl = le16(&cd[at + 28]), xl = le16(&cd[at + 30]), cl = le16(&cd[at + 32]);
+        if (at + 46 + nl + xl + cl > cd.size()) { err = path + ": damaged central directory"; return nullptr; }
+        std::string name(reinterpret_cast<const char *>(&cd[at + 46]), nl);
+        for (size_t x = at + 46 + nl, xe = x + xl; x + 4 <= xe;) {   // the zip64 extra field replaces the 32-bit fields that read 0xffffffff
+            const uint16_t id = le16(&cd[x]), len = le16(&cd[x + 2]);
+            if (x + 4 + len > xe) break;
+            if (id == 0x0001) {
+                size_t q = x + 4;
+                const size_t qe = q + len;
+                if (ze.usize == 0xffffffffu && q + 8 <= qe) ze.usize = le64(&cd[q]), q += 8;
+                if (ze.csize == 0xffffffffu && q + 8 <= qe) ze.csize = le64(&cd[q]), q += 8;
+                if (ze.local_off == 0xffffffffu && q + 8 <= qe) ze.local_off = le64(&cd[q]), q += 8;
+            }
+            x += 4 + (size_t)len;
+        }
+        if (!name.empty() && name.back() != '/') {
+            const size_t sl = name.rfind('/');
+            za->by_base.emplace(sl == std::string::npos ? name : name.substr(sl + 1), ze);   // (the first entry of that file name wins)
+            za->by_name[std::move(name)] = ze;
+        }
+        at += 46 + nl + xl + cl;
+    }
+    return za;
+}
+static std::shared_ptr<ZipArchive> zip_archive(const std::string &path, std::string &err) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::string, std::shared_ptr<ZipArchive>>> cache;   // most recent last
+    struct stat sb;
+    if (stat(path.c_str(), &sb) != 0) { err = "cannot open " + path; return nullptr; }
+    const int64_t mt = (int64_t)sb.st_mtim.tv_sec * 1000000000ll + sb.st_mtim.tv_nsec;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < cache.size(); i++)
+            if (cache[i].first == path) {
+                if (cache[i].second->size == (uint64_t)sb.st_size && cache[i].second->mtime_ns == mt) {
+                    auto hit = cache[i];
+                    cache.erase(cache.begin() + (std::ptrdiff_t)i);
+                    cache.push_back(hit);
+                    return hit.second;
+                }
+                cache.erase(cache.begin() + (std::ptrdiff_t)i);
+                break;
+            }
+    }
+    auto za = zip_parse(path, err);   // (outside the lock: two threads may parse the same archive once each)
+    if (!za) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    cache.emplace_back(path, za);
+    if (cache.size() > 8) cache.erase(cache.begin());
+    return za;
+}
+static bool zip_read(const std::string &archive, const std::string &entry, std::vector<uint8_t> &buf, std::string &err) {
+    auto za = zip_archive(archive, err);
+    if (!za) return false;
+    auto it = za->by_name.find(entry);
+    if (it == za->by_name.end()) {
+        const size_t sl = entry.rfind('/');
+        it = za->by_base.find(sl == std::string::npos ? entry : entry.substr(sl + 1));
+        if (it == za->by_base.end()) { err = "no entry " + entry + " in " + archive; return false; }
+    }
+    const ZipEntry &ze = it->second;
+    const std::string what = archive + "!" + entry;
+    if (ze.flags & 1) { err = what + " is encrypted"; return false; }
+    if (ze.method != 0 && ze.method != 8) { err = what + ": compression method " + std::to_string(ze.method) + " is not supported (stored and deflated entries are)"; return false; }
+    constexpr uint64_t kMaxEntry = (uint64_t)1 << 30;   // (a header is untrusted input)
+    if (ze.usize > kMaxEntry || ze.csize > kMaxEntry || (ze.method == 0 && ze.csize != ze.usize)) { err = what + ": implausible entry size"; return false; }
+    uint8_t lh[30];
+    if (ze.local_off + 30 > za->size || !pread_all(za->fd, lh, 30, ze.local_off) || le32(lh) != 0x04034b50u) { err = what + ": damaged local header"; return false; }
+    const uint64_t data = ze.local_off + 30 + le16(lh + 26) + le16(lh + 28);
+    if (data > za->size || ze.csize > za->size - data) { err = what + ": entry data outside the archive"; return false; }
+    buf.resize((size_t)ze.usize);
+    if (ze.method == 0) {
+        if (ze.usize && !pread_all(za->fd, buf.data(), (size_t)ze.usize, data)) { err = "cannot read " + what; return false; }
+    } else {
+        thread_local std::vector<uint8_t> comp;
+        comp.resize((size_t)ze.csize);
+        if (ze.csize && !pread_all(za->fd, comp.data(), (size_t)ze.csize, data)) { err = "cannot read " + what; return false; }
+        if (!zlib_inflate_exact(comp.data(), comp.size(), buf.data(), buf.size(), true)) { err = what + ": damaged deflate stream"; return false; }
+    }
+    if ((uint32_t)crc32(0L, buf.data(), (uInt)buf.size()) != ze.crc) { err = what + ": CRC mismatch"; return false; }
+    return true;
+}
+
 static bool read_file(const char *path, std::vector<uint8_t> &buf, std::string &err) {
+    {   // `<archive>.zip!<entry>`: an entry of a zip archive
+        const char *bang = nullptr;
+        for (const char *q = path; (q = strchr(q, '!')) != nullptr; q++)
+            if (q - path >= 4 && strncasecmp(q - 4, ".zip", 4) == 0) { bang = q; break; }
+        if (bang) return zip_read(std::string(path, (size_t)(bang - path)), std::string(bang[1] == '/' ? bang + 2 : bang + 1), buf, err);
+    }
     FILE *f = fopen(path, "rb");
     if (!f) { err = std::string("cannot open ") + path; return false; }
     fseek(f, 0, SEEK_END);

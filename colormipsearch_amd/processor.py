@@ -789,12 +789,12 @@ class GpuColorMIPSearchProcessor:
         W, H = alg.width, alg.height
         regions = cds._resolve_regions(excludedRegions, W)
         distinct = np.unique(table.targetIndex)
-        is_path = lambda x: x is None or isinstance(x, (str, bytes, os.PathLike))
+        is_path = cds.is_native_path                 # a path, or the reference's zipEntry FileData as (archive.zip, entry name)
         # Round 5: plain files go through the library's own batch loader (cds_library_load_files: the three files of every target decoded on
         # native threads straight into pinned memory, 64 slots in flight behind the decode) and batch i + 1 is loaded into a second dense
         # library while batch i is scored -- 0.70 K targets/s became 4.5 K (tools/gradscore_files_rate.py: 4,096 targets, 16 cores); what is left
-        # is inflating the 16-bit gradient PNGs (1.4 MB of pixels each), and it scales with the cores.  Anything else (zip entries,
-        # bytes, file objects: mipio.read_mip takes them) keeps the per-item path.
+        # is inflating the 16-bit gradient PNGs (1.4 MB of pixels each), and it scales with the cores.  Anything else (image
+        # bytes, file objects, archives that are not zip files: mipio.read_mip takes them) keeps the per-item path.
         native = all(is_path(target_files[int(t)]) and is_path(gradient_files[int(t)]) and (zgap_files is None or is_path(zgap_files[int(t)])) for t in distinct)
 
         def load_native(lib, chunk):

@@ -230,7 +230,11 @@ int cds_sparse_library_import(cds_sparse_library *slib, int64_t count, const uin
  * (API/imageprocessing/ImageArrayUtils.java:98-121; ImageJ's TIFF opener / LocalTiffDecoder.java, packBitsUncompress :229-258,
  * ImageIO for PNG).  Supported: baseline strip TIFF (8/16-bit, 1/3/4 samples, none / PackBits / LZW / Deflate, predictor 2)
  * and non-interlaced PNG (gray 8/16, RGB(A) 8, palette 8); anything else fails with a message.
- * Decoded layout: channels == 3 -> packed RGB u8 (alpha dropped, palette expanded); channels == 1 -> u8 or host-order u16. */
+ * Decoded layout: channels == 3 -> packed RGB u8 (alpha dropped, palette expanded); channels == 1 -> u8 or host-order u16.
+ * Wherever an entry point below takes the PATH of an image file, `<archive>.zip!<entry>` (or `...zip!/<entry>`) names an entry of a zip archive --
+ * the reference's FileData of type zipEntry (API/model/FileData.java:22-26, API/mips/NeuronMIPUtils.java:177-199): stored and deflated entries,
+ * zip64, CRC checked; an entry not found under its full name is looked up by its file name alone, as the reference does (:163-170).  An
+ * archive's directory is parsed once and kept (the 8 most recent archives). */
 typedef struct cds_image_info {
     int32_t width, height, channels, bits;
 } cds_image_info;

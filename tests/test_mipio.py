@@ -225,6 +225,57 @@ def test_variant_shard_codes_on_the_host(tmp_path, fixtures):
     assert len(cds.VariantShard(empty)) == 0
 
 
+def test_native_loaders_read_zip_entries(tmp_path, fixtures):
+    """The reference's FileData of type zipEntry (an archive + an entry name, NeuronMIPUtils.java:177-199) through the native loaders:
+    `archive.zip!entry` -- stored and deflated entries, nested names, the file-name-only lookup the reference falls back to
+    (:163-170), an archive with more than 65,535 entries (zip64 end records), errors that name the entry.  Checked through the variant
+    shard's packer, which needs no GPU (the GPU loaders share the reader: tests below)."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    from colormipsearch_amd import cds
+    from tests.variant_shard_ref import read_shard
+    img, grad = fixtures["lm_GMR"], fixtures["grad_BJD"]
+    H, W = img.shape[:2]
+
+    def encoded(a, fmt, **kw):
+        b = io.BytesIO()
+        PIL.fromarray(a, "RGB" if a.ndim == 3 else None).save(b, fmt, **kw)
+        return b.getvalue()
+
+    zp = tmp_path / "library.zip"
+    with zipfile.ZipFile(zp, "w") as z:
+        z.writestr("mips/a.tif", encoded(img, "TIFF", compression="packbits"), compress_type=zipfile.ZIP_DEFLATED)
+        z.writestr("mips/deep/b.png", encoded(img[::-1].copy(), "PNG"), compress_type=zipfile.ZIP_STORED)
+        z.writestr("gradients/a.png", encoded(grad, "PNG"), compress_type=zipfile.ZIP_DEFLATED)
+        z.writestr("notes.txt", b"not an image")
+    big = tmp_path / "many.ZIP"                                # (the suffix is matched without regard to case)
+    with zipfile.ZipFile(big, "w") as z:
+        for i in range(65600):
+            z.writestr(f"pad/{i}.txt", b"")
+        z.writestr("mips/last.tif", encoded(img, "TIFF", compression="tiff_lzw"), compress_type=zipfile.ZIP_DEFLATED)
+    path = tmp_path / "z.cdsv"
+    with cds.VariantShardWriter(path, W, H) as w:
+        w.append_files([(str(zp), "mips/a.tif"), (str(zp), "mips/deep/b.png"), (str(zp), "elsewhere/b.png"), str(zp) + "!/mips/a.tif", (str(big), "mips/last.tif")],
+                       [(str(zp), "gradients/a.png"), None, None, None, None], None, threads=2)
+        for bad, what in (((str(zp), "mips/none.tif"), "none.tif"), ((str(zp), "notes.txt"), "notes.txt"), ((str(tmp_path / "absent.zip"), "a.tif"), "absent.zip")):
+            with pytest.raises(cds.CdsError, match=what):
+                w.append_files([bad])
+    _, _, got = read_shard(path)
+    assert [f for f, _, _, _ in got] == [9, 0, 0, 0, 0]
+    assert np.array_equal(got[0][1], img) and np.array_equal(got[0][2], grad)
+    assert np.array_equal(got[1][1], img[::-1]) and np.array_equal(got[2][1], img[::-1])     # found under its full name / by its file name alone
+    assert np.array_equal(got[3][1], img) and np.array_equal(got[4][1], img)
+    raw = bytearray(zp.read_bytes())
+    at = raw.find(b"mips/deep/b.png") + len(b"mips/deep/b.png") + 2000                      # inside the stored entry's data
+    raw[at] ^= 0x55
+    (tmp_path / "damaged.zip").write_bytes(bytes(raw))
+    with cds.VariantShardWriter(tmp_path / "x.cdsv", W, H) as w:
+        with pytest.raises(cds.CdsError, match="CRC"):
+            w.append_files([(str(tmp_path / "damaged.zip"), "mips/deep/b.png")])
+    assert cds.is_native_path((str(zp), "x")) and cds.is_native_path("a.tif") and cds.is_native_path(None)
+    assert not cds.is_native_path(("archive.tar", "x")) and not cds.is_native_path(io.BytesIO(b""))
+
+
 def _random_variant_images(rng, W, H, n):
     """n (image, gradient | None, zgap | None) of W x H: sparse strokes, runs of every length, ramps and non-ramps"""
     out = []
@@ -405,6 +456,24 @@ def test_append_files_to_sparse_library(tmp_path, fixtures):
     for i in range(6):
         (ra, ca), (rb, cb) = host.image_records(i), dev.image_records(i)
         assert np.array_equal(ra, rb) and np.array_equal(ca, cb), i
+    # the same files as entries of a zip archive (the reference's FileData of type zipEntry): the same records; and as the dense
+    # slots + gradient of kernel 2's loader
+    zp = tmp_path / "lib.zip"
+    with zipfile.ZipFile(zp, "w", zipfile.ZIP_DEFLATED) as z:
+        for i, q in enumerate(npaths):
+            z.write(q, f"mips/{i}.tif", compress_type=zipfile.ZIP_STORED if i % 2 else zipfile.ZIP_DEFLATED)
+        gq = tmp_path / "g.png"
+        PIL.fromarray(fixtures["grad_BJD"]).save(gq)
+        z.write(gq, "grad/1.png")
+    zipped = cds.SparseLibrary(1210, 566, 8, 8 * 700000, density_limit=2.0, min_threshold=7)
+    zipped.append_files([(str(zp), f"mips/{i}.tif") for i in range(len(npaths))], threads=3)
+    assert len(zipped) == 6 and zipped.pixels == dev.pixels
+    for i in range(6):
+        (ra, ca), (rb, cb) = zipped.image_records(i), dev.image_records(i)
+        assert np.array_equal(ra, rb) and np.array_equal(ca, cb), i
+    dl = cds.Library(1210, 566, 2)
+    dl.load_files(0, [(str(zp), "mips/1.tif"), (str(zp), "mips/4.tif")], [(str(zp), "grad/1.png"), None])
+    assert np.array_equal(dl.download(0, 2), frames[[1, 4]]) and np.array_equal(dl.download_variants(0, 1)[0][0], fixtures["grad_BJD"])
     bad = tmp_path / "bad.tif"
     bad.write_bytes(open(paths[0], "rb").read()[:5000])
     with pytest.raises(cds.CdsError, match="bad.tif"):
