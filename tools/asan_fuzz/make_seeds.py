@@ -39,3 +39,11 @@ for tag, typ, val in ents:
         out += struct.pack(">HHII", tag, typ, 1, val)
 out += struct.pack(">I", 0) + struct.pack(">HHH", 8, 8, 8) + px
 open("seed_mm_raw.tif", "wb").write(out)
+
+# a zip archive of two of the seeds (one deflated, one stored) and a variant shard of the 64 x 48 seed image: the archive reader and the
+# shard reader see mutated copies of these (fuzz_main.cpp)
+import zipfile
+with zipfile.ZipFile("seed_archive.zip", "w") as z:
+    z.write("seed_rgb_packbits.tif", "mips/a.tif", compress_type=zipfile.ZIP_DEFLATED)
+    z.write("seed_rgb.png", "mips/b.png", compress_type=zipfile.ZIP_STORED)
+    z.write("seed_g16.png", "grad/a.png", compress_type=zipfile.ZIP_DEFLATED)
