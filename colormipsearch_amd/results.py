@@ -288,3 +288,39 @@ def match_entities(matches, mask_entities: Sequence[dict], target_entities: Sequ
             d["highExpressionArea"] = int(mt.highExpressionArea)
         out.append(d)
     return out
+
+
+# ---- the input side: where an entity's images are ----------------------------------------------------------------------------------
+def file_data(value):
+    """A `computeFiles` value as the image loaders of this package take it.  The reference writes a FileData as a plain string when it is
+    a file and as {"dataType": "zipEntry", "fileName": <archive>, "entryName": <entry>} when it is an entry of a zip archive
+    (API/model/json/FileDataSerializer.java:13-26) and reads both, plus {"dataType": "file", "fileName": <dir>, "entryName": <name>} =
+    the file <dir>/<name> (FileDataDeserializer.java:14-36, FileData.fromComponentsUsingParentPath :60-74).
+    -> a path, a pair (archive, entry) -- `mipio.read_mip`, `cds.native_path` and with it the native batch loaders take either --, or None
+    for null / blank."""
+    if value is None:
+        return None
+    if isinstance(value, str):
+        return value if value.strip() else None
+    if isinstance(value, dict):
+        name, entry = value.get("fileName"), value.get("entryName")
+        if value.get("dataType", "file") == "zipEntry":
+            return (name, entry) if name and entry else None
+        if not name:
+            return None
+        return os.path.join(name, entry) if entry else name
+    raise ValueError(f"not a FileData: {value!r}")
+
+
+def compute_file(entity: Optional[dict], compute_file_type: str):
+    """AbstractNeuronEntity.getComputeFileData (API/model/AbstractNeuronEntity.java): the entity's file of that ComputeFileType, or None"""
+    return file_data(((entity or {}).get("computeFiles") or {}).get(compute_file_type))
+
+
+def variant_files(target_entities: Sequence[dict]):
+    """(target files, gradient files, zgap files) of a list of neuron entities: what CalculateGradientScoresCmd's variant suppliers open
+    per match (cmd/CalculateGradientScoresCmd.java:541-586: InputColorDepthImage, GradientImage, ZGapImage) as the three lists
+    `processor.calculateGradientScoresFromFilesTable`, `cds.Library.load_files` and `cds.VariantShardWriter.append_files` take."""
+    return ([compute_file(e, "InputColorDepthImage") for e in target_entities],
+            [compute_file(e, "GradientImage") for e in target_entities],
+            [compute_file(e, "ZGapImage") for e in target_entities])

@@ -5,6 +5,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 from colormipsearch_amd import results
 from colormipsearch_amd.processor import CDMatch
@@ -113,3 +114,22 @@ def test_grouping_is_by_first_mask_of_the_key_and_stable():
     assert [r["matchComputeFiles"]["MaskColorDepthImage"] for r in g[0]["results"]] == ["A_2.tif", "A_1.tif", "A_2.tif"]
     back = results.expand_results_by_mask(g[0])
     assert [m["maskImage"]["computeFiles"]["InputColorDepthImage"] for m in back] == ["A_2.tif", "A_1.tif", "A_2.tif"]
+
+
+def test_compute_files_in_both_json_forms():
+    """FileData as the reference writes and reads it (FileDataSerializer.java:13-26, FileDataDeserializer.java:14-36): a string, a zipEntry
+    object, a file object with a directory and a name; on the reference's own test matches the three variant lists come out."""
+    from colormipsearch_amd import cds
+    assert results.file_data("/a/b.tif") == "/a/b.tif" and results.file_data("  ") is None and results.file_data(None) is None
+    assert results.file_data({"dataType": "zipEntry", "fileName": "/lib/mips.zip", "entryName": "cdm/x.tif"}) == ("/lib/mips.zip", "cdm/x.tif")
+    assert results.file_data({"dataType": "file", "fileName": "/lib/cdm", "entryName": "x.tif"}) == "/lib/cdm/x.tif"
+    assert results.file_data({"fileName": "/lib/x.tif"}) == "/lib/x.tif" and results.file_data({"dataType": "zipEntry", "fileName": "/lib/mips.zip"}) is None
+    assert cds.native_path(results.file_data({"dataType": "zipEntry", "fileName": "/lib/mips.zip", "entryName": "cdm/x.tif"})) == b"/lib/mips.zip!cdm/x.tif"
+    with pytest.raises(ValueError):
+        results.file_data(17)
+    matches = results.read_matches_list(GOLDEN)
+    targets, grads, zgaps = results.variant_files([m["image"] for m in matches])
+    assert len(targets) == len(matches) and all(t and t.endswith(".tif") for t in targets)
+    assert zgaps[0].endswith("Split2_segmented_RGB20px/SS01491-20140729_31_B4-m_20x_CH1_03.tif") and all(cds.is_native_path(x) for x in targets + grads + zgaps)
+    assert results.compute_file(matches[0]["maskImage"], "GradientImage").endswith("grad/1002507170-PFL1-RT_18U_FL.png")
+    assert results.compute_file(None, "GradientImage") is None and results.compute_file({}, "ZGapImage") is None

@@ -3,6 +3,9 @@
 Library.load_variants / processor.calculateGradientScoresFromShardTable) from a library's image files.  No GPU needed.
 
     python tools/make_variant_shard.py OUT.cdsv --targets DIR_OR_LIST [--gradients DIR_OR_LIST] [--zgaps DIR_OR_LIST] [--threads N]
+    python tools/make_variant_shard.py OUT.cdsv --mips-json MIPS.json        # a JSON array of the reference's neuron entities: their
+                                                                             # computeFiles (InputColorDepthImage, GradientImage, ZGapImage;
+                                                                             # files or zip entries) in the array's order
 
 DIR_OR_LIST is a directory (its *.tif / *.tiff / *.png files, sorted by name) or a text file with one path per line.  Variants are
 matched to targets by file stem up to the first of the usual variant suffixes, the way the reference finds a MIP's variant in a
@@ -37,16 +40,22 @@ def matched(targets, variants):
 
 ap = argparse.ArgumentParser()
 ap.add_argument("out")
-ap.add_argument("--targets", required=True)
+ap.add_argument("--targets")
+ap.add_argument("--mips-json")
 ap.add_argument("--gradients")
 ap.add_argument("--zgaps")
 ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--batch", type=int, default=4096)
 a = ap.parse_args()
-targets = listing(a.targets)
-if not targets:
-    sys.exit("no target files")
-grads, zgaps = matched(targets, listing(a.gradients)), matched(targets, listing(a.zgaps))
+if a.mips_json:
+    import json
+    from colormipsearch_amd import results
+    targets, grads, zgaps = results.variant_files(json.load(open(a.mips_json)))
+else:
+    targets = listing(a.targets) if a.targets else None
+    if not targets:
+        sys.exit("no target files (--targets or --mips-json)")
+    grads, zgaps = matched(targets, listing(a.gradients)), matched(targets, listing(a.zgaps))
 H, W = mipio.read_mip(targets[0]).shape[:2]     # the library's image size = its first target's
 t0 = time.perf_counter()
 with cds.VariantShardWriter(a.out, W, H) as w:
