@@ -451,7 +451,7 @@ class VariantShardWriter:
 
 class VariantShard:
     """A variant shard opened for reading (cds_variant_shard_open)."""
-    HAS_GRADIENT, GRADIENT_DELTA2, HAS_ZGAP, GRADIENT_DIFF2 = 1, 2, 4, 8
+    HAS_GRADIENT, GRADIENT_DELTA2, HAS_ZGAP, GRADIENT_DIFF2, RGB_SPANS, ZGAP_SPANS = 1, 2, 4, 8, 16, 32
 
     def __init__(self, path):
         self._lib = capi.load()

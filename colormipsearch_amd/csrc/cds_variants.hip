@@ -11,9 +11,10 @@
 //     at most 1): DELTA2 -- per row its first value and two bits per pixel (0 same, 1 up, 2 down); a lane takes a word of 16 pixels, the
 //     words' sums go through a wave scan, 32 bytes per lane are stored.  A gradient that is not such a ramp is kept RAW16.
 //     (Superseded as the first choice by DIFF2, the non-zero second differences: see grad_encode.)
-// The reference's three test targets pack to 0.22-0.39 MB each, 0.32 MB on average (their PackBits TIFF + 16-bit PNG + PackBits TIFF: 0.41 MB)
-// and the decode moves from 16 host cores to the GPU: 74.3 K targets/s from the page cache (23.4 GB/s of blobs),
-// 14.1 K/s from the box's cold disk, where inflating the files gives 5.5 K/s (tools/gradscore_files_rate.py --real --shard; profiles/
+//     (An RGB image whose signal pixels all differ -- a MIP -- is shorter as SPANS: see spans_encode.)
+// The reference's three test targets pack to 0.18-0.33 MB each, 0.27 MB on average (their PackBits TIFF + 16-bit PNG + PackBits TIFF: 0.41 MB)
+// and the decode moves from 16 host cores to the GPU: 77.5 K targets/s from the page cache (21.1 GB/s of blobs),
+// 17.7 K/s from the box's cold disk, where inflating the files gives 5.3 K/s (tools/gradscore_files_rate.py --real --shard; profiles/
 // r05j_variant_shard.txt).  A slot filled from a shard is an ordinary slot of a dense library (image, gradient, zgap: bit-equal to what
 // cds_library_load_files makes of the files; tests/test_mipio.py), so everything downstream is unchanged.
 //
@@ -40,7 +41,8 @@
 namespace cds {
 namespace {
 
-constexpr uint32_t kVarGrad = CDS_VARIANT_HAS_GRADIENT, kVarDelta2 = CDS_VARIANT_GRADIENT_DELTA2, kVarZgap = CDS_VARIANT_HAS_ZGAP, kVarDiff2 = CDS_VARIANT_GRADIENT_DIFF2;
+constexpr uint32_t kVarGrad = CDS_VARIANT_HAS_GRADIENT, kVarDelta2 = CDS_VARIANT_GRADIENT_DELTA2, kVarZgap = CDS_VARIANT_HAS_ZGAP, kVarDiff2 = CDS_VARIANT_GRADIENT_DIFF2,
+                   kVarRgbSpans = CDS_VARIANT_RGB_SPANS, kVarZgapSpans = CDS_VARIANT_ZGAP_SPANS;
 constexpr char kShardMagic[8] = {'C', 'D', 'S', 'V', 'A', 'R', '0', '1'};
 
 struct ShardHeader {
@@ -78,6 +80,51 @@ void rle4_encode(const uint8_t *rgb, int W, int H, std::vector<uint32_t> &blob) 
         }
     }
     blob[base + (size_t)H] = nruns;
+}
+
+// SPANS: the other code of an RGB image -- per row the spans `x0 | len << 16` of its non-black pixels and their bytes (3 per pixel, row after row,
+// padded to a word): `u32 row_span[H + 1]` (span indices), `u32 row_pixel[H + 1]` (pixels in front of the row), the spans, the bytes.  A MIP's signal
+// pixels all differ from their neighbours (RLE4 then spends 4 bytes on each); a zgap image, a max filter's output, has long runs (RLE4 wins).
+void spans_encode(const uint8_t *rgb, int W, int H, std::vector<uint32_t> &blob) {
+    const size_t base = blob.size();
+    blob.resize(base + 2 * ((size_t)H + 1));
+    std::vector<uint8_t> lit;
+    uint32_t nspans = 0, npx = 0;
+    for (int y = 0; y < H; y++) {
+        blob[base + (size_t)y] = nspans;
+        blob[base + (size_t)H + 1 + (size_t)y] = npx;
+        const uint8_t *p = rgb + (size_t)y * W * 3;
+        int x = 0;
+        while (x < W) {
+            while (x < W && !(p[3 * x] | p[3 * x + 1] | p[3 * x + 2])) x++;
+            if (x >= W) break;
+            const int x0 = x;
+            while (x < W && (p[3 * x] | p[3 * x + 1] | p[3 * x + 2])) x++;
+            blob.push_back((uint32_t)x0 | (uint32_t)(x - x0) << 16);
+            lit.insert(lit.end(), p + 3 * x0, p + 3 * x);
+            nspans++, npx += (uint32_t)(x - x0);
+        }
+    }
+    blob[base + (size_t)H] = nspans;
+    blob[base + 2 * (size_t)H + 1] = npx;
+    lit.resize((lit.size() + 3) & ~(size_t)3, 0);
+    const size_t at = blob.size();
+    blob.resize(at + lit.size() / 4);
+    memcpy(blob.data() + at, lit.data(), lit.size());
+}
+// the shorter of the two codes of an RGB image; true when it is SPANS
+bool rgb_encode(const uint8_t *rgb, int W, int H, std::vector<uint32_t> &blob) {
+    const size_t base = blob.size();
+    rle4_encode(rgb, W, H, blob);
+    const size_t rle_words = blob.size() - base;
+    static const bool no_spans = getenv("CDS_VARIANT_NO_SPANS") != nullptr;   // (A/B runs of the decoders: run lengths only)
+    if (no_spans) return false;
+    std::vector<uint32_t> alt;
+    spans_encode(rgb, W, H, alt);
+    if (alt.size() >= rle_words) return false;
+    blob.resize(base);
+    blob.insert(blob.end(), alt.begin(), alt.end());
+    return true;
 }
 
 // returns the flag bits of the gradient section it appended: the smallest of the three codes
@@ -149,15 +196,11 @@ uint32_t grad_encode(const uint16_t *g, int W, int H, std::vector<uint32_t> &blo
 void pack_target(const uint8_t *rgb, const uint16_t *grad, const uint8_t *zgap, int W, int H, std::vector<uint32_t> &blob, uint32_t &flags) {
     blob.clear();
     blob.resize(4, 0u);
-    rle4_encode(rgb, W, H, blob);
+    flags = rgb_encode(rgb, W, H, blob) ? kVarRgbSpans : 0u;
     const size_t a = blob.size();
-    flags = 0;
     if (grad) flags |= grad_encode(grad, W, H, blob);
     const size_t b = blob.size();
-    if (zgap) {
-        rle4_encode(zgap, W, H, blob);
-        flags |= kVarZgap;
-    }
+    if (zgap) flags |= kVarZgap | (rgb_encode(zgap, W, H, blob) ? kVarZgapSpans : 0u);
     blob[0] = flags;
     blob[1] = (uint32_t)((a - 4) * 4);
     blob[2] = (uint32_t)((b - a) * 4);
@@ -178,7 +221,17 @@ bool blob_ok(const uint32_t *blob, size_t bytes, uint32_t flags_in_index, int W,
             if (sec[y] > sec[y + 1]) return false;
         return true;
     };
-    if (!rle_ok(blob + 4, rb)) return false;
+    auto spans_ok = [&](const uint32_t *sec, uint32_t sb) {
+        const uint64_t tables = 2 * ((uint64_t)H + 1);
+        if (sb < tables * 4) return false;
+        const uint32_t nspans = sec[H], npx = sec[2 * H + 1];
+        if (sec[0] != 0 || sec[H + 1] != 0 || (tables + nspans) * 4 + (((uint64_t)npx * 3 + 3) & ~(uint64_t)3) != sb) return false;
+        for (int y = 0; y < H; y++)
+            if (sec[y] > sec[y + 1] || sec[H + 1 + y] > sec[H + 2 + y]) return false;
+        return true;
+    };
+    if ((flags & kVarZgapSpans) && !(flags & kVarZgap)) return false;
+    if (!((flags & kVarRgbSpans) ? spans_ok(blob + 4, rb) : rle_ok(blob + 4, rb))) return false;
     if ((flags & kVarDelta2) && (flags & kVarDiff2)) return false;
     if ((flags & kVarGrad) && (flags & kVarDiff2)) {
         if (!rle_ok(blob + 4 + rb / 4, gb)) return false;   // (the same shape: a table of H + 1 list indices, then the lists)
@@ -187,7 +240,7 @@ bool blob_ok(const uint32_t *blob, size_t bytes, uint32_t flags_in_index, int W,
         if (gb != want) return false;
     } else if (gb != 0 || (flags & (kVarDelta2 | kVarDiff2))) return false;
     if (flags & kVarZgap) {
-        if (!rle_ok(blob + 4 + rb / 4 + gb / 4, zb)) return false;
+        if (!((flags & kVarZgapSpans) ? spans_ok(blob + 4 + rb / 4 + gb / 4, zb) : rle_ok(blob + 4 + rb / 4 + gb / 4, zb))) return false;
     } else if (zb != 0) return false;
     return true;
 }
@@ -251,9 +304,47 @@ __global__ __launch_bounds__(256) void var_rle4_kernel(VarDecodeParams p) {
         const uint32_t flags = blob[0];
         if (plane == 1 && !(flags & kVarZgap)) continue;
         const uint32_t *sec = blob + 4 + (plane ? (blob[1] + blob[2]) / 4 : 0);
+        uint8_t *dst = (plane ? p.zgap : p.rgb) + (size_t)i * p.img_stride + (size_t)y * p.pitch;
+        if (flags & (plane ? kVarZgapSpans : kVarRgbSpans)) {
+            // SPANS: 64 spans per step, a lane each: an inclusive scan of the lengths gives every span its first literal pixel.  Then the
+            // step's literal pixels 64 at a time, a lane each (neighbouring lanes read neighbouring bytes): a lane finds the span its
+            // pixel belongs to by walking the step's spans (a row has a handful) and writes it to that span's column
+            const uint32_t s0 = sec[y], s1 = sec[y + 1], npx = sec[2 * p.H + 1];
+            const uint32_t *spans = sec + 2 * (p.H + 1);
+            const uint8_t *lit = reinterpret_cast<const uint8_t *>(spans + sec[p.H]);
+            uint32_t first = sec[p.H + 1 + y];   // literal pixel of the step's first span (wave-uniform)
+            for (uint32_t c = s0; c < s1; c += 64) {
+                const uint32_t sp = c + (uint32_t)lane < s1 ? spans[c + lane] : 0u;
+                const int len = (int)(sp >> 16), x0 = (int)(sp & 0xffffu);
+                int incl = len;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                const int start = incl - len;                       // the span's first pixel among the step's literal pixels
+                const int total = __shfl(incl, 63, 64);             // the step's literal pixels (wave-uniform)
+                const int here = (int)min(64u, s1 - c);
+                for (int q0 = 0; q0 < total; q0 += 64) {            // wave-uniform
+                    const int q = q0 + lane;
+                    int x = -1;
+                    for (int j = 0; j < here; j++) {                // wave-uniform
+                        const int sj = __shfl(start, j, 64), lj = __shfl(len, j, 64), xj = __shfl(x0, j, 64);
+                        if (q >= sj && q < sj + lj) x = xj + (q - sj);
+                    }
+                    const uint32_t l = first + (uint32_t)q;
+                    if (x >= 0 && x < p.W && l < npx) {
+                        const uint8_t *g = lit + (size_t)l * 3;
+                        uint8_t *d3 = dst + (size_t)x * 3;
+                        d3[0] = g[0], d3[1] = g[1], d3[2] = g[2];
+                    }
+                }
+                first += (uint32_t)total;
+            }
+            continue;
+        }
         const uint32_t r0 = sec[y], r1 = sec[y + 1];
         const uint32_t *runs = sec + p.H + 1;
-        uint8_t *dst = (plane ? p.zgap : p.rgb) + (size_t)i * p.img_stride + (size_t)y * p.pitch;
         int x = 0;   // first column of the step's first run (wave-uniform)
         for (uint32_t c = r0; c < r1 && x < p.W; c += 64) {
             const uint32_t r = c + (uint32_t)lane < r1 ? runs[c + lane] : 0u;

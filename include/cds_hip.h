@@ -269,6 +269,8 @@ typedef struct cds_variant_shard cds_variant_shard;
 #define CDS_VARIANT_HAS_GRADIENT 1u     /* per-target flags (cds_variant_shard_target_info) */
 #define CDS_VARIANT_GRADIENT_DELTA2 2u  /* the gradient is stored as two bits per pixel (neither this nor DIFF2: raw) */
 #define CDS_VARIANT_HAS_ZGAP 4u
+#define CDS_VARIANT_RGB_SPANS 16u       /* the MIP is stored as the spans of its non-black pixels + their bytes (else run lengths) */
+#define CDS_VARIANT_ZGAP_SPANS 32u      /* the same for the zgap image */
 #define CDS_VARIANT_GRADIENT_DIFF2 8u   /* the gradient is stored as the non-zero second mixed differences (a distance ramp has few) */
 int cds_variant_shard_create(const char *path, int32_t width, int32_t height, cds_variant_writer **out);
 /* `n` targets from host memory: rgb [n][H][W][3]; gradients [n][H][W] u16 or NULL (none of them has one); zgaps like rgb or NULL.

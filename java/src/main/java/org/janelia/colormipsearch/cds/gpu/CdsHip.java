@@ -50,7 +50,7 @@ final class CdsHip {
     static native void libraryLoadFiles(long lib, long first, String[] targets, String[] gradients, String[] zgaps, int threads);
     /**
      * The variant shard: every target's MIP, GradientImage and ZGapImage of a library losslessly in one file (written once from the files
-     * -- no GPU needed), of which libraryLoadVariants decodes any subset ON THE DEVICE into dense slots: 74 K targets/s where inflating
+     * -- no GPU needed), of which libraryLoadVariants decodes any subset ON THE DEVICE into dense slots: 77 K targets/s where inflating
      * the three files of a target on 16 host cores gives 5 K (cmd/CalculateGradientScoresCmd.java:541-586 loads them per match).
      */
     static native long variantShardCreate(String path, int width, int height);

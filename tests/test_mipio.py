@@ -200,7 +200,7 @@ def test_variant_shard_codes_on_the_host(tmp_path, fixtures):
         assert w.count == len(cases) + 2
     shard = cds.VariantShard(path)
     assert (shard.width, shard.height, len(shard)) == (W, H, len(cases) + 2) and shard.file_bytes == os.path.getsize(path)
-    assert shard.flags.tolist() == [13, 13, 1, 0, 13, 4, 9, 0]            # 1 has gradient | 8 second differences (2: two bits per pixel) | 4 has zgap
+    assert shard.flags.tolist() == [29, 29, 17, 16, 29, 36, 25, 16]       # 1 has gradient | 8 second differences (2: two bits per pixel) | 4 has zgap | 16 / 32 the MIP / the zgap image as spans
     assert shard.packed_bytes[0] < 250_000                                # (the reference's target: 3.4 MB + 1.4 MB raw)
     w2, h2, got = read_shard(path)
     assert (w2, h2) == (W, H)
@@ -261,7 +261,7 @@ def test_native_loaders_read_zip_entries(tmp_path, fixtures):
             with pytest.raises(cds.CdsError, match=what):
                 w.append_files([bad])
     _, _, got = read_shard(path)
-    assert [f for f, _, _, _ in got] == [9, 0, 0, 0, 0]
+    assert [f for f, _, _, _ in got] == [25, 16, 16, 16, 16]
     assert np.array_equal(got[0][1], img) and np.array_equal(got[0][2], grad)
     assert np.array_equal(got[1][1], img[::-1]) and np.array_equal(got[2][1], img[::-1])     # found under its full name / by its file name alone
     assert np.array_equal(got[3][1], img) and np.array_equal(got[4][1], img)

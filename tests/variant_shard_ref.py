@@ -23,13 +23,28 @@ def read_shard(path):
             img[y] = np.repeat(colour, length, axis=0)
         return img
 
+    def spans(sec):   # per row the spans `x0 | len << 16` of its non-black pixels; their bytes follow, 3 per pixel
+        row_span, row_pixel = sec[:H + 1], sec[H + 1:2 * H + 2]
+        sp = sec[2 * H + 2:2 * H + 2 + row_span[H]]
+        lit = sec[2 * H + 2 + row_span[H]:].view(np.uint8)[:3 * int(row_pixel[H])].reshape(-1, 3)
+        img = np.zeros((H, W, 3), np.uint8)
+        for y in range(H):
+            at = int(row_pixel[y])
+            for s_ in sp[row_span[y]:row_span[y + 1]]:
+                x0, n = int(s_ & 0xffff), int(s_ >> 16)
+                assert n > 0 and x0 + n <= W and (lit[at:at + n] != 0).any(axis=1).all()
+                img[y, x0:x0 + n] = lit[at:at + n]
+                at += n
+            assert at == row_pixel[y + 1]
+        return img
+
     out = []
     for e in index:
         assert e["off"] % 16 == 0
         blob = np.frombuffer(b, dtype="<u4", count=int(e["bytes"]) // 4, offset=int(e["off"]))
         flags, rb, gb, zb = (int(v) for v in blob[:4])
         assert flags == e["flags"] and 16 + rb + gb + zb == e["bytes"]
-        rgb = rle4(blob[4:4 + rb // 4])
+        rgb = (spans if flags & 16 else rle4)(blob[4:4 + rb // 4])
         grad = None
         if flags & 1:
             sec = blob[4 + rb // 4:4 + (rb + gb) // 4]
@@ -48,6 +63,6 @@ def read_shard(path):
             else:
                 sec = sec.reshape(H, (W + 1) // 2)
                 grad = np.stack([sec & 0xffff, sec >> 16], 2).reshape(H, -1)[:, :W].astype(np.uint16)
-        zgap = rle4(blob[4 + (rb + gb) // 4:]) if flags & 4 else None
+        zgap = (spans if flags & 32 else rle4)(blob[4 + (rb + gb) // 4:]) if flags & 4 else None
         out.append((flags, rgb, grad, zgap))
     return W, H, out
