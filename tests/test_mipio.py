@@ -399,6 +399,48 @@ def test_variant_shard_slots_equal_the_images(tmp_path, fixtures):
 
 
 @pytest.mark.gpu
+def test_variant_shard_random_subsets_of_a_thousand_targets(tmp_path, fixtures):
+    """At a size where batches, double buffering and the staging limit matter: a shard of 1,024 DIFFERENT targets (the reference's images
+    and variants rolled by a target-specific number of columns and rows) and random subsets of it -- any size, any order, repeats --
+    loaded into random slot ranges; every loaded slot is compared (image, gradient, zgap) with what was packed."""
+    from colormipsearch_amd import cds
+    base = [(fixtures["lm_BJD"], fixtures["grad_BJD"], fixtures["zgap_BJD"]), (fixtures["lm_VT016795"], fixtures["grad_VT016795"], None),
+            (fixtures["lm_VT033614"], fixtures["grad_VT033614"], fixtures["zgap_BJD"][:, ::-1]), (fixtures["lm_GMR"], None, None)]
+    H, W = base[0][0].shape[:2]
+    n = 1024
+
+    def target(t):
+        img, g, z = base[t % 4]
+        dx, dy = (t * 37) % W, (t * 11) % H
+        roll = lambda a: None if a is None else np.roll(np.roll(a, dx, axis=1), dy, axis=0)
+        return roll(img), roll(g), roll(z)
+
+    path = tmp_path / "thousand.cdsv"
+    with cds.VariantShardWriter(path, W, H) as w:
+        for t in range(n):
+            img, g, z = target(t)
+            w.append(img, None if g is None else g[None], None if z is None else z[None], threads=1)
+    shard = cds.VariantShard(path)
+    assert len(shard) == n and (shard.flags & shard.HAS_GRADIENT != 0).sum() == 768 and (shard.flags & shard.HAS_ZGAP != 0).sum() == 512
+    lib = cds.Library(W, H, 700)
+    rng = np.random.default_rng(11)
+    for size in (1, 700, 513, 64, 300):
+        first = int(rng.integers(0, 700 - size + 1))
+        picks = rng.integers(0, n, size)
+        flags = lib.load_variants(first, shard, picks, threads=int(rng.integers(1, 9)))
+        check = rng.choice(size, min(size, 24), replace=False)             # (downloading all 700 slots every time would take the test's time)
+        for k in check:
+            img, g, z = target(int(picks[k]))
+            assert np.array_equal(lib.download(first + int(k), 1)[0], img), (size, k)
+            gg, zz = lib.download_variants(first + int(k), 1)
+            assert (flags[k] & 1 != 0) == (g is not None) and (flags[k] & 4 != 0) == (z is not None)
+            if g is not None:
+                assert np.array_equal(gg[0], g), (size, k)
+            if z is not None:
+                assert np.array_equal(zz[0], z), (size, k)
+
+
+@pytest.mark.gpu
 def test_shard_upload_and_search(tmp_path, fixtures, oracle):
     from colormipsearch_amd import cds
     from tests.golden import expected as E
