@@ -525,6 +525,19 @@ static int writer_append(cds_variant_writer *w, int64_t n, int32_t threads, F &&
     std::vector<std::vector<uint32_t>> blobs((size_t)batch);
     std::vector<uint32_t> flags((size_t)batch);
     std::mutex mu;
+    // a call is a transaction: when a target of a later batch fails, what the call has written already is forgotten (the index and the
+    // write position go back; the bytes are overwritten by the next append or left behind the last blob)
+    const size_t idx_before = w->idx.size();
+    const uint64_t pos_before = w->pos;
+    struct Rollback {
+        cds_variant_writer *w;
+        size_t n;
+        uint64_t pos;
+        bool armed = true;
+        ~Rollback() {
+            if (armed) w->idx.resize(n), w->pos = pos;
+        }
+    } rollback{w, idx_before, pos_before};
     for (int64_t b0 = 0; b0 < n; b0 += batch) {
         const int64_t nb = std::min(batch, n - b0);
         run_threads(nthreads, nb, [&](int64_t i) {
@@ -547,6 +560,7 @@ static int writer_append(cds_variant_writer *w, int64_t n, int32_t threads, F &&
             w->pos += b.size() * 4;
         }
     }
+    rollback.armed = false;
     return CDS_OK;
 }
 

@@ -197,6 +197,8 @@ def test_variant_shard_codes_on_the_host(tmp_path, fixtures):
         w.append_files([str(tf), str(tf)], [str(gf), None], None, threads=2)
         with pytest.raises(cds.CdsError, match="nope"):
             w.append_files([str(tf), str(tmp_path / "nope.tif")])
+        with pytest.raises(cds.CdsError, match="nope"):       # ... also when the failing target comes batches after good ones: nothing of the call stays
+            w.append_files([str(tf)] * 40 + [str(tmp_path / "nope.tif")], threads=2)
         assert w.count == len(cases) + 2
     shard = cds.VariantShard(path)
     assert (shard.width, shard.height, len(shard)) == (W, H, len(cases) + 2) and shard.file_bytes == os.path.getsize(path)
