@@ -645,7 +645,7 @@ int cds_variant_shard_finish(cds_variant_writer *w) {
     h.index_off = (w->pos + 15) & ~(uint64_t)15;
     h.file_bytes = h.index_off + w->idx.size() * sizeof(ShardEntry);
     if (ok && !w->idx.empty()) ok = write_all(w->fd, w->idx.data(), w->idx.size() * sizeof(ShardEntry), h.index_off);
-    if (ok && w->idx.empty()) ok = ftruncate(w->fd, (off_t)h.file_bytes) == 0;   // (the padding up to the empty index)
+    if (ok) ok = ftruncate(w->fd, (off_t)h.file_bytes) == 0;   // (cuts off what a failed append left behind; pads up to an empty index)
     if (ok) ok = write_all(w->fd, &h, sizeof h, 0);   // the header last: the file opens only once everything else is in place
     if (ok) ok = fsync(w->fd) == 0;
     close(w->fd);
