@@ -30,7 +30,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -264,11 +266,18 @@ bool read_all(int fd, void *p, size_t n, uint64_t at) {
     return true;
 }
 
+// work(item) for item in [0, items), the calling thread included.  An exception in `work` (an allocation in a packer) does not leave its
+// thread: the remaining items are skipped and the call returns false.
 template <typename F>
-void run_threads(int nthreads, int64_t items, F &&work) {   // work(item) for item in [0, items), the calling thread included
+bool run_threads(int nthreads, int64_t items, F &&work) {
     std::atomic<int64_t> next{0};
+    std::atomic<bool> threw{false};
     auto worker = [&]() {
-        for (int64_t i = next.fetch_add(1); i < items; i = next.fetch_add(1)) work(i);
+        try {
+            for (int64_t i = next.fetch_add(1); i < items && !threw.load(); i = next.fetch_add(1)) work(i);
+        } catch (...) {
+            threw.store(true);
+        }
     };
     std::vector<std::thread> pool;
     try {
@@ -277,6 +286,7 @@ void run_threads(int nthreads, int64_t items, F &&work) {   // work(item) for it
     }
     worker();
     for (auto &th : pool) th.join();
+    return !threw.load();
 }
 
 // ---- device: decoding ----------------------------------------------------------------------------------------------------------
@@ -504,12 +514,14 @@ struct cds_variant_writer {
     uint64_t pos = 64;
     std::vector<ShardEntry> idx;
     bool failed = false;
+    ~cds_variant_writer() { if (fd >= 0) close(fd); }
 };
 struct cds_variant_shard {
     int fd = -1;
     int W = 0, H = 0;
     uint64_t file_bytes = 0;
     std::vector<ShardEntry> idx;
+    ~cds_variant_shard() { if (fd >= 0) close(fd); }
 };
 
 #define CDS_NOEXCEPT_BEGIN try {
@@ -540,13 +552,17 @@ static int writer_append(cds_variant_writer *w, int64_t n, int32_t threads, F &&
     } rollback{w, idx_before, pos_before};
     for (int64_t b0 = 0; b0 < n; b0 += batch) {
         const int64_t nb = std::min(batch, n - b0);
-        run_threads(nthreads, nb, [&](int64_t i) {
+        const bool ran = run_threads(nthreads, nb, [&](int64_t i) {
             std::string err;
             if (!pack(b0 + i, blobs[(size_t)i], flags[(size_t)i], err)) {
                 std::lock_guard<std::mutex> lk(mu);
                 if (first_err.empty()) first_err = err;
             }
         });
+        if (!ran && first_err.empty()) {
+            first_err = "out of host memory while packing";
+            return CDS_ERR_OUT_OF_MEMORY;
+        }
         if (!first_err.empty()) return CDS_ERR_INVALID_ARGUMENT;
         for (int64_t i = 0; i < nb; i++) {
             const std::vector<uint32_t> &b = blobs[(size_t)i];
@@ -577,7 +593,11 @@ int cds_variant_shard_create(const char *path, int32_t W, int32_t H, cds_variant
         close(fd);
         return failf(CDS_ERR_INVALID_ARGUMENT, "cannot write to %s", path);
     }
-    cds_variant_writer *w = new cds_variant_writer();
+    cds_variant_writer *w = new (std::nothrow) cds_variant_writer();
+    if (!w) {
+        close(fd);
+        return fail(CDS_ERR_OUT_OF_MEMORY, "out of host memory");
+    }
     w->fd = fd, w->W = W, w->H = H;
     *out = w;
     return CDS_OK;
@@ -648,7 +668,6 @@ int cds_variant_shard_finish(cds_variant_writer *w) {
     if (ok) ok = ftruncate(w->fd, (off_t)h.file_bytes) == 0;   // (cuts off what a failed append left behind; pads up to an empty index)
     if (ok) ok = write_all(w->fd, &h, sizeof h, 0);   // the header last: the file opens only once everything else is in place
     if (ok) ok = fsync(w->fd) == 0;
-    close(w->fd);
     return ok ? CDS_OK : fail(CDS_ERR_INVALID_ARGUMENT, "cannot write the variant shard");
     CDS_NOEXCEPT_END
 }
@@ -660,8 +679,7 @@ int cds_variant_shard_open(const char *path, cds_variant_shard **out) {
     if (fd < 0) return failf(CDS_ERR_INVALID_ARGUMENT, "cannot open %s", path);
     std::unique_ptr<cds_variant_shard> s(new cds_variant_shard());
     s->fd = fd;
-    auto bad = [&](const char *why) {
-        close(fd);
+    auto bad = [&](const char *why) {   // (`s` closes the file)
         return failf(CDS_ERR_INVALID_ARGUMENT, "%s is not a variant shard: %s", path, why);
     };
     struct stat sb;
@@ -700,11 +718,7 @@ int cds_variant_shard_target_info(const cds_variant_shard *s, int64_t first, int
     return CDS_OK;
 }
 
-void cds_variant_shard_close(cds_variant_shard *s) {
-    if (!s) return;
-    if (s->fd >= 0) close(s->fd);
-    delete s;
-}
+void cds_variant_shard_close(cds_variant_shard *s) { delete s; }
 
 int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant_shard *s, const int64_t *targets, int64_t n, int32_t threads) {
     CDS_NOEXCEPT_BEGIN
@@ -780,11 +794,12 @@ int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant
         const auto t1 = std::chrono::steady_clock::now();
         memcpy(B.h[kk], offs.data(), (size_t)nb * 8);
         std::atomic<int> bad{0};
-        run_threads(nthreads, nb, [&](int64_t i) {
+        const bool ran = run_threads(nthreads, nb, [&](int64_t i) {
             const ShardEntry &e = s->idx[(size_t)targets[b0 + i]];
             uint32_t *dst = reinterpret_cast<uint32_t *>(B.h[kk] + offs[(size_t)i]);
             if (!read_all(s->fd, dst, e.bytes, e.off) || !blob_ok(dst, e.bytes, e.flags, s->W, s->H)) bad.store(1);
         });
+        if (!ran) return fail(CDS_ERR_OUT_OF_MEMORY, "a reader thread failed");
         if (bad.load()) return fail(CDS_ERR_INVALID_ARGUMENT, "the variant shard is damaged: a target's blob does not match its index entry");
         const auto t2 = std::chrono::steady_clock::now();
         t_wait += std::chrono::duration<double>(t1 - t0).count();
