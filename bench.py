@@ -751,11 +751,15 @@ def variant_shard_leg(cds, ctx, fx, rects, failed, n_t=2048, pairs_per_target=2.
         path = os.path.join(d, "variants.cdsv")
         rep = 16
         t0 = time.perf_counter()
-        with cds.VariantShardWriter(path, W, H) as w:   # target i of the shard = fixture i % 3
-            block = (np.concatenate([imgs] * rep), np.concatenate([grads] * rep), np.concatenate([zgaps] * rep))
-            for first in range(0, n_t, len(keys) * rep):
-                k = min(len(keys) * rep, n_t - first)
-                w.append(block[0][:k], block[1][:k], block[2][:k], threads=usable_cores())
+        try:
+            with cds.VariantShardWriter(path, W, H) as w:   # target i of the shard = fixture i % 3
+                block = (np.concatenate([imgs] * rep), np.concatenate([grads] * rep), np.concatenate([zgaps] * rep))
+                for first in range(0, n_t, len(keys) * rep):
+                    k = min(len(keys) * rep, n_t - first)
+                    w.append(block[0][:k], block[1][:k], block[2][:k], threads=usable_cores())
+        except (OSError, cds.CdsError) as e:   # (~0.6 GB in the temporary directory: no room there is the box's business, not a result)
+            proc.close()
+            return {"skipped": f"could not write the shard: {type(e).__name__}: {e}"}
         t_write = time.perf_counter() - t0
         shard = cds.VariantShard(path)
         proc.calculateGradientScoresFromShardTable(masks, table(t_idx[order]).take(np.arange(64)), shard, 20, excludedRegions=rects, batch=512, threads=usable_cores())
