@@ -601,6 +601,21 @@ class SparseLibrary:
             raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "image size does not match the library")
         capi.check(self._lib.cds_sparse_library_append_host(self._h, imgs.shape[0], capi.as_u8p(imgs)))
 
+    def append_from_shard(self, shard, targets=None, batch=1024, threads=0):
+        """Append targets of a VariantShard (all of them, in the shard's order, unless `targets` lists some): their blobs are decoded on the
+        device into `batch` dense staging slots and converted from there -- one file then serves both kernels, the pixel-match scan's
+        resident library and the gradient-score step's variants.  (The records come out as from the image files: tests/test_mipio.py.)"""
+        idx = np.arange(len(shard), dtype=np.int64) if targets is None else np.ascontiguousarray(targets, dtype=np.int64)
+        if (shard.width, shard.height) != (self.width, self.height):
+            raise CdsInvalidArgument(capi.CDS_ERR_INVALID_ARGUMENT, "the shard's image size differs from the library's")
+        if len(idx) == 0:
+            return
+        staging = Library(self.width, self.height, min(int(batch), len(idx)), context=self.ctx)
+        for first in range(0, len(idx), staging.capacity):
+            part = idx[first:first + staging.capacity]
+            staging.load_variants(0, shard, part, threads=threads)
+            self.append_from(staging, 0, len(part))
+
     def append_files(self, paths, threads=0):
         """Append 8-bit RGB image files (TIFF / PNG, the library's size): decoded natively on `threads` host threads
         (0 = all cores), two batches in flight (decode || upload + conversion).  A path may be a pair (archive.zip, entry name)."""

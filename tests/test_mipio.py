@@ -515,6 +515,15 @@ def test_append_files_to_sparse_library(tmp_path, fixtures):
     for i in range(6):
         (ra, ca), (rb, cb) = zipped.image_records(i), dev.image_records(i)
         assert np.array_equal(ra, rb) and np.array_equal(ca, cb), i
+    # ... and through a variant shard written from the same archive (decoded on the device, converted from dense staging slots)
+    with cds.VariantShardWriter(tmp_path / "lib.cdsv", 1210, 566) as w:
+        w.append_files([(str(zp), f"mips/{i}.tif") for i in range(len(npaths))], threads=3)
+    sharded = cds.SparseLibrary(1210, 566, 8, 8 * 700000, density_limit=2.0, min_threshold=7)
+    sharded.append_from_shard(cds.VariantShard(tmp_path / "lib.cdsv"), batch=4)
+    assert len(sharded) == 6 and sharded.pixels == dev.pixels
+    for i in range(6):
+        (ra, ca), (rb, cb) = sharded.image_records(i), dev.image_records(i)
+        assert np.array_equal(ra, rb) and np.array_equal(ca, cb), i
     dl = cds.Library(1210, 566, 2)
     dl.load_files(0, [(str(zp), "mips/1.tif"), (str(zp), "mips/4.tif")], [(str(zp), "grad/1.png"), None])
     assert np.array_equal(dl.download(0, 2), frames[[1, 4]]) and np.array_equal(dl.download_variants(0, 1)[0][0], fixtures["grad_BJD"])

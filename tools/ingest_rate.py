@@ -51,7 +51,9 @@ with tempfile.TemporaryDirectory() as d:
             dl.load_variants(0, shard, np.arange(first, min(first + dl.capacity, a.files)), threads=a.threads)
         tl = time.perf_counter() - t0
         same = bool(np.array_equal(dl.download(0, 4), np.stack([mipio.read_mip(q) for q in paths[(a.files - 1) // dl.capacity * dl.capacity:][:4]])))
-        extra = {"variant_shard": {"write_images_per_s": round(a.files / tw), "load_images_per_s": round(a.files / tl), "bytes_per_image": round(shard.file_bytes / a.files),
+        sl2 = cds.SparseLibrary(W, H, a.files, 46000 * a.files)
+        t0 = time.perf_counter(); sl2.append_from_shard(shard, threads=a.threads); ts = time.perf_counter() - t0
+        extra = {"variant_shard": {"sparse_append_images_per_s": round(a.files / ts), "sparse_records_equal": bool(sl2.pixels == sl.pixels),"write_images_per_s": round(a.files / tw), "load_images_per_s": round(a.files / tl), "bytes_per_image": round(shard.file_bytes / a.files),
                                    "read_GBps": round(shard.file_bytes / tl / 1e9, 2), "last_batch_equals_the_files": same}}
     print(json.dumps({**extra, "files": a.files, "compression": a.compression, "mean_file_bytes": round(nbytes / a.files), "threads": a.threads or os.cpu_count(),
                       "append_files_s": round(t, 3), "images_per_s": round(a.files / t), "decoded_GBps": round(a.files * 3 * W * H / t / 1e9, 2),
