@@ -485,7 +485,7 @@ size_t cds_library_bytes(int32_t W, int32_t H, int64_t capacity) {
 
 static int library_init(cds_context *ctx, int W, int H, int64_t capacity, cds_library **out) {
     if (!ctx || !out) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (W < 8 || H < 1 || W > kMaxW || H > kMaxH) return fail(CDS_ERR_UNSUPPORTED, "image size outside 8..2000 x 1..1000");
+    if (!image_size_ok(W, H)) return fail(CDS_ERR_UNSUPPORTED, kImageSizeMessage);
     if (capacity <= 0) return fail(CDS_ERR_INVALID_ARGUMENT, "capacity must be positive");
     cds_library *lib = new cds_library();
     lib->ctx = ctx; lib->W = W; lib->H = H; lib->capacity = capacity;
@@ -714,7 +714,7 @@ int cds_maskset_create(cds_context *ctx, int32_t n_masks, const uint8_t *masks_r
     if (!ctx || !out || !params) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     *out = nullptr;
     if (n_masks <= 0 || !masks_rgb) return fail(CDS_ERR_INVALID_ARGUMENT, "no masks");
-    if (W < 8 || H < 1 || W > kMaxW || H > kMaxH) return fail(CDS_ERR_UNSUPPORTED, "image size outside 8..2000 x 1..1000");
+    if (!image_size_ok(W, H)) return fail(CDS_ERR_UNSUPPORTED, kImageSizeMessage);
     if (params->xy_shift & 1) return fail(CDS_ERR_INVALID_ARGUMENT, "XY shift parameter must be an even number.");
     if (params->xy_shift < 0 || params->xy_shift > 2)
         return fail(CDS_ERR_UNSUPPORTED, "xy_shift must be 0 or 2 (the reference overruns its shift table for >= 4)");
@@ -888,6 +888,14 @@ static int build_dense_layout(cds_maskset *ms) {
         const size_t px_per_band = total / (size_t)std::max(1, (m1 - m0 + kScanBandRows - 1) / kScanBandRows);
         const bool big = px_per_band > (size_t)kBatchForSinglePxPerBand;
         if ((fb ? atoi(fb) != 0 : big) && scan_lds_bytes(ms->wc, 1, true, shift == 2, mirror) <= ctx->lds_per_block) batch = true;
+    }
+    if (!batch && nrows > 1023) {
+        // the single-mask records keep a pixel's row in 10 bits (relative to the mask's first row): a taller mask -- a descending neuron in a
+        // 573 x 1119 VNC MIP -- takes the batch layout, whose records address the LDS ring instead
+        if (scan_lds_bytes(ms->wc, 1, true, shift == 2, mirror) > ctx->lds_per_block)
+            return fail(CDS_ERR_UNSUPPORTED, "a mask spanning more than 1,023 rows whose window does not fit the batch kernel's LDS cannot be scanned over a dense "
+                                             "library: use a sparse library");
+        batch = true;
     }
     ms->batch = batch;
     const int ngroups = (n_masks + group - 1) / group;

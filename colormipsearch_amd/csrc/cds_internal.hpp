@@ -42,8 +42,15 @@ constexpr int kScanPrefetchSlack = 16;  // chunks of slack behind the record arr
 constexpr int kBatchForSinglePxPerBand = 1 << 30;
 
 // ---- geometry limits (bit-packing of the mask pixel records, see cds_scan.hip) ----
+// Width: 11-bit window columns, four 512-column strips of a sparse library.  Height: round 5 raised it from 1,000 so that the VNC alignment
+// spaces' 573 x 1119 MIPs fit (the dense single-mask layout's 10-bit row field is the only thing that counted rows: a mask spanning more
+// than 1,023 rows goes through the batch layout, cds_host.hip); the AREA stays where it was -- the scorer's per-lane sums and the
+// multi-mask kernel's 20-bit plane offsets were sized for it.
 constexpr int kMaxW = 2000;
-constexpr int kMaxH = 1000;
+constexpr int kMaxH = 1536;
+constexpr int64_t kMaxPixels = 2000000;
+inline bool image_size_ok(int W, int H) { return W >= 8 && H >= 1 && W <= kMaxW && H <= kMaxH && (int64_t)W * H <= kMaxPixels; }
+constexpr const char *kImageSizeMessage = "image size outside 8..2000 x 1..1536 (at most 2,000,000 pixels)";
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // floor to a multiple of 4, also for negatives

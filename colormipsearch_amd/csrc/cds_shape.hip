@@ -945,7 +945,7 @@ extern "C" {
 int cds_make_zgap(cds_context *ctx, const uint8_t *target_rgb, int32_t W, int32_t H, int32_t threshold, double radius,
                   const cds_rect *excluded, int32_t n_excluded, uint8_t *zgap_rgb) {
     if (!ctx || !target_rgb || !zgap_rgb) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (W < 8 || H < 1 || W > kMaxW || H > kMaxH) return fail(CDS_ERR_UNSUPPORTED, "image size outside 8..2000 x 1..1000");
+    if (!image_size_ok(W, H)) return fail(CDS_ERR_UNSUPPORTED, kImageSizeMessage);
     if (n_excluded < 0 || n_excluded > CDS_MAX_RECTS || (n_excluded > 0 && !excluded)) return fail(CDS_ERR_INVALID_ARGUMENT, "bad excluded-region list");
     if (!(radius >= 0 && radius <= 200)) return fail(CDS_ERR_INVALID_ARGUMENT, "radius outside 0..200");
     // the bbox shortcut in max_filter_host looks at the unfiltered source: harmless (a superset)
@@ -1011,7 +1011,7 @@ int cds_shapeset_create_bordered(cds_context *ctx, int32_t n_masks, const uint8_
     *out = nullptr;
     if (query_border_size < 0) return fail(CDS_ERR_INVALID_ARGUMENT, "queryBorderSize is negative");
     if (n_masks <= 0 || !masks_rgb) return fail(CDS_ERR_INVALID_ARGUMENT, "no masks");
-    if (W < 8 || H < 1 || W > kMaxW || H > kMaxH) return fail(CDS_ERR_UNSUPPORTED, "image size outside 8..2000 x 1..1000");
+    if (!image_size_ok(W, H)) return fail(CDS_ERR_UNSUPPORTED, kImageSizeMessage);
     if (n_excluded < 0 || n_excluded > CDS_MAX_RECTS || (n_excluded > 0 && !excluded)) return fail(CDS_ERR_INVALID_ARGUMENT, "bad excluded-region list");
     int rc = ensure_slice_lut(ctx);
     if (rc) return rc;

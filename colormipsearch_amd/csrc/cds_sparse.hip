@@ -2580,7 +2580,7 @@ int cds_sparse_library_create(cds_context *ctx, int32_t W, int32_t H, int64_t ca
                               cds_sparse_library **out) {
     if (!ctx || !out) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     *out = nullptr;
-    if (W < 8 || H < 1 || W > kMaxW || H > kMaxH) return fail(CDS_ERR_UNSUPPORTED, "image size outside 8..2000 x 1..1000");
+    if (!image_size_ok(W, H)) return fail(CDS_ERR_UNSUPPORTED, kImageSizeMessage);
     if (capacity_images <= 0 || capacity_pixels <= 0) return fail(CDS_ERR_INVALID_ARGUMENT, "capacities must be positive");
     CDS_HIP(hipSetDevice(ctx->device));
     cds_sparse_library *sl = new cds_sparse_library();

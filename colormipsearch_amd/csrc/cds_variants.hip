@@ -585,7 +585,7 @@ extern "C" {
 int cds_variant_shard_create(const char *path, int32_t W, int32_t H, cds_variant_writer **out) {
     CDS_NOEXCEPT_BEGIN
     if (!path || !out) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (W < 8 || H < 1 || W > kMaxW || H > kMaxH) return fail(CDS_ERR_UNSUPPORTED, "image size outside 8..2000 x 1..1000");
+    if (!image_size_ok(W, H)) return fail(CDS_ERR_UNSUPPORTED, kImageSizeMessage);
     const int fd = open(path, O_CREAT | O_TRUNC | O_WRONLY | O_CLOEXEC, 0644);
     if (fd < 0) return failf(CDS_ERR_INVALID_ARGUMENT, "cannot create %s", path);
     ShardHeader h{};   // (no magic until cds_variant_shard_finish: a file that was never finished does not open)
@@ -686,7 +686,7 @@ int cds_variant_shard_open(const char *path, cds_variant_shard **out) {
     ShardHeader h{};
     if (fstat(fd, &sb) != 0 || (uint64_t)sb.st_size < sizeof h || !read_all(fd, &h, sizeof h, 0)) return bad("no header");
     if (memcmp(h.magic, kShardMagic, 8) != 0) return bad("wrong magic (unfinished file?)");
-    if (h.W < 8 || h.H < 1 || h.W > (uint32_t)kMaxW || h.H > (uint32_t)kMaxH) return bad("image size outside 8..2000 x 1..1000");
+    if (h.W > (uint32_t)kMaxW || h.H > (uint32_t)kMaxH || !image_size_ok((int)h.W, (int)h.H)) return bad(kImageSizeMessage);
     if (h.file_bytes > (uint64_t)sb.st_size || h.index_off < 64 || h.index_off > h.file_bytes || h.n > (h.file_bytes - h.index_off) / sizeof(ShardEntry))
         return bad("index outside the file");
     s->W = (int)h.W, s->H = (int)h.H, s->file_bytes = h.file_bytes;

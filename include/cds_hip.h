@@ -13,6 +13,8 @@
  * the last failing call on the calling thread.  Handles are immutable after creation and may be used
  * from several host threads at once (the reference shares one algorithm object between all worker
  * threads: tools cmd/cdsprocess/LocalColorMIPSearchProcessor.java:88-105).
+ * Image sizes: 8..2000 columns, 1..1536 rows, at most 2,000,000 pixels (the brain alignment spaces' 1210 x 566 and the VNC ones' 573 x 1119 fit); the
+ * create calls of libraries, mask sets and shards answer CDS_ERR_UNSUPPORTED beyond that.
  * There is NO CPU fallback: every call that computes fails with CDS_ERR_NO_DEVICE when no gfx950 GPU
  * is usable.
  *

@@ -303,7 +303,7 @@ def _random_variant_images(rng, W, H, n):
     return out
 
 
-@pytest.mark.parametrize("W,H", [(8, 1), (9, 3), (16, 2), (17, 5), (33, 4), (255, 3), (256, 2), (257, 2), (511, 1), (1210, 3), (2000, 2)])
+@pytest.mark.parametrize("W,H", [(8, 1), (9, 3), (16, 2), (17, 5), (33, 4), (255, 3), (256, 2), (257, 2), (511, 1), (1210, 3), (2000, 2), (573, 1119)])
 def test_variant_shard_codes_at_other_image_sizes(tmp_path, W, H):
     """the packer at the sizes where its words end unevenly (W not a multiple of 16, of 2; one row; the widest image) against the numpy reading"""
     from colormipsearch_amd import cds
