@@ -85,6 +85,7 @@ SIGNATURES = {
     "cds_variant_shard_target_info": (_i, [_vp, _i64, _i64, _u32p, _u32p]),
     "cds_variant_shard_close": (None, [_vp]),
     "cds_library_load_variants": (_i, [_vp, _i64, _vp, _i64p, _i64, _i32]),
+    "cds_library_load_variant_images": (_i, [_vp, _i64, _vp, _i64p, _i64, _i32]),
     "cds_library_download_variants": (_i, [_vp, _i64, _i64, _u16p, _u8p]),
     "cds_library_generate_synthetic": (_i, [_vp, ctypes.c_uint64, _i64, _i64, _i64, _i32, _i32]),
     "cds_library_generate_synthetic_list": (_i, [_vp, ctypes.c_uint64, _i64p, _i64, _i64, _i32, _i32]),

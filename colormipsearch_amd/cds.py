@@ -333,11 +333,15 @@ class Library:
         capi.check(self._lib.cds_library_load_files(self._h, int(first), n, _path_array(target_paths, n), _path_array(gradient_paths, n),
                                                     _path_array(zgap_paths, n), int(threads)))
 
-    def load_variants(self, first, shard, targets, threads=0):
+    def load_variants(self, first, shard, targets, threads=0, images_only=False):
         """Slots first.. <- the targets `targets` of a VariantShard: image, gradient and zgap as stored, decoded on the device
         (cds_library_load_variants).  Returns the targets' flags (VariantShard.HAS_GRADIENT / HAS_ZGAP bits) so that the caller knows
-        which slots came without a gradient or a zgap."""
+        which slots came without a gradient or a zgap.  `images_only`: the MIPs alone (cds_library_load_variant_images: only their
+        sections of the blobs are read; the slots have no variants, the flags returned are 0)."""
         idx = np.ascontiguousarray(targets, dtype=np.int64)
+        if images_only:
+            capi.check(self._lib.cds_library_load_variant_images(self._h, int(first), shard._h, capi.as_i64p(idx), len(idx), int(threads)))
+            return np.zeros(len(idx), dtype=np.uint32)
         capi.check(self._lib.cds_library_load_variants(self._h, int(first), shard._h, capi.as_i64p(idx), len(idx), int(threads)))
         return shard.flags[idx]
 
@@ -613,7 +617,7 @@ class SparseLibrary:
         staging = Library(self.width, self.height, min(int(batch), len(idx)), context=self.ctx)
         for first in range(0, len(idx), staging.capacity):
             part = idx[first:first + staging.capacity]
-            staging.load_variants(0, shard, part, threads=threads)
+            staging.load_variants(0, shard, part, threads=threads, images_only=True)
             self.append_from(staging, 0, len(part))
 
     def append_files(self, paths, threads=0):

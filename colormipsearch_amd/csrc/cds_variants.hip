@@ -720,7 +720,11 @@ int cds_variant_shard_target_info(const cds_variant_shard *s, int64_t first, int
 
 void cds_variant_shard_close(cds_variant_shard *s) { delete s; }
 
-int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant_shard *s, const int64_t *targets, int64_t n, int32_t threads) {
+}  // extern "C"
+
+// images_only: of every blob only the header and the MIP's section are read, staged and decoded (the ingest of a sparse library wants the images
+// of ALL targets and none of their variants: a third to a half of the bytes); the slots come out without gradient and zgap
+static int load_variants_impl(cds_library *lib, int64_t first, const cds_variant_shard *s, const int64_t *targets, int64_t n, int32_t threads, bool images_only) {
     CDS_NOEXCEPT_BEGIN
     if (!lib || !s || (n > 0 && !targets)) return fail(CDS_ERR_INVALID_ARGUMENT, "NULL argument");
     if (first < 0 || n < 0 || first + n > lib->capacity) return fail(CDS_ERR_INVALID_ARGUMENT, "slot range outside the library");
@@ -728,16 +732,32 @@ int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant
     for (int64_t i = 0; i < n; i++)
         if (targets[i] < 0 || targets[i] >= (int64_t)s->idx.size()) return fail(CDS_ERR_INVALID_ARGUMENT, "target index outside the shard");
     if (n == 0) return CDS_OK;
-    int rc = cds_library_ensure_variants(lib);
-    if (rc) return rc;
+    if (!images_only) {
+        const int rc = cds_library_ensure_variants(lib);
+        if (rc) return rc;
+    }
     cds_context *ctx = lib->ctx;
     CDS_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int nthreads = std::max(1, std::min(threads > 0 ? threads : (int)std::thread::hardware_concurrency(), 64));
+    // bytes[i]: what is staged of target i -- its whole blob, or header + MIP section (their headers are read first: 16 bytes each)
+    std::vector<uint32_t> bytes((size_t)n);
+    for (int64_t i = 0; i < n; i++) bytes[(size_t)i] = s->idx[(size_t)targets[i]].bytes;
+    if (images_only) {
+        std::atomic<int> bad_header{0};
+        const bool ran = run_threads(nthreads, n, [&](int64_t i) {
+            const ShardEntry &e = s->idx[(size_t)targets[i]];
+            uint32_t h[4];
+            if (!read_all(s->fd, h, 16, e.off) || h[0] != e.flags || (h[1] & 3) || (uint64_t)16 + h[1] > e.bytes) bad_header.store(1);
+            else bytes[(size_t)i] = 16 + h[1];
+        });
+        if (!ran) return fail(CDS_ERR_OUT_OF_MEMORY, "a reader thread failed");
+        if (bad_header.load()) return fail(CDS_ERR_INVALID_ARGUMENT, "the variant shard is damaged: a target's blob does not match its index entry");
+    }
     // a batch: as many targets as fit one staging buffer -- [u64 offsets][blobs, 16-byte aligned]
     constexpr int64_t kMaxBatch = 1024;
     size_t biggest = 0;
-    for (int64_t i = 0; i < n; i++) biggest = std::max<size_t>(biggest, s->idx[(size_t)targets[i]].bytes);
+    for (int64_t i = 0; i < n; i++) biggest = std::max<size_t>(biggest, bytes[(size_t)i]);
     const size_t table = (size_t)kMaxBatch * 8;
     const size_t stage_bytes = std::max<size_t>((size_t)64 << 20, table + biggest + 16);
     struct Buffers {   // (device blocks from the context's cache: hipFree would wait for the scoring another thread has in flight)
@@ -758,7 +778,7 @@ int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant
     const bool two = [&]() {   // (a call that fits one batch needs one pair of buffers)
         size_t used = table;
         for (int64_t i = 0; i < n; i++) {
-            used += ((size_t)s->idx[(size_t)targets[i]].bytes + 15) & ~(size_t)15;
+            used += ((size_t)bytes[(size_t)i] + 15) & ~(size_t)15;
             if (used > stage_bytes || i >= kMaxBatch) return true;
         }
         return false;
@@ -780,10 +800,10 @@ int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant
         size_t used = table;
         std::vector<uint64_t> offs;
         while (b0 + nb < n && nb < kMaxBatch) {
-            const size_t bytes = ((size_t)s->idx[(size_t)targets[b0 + nb]].bytes + 15) & ~(size_t)15;
-            if (used + bytes > stage_bytes) break;
+            const size_t room = ((size_t)bytes[(size_t)(b0 + nb)] + 15) & ~(size_t)15;
+            if (used + room > stage_bytes) break;
             offs.push_back(used);
-            used += bytes;
+            used += room;
             nb++;
         }
         const auto t0 = std::chrono::steady_clock::now();
@@ -797,7 +817,15 @@ int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant
         const bool ran = run_threads(nthreads, nb, [&](int64_t i) {
             const ShardEntry &e = s->idx[(size_t)targets[b0 + i]];
             uint32_t *dst = reinterpret_cast<uint32_t *>(B.h[kk] + offs[(size_t)i]);
-            if (!read_all(s->fd, dst, e.bytes, e.off) || !blob_ok(dst, e.bytes, e.flags, s->W, s->H)) bad.store(1);
+            const uint32_t want = bytes[(size_t)(b0 + i)];
+            if (!read_all(s->fd, dst, want, e.off)) { bad.store(1); return; }
+            uint32_t flags = e.flags;
+            if (images_only) {   // the staged blob is a blob of its own: the MIP alone
+                if (dst[0] != e.flags || 16 + dst[1] != want) { bad.store(1); return; }
+                flags = e.flags & kVarRgbSpans;
+                dst[0] = flags, dst[2] = 0, dst[3] = 0;
+            }
+            if (!blob_ok(dst, want, flags, s->W, s->H)) bad.store(1);
         });
         if (!ran) return fail(CDS_ERR_OUT_OF_MEMORY, "a reader thread failed");
         if (bad.load()) return fail(CDS_ERR_INVALID_ARGUMENT, "the variant shard is damaged: a target's blob does not match its index entry");
@@ -807,7 +835,7 @@ int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant
         const int64_t slot0 = first + b0;
         bool any_grad = false, any_zgap = false, any_diff2 = false;
         for (int64_t i = 0; i < nb; i++) {
-            const uint32_t f = s->idx[(size_t)targets[b0 + i]].flags;
+            const uint32_t f = images_only ? 0u : s->idx[(size_t)targets[b0 + i]].flags;
             slot_flags[(size_t)(b0 + i)] = (uint8_t)f;
             any_grad |= (f & kVarGrad) != 0, any_zgap |= (f & kVarZgap) != 0, any_diff2 |= (f & kVarDiff2) != 0;
         }
@@ -818,8 +846,8 @@ int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant
         p.stage = static_cast<const uint8_t *>(B.d[kk]);
         p.nb = nb, p.W = lib->W, p.H = lib->H;
         p.rgb = lib->d_rgb + (size_t)slot0 * lib->img_stride;
-        p.zgap = lib->d_zgap + (size_t)slot0 * lib->img_stride;
-        p.grad = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(lib->d_grad) + (size_t)slot0 * lib->grad_stride);
+        p.zgap = lib->d_zgap ? lib->d_zgap + (size_t)slot0 * lib->img_stride : nullptr;                 // (images_only: the library may have no variant planes)
+        p.grad = lib->d_grad ? reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(lib->d_grad) + (size_t)slot0 * lib->grad_stride) : nullptr;
         p.pitch = lib->pitch, p.gpitch = lib->gpitch, p.img_stride = lib->img_stride, p.grad_stride = lib->grad_stride;
         const int64_t cap_grid = (int64_t)ctx->n_cus * 32;
         hipLaunchKernelGGL(var_rle4_kernel, dim3((unsigned)std::min<int64_t>((nb * lib->H * 2 + 3) / 4, cap_grid)), dim3(256), 0, st, p);
@@ -848,6 +876,15 @@ int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count(), t_read, t_wait, nthreads);
     return CDS_OK;
     CDS_NOEXCEPT_END
+}
+
+extern "C" {
+
+int cds_library_load_variants(cds_library *lib, int64_t first, const cds_variant_shard *s, const int64_t *targets, int64_t n, int32_t threads) {
+    return load_variants_impl(lib, first, s, targets, n, threads, false);
+}
+int cds_library_load_variant_images(cds_library *lib, int64_t first, const cds_variant_shard *s, const int64_t *targets, int64_t n, int32_t threads) {
+    return load_variants_impl(lib, first, s, targets, n, threads, true);
 }
 
 }  // extern "C"

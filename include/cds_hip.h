@@ -296,6 +296,9 @@ void cds_variant_shard_close(cds_variant_shard *s);
  * to 64 MB at a time, while the previous batch is copied and decoded.  Safe to call while another thread scores OTHER slots or another
  * library of the same context. */
 int cds_library_load_variants(cds_library *lib, int64_t first_slot, const cds_variant_shard *s, const int64_t *targets, int64_t n, int32_t threads);
+/* The same for the targets' IMAGES alone: of every blob only the MIP's section is read and decoded, the slots come out without gradient and zgap
+ * -- what the ingest of a sparse library wants (cds_sparse_library_append from these slots: one shard then serves both kernels). */
+int cds_library_load_variant_images(cds_library *lib, int64_t first_slot, const cds_variant_shard *s, const int64_t *targets, int64_t n, int32_t threads);
 
 /* The scan over images [first, first+count) of a sparse library: same outputs as cds_search / cds_search_device /
  * cds_search_counts. */

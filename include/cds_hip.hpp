@@ -142,6 +142,9 @@ public:
     void loadVariants(int64_t first, const VariantShard &shard, const std::vector<int64_t> &targets, int threads = 0) {
         check(cds_library_load_variants(lib_, first, shard.handle(), targets.data(), (int64_t)targets.size(), threads));
     }
+    void loadVariantImages(int64_t first, const VariantShard &shard, const std::vector<int64_t> &targets, int threads = 0) {   // the MIPs alone
+        check(cds_library_load_variant_images(lib_, first, shard.handle(), targets.data(), (int64_t)targets.size(), threads));
+    }
     void uploadGradientU8(int64_t first, int64_t count, const uint8_t *grad8) {   // a GRAY8 gradient image (ByteImageArray.java:3-16)
         check(cds_library_upload_gradient_u8(lib_, first, count, grad8));
     }

@@ -327,6 +327,15 @@ JNIEXPORT void JNICALL CLS(libraryLoadVariants)(JNIEnv *env, jclass c, jlong lib
     (*env)->ReleaseLongArrayElements(env, targets, t, JNI_ABORT);
     if (rc) throw_for(env, rc);
 }
+JNIEXPORT void JNICALL CLS(libraryLoadVariantImages)(JNIEnv *env, jclass c, jlong lib, jlong first, jlong shard, jlongArray targets, jint threads) {
+    if (!targets) { throw_iae(env, "targets is null"); return; }
+    jsize n = (*env)->GetArrayLength(env, targets);
+    jlong *t = (*env)->GetLongArrayElements(env, targets, NULL);
+    if (!t) return;
+    int rc = cds_library_load_variant_images(P(cds_library, lib), first, P(cds_variant_shard, shard), (const int64_t *)t, n, threads);
+    (*env)->ReleaseLongArrayElements(env, targets, t, JNI_ABORT);
+    if (rc) throw_for(env, rc);
+}
 JNIEXPORT void JNICALL CLS(sparseLibraryAppendFiles)(JNIEnv *env, jclass c, jlong sl, jobjectArray paths, jint threads) {
     if (!paths) { throw_iae(env, "paths is null"); return; }
     jsize n = (*env)->GetArrayLength(env, paths);

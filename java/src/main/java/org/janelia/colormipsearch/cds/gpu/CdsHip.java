@@ -62,6 +62,8 @@ final class CdsHip {
     static native int variantShardTargetFlags(long shard, long target);
     static native void variantShardClose(long shard);
     static native void libraryLoadVariants(long lib, long first, long shard, long[] targets, int threads);
+    /** the targets' MIPs alone (the slots have no variants): what filling a sparse library from a shard reads */
+    static native void libraryLoadVariantImages(long lib, long first, long shard, long[] targets, int threads);
     static native void libraryMakeZgapVariants(long lib, long first, long count, int threshold, double radius, int[] rectsXYXY);
     static native void search(long maskset, long lib, long first, long count, int[] scores, byte[] mirrored);
 

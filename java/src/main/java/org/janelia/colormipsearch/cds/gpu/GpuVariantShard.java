@@ -78,6 +78,11 @@ public final class GpuVariantShard implements AutoCloseable {
         CdsHip.libraryLoadVariants(denseLibrary, firstSlot, handle, targets, threads);
     }
 
+    /** The targets' MIPs alone into dense slots (no variants): the staging step of filling a GpuTargetLibrary from the shard. */
+    public void loadImages(long denseLibrary, long firstSlot, long[] targets, int threads) {
+        CdsHip.libraryLoadVariantImages(denseLibrary, firstSlot, handle, targets, threads);
+    }
+
     @Override
     public synchronized void close() {
         if (handle != 0) {

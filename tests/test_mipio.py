@@ -385,6 +385,17 @@ def test_variant_shard_slots_equal_the_images(tmp_path, fixtures):
     g_ref, h_ref, _ = alg.scoreLibraryPairs(ref, np.zeros(2, np.int32), np.array([0, 1]))
     g_got, h_got, _ = alg.scoreLibraryPairs(lib, np.zeros(3, np.int32), np.array([3, 8, 4]))   # targets 0, 1 and 3 (no gradient)
     assert (g_got[:2].tolist(), h_got[:2].tolist()) == (g_ref.tolist(), h_ref.tolist()) and (g_got[2], h_got[2]) == (-1, -1)
+    # the MIPs alone (what filling a sparse library reads): the images come, the slots have no variants
+    only = cds.Library(W, H, 4)
+    only.upload_variants(0, gradients=np.full((4, H, W), 5, np.uint16), zgaps=np.full((4, H, W, 3), 5, np.uint8))
+    assert not only.load_variants(1, shard, [4, 0, 5], images_only=True).any()
+    got = only.download(1, 3)
+    assert np.array_equal(got[0], cases[4][0]) and np.array_equal(got[1], cases[0][0]) and np.array_equal(got[2], cases[5][0])
+    g_only, h_only, _ = alg.scoreLibraryPairs(only, np.zeros(2, np.int32), np.array([2, 0]))
+    assert (g_only[0], h_only[0]) == (-1, -1) and g_only[1] >= 0                  # slot 2 lost its variants to the load; slot 0 kept the uploaded ones
+    bare = cds.Library(W, H, 2)                                                   # (a library that never had variant planes)
+    bare.load_variants(0, shard, [1, 2], images_only=True)
+    assert np.array_equal(bare.download(0, 2), np.stack([cases[1][0], cases[2][0]]))
     with pytest.raises(ValueError):
         lib.load_variants(0, shard, [len(cases)])
     with pytest.raises(ValueError):
