@@ -217,6 +217,12 @@ JNIEXPORT void JNICALL CLS(sparseLibraryAppend)(JNIEnv *env, jclass c, jlong sl,
     int rc = cds_sparse_library_append_host(P(cds_sparse_library, sl), count, px);
     if (rc) throw_for(env, rc);
 }
+/* cds_sparse_library_append: dense resident slots [first, first + count) of `lib` converted on the device (what follows libraryLoadVariantImages when
+ * the target library is filled from a variant shard) */
+JNIEXPORT void JNICALL CLS(sparseLibraryAppendFrom)(JNIEnv *env, jclass c, jlong sl, jlong lib, jlong first, jlong count) {
+    int rc = cds_sparse_library_append(P(cds_sparse_library, sl), P(cds_library, lib), first, count);
+    if (rc) throw_for(env, rc);
+}
 /* a String[] as a malloc'ed array of strdup'ed UTF-8 paths (NULL elements stay NULL when allow_null); every local reference is dropped
  * inside the loop: a library has millions of files and the local-reference table holds a few hundred entries.  NULL on failure. */
 static const char **copy_paths(JNIEnv *env, jobjectArray paths, jsize n, int allow_null) {

@@ -77,6 +77,8 @@ final class CdsHip {
     static native void sparseLibrarySetMinThreshold(long slib, int minDataThreshold);
     static native void sparseLibraryAppend(long slib, long count, ByteBuffer directRgb);
     static native void sparseLibraryAppendFiles(long slib, String[] paths, int threads);
+    /** dense resident slots first.. of a library (libraryCreate), converted on the device */
+    static native void sparseLibraryAppendFrom(long slib, long lib, long first, long count);
     static native long sparseLibrarySize(long slib);
     static native long sparseLibraryPixels(long slib);
     static native void sparseLibraryClear(long slib);
